@@ -1,0 +1,4 @@
+"""Parity oracle (TEST INFRASTRUCTURE ONLY -- see oracle/cvx_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+"""

@@ -1,0 +1,211 @@
+"""ctypes/numpy front-end of oracle/libcvx_oracle.so (the C restatement of the reference hot path).
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package `convexadam_amd` imports this module; it is
+used by tests/, by __graft_entry__.smoke() as the checker and by bench.py's `cpu_baseline` leg.
+Every function mirrors one reference operator; see cvx_oracle.c for the reference file:line cites.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcvx_oracle.so")
+_lib = None
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (idempotent)."""
+    src = os.path.join(_HERE, "cvx_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libcvx_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_expf_array.argtypes = [_f32p, _f32p, C.c_int64]
+        L.orc_linspace_pm1.argtypes = [C.c_int, _f32p]
+        L.orc_affine_base.argtypes = [C.c_int, _f32p]
+        L.orc_disp_mesh.argtypes = [C.c_int, _f32p]
+        L.orc_box_zero.argtypes = [_f32p, _f32p] + [C.c_int] * 5
+        L.orc_box_zero_backward.argtypes = [_f32p, _f32p] + [C.c_int] * 5
+        L.orc_avgpool_stride.argtypes = [_f32p, _f32p] + [C.c_int] * 5
+        L.orc_mindssc.argtypes = [_f32p] + [C.c_int] * 5 + [_f32p, C.POINTER(C.c_float)]
+        L.orc_correlate.argtypes = [_f32p, _f32p] + [C.c_int] * 5 + [_f32p, _i64p]
+        L.orc_coupled_convex.argtypes = [_f32p, _i64p, _f32p] + [C.c_int] * 4 + [_f32p]
+        L.orc_grid_sample.argtypes = [_f32p] + [C.c_int] * 4 + [_f32p] + [C.c_int] * 3 + [_f32p]
+        L.orc_inverse_consistency.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [_f32p, _f32p]
+        L.orc_resize_trilinear.argtypes = [_f32p] + [C.c_int] * 4 + [_f32p] + [C.c_int] * 3
+        L.orc_adam_run.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [_f32p, _f32p, _f32p, C.c_float, C.c_int,
+                                                                   C.c_int, C.c_float, _f32p, C.c_void_p, C.c_void_p]
+        L.orc_label_features.argtypes = [_f32p, _f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_label_features.restype = C.c_int
+        L.orc_mind_tables.argtypes = [_i32p, _i32p, _i32p]
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def num_threads() -> int:
+    return lib().orc_num_threads()
+
+
+def set_num_threads(n: int) -> None:
+    lib().orc_set_num_threads(int(n))
+
+
+def expf(x):
+    x = _f(x); out = np.empty_like(x); lib().orc_expf_array(x.reshape(-1), out.reshape(-1), x.size); return out
+
+
+def linspace_pm1(S):
+    out = np.empty(S, np.float32); lib().orc_linspace_pm1(S, out); return out
+
+
+def affine_base(S):
+    out = np.empty(S, np.float32); lib().orc_affine_base(S, out); return out
+
+
+def disp_mesh(hw):
+    """(3, n^3) search mesh, convex_adam_MIND.py:127."""
+    n = 2 * hw + 1
+    out = np.empty((3, n ** 3), np.float32); lib().orc_disp_mesh(hw, out.reshape(-1)); return out
+
+
+def box_zero(x, k=3):
+    x = _f(x); c, h, w, d = x.shape
+    out = np.empty_like(x); lib().orc_box_zero(x.reshape(-1), out.reshape(-1), c, h, w, d, k); return out
+
+
+def box_zero_backward(x, k=3):
+    x = _f(x); c, h, w, d = x.shape
+    out = np.empty_like(x); lib().orc_box_zero_backward(x.reshape(-1), out.reshape(-1), c, h, w, d, k); return out
+
+
+def avgpool_stride(x, g):
+    x = _f(x); c, h, w, d = x.shape
+    out = np.empty((c, h // g, w // g, d // g), np.float32)
+    lib().orc_avgpool_stride(x.reshape(-1), out.reshape(-1), c, h, w, d, g); return out
+
+
+def mindssc(img, radius=2, dilation=2, return_mean=False):
+    """img (H,W,D) -> (12,H,W,D); convex_adam_utils.py:24-68."""
+    img = _f(img); h, w, d = img.shape
+    out = np.empty((12, h, w, d), np.float32); gm = C.c_float(0)
+    lib().orc_mindssc(img.reshape(-1), h, w, d, radius, dilation, out.reshape(-1), C.byref(gm))
+    return (out, gm.value) if return_mean else out
+
+
+def correlate(fix, mov, disp_hw):
+    """fix/mov (C,h,w,d) -> ssd (n^3,h,w,d), argmin (h,w,d) int64; convex_adam_utils.py:72-89."""
+    fix = _f(fix); mov = _f(mov); c, h, w, d = fix.shape; n = 2 * disp_hw + 1
+    ssd = np.empty((n ** 3, h, w, d), np.float32); am = np.empty((h, w, d), np.int64)
+    lib().orc_correlate(fix.reshape(-1), mov.reshape(-1), c, h, w, d, disp_hw, ssd.reshape(-1), am.reshape(-1))
+    return ssd, am
+
+
+def coupled_convex(ssd, argmin, mesh, disp_hw):
+    """-> (3,h,w,d); convex_adam_utils.py:93-109."""
+    ssd = _f(ssd); _, h, w, d = ssd.shape
+    out = np.empty((3, h, w, d), np.float32)
+    lib().orc_coupled_convex(ssd.reshape(-1), np.ascontiguousarray(argmin, np.int64).reshape(-1), _f(mesh).reshape(-1),
+                             h, w, d, disp_hw, out.reshape(-1))
+    return out
+
+
+def grid_sample(vol, grid):
+    """vol (C,h,w,d), grid (ho,wo,do,3) normalised (x,y,z) -> (C,ho,wo,do)."""
+    vol = _f(vol); grid = _f(grid); c, h, w, d = vol.shape; ho, wo, do_, _ = grid.shape
+    out = np.empty((c, ho, wo, do_), np.float32)
+    lib().orc_grid_sample(vol.reshape(-1), c, h, w, d, grid.reshape(-1), ho, wo, do_, out.reshape(-1)); return out
+
+
+def inverse_consistency(f1, f2, iters=20):
+    f1 = _f(f1); f2 = _f(f2); _, h, w, d = f1.shape
+    o1 = np.empty_like(f1); o2 = np.empty_like(f2)
+    lib().orc_inverse_consistency(f1.reshape(-1), f2.reshape(-1), h, w, d, iters, o1.reshape(-1), o2.reshape(-1))
+    return o1, o2
+
+
+def resize_trilinear(x, size):
+    x = _f(x); c, h, w, d = x.shape; H, W, D = size
+    out = np.empty((c, H, W, D), np.float32)
+    lib().orc_resize_trilinear(x.reshape(-1), c, h, w, d, out.reshape(-1), H, W, D); return out
+
+
+def adam_run(F2, M2, P, lambda_weight, niter, m=None, v=None, step0=0, cost_scale=12.0, want_grad=False):
+    """Runs `niter` Adam iterations in place on copies; returns dict(P, m, v, U, G, loss)."""
+    F2 = _f(F2); M2 = _f(M2); c, h, w, d = F2.shape
+    P = _f(P).copy(); m = np.zeros_like(P) if m is None else _f(m).copy(); v = np.zeros_like(P) if v is None else _f(v).copy()
+    U = np.zeros_like(P); G = np.zeros_like(P) if want_grad else None; loss = np.zeros(max(niter, 1), np.float32)
+    lib().orc_adam_run(F2.reshape(-1), M2.reshape(-1), c, h, w, d, P.reshape(-1), m.reshape(-1), v.reshape(-1),
+                       float(lambda_weight), int(niter), int(step0), float(cost_scale), U.reshape(-1),
+                       G.ctypes.data_as(C.c_void_p) if G is not None else None, loss.ctypes.data_as(C.c_void_p))
+    return dict(P=P, m=m, v=v, U=U, G=G, loss=loss[:niter])
+
+
+def label_features(lab_fix, lab_mov, mult=10.0):
+    lf = _f(lab_fix).reshape(-1); lm = _f(lab_mov).reshape(-1); V = lf.size
+    mx = int(max(lf.max(), lm.max()))
+    Cn = lib().orc_label_features(lf, lm, V, mx, mult, None, None, None)
+    ff = np.empty((Cn,) + tuple(np.shape(lab_fix)), np.float32); fm = np.empty_like(ff); pres = np.empty(Cn, np.int32)
+    lib().orc_label_features(lf, lm, V, mx, mult, ff.ctypes.data_as(C.c_void_p), fm.ctypes.data_as(C.c_void_p),
+                             pres.ctypes.data_as(C.c_void_p))
+    return ff, fm, pres
+
+
+# ---- whole pipeline (convex_adam_MIND.py:64-202), composed from the operators above -------------
+def convex_adam_pipeline(img_fixed, img_moving, mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6, disp_hw=4,
+                         selected_niter=80, selected_smooth=0, grid_sp_adam=2, ic=True, features=None,
+                         return_stages=False):
+    """float32 restatement of convex_adam_pt(); returns (H,W,D,3) float64 like the reference."""
+    st = {}
+    if features is None:
+        img_fixed = _f(img_fixed); img_moving = _f(img_moving)
+        ffix = mindssc(img_fixed, mind_r, mind_d); fmov = mindssc(img_moving, mind_r, mind_d)
+    else:
+        ffix, fmov = _f(features[0]), _f(features[1])
+    H, W, D = ffix.shape[1:]
+    fs = avgpool_stride(ffix, grid_sp); ms = avgpool_stride(fmov, grid_sp)
+    h, w, d = fs.shape[1:]
+    mesh = disp_mesh(disp_hw)
+    ssd, am = correlate(fs, ms, disp_hw)
+    soft = coupled_convex(ssd, am, mesh, disp_hw)
+    st.update(fs=fs, ms=ms, argmin=am, soft=soft)
+    if ic:
+        scale = (np.array([h - 1, w - 1, d - 1], np.float32) / np.float32(2)).reshape(3, 1, 1, 1)
+        ssd_, am_ = correlate(ms, fs, disp_hw)
+        soft_ = coupled_convex(ssd_, am_, mesh, disp_hw)
+        i1, _ = inverse_consistency((soft / scale)[::-1], (soft_ / scale)[::-1], 15)
+        disp_hr = resize_trilinear((i1[::-1] * scale) * np.float32(grid_sp), (H, W, D))
+        st.update(soft_=soft_, ice=i1)
+    else:
+        disp_hr = soft
+    st.update(disp_hr0=disp_hr)
+    if lambda_weight > 0:
+        g = grid_sp_adam
+        F2 = avgpool_stride(ffix, g); M2 = avgpool_stride(fmov, g)
+        disp_lr = resize_trilinear(disp_hr, (H // g, W // g, D // g))
+        P0 = disp_lr / np.float32(g)
+        r = adam_run(F2, M2, P0, lambda_weight, selected_niter)
+        st.update(P0=P0, U=r["U"])
+        disp_hr = resize_trilinear(r["U"] * np.float32(g), (H, W, D))
+        if selected_smooth > 0:
+            for _ in range(3):
+                disp_hr = box_zero(disp_hr, selected_smooth)
+    out = np.stack([disp_hr[0], disp_hr[1], disp_hr[2]], 3).astype(np.float64)
+    return (out, st) if return_stages else out

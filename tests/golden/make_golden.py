@@ -1,0 +1,157 @@
+"""Regenerates tests/golden/*.npz by importing and running the upstream reference (CPU, float32).
+
+Run ONLY in the build container (needs /root/reference):   python tests/golden/make_golden.py
+The fixtures are data: seeded inputs (or the seeds to rebuild them) plus the reference's outputs.
+No reference source text is stored.  torch 2.10.0 CPU (AVX512, MKL VML) produced the committed files.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _ref_import import import_reference  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from convexadam_amd.phantom import phantom, smooth_warp  # noqa: E402  (shared synthetic-data recipe)
+
+U, M = import_reference()
+CPU = torch.device("cpu")
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print("wrote %-28s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def main():
+    torch.manual_seed(1234)
+    torch.set_num_threads(8)
+
+    # ---- A: MINDSSC (convex_adam_utils.py:24-68) -------------------------------------------------
+    img = phantom((20, 18, 23), 3, 30)            # V = 8280, V mod 32 = 24 -> exercises the tail rule
+    save("mind", img=img.numpy(),
+         mind_r1d2=U.MINDSSC(img[None, None], 1, 2, device="cpu")[0].numpy(),
+         mind_r2d2=U.MINDSSC(img[None, None], 2, 2, device="cpu")[0].numpy(),
+         mind_r1d1=U.MINDSSC(img[None, None], 1, 1, device="cpu")[0].numpy())
+
+    # ---- B: pooling + correlate + coupled_convex + IC + resize on one small pair -----------------
+    H, W, D, gs, hw = 36, 30, 42, 3, 2
+    fix = phantom((H, W, D), 2, 20)
+    mov = torch.roll(phantom((H, W, D), 2, 21), (2, -1, 3), (0, 1, 2))
+    ff = U.MINDSSC(fix[None, None], 1, 2, device="cpu")
+    fm = U.MINDSSC(mov[None, None], 1, 2, device="cpu")
+    fs = F.avg_pool3d(ff, gs, stride=gs)
+    ms = F.avg_pool3d(fm, gs, stride=gs)
+    ssd, am = U.correlate(fs, ms, hw, gs, (H, W, D), 12)
+    n = 2 * hw + 1
+    mesh = F.affine_grid(hw * torch.eye(3, 4).unsqueeze(0), (1, 1, n, n, n), align_corners=True).permute(0, 4, 1, 2, 3).reshape(3, -1, 1)
+    soft = U.coupled_convex(ssd, am, mesh, gs, (H, W, D))
+    ssd_, am_ = U.correlate(ms, fs, hw, gs, (H, W, D), 12)
+    soft_ = U.coupled_convex(ssd_, am_, mesh, gs, (H, W, D))
+    h, w, d = H // gs, W // gs, D // gs
+    scale = torch.tensor([h - 1, w - 1, d - 1]).view(1, 3, 1, 1, 1).float() / 2
+    in1, in2 = (soft / scale).flip(1), (soft_ / scale).flip(1)
+    i1, i2 = U.inverse_consistency(in1, in2, iter=15)
+    hr = F.interpolate(i1.flip(1) * scale * gs, size=(H, W, D), mode="trilinear", align_corners=False)
+    lr = F.interpolate(hr, size=(H // 2, W // 2, D // 2), mode="trilinear", align_corners=False)
+    save("convex", shape=np.array([H, W, D, gs, hw]), feat_fix=fs[0].numpy(), feat_mov=ms[0].numpy(), ssd=ssd.numpy(), argmin=am.numpy(),
+         mesh=mesh[:, :, 0].numpy(), soft=soft[0].numpy(), ssd_rev_sum=np.float64(ssd_.double().sum().item()),
+         argmin_rev=am_.numpy(), soft_rev=soft_[0].numpy(), ic_in1=in1[0].numpy(), ic_in2=in2[0].numpy(),
+         ic_out1=i1[0].numpy(), ic_out2=i2[0].numpy(), disp_hr=hr[0].numpy(), disp_lr=lr[0].numpy())
+
+    # avg_pool3d(g, stride=g) with remainders (convex_adam_MIND.py:118-119,149-150)
+    x = torch.randn(1, 5, 13, 14, 15)
+    save("pool", x=x[0].numpy(), g2=F.avg_pool3d(x, 2, stride=2)[0].numpy(), g3=F.avg_pool3d(x, 3, stride=3)[0].numpy(),
+         g6=F.avg_pool3d(x, 6, stride=6)[0].numpy(), box3=F.avg_pool3d(x, 3, stride=1, padding=1)[0].numpy(),
+         box5=F.avg_pool3d(x, 5, stride=1, padding=2)[0].numpy())
+
+    # multi-channel correlate with C >= 16 (cascade sum) and ragged inner size (tail rule)
+    f20 = torch.rand(1, 20, 7, 5, 9)
+    m20 = torch.rand(1, 20, 7, 5, 9)
+    s20, a20 = U.correlate(f20, m20, 1, 1, (7, 5, 9), 20)
+    save("correlate_c20", fix=f20[0].numpy(), mov=m20[0].numpy(), ssd=s20.numpy(), argmin=a20.numpy())
+
+    # ---- C: Adam instance optimisation (convex_adam_MIND.py:147-182), inline restatement of the
+    #         reference loop body is NOT stored; we run the reference pipeline pieces through torch.
+    g, lam = 2, 1.25
+    pf = F.avg_pool3d(ff, g, stride=g)
+    pm = F.avg_pool3d(fm, g, stride=g)
+    out = {}
+    for niter in (1, 2, 5, 20):
+        net = nn.Sequential(nn.Conv3d(3, 1, (H // g, W // g, D // g), bias=False))
+        net[0].weight.data[:] = lr.float().cpu().data / g
+        P0 = net[0].weight.data[0].numpy().copy()
+        opt = torch.optim.Adam(net.parameters(), lr=1)
+        grid0 = F.affine_grid(torch.eye(3, 4).unsqueeze(0), (1, 1, H // g, W // g, D // g), align_corners=False)
+        for it in range(niter):
+            opt.zero_grad()
+            ds = F.avg_pool3d(F.avg_pool3d(F.avg_pool3d(net[0].weight, 3, stride=1, padding=1), 3, stride=1, padding=1), 3, stride=1, padding=1).permute(0, 2, 3, 4, 1)
+            reg = lam * ((ds[0, :, 1:, :] - ds[0, :, :-1, :]) ** 2).mean() + lam * ((ds[0, 1:, :, :] - ds[0, :-1, :, :]) ** 2).mean() + lam * ((ds[0, :, :, 1:] - ds[0, :, :, :-1]) ** 2).mean()
+            sc = torch.tensor([(H // g - 1) / 2, (W // g - 1) / 2, (D // g - 1) / 2]).unsqueeze(0)
+            gd = grid0.view(-1, 3).float() + ((ds.view(-1, 3)) / sc).flip(1).float()
+            pms = F.grid_sample(pm.float(), gd.view(1, H // g, W // g, D // g, 3), align_corners=False, mode="bilinear")
+            loss = ((pms - pf).pow(2).mean(1) * 12).mean()
+            (loss + reg).backward()
+            grad = net[0].weight.grad[0].numpy().copy()
+            opt.step()
+        out["U_%d" % niter] = ds.detach().permute(0, 4, 1, 2, 3)[0].numpy().copy()
+        out["G_%d" % niter] = grad
+        out["P_%d" % niter] = net[0].weight.data[0].numpy().copy()
+    save("adam", F2=pf[0].numpy(), M2=pm[0].numpy(), P0=P0, lam=np.float32(lam), **out)
+
+    # ---- D: whole pipeline convex_adam_pt (convex_adam_MIND.py:64-202) ---------------------------
+    H, W, D = 32, 28, 36
+    fix = phantom((H, W, D), 1, 10)
+    u = smooth_warp((H, W, D), 5, amp=2.0)
+    mov = F.grid_sample(phantom((H, W, D), 1, 11)[None, None], u, mode="bilinear", padding_mode="border", align_corners=False)[0, 0]
+    pipe = dict(fix=fix.numpy(), mov=mov.numpy())
+    kw = dict(mind_r=1, mind_d=2, grid_sp=4, disp_hw=3, grid_sp_adam=2, dtype=torch.float32, device=CPU)
+    pipe["convex_only_ic"] = M.convex_adam_pt(fix, mov, lambda_weight=0, ic=True, **kw).astype(np.float32)
+    pipe["convex_only_noic"] = M.convex_adam_pt(fix, mov, lambda_weight=0, ic=False, **kw).astype(np.float32)
+    for niter in (1, 5, 20):
+        pipe["adam_%d" % niter] = M.convex_adam_pt(fix, mov, lambda_weight=1.25, selected_niter=niter, ic=True, **kw).astype(np.float32)
+    pipe["adam_5_smooth3"] = M.convex_adam_pt(fix, mov, lambda_weight=1.25, selected_niter=5, selected_smooth=3, ic=True, **kw).astype(np.float32)
+    pipe["adam_5_noic"] = M.convex_adam_pt(fix, mov, lambda_weight=1.25, selected_niter=5, ic=False, **kw).astype(np.float32)
+    save("pipeline", **pipe)
+
+    # ---- E: known answers of SURVEY appendix A (64^3 translated pair, convex only) ---------------
+    fix = phantom((64, 64, 64), 2, 20)
+    ka = {}
+    for name, sh, gs_ in (("roll_4_0_m8_gs4", (4, 0, -8), 4), ("roll_6_m6_0_gs6", (6, -6, 0), 6)):
+        mov = torch.roll(fix, sh, (0, 1, 2))
+        dsp = M.convex_adam_pt(fix, mov, lambda_weight=0, grid_sp=gs_, disp_hw=4, dtype=torch.float32, device=CPU)
+        ka[name] = dsp[16:48, 16:48, 16:48].mean((0, 1, 2))
+        ka[name + "_sub"] = dsp[::4, ::4, ::4].astype(np.float32)
+    save("translation64", **ka)
+
+    # ---- F: nnUNet label features (convex_adam_nnUNet.py:19-38), CUDA/half calls neutralised -----
+    import importlib
+    nib = sys.modules["nibabel"]
+    _cuda, _half = torch.Tensor.cuda, torch.Tensor.half
+    torch.Tensor.cuda = lambda s, *a, **k: s
+    torch.Tensor.half = lambda s, *a, **k: s.float()
+    try:
+        N = importlib.import_module("convexAdam.convex_adam_nnUNet")
+        gl = torch.Generator().manual_seed(7)
+        lab = torch.argmax(F.interpolate(torch.randn(1, 9, 5, 5, 5, generator=gl), size=(24, 20, 28), mode="trilinear"), 1)[0].float()
+        lab[lab == 4] = 6   # leave a gap in the label set
+        labm = torch.roll(lab, (2, -1, 1), (0, 1, 2))
+        labm[:3] = 10       # label only present in moving
+        lab[0, 0, 0] = 11   # the reference needs equal max labels in both maps (bincount / one_hot sizes)
+        labm[-1, -1, -1] = 11
+        f_fix, f_mov = N.extract_features(lab, labm)
+        save("labels", lab_fix=lab.numpy().astype(np.int16), lab_mov=labm.numpy().astype(np.int16),
+             feat_fix_sum=f_fix[0].double().sum((1, 2, 3)).numpy(), feat_mov_sum=f_mov[0].double().sum((1, 2, 3)).numpy(),
+             weights=f_fix[0].amax((1, 2, 3)).numpy(), feat_fix_pool2=F.avg_pool3d(f_fix, 2, stride=2)[0].numpy())
+    finally:
+        torch.Tensor.cuda, torch.Tensor.half = _cuda, _half
+
+
+if __name__ == "__main__":
+    main()
