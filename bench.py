@@ -1,0 +1,149 @@
+#!/usr/bin/env python
+"""bench.py -- pairs/s of the convexAdam hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full registration of a 160x192x224 pair (BASELINE.json configs[1]: MIND-SSC r=1 d=2,
+grid_sp 6, disp_hw 6, inverse consistency, lambda 1.25, grid_sp_adam 2, 80 Adam iterations, float32)
+through the C ABI (cvx_register_pair_f32), inputs already resident in HBM.  With N GPUs every rank
+registers its own pairs (no collective on the data path); the timed region is bracketed by
+barrier + synchronize and the slowest rank's time is used: value = N*K / T (weak scaling).
+
+Extra objects on the JSON line:
+  roofline     the SSD correlation stage (k_corr_prep/raw/tail/box of one direction): algorithmic bytes
+               (n^3*v*4 written + 2*C*v*4 read = 273.5 MB) / its mean duration measured with HIP events on the
+               launch stream inside the timed region, against 8 TB/s HBM3E peak.
+  cpu_baseline the CPU oracle (kind "port", OpenMP over all host cores) timed on one full pair of the same
+               workload, rank 0 / N=1 only.  It is the checker, timed as a baseline -- never the product.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SHAPE = (160, 192, 224)
+CFG = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6, disp_hw=6, selected_niter=80, selected_smooth=0,
+           grid_sp_adam=2, ic=True)
+HBM_PEAK_GBS = 8000.0
+
+
+def make_pair(device, idx):
+    """multi-octave phantom, moving = other noise realisation warped by a smooth field."""
+    import torch.nn.functional as F
+    from convexadam_amd.phantom import phantom, smooth_warp
+    fix = phantom(SHAPE, 1 + idx, 10 + idx)
+    grid = smooth_warp(SHAPE, 5 + idx, amp=4.0)
+    mov = F.grid_sample(phantom(SHAPE, 1 + idx, 110 + idx)[None, None], grid, mode="bilinear", padding_mode="border",
+                        align_corners=False)[0, 0]
+    return fix.to(device).contiguous(), mov.to(device).contiguous()
+
+
+def cpu_baseline(fix, mov):
+    """Times the C oracle (oracle/, the parity checker) on the host cores for one full pair."""
+    from oracle import oracle
+    oracle.build()
+    cores = oracle.num_threads()
+    t0 = time.time()
+    oracle.convex_adam_pipeline(fix, mov, **CFG)
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port", seconds_per_pair=dt,
+                sample="1 full 160x192x224 pair (MIND r1 d2, gs6, hw6, ic, 80 Adam its) with oracle/cvx_oracle.c, "
+                       "OpenMP over %d threads; reference PyTorch-CPU figure from BASELINE.md: 77.4 s/pair on 8 cores" % cores)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from convexadam_amd.convex_adam_MIND import last_profile, register_pair_device
+
+    fix, mov = make_pair(dev, rank)
+    out = torch.empty((3,) + SHAPE, dtype=torch.float32, device=dev)
+
+    for _ in range(a.warmup):
+        register_pair_device(fix, mov, out=out, **CFG)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    stage_ms = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        register_pair_device(fix, mov, out=out, profile=True, **CFG)
+        # reading the stage events waits for this pair only (the next one would start right after anyway)
+        for name, ms in last_profile():
+            stage_ms.setdefault(name, []).append(ms)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n = world
+        h, w, d = (s // CFG["grid_sp"] for s in SHAPE)
+        K = (2 * CFG["disp_hw"] + 1) ** 3
+        v = h * w * d
+        alg_bytes = K * v * 4 + 2 * 12 * v * 4
+        corr = stage_ms.get("correlate", []) + stage_ms.get("correlate_rev", [])
+        corr_ms = sum(corr) / max(len(corr), 1)
+        achieved = alg_bytes / (corr_ms * 1e-3) / 1e9 if corr_ms > 0 else 0.0
+        res = {
+            "metric": "volume-pairs/sec (160x192x224 MIND convex+Adam(80it))",
+            "value": n * a.steps / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": n,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 160x192x224 pair, MIND-SSC r1 d2, grid_sp 6, disp_hw 6, ic, "
+                                   "lambda 1.25, grid_sp_adam 2, 80 Adam iterations, float32",
+                       "pairs_per_gpu_per_step": 1, "parallelism": "one pair per GPU, no collectives"},
+            "roofline": {"kernel": "correlate stage = k_corr_prep + k_corr_raw + k_corr_tail + k_corr_box (one direction)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
+                         "avg_launch_ms": corr_ms},
+            "stages_ms": {k: sum(vs) / len(vs) for k, vs in stage_ms.items()},
+        }
+        if n == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(fix.cpu().numpy(), mov.cpu().numpy())
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

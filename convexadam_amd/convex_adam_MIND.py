@@ -1,0 +1,236 @@
+"""Pipeline-level mirror of the reference's `convexAdam.convex_adam_MIND`
+(src/convexAdam/convex_adam_MIND.py): extract_features (:22-61), convex_adam_pt (:64-202),
+convex_adam (:205-248).  Same keyword arguments, same output: np.ndarray (H,W,D,3) float64,
+channel a = displacement along array axis a in voxels, fixed(x) ~ moving(x + u(x)).
+
+The whole pair runs inside one C-ABI call (cvx_register_pair_f32): MIND-SSC -> pooling ->
+correlation -> coupled convex (-> reverse direction -> inverse consistency) -> Adam instance
+optimisation -> up-sampling, all on the current HIP stream, with no host round trips (the
+reference's `.cpu()` hop at :156 and `.item()` syncs at convex_adam_utils.py:61 do not exist here).
+"""
+import ctypes as C
+import os
+import time
+import warnings
+from pathlib import Path
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PairParams, check, f32c, lib, ptr, stream_ptr, workspace
+from .convex_adam_utils import MINDSSC, validate_image
+
+_DEFAULT_DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def _require_hip(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("convexadam_amd runs only on a HIP device (torch device 'cuda'); got %s. "
+                           "There is no CPU fallback -- use the upstream reference for CPU runs." % device)
+    return device
+
+
+def _load_mask(path):
+    import nibabel as nib   # same dependency as the reference (:94-95)
+    return torch.from_numpy(nib.load(path).get_fdata()).float()
+
+
+def _replicate_fill(img, mask, device):
+    """Masked 'replicate fill' of convex_adam_MIND.py:40-51: outside the eroded mask the image takes the
+    value of the nearest in-mask voxel (found at half resolution with scipy's EDT on the host, exactly
+    like the reference), tri-linearly up-sampled; inside it keeps its own values."""
+    import torch.nn.functional as F
+    from scipy.ndimage import distance_transform_edt as edt
+    H, W, D = img.shape[-3:]
+    m = F.avg_pool3d(F.pad(mask.view(1, 1, H, W, D).to(device), (1,) * 6, mode="replicate"), 3, stride=1)
+    m = (m > 0.9).float()
+    _, idx = edt((m[0, 0, ::2, ::2, ::2] == 0).squeeze().cpu().numpy(), return_indices=True)
+    idx = torch.from_numpy(idx).to(device)
+    lin = idx[0] * D // 2 * W // 2 + idx[1] * D // 2 + idx[2]          # same index expression as :45
+    half = img[::2, ::2, ::2].to(device).reshape(-1)[lin]
+    filled = F.interpolate(half.unsqueeze(0).unsqueeze(0), scale_factor=2, mode="trilinear")
+    sel = m.view(-1) != 0
+    filled.view(-1)[sel] = img.to(device).reshape(-1)[sel]
+    return filled
+
+
+def extract_features(img_fixed: torch.Tensor, img_moving: torch.Tensor, mind_r: int, mind_d: int, use_mask: bool,
+                     mask_fixed: torch.Tensor, mask_moving: torch.Tensor, device: torch.device = torch.device("cuda"),
+                     dtype: torch.dtype = torch.float16):
+    """MIND-SSC features of both images, (1,12,H,W,D) each in `dtype`.  (convex_adam_MIND.py:22-61)"""
+    device = _require_hip(device)
+    if use_mask:
+        fixed_r = _replicate_fill(img_fixed, mask_fixed, device)
+        moving_r = _replicate_fill(img_moving, mask_moving, device)
+    else:
+        fixed_r = img_fixed.unsqueeze(0).unsqueeze(0).to(device)
+        moving_r = img_moving.unsqueeze(0).unsqueeze(0).to(device)
+    features_fix = MINDSSC(fixed_r, mind_r, mind_d, device=device).to(dtype)
+    features_mov = MINDSSC(moving_r, mind_r, mind_d, device=device).to(dtype)
+    return features_fix, features_mov
+
+
+def register_pair_device(img_fixed=None, img_moving=None, feat_fixed=None, feat_moving=None, mind_r=1, mind_d=2,
+                         lambda_weight=1.25, grid_sp=6, disp_hw=4, selected_niter=80, selected_smooth=0, grid_sp_adam=2,
+                         ic=True, cost_scale=12.0, out=None, profile=False):
+    """One registration, device in / device out: returns the displacement field as a (3,H',W',D') float32
+    device tensor (full resolution, or the coarse grid for the reference's ic=False & lambda_weight<=0 case).
+    Either two (H,W,D) images (MIND-SSC features are computed) or two (C,H,W,D) feature volumes."""
+    if feat_fixed is not None:
+        ff, fm = f32c(feat_fixed), f32c(feat_moving)
+        n_feat = int(ff.shape[0])
+        H, W, D = [int(s) for s in ff.shape[1:]]
+        dev = ff.device
+        a = b = None
+    else:
+        a, b = f32c(img_fixed), f32c(img_moving)
+        if a.dim() != 3 or a.shape != b.shape:
+            raise ValueError("register_pair_device expects two (H,W,D) volumes of equal shape")
+        H, W, D = [int(s) for s in a.shape]
+        dev = a.device
+        ff = fm = None
+        n_feat = 0
+    _require_hip(dev)
+    if lambda_weight > 0 and selected_niter < 1:
+        # the reference reads `disp_sample` after a loop that never ran (:181)
+        raise UnboundLocalError("local variable 'disp_sample' referenced before assignment "
+                                "(selected_niter=0 with lambda_weight>0, convex_adam_MIND.py:181)")
+    p = PairParams(H, W, D, int(mind_r), int(mind_d), float(lambda_weight), int(grid_sp), int(disp_hw), int(selected_niter),
+                   int(selected_smooth), int(grid_sp_adam), 1 if ic else 0, n_feat, float(cost_scale))
+    L = lib()
+    nws = L.cvx_register_pair_workspace_bytes(C.byref(p))
+    if nws == 0:
+        raise _lib.CvxError(_lib.CVX_ERR_INVALID_ARG, L.cvx_last_error().decode())
+    full = ic or lambda_weight > 0
+    oshape = (3, H, W, D) if full else (3, H // grid_sp, W // grid_sp, D // grid_sp)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=dev)
+    ws = workspace(nws, dev)
+    dims = (C.c_int * 3)()
+    with torch.cuda.device(dev):
+        L.cvx_set_profiling(1 if profile else 0)
+        check(L.cvx_register_pair_f32(ptr(a), ptr(b), ptr(ff), ptr(fm), C.byref(p), ptr(out), C.cast(dims, C.c_void_p), ptr(ws), nws,
+                                      stream_ptr(dev)))
+    assert tuple(dims) == tuple(oshape[1:]), (tuple(dims), oshape)
+    return out
+
+
+def last_profile():
+    """[(stage, milliseconds)] of the last profiled register_pair_device call (hipEvent timing)."""
+    names = (C.c_char_p * 32)()
+    ms = (C.c_float * 32)()
+    n = lib().cvx_last_pair_profile(C.cast(names, C.c_void_p), C.cast(ms, C.c_void_p), 32)
+    return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+
+def convex_adam_pt(
+    img_fixed,
+    img_moving,
+    mind_r: int = 1,
+    mind_d: int = 2,
+    lambda_weight: float = 1.25,
+    grid_sp: int = 6,
+    disp_hw: int = 4,
+    selected_niter: int = 80,
+    selected_smooth: int = 0,
+    grid_sp_adam: int = 2,
+    ic: bool = True,
+    use_mask: bool = False,
+    path_fixed_mask: Optional[Union[Path, str]] = None,
+    path_moving_mask: Optional[Union[Path, str]] = None,
+    dtype: torch.dtype = torch.float16,
+    verbose: bool = False,
+    device: torch.device = _DEFAULT_DEVICE,
+) -> np.ndarray:
+    """Coupled convex optimisation with Adam instance optimisation.  (convex_adam_MIND.py:64-202)
+
+    Computes in float32 on the HIP device whatever `dtype` says; `dtype` only quantises the returned
+    field the way the reference's `.cpu().to(dtype)` does (:198-200) -- pass torch.float32 for
+    full-precision output.  Returns np.ndarray (H,W,D,3) float64."""
+    device = _require_hip(device)
+    img_fixed = validate_image(img_fixed).float()
+    img_moving = validate_image(img_moving).float()
+    if selected_smooth > 0 and selected_smooth % 2 == 0:
+        # the reference prints this and then overwrites its own fix (:185-189), growing the volume;
+        # an even kernel has no sensible meaning here, so refuse instead of silently changing shape
+        raise ValueError("selected_smooth should be an odd number")
+    H, W, D = img_fixed.shape
+    t0 = time.time()
+    if use_mask:
+        mask_fixed = _load_mask(path_fixed_mask)
+        mask_moving = _load_mask(path_moving_mask)
+        ff, fm = extract_features(img_fixed, img_moving, mind_r, mind_d, True, mask_fixed, mask_moving, device, torch.float32)
+        disp = register_pair_device(feat_fixed=ff[0], feat_moving=fm[0], lambda_weight=lambda_weight, grid_sp=grid_sp,
+                                    disp_hw=disp_hw, selected_niter=selected_niter, selected_smooth=selected_smooth,
+                                    grid_sp_adam=grid_sp_adam, ic=ic)
+    else:
+        disp = register_pair_device(img_fixed.to(device), img_moving.to(device), mind_r=mind_r, mind_d=mind_d,
+                                    lambda_weight=lambda_weight, grid_sp=grid_sp, disp_hw=disp_hw,
+                                    selected_niter=selected_niter, selected_smooth=selected_smooth,
+                                    grid_sp_adam=grid_sp_adam, ic=ic)
+    field = disp.permute(1, 2, 3, 0)                      # (H,W,D,3): np.stack((x,y,z),3) of :198-201
+    if dtype != torch.float32:
+        field = field.to(dtype)
+    displacements = field.cpu().numpy().astype(float)
+    if verbose:
+        print(f'case time: {time.time() - t0}')
+    return displacements
+
+
+def convex_adam(
+    path_img_fixed: Union[Path, str],
+    path_img_moving: Union[Path, str],
+    mind_r: int = 1,
+    mind_d: int = 2,
+    lambda_weight: float = 1.25,
+    grid_sp: int = 6,
+    disp_hw: int = 4,
+    selected_niter: int = 80,
+    selected_smooth: int = 0,
+    grid_sp_adam: int = 2,
+    ic: bool = True,
+    use_mask: bool = False,
+    path_fixed_mask: Optional[Union[Path, str]] = None,
+    path_moving_mask: Optional[Union[Path, str]] = None,
+    result_path: Union[Path, str] = './',
+    verbose: bool = False,
+) -> None:
+    """File wrapper: reads two NIfTI images, writes `disp.nii.gz` with the fixed image's affine.
+    (convex_adam_MIND.py:205-248; needs nibabel like the reference)"""
+    import nibabel as nib
+    img_fixed = torch.from_numpy(nib.load(path_img_fixed).get_fdata()).float()
+    img_moving = torch.from_numpy(nib.load(path_img_moving).get_fdata()).float()
+    displacements = convex_adam_pt(img_fixed=img_fixed, img_moving=img_moving, mind_r=mind_r, mind_d=mind_d,
+                                   lambda_weight=lambda_weight, grid_sp=grid_sp, disp_hw=disp_hw,
+                                   selected_niter=selected_niter, selected_smooth=selected_smooth,
+                                   grid_sp_adam=grid_sp_adam, ic=ic, use_mask=use_mask, path_fixed_mask=path_fixed_mask,
+                                   path_moving_mask=path_moving_mask, verbose=verbose)
+    affine = nib.load(path_img_fixed).affine
+    nib.save(nib.Nifti1Image(displacements, affine), os.path.join(result_path, 'disp.nii.gz'))
+
+
+if __name__ == "__main__":
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-f", "--path_img_fixed", type=str, required=True)
+    parser.add_argument("-m", '--path_img_moving', type=str, required=True)
+    parser.add_argument('--mind_r', type=int, default=1)
+    parser.add_argument('--mind_d', type=int, default=2)
+    parser.add_argument('--lambda_weight', type=float, default=1.25)
+    parser.add_argument('--grid_sp', type=int, default=6)
+    parser.add_argument('--disp_hw', type=int, default=4)
+    parser.add_argument('--selected_niter', type=int, default=80)
+    parser.add_argument('--selected_smooth', type=int, default=0)
+    parser.add_argument('--grid_sp_adam', type=int, default=2)
+    parser.add_argument('--ic', choices=('True', 'False'), default='True')
+    parser.add_argument('--use_mask', choices=('True', 'False'), default='False')
+    parser.add_argument('--path_mask_fixed', type=str, default=None)
+    parser.add_argument('--path_mask_moving', type=str, default=None)
+    parser.add_argument('--result_path', type=str, default='./')
+    a = parser.parse_args()
+    convex_adam(a.path_img_fixed, a.path_img_moving, a.mind_r, a.mind_d, a.lambda_weight, a.grid_sp, a.disp_hw,
+                a.selected_niter, a.selected_smooth, a.grid_sp_adam, a.ic == 'True', a.use_mask == 'True',
+                a.path_mask_fixed, a.path_mask_moving, a.result_path)

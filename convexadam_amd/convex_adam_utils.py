@@ -1,0 +1,240 @@
+"""Operator-level mirror of the reference's `convexAdam.convex_adam_utils` (src/convexAdam/
+convex_adam_utils.py) on top of libconvexadam_hip.so.
+
+Same names, argument meaning and return formats as the reference:
+    MINDSSC             convex_adam_utils.py:24-68
+    correlate           convex_adam_utils.py:72-89
+    coupled_convex      convex_adam_utils.py:93-109
+    inverse_consistency convex_adam_utils.py:114-129
+    combineDeformation3d convex_adam_utils.py:133-135
+    validate_image      convex_adam_utils.py:268-279
+Tensors must live on the HIP device (torch device type 'cuda'); the kernels compute in float32 and
+results are cast back to the dtype the reference would return.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, f32c, lib, ptr, require_device_tensor, stream_ptr, workspace
+
+
+# ---- table helpers (host, exact restatements of torch.linspace / affine_grid) ----------------------
+def affine_base(S: int) -> np.ndarray:
+    """Identity coordinate of F.affine_grid(eye, ..., align_corners=False) along an axis of size S."""
+    out = np.empty(int(S), np.float32)
+    lib().cvx_affine_base_host(int(S), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def disp_mesh(disp_hw: int) -> np.ndarray:
+    """(3, n^3) search mesh: what convex_adam_MIND.py:127 builds with affine_grid(align_corners=True)."""
+    n = 2 * int(disp_hw) + 1
+    out = np.empty((3, n ** 3), np.float32)
+    lib().cvx_disp_mesh_host(int(disp_hw), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def disp_mesh_t(disp_hw: int, device, dtype=torch.float32) -> torch.Tensor:
+    """(3, n^3, 1) tensor, the `disp_mesh_t` argument of coupled_convex()."""
+    return torch.from_numpy(disp_mesh(disp_hw)).to(device=device, dtype=dtype).unsqueeze(-1)
+
+
+def _base_tables(h, w, d, device):
+    return [torch.from_numpy(affine_base(s)).to(device) for s in (h, w, d)]
+
+
+# ---- reference operators ---------------------------------------------------------------------------
+def MINDSSC(img, radius=2, dilation=2, device='cuda'):
+    """MIND-SSC descriptor: img (1,1,H,W,D) -> (1,12,H,W,D) in img's dtype.  (convex_adam_utils.py:24-68)"""
+    img = require_device_tensor(img.to(device), "img")
+    if img.dim() != 5 or img.shape[0] != 1 or img.shape[1] != 1:
+        raise ValueError("MINDSSC expects a (1,1,H,W,D) tensor, got %s" % (tuple(img.shape),))
+    H, W, D = [int(s) for s in img.shape[2:]]
+    x = f32c(img)
+    out = torch.empty((1, 12, H, W, D), dtype=torch.float32, device=x.device)
+    nws = lib().cvx_mindssc_workspace_bytes(H, W, D, int(radius), int(dilation))
+    ws = workspace(nws, x.device)
+    with torch.cuda.device(x.device):
+        check(lib().cvx_mindssc_f32(ptr(x), H, W, D, int(radius), int(dilation), ptr(out), ptr(ws), nws, stream_ptr(x.device)))
+    return out if img.dtype == torch.float32 else out.to(img.dtype)
+
+
+def avg_pool(features, g):
+    """F.avg_pool3d(features, g, stride=g) for a (1,C,H,W,D) device tensor.  (convex_adam_MIND.py:118-119)"""
+    features = require_device_tensor(features, "features")
+    _, Cn, H, W, D = [int(s) for s in features.shape]
+    x = f32c(features)
+    out = torch.empty((1, Cn, H // g, W // g, D // g), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().cvx_avgpool_f32(ptr(x), Cn, H, W, D, int(g), ptr(out), stream_ptr(x.device)))
+    return out if features.dtype == torch.float32 else out.to(features.dtype)
+
+
+def correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch=12):
+    """SSD cost volume + argmin.  (convex_adam_utils.py:72-89)
+    mind_fix/mind_mov (1,C,H',W',D') -> ssd (n^3,H',W',D') in the feature dtype, argmin (H',W',D') int64."""
+    mind_fix = require_device_tensor(mind_fix, "mind_fix")
+    mind_mov = require_device_tensor(mind_mov, "mind_mov")
+    H, W, D = int(shape[0]), int(shape[1]), int(shape[2])
+    h, w, d = H // grid_sp, W // grid_sp, D // grid_sp
+    if tuple(mind_fix.shape) != (1, ch, h, w, d) or tuple(mind_mov.shape) != (1, ch, h, w, d):
+        raise ValueError("correlate: features %s / %s do not match (1,%d,%d,%d,%d)" %
+                         (tuple(mind_fix.shape), tuple(mind_mov.shape), ch, h, w, d))
+    n = 2 * int(disp_hw) + 1
+    f, m = f32c(mind_fix), f32c(mind_mov)
+    ssd = torch.empty((n ** 3, h, w, d), dtype=torch.float32, device=f.device)
+    am = torch.empty((h, w, d), dtype=torch.int64, device=f.device)
+    nws = lib().cvx_correlate_workspace_bytes(ch, h, w, d, int(disp_hw))
+    ws = workspace(nws, f.device)
+    with torch.cuda.device(f.device):
+        check(lib().cvx_correlate_f32(ptr(f), ptr(m), ch, h, w, d, int(disp_hw), ptr(ssd), ptr(am), ptr(ws), nws, stream_ptr(f.device)))
+    if mind_fix.dtype != torch.float32:
+        ssd = ssd.to(mind_fix.dtype)
+    return ssd, am
+
+
+def coupled_convex(ssd, ssd_argmin, disp_mesh_t, grid_sp, shape):
+    """Coupled convex regularisation -> (1,3,H',W',D') in coarse-voxel units.  (convex_adam_utils.py:93-109)"""
+    ssd = require_device_tensor(ssd, "ssd")
+    H, W, D = int(shape[0]), int(shape[1]), int(shape[2])
+    h, w, d = H // grid_sp, W // grid_sp, D // grid_sp
+    K = int(ssd.shape[0])
+    n = int(round(K ** (1.0 / 3.0)))
+    if n ** 3 != K or tuple(ssd.shape[1:]) != (h, w, d):
+        raise ValueError("coupled_convex: ssd shape %s does not match (n^3,%d,%d,%d)" % (tuple(ssd.shape), h, w, d))
+    s = f32c(ssd)
+    am = ssd_argmin.to(device=s.device, dtype=torch.int64).contiguous()
+    mesh = f32c(disp_mesh_t.to(s.device)).reshape(3, K)
+    out = torch.empty((1, 3, h, w, d), dtype=torch.float32, device=s.device)
+    nws = lib().cvx_coupled_convex_workspace_bytes(h, w, d, (n - 1) // 2)
+    ws = workspace(nws, s.device)
+    with torch.cuda.device(s.device):
+        check(lib().cvx_coupled_convex_f32(ptr(s), ptr(am), ptr(mesh), h, w, d, (n - 1) // 2, ptr(out), ptr(ws), nws, stream_ptr(s.device)))
+    return out if disp_mesh_t.dtype == torch.float32 else out.to(disp_mesh_t.dtype)
+
+
+def inverse_consistency(disp_field1s, disp_field2s, iter=20):
+    """Symmetric inverse-consistency fixed point on two normalised fields (1,3,h,w,d).  (convex_adam_utils.py:114-129)"""
+    d1 = require_device_tensor(disp_field1s, "disp_field1s")
+    d2 = require_device_tensor(disp_field2s, "disp_field2s")
+    B, Cn, h, w, d = [int(s) for s in d1.shape]
+    if B != 1 or Cn != 3 or d2.shape != d1.shape:
+        raise ValueError("inverse_consistency expects two (1,3,h,w,d) fields")
+    a, b = f32c(d1), f32c(d2)
+    o1, o2 = torch.empty_like(a), torch.empty_like(b)
+    bh, bw, bd = _base_tables(h, w, d, a.device)
+    nws = lib().cvx_inverse_consistency_workspace_bytes(h, w, d)
+    ws = workspace(nws, a.device)
+    with torch.cuda.device(a.device):
+        check(lib().cvx_inverse_consistency_f32(ptr(a), ptr(b), h, w, d, int(iter), ptr(bh), ptr(bw), ptr(bd), ptr(o1), ptr(o2),
+                                                ptr(ws), nws, stream_ptr(a.device)))
+    if d1.dtype != torch.float32:
+        o1, o2 = o1.to(d1.dtype), o2.to(d1.dtype)
+    return o1, o2
+
+
+def resize_trilinear(x, size):
+    """F.interpolate(x, size=size, mode='trilinear', align_corners=False) for (1,C,h,w,d).  (convex_adam_MIND.py:141,153,182)"""
+    x = require_device_tensor(x, "x")
+    _, Cn, h, w, d = [int(s) for s in x.shape]
+    H, W, D = [int(s) for s in size]
+    a = f32c(x)
+    out = torch.empty((1, Cn, H, W, D), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib().cvx_resize_trilinear_f32(ptr(a), Cn, h, w, d, ptr(out), H, W, D, stream_ptr(a.device)))
+    return out if x.dtype == torch.float32 else out.to(x.dtype)
+
+
+def grid_sample(vol, grid):
+    """F.grid_sample(vol, grid) (bilinear, zeros, align_corners=False): vol (1,C,h,w,d), grid (1,ho,wo,do,3)."""
+    vol = require_device_tensor(vol, "vol")
+    _, Cn, h, w, d = [int(s) for s in vol.shape]
+    _, ho, wo, do_, three = [int(s) for s in grid.shape]
+    if three != 3:
+        raise ValueError("grid_sample: grid must be (1,ho,wo,do,3)")
+    a, g = f32c(vol), f32c(grid.to(vol.device))
+    out = torch.empty((1, Cn, ho, wo, do_), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib().cvx_grid_sample_f32(ptr(a), Cn, h, w, d, ptr(g), ho, wo, do_, ptr(out), stream_ptr(a.device)))
+    return out if vol.dtype == torch.float32 else out.to(vol.dtype)
+
+
+def box_smooth(x, k, passes=1):
+    """`passes` x F.avg_pool3d(x, k, stride=1, padding=k//2) for (1,C,H,W,D).  (convex_adam_MIND.py:166,191)"""
+    x = require_device_tensor(x, "x")
+    _, Cn, H, W, D = [int(s) for s in x.shape]
+    a = f32c(x)
+    out = torch.empty_like(a)
+    nws = lib().cvx_box_smooth_workspace_bytes(Cn, H, W, D, int(passes))
+    ws = workspace(max(nws, 256), a.device)
+    with torch.cuda.device(a.device):
+        check(lib().cvx_box_smooth_f32(ptr(a), Cn, H, W, D, int(k), int(passes), ptr(out), ptr(ws), nws, stream_ptr(a.device)))
+    return out if x.dtype == torch.float32 else out.to(x.dtype)
+
+
+def combineDeformation3d(disp_1st, disp_2nd, identity):
+    """disp_2nd + grid_sample(disp_1st, disp_2nd.permute(0,2,3,4,1) + identity).  (convex_adam_utils.py:133-135)"""
+    return disp_2nd + grid_sample(disp_1st, disp_2nd.permute(0, 2, 3, 4, 1) + identity)
+
+
+def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snapshot_iters=(), return_state=False,
+             state=None):
+    """Adam instance optimisation of convex_adam_MIND.py:155-182 on pooled features (1,C,h,w,d) and an
+    initial control grid P0 (1,3,h,w,d) in grid units.  Returns disp_sample of the last forward pass
+    (1,3,h,w,d) [and optionally snapshots / optimiser state]."""
+    F2 = f32c(require_device_tensor(feat_fix, "feat_fix"))
+    M2 = f32c(require_device_tensor(feat_mov, "feat_mov"))
+    _, Cn, h, w, d = [int(s) for s in F2.shape]
+    dev = F2.device
+    if state is None:
+        P = f32c(P0.to(dev)).clone()
+        m = torch.zeros_like(P)
+        v = torch.zeros_like(P)
+        step0 = 0
+    else:
+        P, m, v, step0 = state["P"], state["m"], state["v"], state["step"]
+    U = torch.zeros_like(P)
+    G = torch.zeros_like(P)
+    bh, bw, bd = _base_tables(h, w, d, dev)
+    snaps = sorted(int(i) for i in snapshot_iters)
+    snap_arr = (C.c_int * max(len(snaps), 1))(*snaps) if snaps else None
+    snap_buf = torch.empty((len(snaps), 3, h, w, d), dtype=torch.float32, device=dev) if snaps else None
+    nws = lib().cvx_adam_workspace_bytes(Cn, h, w, d)
+    ws = workspace(nws, dev)
+    with torch.cuda.device(dev):
+        check(lib().cvx_adam_run_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
+                                     int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
+                                     C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf), ptr(ws), nws,
+                                     stream_ptr(dev)))
+    if return_state:
+        return U, dict(P=P, m=m, v=v, step=step0 + int(niter), G=G, snapshots=snap_buf)
+    return U
+
+
+def validate_image(img):
+    """np.ndarray / torch.Tensor (and SimpleITK / nibabel images when those packages are installed) -> torch.Tensor.
+    (convex_adam_utils.py:268-279; raises ValueError for unsupported types like the reference)"""
+    try:
+        import SimpleITK as sitk  # noqa: N813
+        if isinstance(img, sitk.Image):
+            img = sitk.GetArrayFromImage(img)
+    except ImportError:
+        pass
+    try:
+        import nibabel as nib
+        if isinstance(img, nib.Nifti1Image):
+            img = img.get_fdata()
+    except ImportError:
+        pass
+    if isinstance(img, np.ndarray):
+        img = torch.from_numpy(np.ascontiguousarray(img))
+    if not isinstance(img, torch.Tensor):
+        raise ValueError("Input image must be a SimpleITK image, a nibabel image, a numpy array or a torch tensor")
+    return img
+
+
+def gpu_usage():
+    print('gpu usage (current/max): {:.2f} / {:.2f} GB'.format(torch.cuda.memory_allocated() * 1e-9,
+                                                                 torch.cuda.max_memory_allocated() * 1e-9))

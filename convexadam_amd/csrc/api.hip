@@ -1,0 +1,67 @@
+// api.hip -- error plumbing, version/device queries and the host-side table helpers of the C ABI.
+#include <math.h>
+#include <string.h>
+
+#include "cvx_common.h"
+
+namespace cvx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int check_last(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CVX_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return CVX_OK;
+}
+
+}  // namespace cvx
+
+extern "C" int cvx_version(void) { return 1000 * 0 + 1; }
+extern "C" const char* cvx_last_error(void) { return cvx::g_err; }
+extern "C" int cvx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// torch.linspace(-1, 1, S) in float32: step = 2/(S-1); lower half start + step*i, upper half
+// end - step*(S-1-i), each with a single (fused) rounding.  Checked against torch for S = 2..399.
+static void linspace_pm1(int S, float* out) {
+    if (S == 1) { out[0] = -1.0f; return; }
+    const float step = (1.0f - (-1.0f)) / (float)(S - 1);
+    const int half = S / 2;
+    for (int i = 0; i < S; ++i)
+        out[i] = (i < half) ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(S - 1 - i), 1.0f);
+}
+extern "C" void cvx_affine_base_host(int S, float* out_host) {
+    linspace_pm1(S, out_host);
+    for (int i = 0; i < S; ++i) out_host[i] = (out_host[i] * (float)(S - 1)) / (float)S;
+}
+extern "C" void cvx_disp_mesh_host(int disp_hw, float* out_host) {
+    const int n = 2 * disp_hw + 1;
+    float lin[1024];
+    if (n == 1) lin[0] = 0.0f;
+    else linspace_pm1(n, lin);
+    const size_t K = (size_t)n * n * n;
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b)
+            for (int c = 0; c < n; ++c) {
+                const size_t k = ((size_t)a * n + b) * n + c;
+                out_host[0 * K + k] = lin[c] * (float)disp_hw;   // axis 0 (H) shift is the fastest index of k
+                out_host[1 * K + k] = lin[b] * (float)disp_hw;
+                out_host[2 * K + k] = lin[a] * (float)disp_hw;
+            }
+}

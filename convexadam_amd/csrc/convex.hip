@@ -1,0 +1,192 @@
+// convex.hip -- argmin over the search window, coupled-convex regularisation and inverse consistency.
+//
+// References: torch.argmin(ssd, 0) convex_adam_utils.py:87; coupled_convex :93-109;
+// inverse_consistency :114-129.
+//
+// k_argmin streams the cost volume once ([K][v] float32, v contiguous): the grid is
+// (v/256) x (K-slices); each thread walks its K-slice for one voxel (coalesced across the wave),
+// keeps the first minimum, and merges slices with one 64-bit atomicMin on an order-preserving
+// (cost bits << 32 | k) key -- ties resolve to the lowest k, like ATen's CPU argmin.
+// The coupled variant adds coef * sum_a (mesh[a,k] - u[a,x])^2 in the reference's evaluation order.
+// HBM-bound: K*v*4 bytes per pass, 1 + 6 passes per direction.
+#include "cvx_common.h"
+
+namespace cvx {
+
+template <bool COUPLED>
+__global__ __launch_bounds__(256) void k_argmin(const float* __restrict__ ssd, const float* __restrict__ mesh,
+                                                const float* __restrict__ u, float coef, int K, size_t v, int kslice,
+                                                unsigned long long* __restrict__ keys) {
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k0 = blockIdx.y * kslice, k1 = min(k0 + kslice, K);
+    if (x >= v) return;
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+    if (COUPLED) { u0 = u[x]; u1 = u[v + x]; u2 = u[2 * v + x]; }
+    float best = 0.f;
+    int bi = -1;
+    const float* p = ssd + (size_t)k0 * v + x;
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k, p += v) {
+        float cost = *p;
+        if (COUPLED) {
+            const float e0 = mesh[k] - u0, e1 = mesh[K + k] - u1, e2 = mesh[2 * K + k] - u2;
+            float q = e0 * e0;          // (..).pow(2).sum(0): sequential over the 3 components
+            q += e1 * e1;
+            q += e2 * e2;
+            cost = cost + coef * q;     // ssd + coeffs[j]*(...)                       (:104)
+        }
+        if (bi < 0 || cost < best) { best = cost; bi = k; }
+    }
+    if (bi >= 0) atomicMin(&keys[x], pack_min_key(best, (unsigned)bi));
+}
+
+__global__ __launch_bounds__(256) void k_keys_to_index(const unsigned long long* __restrict__ keys, size_t v,
+                                                       int* __restrict__ idx32, int64_t* __restrict__ idx64) {
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= v) return;
+    const unsigned k = (unsigned)(keys[x] & 0xffffffffull);
+    if (idx32) idx32[x] = (int)k;
+    if (idx64) idx64[x] = (int64_t)k;
+}
+__global__ __launch_bounds__(256) void k_index64_to_32(const int64_t* __restrict__ in, size_t v, int* __restrict__ out) {
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < v) out[x] = (int)in[x];
+}
+
+// u_a(x) = avg_pool3d(mesh[a, idx], 3, padding=1)  -- raster-order 27-tap sum of the in-range taps, / 27
+__global__ __launch_bounds__(256) void k_gather_box3(const int* __restrict__ idx, const float* __restrict__ mesh, int K,
+                                                     int h, int w, int d, float* __restrict__ out) {
+    const size_t v = (size_t)h * w * d;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    const int x = (int)(i % d), y = (int)((i / d) % w), z = (int)(i / ((size_t)d * w));
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int a = max(z - 1, 0); a <= min(z + 1, h - 1); ++a)
+        for (int b = max(y - 1, 0); b <= min(y + 1, w - 1); ++b)
+            for (int c = max(x - 1, 0); c <= min(x + 1, d - 1); ++c) {
+                const int k = idx[((size_t)a * w + b) * d + c];
+                s0 += mesh[k];
+                s1 += mesh[K + k];
+                s2 += mesh[2 * K + k];
+            }
+    out[i] = fdiv(s0, 27.0f);
+    out[v + i] = fdiv(s1, 27.0f);
+    out[2 * v + i] = fdiv(s2, 27.0f);
+}
+
+static int argmin_pass(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
+                       unsigned long long* keys, hipStream_t s) {
+    if (hipMemsetAsync(keys, 0xff, sizeof(unsigned long long) * v, s) != hipSuccess)
+        return fail(CVX_ERR_LAUNCH, "argmin: memset failed");
+    const int xb = (int)cdiv64((int64_t)v, 256);
+    int nslices = cdiv(2048, xb);
+    if (nslices > K) nslices = K;
+    if (nslices < 1) nslices = 1;
+    const int kslice = cdiv(K, nslices);
+    nslices = cdiv(K, kslice);
+    const dim3 grid(xb, nslices);
+    if (coupled) hipLaunchKernelGGL(k_argmin<true>, grid, dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, keys);
+    else hipLaunchKernelGGL(k_argmin<false>, grid, dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, keys);
+    return check_last("argmin");
+}
+
+int launch_argmin(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
+                  unsigned long long* keys, int64_t* argmin_out, hipStream_t s) {
+    int rc = argmin_pass(ssd, mesh, u, coef, coupled, K, v, keys, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_keys_to_index, dim3((unsigned)cdiv64((int64_t)v, 256)), dim3(256), 0, s, keys, v, (int*)nullptr,
+                       argmin_out);
+    return check_last("argmin index");
+}
+
+// ---- inverse consistency -------------------------------------------------------------------------------
+//   d1 <- 0.5*(d1 - d2 o (id + d1)),  d2 <- 0.5*(d2 - d1 o (id + d2))   simultaneously, `iters` times
+__global__ __launch_bounds__(256) void k_ic_step(const float* __restrict__ a1, const float* __restrict__ a2, int h, int w,
+                                                 int d, const float* __restrict__ bh, const float* __restrict__ bw,
+                                                 const float* __restrict__ bd, float* __restrict__ o1,
+                                                 float* __restrict__ o2) {
+    const size_t v = (size_t)h * w * d;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= v) return;
+    const int x = (int)(p % d), y = (int)((p / d) % w), z = (int)(p / ((size_t)d * w));
+    Tri t;
+    tri_setup(t, bd[x] + a1[p], bw[y] + a1[v + p], bh[z] + a1[2 * v + p], h, w, d);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o1[(size_t)c * v + p] = 0.5f * (a1[(size_t)c * v + p] - tri_sample(t, a2 + (size_t)c * v, h, w, d));
+    tri_setup(t, bd[x] + a2[p], bw[y] + a2[v + p], bh[z] + a2[2 * v + p], h, w, d);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o2[(size_t)c * v + p] = 0.5f * (a2[(size_t)c * v + p] - tri_sample(t, a1 + (size_t)c * v, h, w, d));
+}
+
+}  // namespace cvx
+
+using namespace cvx;
+
+extern "C" size_t cvx_coupled_convex_workspace_bytes(int h, int w, int d, int disp_hw) {
+    (void)disp_hw;
+    const size_t v = (size_t)h * w * d;
+    size_t used = 0;
+    used = carve_size(used, sizeof(unsigned long long) * v);
+    used = carve_size(used, sizeof(int) * v);
+    return used + 256;
+}
+
+extern "C" int cvx_coupled_convex_f32(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d,
+                                      int disp_hw, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    CVX_REQUIRE(ssd && argmin && mesh && out && workspace, "cvx_coupled_convex_f32: null pointer");
+    CVX_REQUIRE(h > 0 && w > 0 && d > 0 && disp_hw >= 0, "cvx_coupled_convex_f32: bad arguments");
+    if (workspace_bytes < cvx_coupled_convex_workspace_bytes(h, w, d, disp_hw))
+        return fail(CVX_ERR_WORKSPACE, "cvx_coupled_convex_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int n = 2 * disp_hw + 1, K = n * n * n;
+    const size_t v = (size_t)h * w * d;
+    Carver cv(workspace, workspace_bytes);
+    unsigned long long* keys = cv.take<unsigned long long>(v);
+    int* idx = cv.take<int>(v);
+    const dim3 gv((unsigned)cdiv64((int64_t)v, 256));
+    hipLaunchKernelGGL(k_index64_to_32, gv, dim3(256), 0, s, argmin, v, idx);
+    static const float coeffs[6] = {0.003f, 0.01f, 0.03f, 0.1f, 0.3f, 1.0f};   // torch.tensor([...]) float32 (:98)
+    for (int it = 0; it <= 6; ++it) {
+        hipLaunchKernelGGL(k_gather_box3, gv, dim3(256), 0, s, idx, mesh, K, h, w, d, out);
+        if (it == 6) break;
+        int rc = argmin_pass(ssd, mesh, out, coeffs[it], true, K, v, keys, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_keys_to_index, gv, dim3(256), 0, s, keys, v, idx, (int64_t*)nullptr);
+    }
+    return check_last("coupled_convex");
+}
+
+extern "C" size_t cvx_inverse_consistency_workspace_bytes(int h, int w, int d) {
+    return 2 * (256 + sizeof(float) * 3 * (size_t)h * w * d) + 256;
+}
+
+extern "C" int cvx_inverse_consistency_f32(const float* f1, const float* f2, int h, int w, int d, int iters,
+                                           const float* base_h, const float* base_w, const float* base_d, float* o1,
+                                           float* o2, void* workspace, size_t workspace_bytes, void* stream) {
+    CVX_REQUIRE(f1 && f2 && o1 && o2 && base_h && base_w && base_d, "cvx_inverse_consistency_f32: null pointer");
+    CVX_REQUIRE(h > 0 && w > 0 && d > 0 && iters >= 0, "cvx_inverse_consistency_f32: bad arguments");
+    CVX_REQUIRE(o1 != f1 && o2 != f2 && o1 != f2 && o2 != f1, "cvx_inverse_consistency_f32: outputs must not alias inputs");
+    if (workspace_bytes < cvx_inverse_consistency_workspace_bytes(h, w, d) || !workspace)
+        return fail(CVX_ERR_WORKSPACE, "cvx_inverse_consistency_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const size_t v = (size_t)h * w * d, bytes = sizeof(float) * 3 * v;
+    Carver cv(workspace, workspace_bytes);
+    float* t1 = cv.take<float>(3 * v);
+    float* t2 = cv.take<float>(3 * v);
+    if (iters == 0) {
+        if (o1 != f1) (void)hipMemcpyAsync(o1, f1, bytes, hipMemcpyDeviceToDevice, s);
+        if (o2 != f2) (void)hipMemcpyAsync(o2, f2, bytes, hipMemcpyDeviceToDevice, s);
+        return check_last("inverse_consistency");
+    }
+    // ping-pong (tmp <-> out) arranged so that the last iteration writes o1/o2
+    const float *s1 = f1, *s2 = f2;
+    const dim3 gv((unsigned)cdiv64((int64_t)v, 256));
+    for (int it = 0; it < iters; ++it) {
+        const bool to_out = ((iters - 1 - it) & 1) == 0;
+        float* d1 = to_out ? o1 : t1;
+        float* d2 = to_out ? o2 : t2;
+        hipLaunchKernelGGL(k_ic_step, gv, dim3(256), 0, s, s1, s2, h, w, d, base_h, base_w, base_d, d1, d2);
+        s1 = d1; s2 = d2;
+    }
+    return check_last("inverse_consistency");
+}

@@ -1,0 +1,172 @@
+// cvx_common.h -- shared host/device helpers of libconvexadam_hip.so (gfx950 only).
+//
+// All kernels are compiled with -ffp-contract=off: a multiply-add is fused only where the code
+// says fmaf()/__builtin_fmaf(), because the evaluation order (and the absence or presence of a
+// fused rounding) is part of the contract with the reference's ATen CPU kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "convexadam_hip.h"
+
+namespace cvx {
+
+// ---- error plumbing ------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+int check_last(const char* what);   // hipGetLastError -> CVX_ERR_LAUNCH
+
+#define CVX_REQUIRE(cond, ...)                                      \
+    do {                                                            \
+        if (!(cond)) return ::cvx::fail(CVX_ERR_INVALID_ARG, __VA_ARGS__); \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// bump allocator over the caller's workspace (256-byte aligned carves)
+struct Carver {
+    char* base;
+    size_t size, used;
+    Carver(void* p, size_t n) : base(static_cast<char*>(p)), size(n), used(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        size_t off = align_up(used, 256);
+        used = off + count * sizeof(T);
+        return reinterpret_cast<T*>(base + off);
+    }
+    bool ok() const { return used <= size && (base != nullptr || used == 0); }
+};
+static inline size_t carve_size(size_t used, size_t bytes) { return align_up(used, 256) + bytes; }
+
+// ---- exact device math ---------------------------------------------------------------------------
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// IEEE correctly rounded division / sqrt (never the fast approximations)
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ float fsqrt(float a) { return __fsqrt_rn(a); }
+
+// exp(): SLEEF-style expf (Cody-Waite reduction, degree-6 FMA polynomial, two-step ldexp).
+// Bit-identical to oracle/cvx_oracle.c::orc_expf; <= 1 ulp from the reference's MKL vsExp.
+__device__ __forceinline__ float cvx_expf(float d) {
+    const float R_LN2f = 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    const float L2Uf = 0.693145751953125f, L2Lf = 1.428606765330187045e-06f;
+    const float qf = rintf(d * R_LN2f);
+    const int q = (int)qf;
+    float s = __builtin_fmaf(qf, -L2Uf, d);
+    s = __builtin_fmaf(qf, -L2Lf, s);
+    float u = 0.000198527617612853646278381f;
+    u = __builtin_fmaf(u, s, 0.00139304355252534151077271f);
+    u = __builtin_fmaf(u, s, 0.00833336077630519866943359f);
+    u = __builtin_fmaf(u, s, 0.0416664853692054748535156f);
+    u = __builtin_fmaf(u, s, 0.166666671633720397949219f);
+    u = __builtin_fmaf(u, s, 0.5f);
+    u = 1.0f + __builtin_fmaf(s * s, u, s);
+    const float a = __int_as_float(((q >> 1) + 127) << 23);
+    const float b = __int_as_float(((q - (q >> 1)) + 127) << 23);
+    u = u * a * b;
+    if (d < -104.0f) u = 0.0f;
+    if (d > 100.0f) u = __int_as_float(0x7f800000);
+    return u;
+}
+
+// ATen outer-dimension sum order over `n` values held in registers (see oracle outer_sum_rows):
+// plain sequential cascade (level step 16) or, for the last (ncols mod 32) columns, the 4-way
+// interleaved `row_sum` order.  n is a compile-time constant at every call site that matters.
+template <int N>
+__device__ __forceinline__ float cascade_seq(const float (&v)[N]) {
+    static_assert(N < 256, "two cascade levels");
+    float a0 = 0.f, a1 = 0.f;
+    int i = 0;
+#pragma unroll
+    for (; i + 16 <= N; i += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a0 += v[i + j];
+        a1 += a0;
+        a0 = 0.f;
+    }
+#pragma unroll
+    for (; i < N; ++i) a0 += v[i];
+    a0 += a1;      // + acc[2], acc[3] are zero: exact no-ops
+    return a0;
+}
+template <int N>
+__device__ __forceinline__ float outer_sum_ilp(const float (&v)[N]) {
+    static_assert(N / 4 < 16, "single cascade level inside the interleaved sums");
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] += v[4 * i + k];
+#pragma unroll
+    for (int i = (N / 4) * 4; i < N; ++i) p[0] += v[i];
+    p[0] += p[1];
+    p[0] += p[2];
+    p[0] += p[3];
+    return p[0];
+}
+
+// order-preserving key for non-negative floats (+NaN sorts last): packs (value, index) so that a
+// 64-bit atomicMin returns the smallest value and, among equals, the smallest index.
+__device__ __forceinline__ unsigned long long pack_min_key(float v, unsigned idx) {
+    unsigned b = __float_as_uint(v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // total order for any sign
+    return ((unsigned long long)b << 32) | idx;
+}
+
+// trilinear sampling set-up shared by grid_sample-like kernels (ATen GridSampler.cpp order)
+struct Tri {
+    float ix, iy, iz;
+    int x0, y0, z0;
+    float tnw, tne, tsw, tse, bnw, bne, bsw, bse;
+};
+__device__ __forceinline__ float unnormalize(float g, int S) { return ((g + 1.0f) * (float)S - 1.0f) * 0.5f; }  // /2 is exact
+__device__ __forceinline__ void tri_setup(Tri& t, float gx, float gy, float gz, int h, int w, int d) {
+    t.ix = unnormalize(gx, d);
+    t.iy = unnormalize(gy, w);
+    t.iz = unnormalize(gz, h);
+    const float fx = floorf(t.ix), fy = floorf(t.iy), fz = floorf(t.iz);
+    t.x0 = (int)fmaxf(fminf(fx, 1.0e9f), -1.0e9f);
+    t.y0 = (int)fmaxf(fminf(fy, 1.0e9f), -1.0e9f);
+    t.z0 = (int)fmaxf(fminf(fz, 1.0e9f), -1.0e9f);
+    const float x1 = (float)(t.x0 + 1), y1 = (float)(t.y0 + 1), z1 = (float)(t.z0 + 1);
+    const float x0f = (float)t.x0, y0f = (float)t.y0, z0f = (float)t.z0;
+    t.tnw = (x1 - t.ix) * (y1 - t.iy) * (z1 - t.iz);
+    t.tne = (t.ix - x0f) * (y1 - t.iy) * (z1 - t.iz);
+    t.tsw = (x1 - t.ix) * (t.iy - y0f) * (z1 - t.iz);
+    t.tse = (t.ix - x0f) * (t.iy - y0f) * (z1 - t.iz);
+    t.bnw = (x1 - t.ix) * (y1 - t.iy) * (t.iz - z0f);
+    t.bne = (t.ix - x0f) * (y1 - t.iy) * (t.iz - z0f);
+    t.bsw = (x1 - t.ix) * (t.iy - y0f) * (t.iz - z0f);
+    t.bse = (t.ix - x0f) * (t.iy - y0f) * (t.iz - z0f);
+}
+__device__ __forceinline__ bool inb3(int z, int y, int x, int h, int w, int d) {
+    return z >= 0 && z < h && y >= 0 && y < w && x >= 0 && x < d;
+}
+__device__ __forceinline__ float tri_sample(const Tri& t, const float* __restrict__ vol, int h, int w, int d) {
+    const int x0 = t.x0, y0 = t.y0, z0 = t.z0, x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    float o = 0.0f;
+    if (inb3(z0, y0, x0, h, w, d)) o += vol[((size_t)z0 * w + y0) * d + x0] * t.tnw;
+    if (inb3(z0, y0, x1, h, w, d)) o += vol[((size_t)z0 * w + y0) * d + x1] * t.tne;
+    if (inb3(z0, y1, x0, h, w, d)) o += vol[((size_t)z0 * w + y1) * d + x0] * t.tsw;
+    if (inb3(z0, y1, x1, h, w, d)) o += vol[((size_t)z0 * w + y1) * d + x1] * t.tse;
+    if (inb3(z1, y0, x0, h, w, d)) o += vol[((size_t)z1 * w + y0) * d + x0] * t.bnw;
+    if (inb3(z1, y0, x1, h, w, d)) o += vol[((size_t)z1 * w + y0) * d + x1] * t.bne;
+    if (inb3(z1, y1, x0, h, w, d)) o += vol[((size_t)z1 * w + y1) * d + x0] * t.bsw;
+    if (inb3(z1, y1, x1, h, w, d)) o += vol[((size_t)z1 * w + y1) * d + x1] * t.bse;
+    return o;
+}
+
+// ---- internal (non-ABI) launchers shared between translation units -------------------------------
+int launch_box_zero(const float* in, float* out, int C, int H, int W, int D, int k, bool backward, hipStream_t s);
+int launch_argmin(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
+                  unsigned long long* keys, int64_t* argmin_out, hipStream_t s);
+// out = interp(in * pre_mul) / post_div   (pre_mul, post_div = 1 -> plain F.interpolate)
+int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D, float pre_mul,
+                  float post_div, hipStream_t s);
+
+}  // namespace cvx

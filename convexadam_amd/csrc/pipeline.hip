@@ -1,0 +1,276 @@
+// pipeline.hip -- one registration of an image pair, end to end on one stream
+// (reference: convex_adam_pt, src/convexAdam/convex_adam_MIND.py:64-202; multi-channel variant
+// convex_adam_nnUNet.py:41-159).  Every stage is one of the C-ABI operators; nothing touches the host
+// between the upload of the two images and the finished displacement field.
+#include <vector>
+
+#include "cvx_common.h"
+
+namespace cvx {
+
+// identity coordinate of F.affine_grid(align_corners=False) and the search mesh of
+// convex_adam_MIND.py:127, built on the device with the same float ops as the host helpers
+// (torch.linspace restated: start + step*i / end - step*(S-1-i), each a single fused rounding).
+__device__ __forceinline__ float linspace_pm1_at(int S, int i) {
+    if (S == 1) return -1.0f;
+    const float step = fdiv(1.0f - (-1.0f), (float)(S - 1));
+    return (i < S / 2) ? __builtin_fmaf(step, (float)i, -1.0f) : __builtin_fmaf(-step, (float)(S - 1 - i), 1.0f);
+}
+__global__ void k_affine_base(int S, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S) out[i] = fdiv(linspace_pm1_at(S, i) * (float)(S - 1), (float)S);
+}
+__global__ void k_disp_mesh(int hw, float* out) {
+    const int n = 2 * hw + 1, K = n * n * n;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int c = k % n, b = (k / n) % n, a = k / (n * n);
+    const float la = n == 1 ? 0.f : linspace_pm1_at(n, a), lb = n == 1 ? 0.f : linspace_pm1_at(n, b),
+                lc = n == 1 ? 0.f : linspace_pm1_at(n, c);
+    out[k] = lc * (float)hw;
+    out[K + k] = lb * (float)hw;
+    out[2 * K + k] = la * (float)hw;
+}
+
+// (disp_soft / scale).flip(1)                                             convex_adam_MIND.py:134,139
+__global__ __launch_bounds__(256) void k_ic_prepare(const float* __restrict__ soft, int h, int w, int d, float* __restrict__ out) {
+    const size_t v = (size_t)h * w * d;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= v) return;
+    const float sc[3] = {(float)(h - 1) / 2.0f, (float)(w - 1) / 2.0f, (float)(d - 1) / 2.0f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(size_t)c * v + p] = fdiv(soft[(size_t)(2 - c) * v + p], sc[2 - c]);
+}
+// disp_ice.flip(1) * scale * grid_sp                                        convex_adam_MIND.py:141
+__global__ __launch_bounds__(256) void k_ic_finish(const float* __restrict__ ice, int h, int w, int d, float gs, float* __restrict__ out) {
+    const size_t v = (size_t)h * w * d;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= v) return;
+    const float sc[3] = {(float)(h - 1) / 2.0f, (float)(w - 1) / 2.0f, (float)(d - 1) / 2.0f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out[(size_t)a * v + p] = (ice[(size_t)(2 - a) * v + p] * sc[a]) * gs;
+}
+
+struct PairLayout {
+    // extents
+    int H, W, D, h, w, d, h2, w2, d2, C, K;
+    size_t V, v, V2;
+    // byte offsets into the workspace (0 = not used)
+    size_t featF, featM, mind_ws, fs, ms, corr_ws, ssd, argmin, mesh, conv_ws, soft, soft2, in1, in2, ic1, ic2, ic_ws,
+        upin, disp_hr, F2, M2, P, m, v_, U, adam_ws, smooth_ws, bh, bw, bd, bh2, bw2, bd2, total;
+};
+
+static size_t take(size_t& used, size_t bytes) {
+    const size_t off = align_up(used, 256);
+    used = off + bytes;
+    return off;
+}
+
+static PairLayout pair_layout(const cvx_pair_params& p) {
+    PairLayout L{};
+    L.H = p.H; L.W = p.W; L.D = p.D;
+    L.h = p.H / p.grid_sp; L.w = p.W / p.grid_sp; L.d = p.D / p.grid_sp;
+    L.h2 = p.H / p.grid_sp_adam; L.w2 = p.W / p.grid_sp_adam; L.d2 = p.D / p.grid_sp_adam;
+    L.C = p.n_feat > 0 ? p.n_feat : 12;
+    const int n = 2 * p.disp_hw + 1;
+    L.K = n * n * n;
+    L.V = (size_t)p.H * p.W * p.D; L.v = (size_t)L.h * L.w * L.d; L.V2 = (size_t)L.h2 * L.w2 * L.d2;
+    size_t u = 256;      // offset 0 is reserved as "unused"
+    const size_t f = sizeof(float);
+    if (p.n_feat == 0) {
+        L.featF = take(u, f * 12 * L.V);
+        L.featM = take(u, f * 12 * L.V);
+        L.mind_ws = take(u, cvx_mindssc_workspace_bytes(p.H, p.W, p.D, p.mind_r, p.mind_d));
+    }
+    L.fs = take(u, f * L.C * L.v);
+    L.ms = take(u, f * L.C * L.v);
+    L.corr_ws = take(u, cvx_correlate_workspace_bytes(L.C, L.h, L.w, L.d, p.disp_hw));
+    L.ssd = take(u, f * (size_t)L.K * L.v);
+    L.argmin = take(u, sizeof(int64_t) * L.v);
+    L.mesh = take(u, f * 3 * (size_t)L.K);
+    L.conv_ws = take(u, cvx_coupled_convex_workspace_bytes(L.h, L.w, L.d, p.disp_hw));
+    L.soft = take(u, f * 3 * L.v);
+    L.bh = take(u, f * L.h); L.bw = take(u, f * L.w); L.bd = take(u, f * L.d);
+    if (p.ic) {
+        L.soft2 = take(u, f * 3 * L.v);
+        L.in1 = take(u, f * 3 * L.v); L.in2 = take(u, f * 3 * L.v);
+        L.ic1 = take(u, f * 3 * L.v); L.ic2 = take(u, f * 3 * L.v);
+        L.ic_ws = take(u, cvx_inverse_consistency_workspace_bytes(L.h, L.w, L.d));
+        L.upin = take(u, f * 3 * L.v);
+        L.disp_hr = take(u, f * 3 * L.V);
+    }
+    if (p.lambda_weight > 0) {
+        L.F2 = take(u, f * L.C * L.V2);
+        L.M2 = take(u, f * L.C * L.V2);
+        L.P = take(u, f * 3 * L.V2); L.m = take(u, f * 3 * L.V2); L.v_ = take(u, f * 3 * L.V2); L.U = take(u, f * 3 * L.V2);
+        L.adam_ws = take(u, cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2));
+        L.bh2 = take(u, f * L.h2); L.bw2 = take(u, f * L.w2); L.bd2 = take(u, f * L.d2);
+        if (p.selected_smooth > 0) L.smooth_ws = take(u, 2 * (256 + f * 3 * L.V));
+    }
+    L.total = u + 256;
+    return L;
+}
+
+// ---- optional per-stage timing -------------------------------------------------------------------------
+static thread_local bool g_profiling = false;
+struct StageMark { const char* name; hipEvent_t ev; };
+static thread_local std::vector<StageMark> g_marks;
+static thread_local std::vector<hipEvent_t> g_pool;
+static thread_local size_t g_pool_used = 0;
+
+static void mark(const char* name, hipStream_t s) {
+    if (!g_profiling) return;
+    if (g_pool_used == g_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        g_pool.push_back(e);
+    }
+    hipEvent_t e = g_pool[g_pool_used++];
+    (void)hipEventRecord(e, s);
+    g_marks.push_back({name, e});
+}
+
+static int validate(const cvx_pair_params* p) {
+    CVX_REQUIRE(p, "cvx_register_pair: null params");
+    CVX_REQUIRE(p->H > 0 && p->W > 0 && p->D > 0, "cvx_register_pair: bad extent");
+    CVX_REQUIRE(p->grid_sp >= 1 && p->grid_sp_adam >= 1, "cvx_register_pair: grid spacing must be >= 1");
+    CVX_REQUIRE(p->H / p->grid_sp >= 2 && p->W / p->grid_sp >= 2 && p->D / p->grid_sp >= 2,
+                "cvx_register_pair: volume too small for grid_sp %d", p->grid_sp);
+    CVX_REQUIRE(p->disp_hw >= 0 && p->disp_hw <= 8, "cvx_register_pair: disp_hw %d not in 0..8", p->disp_hw);
+    CVX_REQUIRE(p->n_feat >= 0 && p->n_feat < 256, "cvx_register_pair: n_feat out of range");
+    CVX_REQUIRE(p->selected_smooth == 0 || (p->selected_smooth & 1), "cvx_register_pair: selected_smooth must be odd "
+                "(an even kernel changes the volume size in the reference, convex_adam_MIND.py:185-191)");
+    if (p->lambda_weight > 0) {
+        CVX_REQUIRE(p->selected_niter >= 1, "cvx_register_pair: selected_niter must be >= 1 when lambda_weight > 0 "
+                    "(the reference raises UnboundLocalError, convex_adam_MIND.py:181)");
+        CVX_REQUIRE(p->H / p->grid_sp_adam >= 2 && p->W / p->grid_sp_adam >= 2 && p->D / p->grid_sp_adam >= 2,
+                    "cvx_register_pair: volume too small for grid_sp_adam %d", p->grid_sp_adam);
+    }
+    return CVX_OK;
+}
+
+}  // namespace cvx
+
+using namespace cvx;
+
+extern "C" void cvx_set_profiling(int enabled) { g_profiling = enabled != 0; }
+
+extern "C" int cvx_last_pair_profile(const char** names_host, float* ms_host, int max_stages) {
+    if (g_marks.size() < 2) return 0;
+    (void)hipEventSynchronize(g_marks.back().ev);
+    int n = 0;
+    for (size_t i = 1; i < g_marks.size() && n < max_stages; ++i, ++n) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, g_marks[i - 1].ev, g_marks[i].ev);
+        names_host[n] = g_marks[i].name;
+        ms_host[n] = ms;
+    }
+    return n;
+}
+
+extern "C" size_t cvx_register_pair_workspace_bytes(const cvx_pair_params* p) {
+    if (validate(p) != CVX_OK) return 0;
+    return pair_layout(*p).total;
+}
+
+extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_moving, const float* feat_fixed,
+                                     const float* feat_moving, const cvx_pair_params* p, float* out_field,
+                                     int* out_dims_host, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = validate(p);
+    if (rc) return rc;
+    CVX_REQUIRE(out_field && workspace, "cvx_register_pair_f32: null pointer");
+    if (p->n_feat == 0) CVX_REQUIRE(img_fixed && img_moving, "cvx_register_pair_f32: images missing");
+    else CVX_REQUIRE(feat_fixed && feat_moving, "cvx_register_pair_f32: feature volumes missing");
+    const PairLayout L = pair_layout(*p);
+    if (workspace_bytes < L.total) return fail(CVX_ERR_WORKSPACE, "cvx_register_pair_f32: workspace %zu < %zu", workspace_bytes, L.total);
+    hipStream_t s = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    g_marks.clear();
+    g_pool_used = 0;
+    mark("start", s);
+
+    // 1. features                                                              (:106-116)
+    const float *featF = feat_fixed, *featM = feat_moving;
+    if (p->n_feat == 0) {
+        const size_t mws = cvx_mindssc_workspace_bytes(p->H, p->W, p->D, p->mind_r, p->mind_d);
+        if ((rc = cvx_mindssc_f32(img_fixed, p->H, p->W, p->D, p->mind_r, p->mind_d, F(L.featF), ws + L.mind_ws, mws, stream))) return rc;
+        if ((rc = cvx_mindssc_f32(img_moving, p->H, p->W, p->D, p->mind_r, p->mind_d, F(L.featM), ws + L.mind_ws, mws, stream))) return rc;
+        featF = F(L.featF); featM = F(L.featM);
+    }
+    mark("mind", s);
+    // 2. coarse features                                                       (:118-119)
+    if ((rc = cvx_avgpool_f32(featF, L.C, p->H, p->W, p->D, p->grid_sp, F(L.fs), stream))) return rc;
+    if ((rc = cvx_avgpool_f32(featM, L.C, p->H, p->W, p->D, p->grid_sp, F(L.ms), stream))) return rc;
+    hipLaunchKernelGGL(k_disp_mesh, dim3(cdiv(L.K, 256)), dim3(256), 0, s, p->disp_hw, F(L.mesh));
+    hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.h, 64)), dim3(64), 0, s, L.h, F(L.bh));
+    hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.w, 64)), dim3(64), 0, s, L.w, F(L.bw));
+    hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.d, 64)), dim3(64), 0, s, L.d, F(L.bd));
+    mark("pool", s);
+    // 3. forward correlation + coupled convex                                  (:124-130)
+    const size_t cws = cvx_correlate_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);
+    const size_t vws = cvx_coupled_convex_workspace_bytes(L.h, L.w, L.d, p->disp_hw);
+    int64_t* am = reinterpret_cast<int64_t*>(ws + L.argmin);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + L.conv_ws);   // same scratch the coupled pass uses first
+    if ((rc = cvx_correlate_f32(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
+    mark("correlate", s);
+    if ((rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s))) return rc;
+    mark("argmin", s);
+    if ((rc = cvx_coupled_convex_f32(F(L.ssd), am, F(L.mesh), L.h, L.w, L.d, p->disp_hw, F(L.soft), ws + L.conv_ws, vws, stream))) return rc;
+    mark("coupled_convex", s);
+
+    const float* disp_hr = F(L.soft);          // ic=False: coarse field, coarse units (:143-144)
+    int hh = L.h, hw_ = L.w, hd = L.d;
+    if (p->ic) {                                // (:133-141)
+        if ((rc = cvx_correlate_f32(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
+        mark("correlate_rev", s);
+        if ((rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s))) return rc;
+        mark("argmin_rev", s);
+        if ((rc = cvx_coupled_convex_f32(F(L.ssd), am, F(L.mesh), L.h, L.w, L.d, p->disp_hw, F(L.soft2), ws + L.conv_ws, vws, stream))) return rc;
+        mark("coupled_convex_rev", s);
+        const dim3 gv((unsigned)cdiv64((int64_t)L.v, 256));
+        hipLaunchKernelGGL(k_ic_prepare, gv, dim3(256), 0, s, F(L.soft), L.h, L.w, L.d, F(L.in1));
+        hipLaunchKernelGGL(k_ic_prepare, gv, dim3(256), 0, s, F(L.soft2), L.h, L.w, L.d, F(L.in2));
+        if ((rc = cvx_inverse_consistency_f32(F(L.in1), F(L.in2), L.h, L.w, L.d, 15, F(L.bh), F(L.bw), F(L.bd), F(L.ic1), F(L.ic2),
+                                              ws + L.ic_ws, cvx_inverse_consistency_workspace_bytes(L.h, L.w, L.d), stream))) return rc;
+        hipLaunchKernelGGL(k_ic_finish, gv, dim3(256), 0, s, F(L.ic1), L.h, L.w, L.d, (float)p->grid_sp, F(L.upin));
+        float* hr = (p->lambda_weight > 0) ? F(L.disp_hr) : out_field;
+        if ((rc = launch_resize(F(L.upin), 3, L.h, L.w, L.d, hr, p->H, p->W, p->D, 1.0f, 1.0f, s))) return rc;
+        disp_hr = hr; hh = p->H; hw_ = p->W; hd = p->D;
+        mark("inverse_consistency", s);
+    }
+
+    if (p->lambda_weight > 0) {                 // (:147-191)
+        if ((rc = cvx_avgpool_f32(featF, L.C, p->H, p->W, p->D, p->grid_sp_adam, F(L.F2), stream))) return rc;
+        if ((rc = cvx_avgpool_f32(featM, L.C, p->H, p->W, p->D, p->grid_sp_adam, F(L.M2), stream))) return rc;
+        hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.h2, 64)), dim3(64), 0, s, L.h2, F(L.bh2));
+        hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.w2, 64)), dim3(64), 0, s, L.w2, F(L.bw2));
+        hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.d2, 64)), dim3(64), 0, s, L.d2, F(L.bd2));
+        // disp_lr = interpolate(disp_hr, (H2,W2,D2)); weight = disp_lr / grid_sp_adam       (:153,156)
+        if ((rc = launch_resize(disp_hr, 3, hh, hw_, hd, F(L.P), L.h2, L.w2, L.d2, 1.0f, (float)p->grid_sp_adam, s))) return rc;
+        (void)hipMemsetAsync(F(L.m), 0, sizeof(float) * 3 * L.V2, s);
+        (void)hipMemsetAsync(F(L.v_), 0, sizeof(float) * 3 * L.V2, s);
+        mark("adam_setup", s);
+        if ((rc = cvx_adam_run_f32(F(L.F2), F(L.M2), L.C, L.h2, L.w2, L.d2, F(L.P), F(L.m), F(L.v_), p->lambda_weight,
+                                   p->selected_niter, 0, p->cost_scale, F(L.bh2), F(L.bw2), F(L.bd2), F(L.U), nullptr, nullptr, 0,
+                                   nullptr, ws + L.adam_ws, cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2), stream))) return rc;
+        mark("adam", s);
+        // disp_hr = interpolate(fitted_grid * grid_sp_adam, (H,W,D))                            (:182)
+        if (p->selected_smooth > 0) {
+            float* tmp = F(L.smooth_ws);
+            float* tmp2 = reinterpret_cast<float*>(ws + align_up(L.smooth_ws + sizeof(float) * 3 * L.V, 256));
+            if ((rc = launch_resize(F(L.U), 3, L.h2, L.w2, L.d2, tmp, p->H, p->W, p->D, (float)p->grid_sp_adam, 1.0f, s))) return rc;
+            if ((rc = launch_box_zero(tmp, tmp2, 3, p->H, p->W, p->D, p->selected_smooth, false, s))) return rc;
+            if ((rc = launch_box_zero(tmp2, tmp, 3, p->H, p->W, p->D, p->selected_smooth, false, s))) return rc;
+            if ((rc = launch_box_zero(tmp, out_field, 3, p->H, p->W, p->D, p->selected_smooth, false, s))) return rc;
+        } else {
+            if ((rc = launch_resize(F(L.U), 3, L.h2, L.w2, L.d2, out_field, p->H, p->W, p->D, (float)p->grid_sp_adam, 1.0f, s))) return rc;
+        }
+        hh = p->H; hw_ = p->W; hd = p->D;
+        mark("upsample", s);
+    } else if (!p->ic) {
+        (void)hipMemcpyAsync(out_field, F(L.soft), sizeof(float) * 3 * L.v, hipMemcpyDeviceToDevice, s);
+    }
+    if (out_dims_host) { out_dims_host[0] = hh; out_dims_host[1] = hw_; out_dims_host[2] = hd; }
+    return check_last("register_pair");
+}

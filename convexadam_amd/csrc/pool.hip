@@ -1,0 +1,253 @@
+// pool.hip -- pooling / box smoothing / trilinear resize / grid_sample / label features.
+//
+// Reference call sites: F.avg_pool3d(g, stride=g) convex_adam_MIND.py:118-119,149-150;
+// F.avg_pool3d(k, stride=1, padding=k/2) convex_adam_utils.py:96,107 and convex_adam_MIND.py:166,191;
+// F.interpolate(trilinear) convex_adam_MIND.py:141,153,182; F.grid_sample convex_adam_utils.py:126-127;
+// label one-hot features convex_adam_nnUNet.py:19-38.
+// All of them are HBM/L2-bound gathers; arithmetic follows the ATen CPU kernels (raster-order sums,
+// one division; FMA exactly where the ATen build fuses).
+#include "cvx_common.h"
+
+namespace cvx {
+
+// ---- avg_pool3d(g, stride g): one thread per output, raster sum of g^3 taps, one division -------
+__global__ __launch_bounds__(256) void k_avgpool(const float* __restrict__ in, int C, int H, int W, int D, int g,
+                                                 float* __restrict__ out) {
+    const int Ho = H / g, Wo = W / g, Do = D / g;
+    const size_t n = (size_t)C * Ho * Wo * Do;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)(i % Do), w = (int)((i / Do) % Wo), h = (int)((i / ((size_t)Do * Wo)) % Ho);
+    const int c = (int)(i / ((size_t)Do * Wo * Ho));
+    const float* base = in + (((size_t)c * H + (size_t)h * g) * W + (size_t)w * g) * D + (size_t)d * g;
+    float s = 0.0f;
+    for (int z = 0; z < g; ++z)
+        for (int y = 0; y < g; ++y) {
+            const float* row = base + ((size_t)z * W + y) * D;
+            for (int x = 0; x < g; ++x) s += row[x];
+        }
+    out[i] = fdiv(s, (float)(g * g * g));
+}
+
+// ---- avg_pool3d(k, stride 1, pad k/2), forward and ATen-ordered backward (global-memory version)
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void k_box_zero(const float* __restrict__ in, float* __restrict__ out, int C, int H,
+                                                  int W, int D, int k) {
+    const size_t n = (size_t)C * H * W * D;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)(i % D), w = (int)((i / D) % W), h = (int)((i / ((size_t)D * W)) % H);
+    const int c = (int)(i / ((size_t)D * W * H));
+    const int p = k / 2;
+    const float div = (float)(k * k * k);
+    const int h0 = max(h - p, 0), h1 = min(h + p, H - 1), w0 = max(w - p, 0), w1 = min(w + p, W - 1),
+              d0 = max(d - p, 0), d1 = min(d + p, D - 1);
+    const float* ic = in + (size_t)c * H * W * D;
+    float s = 0.0f;
+    for (int z = h0; z <= h1; ++z)
+        for (int y = w0; y <= w1; ++y)
+            for (int x = d0; x <= d1; ++x) {
+                const float v = ic[((size_t)z * W + y) * D + x];
+                s += BACKWARD ? fdiv(v, div) : v;     // backward: every output adds gradOut/k^3
+            }
+    out[i] = BACKWARD ? s : fdiv(s, div);
+}
+
+int launch_box_zero(const float* in, float* out, int C, int H, int W, int D, int k, bool backward, hipStream_t s) {
+    const size_t n = (size_t)C * H * W * D;
+    const dim3 grid((unsigned)cdiv64((int64_t)n, 256));
+    if (backward) hipLaunchKernelGGL(k_box_zero<true>, grid, dim3(256), 0, s, in, out, C, H, W, D, k);
+    else hipLaunchKernelGGL(k_box_zero<false>, grid, dim3(256), 0, s, in, out, C, H, W, D, k);
+    return check_last("box_zero");
+}
+
+// ---- trilinear resize (ATen upsample_trilinear3d, align_corners=False) ----------------------------
+//   src = max(fma(in/out, dst + 0.5, -0.5), 0); i0 = min(floor(src), in-1); l1 = clamp(src - i0, 0, 1)
+//   l0 = 1 - l1; i1 = i0 + (i0 < in-1); per level (last dim first): r = fma(v0, l0, v1 * l1)
+__device__ __forceinline__ void lin_coef(int o, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+    if (in == out) { i0 = o; i1 = o; l0 = 1.0f; l1 = 0.0f; return; }
+    const float ratio = fdiv((float)in, (float)out);
+    float src = __builtin_fmaf(ratio, (float)o + 0.5f, -0.5f);
+    src = src < 0.0f ? 0.0f : src;
+    int a = (int)floorf(src);
+    a = a > in - 1 ? in - 1 : a;
+    float l = src - (float)a;
+    l = l < 0.f ? 0.f : (l > 1.f ? 1.f : l);
+    i0 = a;
+    i1 = a + ((a < in - 1) ? 1 : 0);
+    l1 = l;
+    l0 = 1.0f - l;
+}
+__global__ __launch_bounds__(256) void k_resize(const float* __restrict__ in, int C, int h, int w, int d,
+                                                float* __restrict__ out, int H, int W, int D, float pre_mul,
+                                                float post_div) {
+    const size_t n = (size_t)H * W * D;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % D), y = (int)((i / D) % W), z = (int)(i / ((size_t)D * W));
+    int z0, z1, y0, y1, x0, x1;
+    float lz0, lz1, ly0, ly1, lx0, lx1;
+    lin_coef(z, h, H, z0, z1, lz0, lz1);
+    lin_coef(y, w, W, y0, y1, ly0, ly1);
+    lin_coef(x, d, D, x0, x1, lx0, lx1);
+    for (int c = 0; c < C; ++c) {
+        const float* ic = in + (size_t)c * h * w * d;
+        float lev1[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int zz = a ? z1 : z0;
+            float lev2[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int yy = b ? y1 : y0;
+                const float* row = ic + ((size_t)zz * w + yy) * d;
+                const float v0 = row[x0] * pre_mul, v1 = row[x1] * pre_mul;   // pre_mul = 1: exact no-op
+                lev2[b] = __builtin_fmaf(v0, lx0, v1 * lx1);
+            }
+            lev1[a] = __builtin_fmaf(lev2[0], ly0, lev2[1] * ly1);
+        }
+        float r = __builtin_fmaf(lev1[0], lz0, lev1[1] * lz1);
+        if (post_div != 1.0f) r = fdiv(r, post_div);
+        out[(size_t)c * n + i] = r;
+    }
+}
+int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D, float pre_mul,
+                  float post_div, hipStream_t s) {
+    const size_t n = (size_t)H * W * D;
+    hipLaunchKernelGGL(k_resize, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, s, in, C, h, w, d, out, H, W, D,
+                       pre_mul, post_div);
+    return check_last("resize_trilinear");
+}
+
+// ---- generic grid_sample ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid_sample(const float* __restrict__ vol, int C, int h, int w, int d,
+                                                     const float* __restrict__ grid, size_t vo, float* __restrict__ out) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= vo) return;
+    Tri t;
+    tri_setup(t, grid[3 * p], grid[3 * p + 1], grid[3 * p + 2], h, w, d);
+    const size_t vi = (size_t)h * w * d;
+    for (int c = 0; c < C; ++c) out[(size_t)c * vo + p] = tri_sample(t, vol + (size_t)c * vi, h, w, d);
+}
+
+// ---- label features ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_label_hist(const float* __restrict__ lab, int64_t V, int max_label,
+                                                    unsigned long long* __restrict__ hist) {
+    extern __shared__ unsigned int sh[];
+    for (int i = threadIdx.x; i <= max_label; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)lab[i];
+        if (l >= 0 && l <= max_label) atomicAdd(&sh[l], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= max_label; i += blockDim.x)
+        if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
+}
+__global__ __launch_bounds__(256) void k_label_features(const float* __restrict__ lab, int64_t V, int C,
+                                                        const int* __restrict__ present,
+                                                        const float* __restrict__ weights, float mult,
+                                                        float* __restrict__ feat) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const int l = (int)lab[i];
+    for (int c = 0; c < C; ++c) {
+        const float oh = (l == present[c]) ? 1.0f : 0.0f;
+        feat[(size_t)c * V + i] = mult * (oh * weights[c]);      // 10*(onehot*weight), convex_adam_nnUNet.py:35
+    }
+}
+
+}  // namespace cvx
+
+using namespace cvx;
+
+extern "C" int cvx_avgpool_f32(const float* in, int C, int H, int W, int D, int g, float* out, void* stream) {
+    CVX_REQUIRE(in && out, "cvx_avgpool_f32: null pointer");
+    CVX_REQUIRE(C > 0 && H > 0 && W > 0 && D > 0 && g > 0, "cvx_avgpool_f32: bad arguments");
+    CVX_REQUIRE(H / g > 0 && W / g > 0 && D / g > 0, "cvx_avgpool_f32: pooling window %d larger than the volume", g);
+    const size_t n = (size_t)C * (H / g) * (W / g) * (D / g);
+    hipLaunchKernelGGL(k_avgpool, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, as_stream(stream), in, C, H, W,
+                       D, g, out);
+    return check_last("avgpool");
+}
+
+extern "C" size_t cvx_box_smooth_workspace_bytes(int C, int H, int W, int D, int passes) {
+    return passes > 1 ? 256 + sizeof(float) * (size_t)C * H * W * D : 0;
+}
+extern "C" int cvx_box_smooth_f32(const float* in, int C, int H, int W, int D, int k, int passes, float* out,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    CVX_REQUIRE(in && out, "cvx_box_smooth_f32: null pointer");
+    CVX_REQUIRE(C > 0 && H > 0 && W > 0 && D > 0, "cvx_box_smooth_f32: bad extent");
+    CVX_REQUIRE(k >= 1 && (k & 1), "cvx_box_smooth_f32: kernel %d must be odd (the reference's even-kernel path changes the "
+                "volume size, convex_adam_MIND.py:185-191)", k);
+    CVX_REQUIRE(passes >= 1, "cvx_box_smooth_f32: passes must be >= 1");
+    if (workspace_bytes < cvx_box_smooth_workspace_bytes(C, H, W, D, passes))
+        return fail(CVX_ERR_WORKSPACE, "cvx_box_smooth_f32: workspace too small");
+    CVX_REQUIRE(in != out, "cvx_box_smooth_f32: in-place not supported");
+    hipStream_t s = as_stream(stream);
+    Carver cv(workspace, workspace_bytes);
+    float* tmp = passes > 1 ? cv.take<float>((size_t)C * H * W * D) : nullptr;
+    // ping-pong so that the last pass lands in `out`
+    const float* src = in;
+    for (int p = 0; p < passes; ++p) {
+        float* dst = ((passes - 1 - p) & 1) ? tmp : out;
+        int rc = launch_box_zero(src, dst, C, H, W, D, k, false, s);
+        if (rc) return rc;
+        src = dst;
+    }
+    return CVX_OK;
+}
+
+extern "C" int cvx_resize_trilinear_f32(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D,
+                                        void* stream) {
+    CVX_REQUIRE(in && out, "cvx_resize_trilinear_f32: null pointer");
+    CVX_REQUIRE(C > 0 && h > 0 && w > 0 && d > 0 && H > 0 && W > 0 && D > 0, "cvx_resize_trilinear_f32: bad extent");
+    return launch_resize(in, C, h, w, d, out, H, W, D, 1.0f, 1.0f, as_stream(stream));
+}
+
+extern "C" int cvx_grid_sample_f32(const float* vol, int C, int h, int w, int d, const float* grid, int ho, int wo,
+                                   int dd, float* out, void* stream) {
+    CVX_REQUIRE(vol && grid && out, "cvx_grid_sample_f32: null pointer");
+    CVX_REQUIRE(C > 0 && h > 0 && w > 0 && d > 0 && ho > 0 && wo > 0 && dd > 0, "cvx_grid_sample_f32: bad extent");
+    const size_t vo = (size_t)ho * wo * dd;
+    hipLaunchKernelGGL(k_grid_sample, dim3((unsigned)cdiv64((int64_t)vo, 256)), dim3(256), 0, as_stream(stream), vol, C,
+                       h, w, d, grid, vo, out);
+    return check_last("grid_sample");
+}
+
+extern "C" int cvx_label_histogram_i64(const float* lab, int64_t V, int max_label, int64_t* hist, void* stream) {
+    CVX_REQUIRE(lab && hist && V > 0, "cvx_label_histogram_i64: bad arguments");
+    CVX_REQUIRE(max_label >= 0 && max_label < 8192, "cvx_label_histogram_i64: max_label %d out of range", max_label);
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(hist, 0, sizeof(int64_t) * (size_t)(max_label + 1), s) != hipSuccess)
+        return fail(CVX_ERR_LAUNCH, "cvx_label_histogram_i64: memset failed");
+    const int nb = (int)(cdiv64(V, 256 * 16) < 1024 ? cdiv64(V, 256 * 16) : 1024);
+    hipLaunchKernelGGL(k_label_hist, dim3(nb), dim3(256), sizeof(unsigned) * (size_t)(max_label + 1), s, lab, V, max_label,
+                       reinterpret_cast<unsigned long long*>(hist));
+    return check_last("label_histogram");
+}
+
+// weight = 1/((n_fix + n_mov) + eps).float().pow(.3); weight /= weight.mean()   (convex_adam_nnUNet.py:32-33)
+extern "C" int cvx_label_weights_host(const int64_t* hist_fix_host, const int64_t* hist_mov_host, int max_label,
+                                      int* present_host, float* weights_host) {
+    int C = 0;
+    for (int l = 0; l <= max_label; ++l)
+        if (hist_fix_host[l] + hist_mov_host[l] > 0) present_host[C++] = l;
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float cnt = (float)(hist_fix_host[present_host[c]] + hist_mov_host[present_host[c]]) + 1e-32f;
+        weights_host[c] = 1.0f / powf(cnt, 0.3f);
+        sum += weights_host[c];
+    }
+    const float mean = sum / (float)C;
+    for (int c = 0; c < C; ++c) weights_host[c] = weights_host[c] / mean;
+    return C;
+}
+
+extern "C" int cvx_label_features_f32(const float* lab, int64_t V, int C, const int* present, const float* weights,
+                                      float mult, float* feat, void* stream) {
+    CVX_REQUIRE(lab && present && weights && feat && V > 0 && C > 0, "cvx_label_features_f32: bad arguments");
+    hipLaunchKernelGGL(k_label_features, dim3((unsigned)cdiv64(V, 256)), dim3(256), 0, as_stream(stream), lab, V, C, present,
+                       weights, mult, feat);
+    return check_last("label_features");
+}

@@ -1,0 +1,167 @@
+/*
+ * convexadam_hip.h -- C ABI of libconvexadam_hip.so, the MI355X (gfx950) engine behind the
+ * convexAdam registration hot path.
+ *
+ * The upstream reference (multimodallearning/convexAdam) has no FFI: its hot path is a set of
+ * Python functions that call ATen operators in-process.  This header declares the entry points a
+ * binding for that path needs, one per reference operator, and cites the reference interface each
+ * one replaces (paths relative to the reference tree).  The Python side of this repository
+ * (package convexadam_amd) binds them with ctypes; INTEGRATION.md shows the stub a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP, current device) unless the name ends in `_host`;
+ *   - volumes are dense float32, layout [C][H][W][D] with D fastest (torch contiguous NCDHW, N=1);
+ *   - displacement fields are [3][H][W][D]; channel a = displacement along array axis a, in voxels
+ *     of the grid the field lives on; fixed(x) ~ moving(x + u(x))   (apply_convex.py:22-23);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls enqueue work and
+ *     return without synchronising; nothing is allocated: the caller supplies outputs and a
+ *     scratch workspace whose size comes from the matching *_workspace_bytes() query;
+ *   - return value 0 = ok, negative = CVX_ERR_*; cvx_last_error() gives a thread-local message;
+ *   - floating-point evaluation order follows the ATen CPU kernels the reference calls, so results
+ *     are reproducible bit-for-bit against the CPU oracle (oracle/cvx_oracle.c).
+ */
+#ifndef CONVEXADAM_HIP_H
+#define CONVEXADAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* all entry points have default visibility; everything else in the library is hidden */
+#pragma GCC visibility push(default)
+
+#define CVX_OK 0
+#define CVX_ERR_INVALID_ARG (-1)
+#define CVX_ERR_WORKSPACE (-2)
+#define CVX_ERR_LAUNCH (-3)
+#define CVX_ERR_UNSUPPORTED (-4)
+
+/* library / device ------------------------------------------------------------------------------ */
+int cvx_version(void);                 /* 1000*major + minor */
+const char* cvx_last_error(void);      /* message of the last failing call on this thread */
+int cvx_device_count(void);            /* number of visible HIP devices (0 on a CPU-only host) */
+
+/* host helpers (exact restatements of torch.linspace / affine_grid tables) ----------------------- */
+/* F.affine_grid(eye, size S, align_corners=False) identity coordinate along an axis of extent S.
+ * replaces: convex_adam_utils.py:121, convex_adam_MIND.py:160 */
+void cvx_affine_base_host(int S, float* out_host);
+/* search mesh of convex_adam_MIND.py:127: out_host[3][n^3], n = 2*disp_hw+1,
+ * flat k = (dD+hw)*n*n + (dW+hw)*n + (dH+hw), channel a = displacement along axis a. */
+void cvx_disp_mesh_host(int disp_hw, float* out_host);
+
+/* MIND-SSC descriptors ---------------------------------------------------------------------------
+ * replaces MINDSSC(img, radius, dilation, device)          convex_adam_utils.py:24-68
+ *   img [H][W][D] -> out [12][H][W][D] (reference channel order after the permutation at :66) */
+size_t cvx_mindssc_workspace_bytes(int H, int W, int D, int radius, int dilation);
+int cvx_mindssc_f32(const float* img, int H, int W, int D, int radius, int dilation, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* F.avg_pool3d(x, g, stride=g)                              convex_adam_MIND.py:118-119,149-150
+ *   in [C][H][W][D] -> out [C][H/g][W/g][D/g] (floor) */
+int cvx_avgpool_f32(const float* in, int C, int H, int W, int D, int g, float* out, void* stream);
+
+/* F.avg_pool3d(x, k, stride=1, padding=k/2) applied `passes` times (zero pad, divisor k^3)
+ *                                                            convex_adam_MIND.py:166,191
+ *   in/out [C][H][W][D]; workspace needed when passes > 1 (one volume of the same size) */
+size_t cvx_box_smooth_workspace_bytes(int C, int H, int W, int D, int passes);
+int cvx_box_smooth_f32(const float* in, int C, int H, int W, int D, int k, int passes, float* out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* label-map features                                         convex_adam_nnUNet.py:19-38
+ *   lab_* [V] float-valued integer labels in [0, max_label]; weights_host[C] and present_host[C]
+ *   are computed on the host by the caller (cvx_label_weights_host) from the two histograms;
+ *   feat [C][V] = mult * w_c * (lab == present_c). */
+int cvx_label_histogram_i64(const float* lab, int64_t V, int max_label, int64_t* hist /* device [max_label+1] */,
+                            void* stream);
+int cvx_label_weights_host(const int64_t* hist_fix_host, const int64_t* hist_mov_host, int max_label,
+                           int* present_host, float* weights_host); /* returns C */
+int cvx_label_features_f32(const float* lab, int64_t V, int C, const int* present /* device [C] */,
+                           const float* weights /* device [C] */, float mult, float* feat, void* stream);
+
+/* SSD correlation volume ---------------------------------------------------------------------------
+ * replaces correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch)   convex_adam_utils.py:72-89
+ *   fix, mov [C][h][w][d] (already pooled to the coarse grid)
+ *   ssd [n^3][h][w][d], argmin int64 [h][w][d] (may be NULL) */
+size_t cvx_correlate_workspace_bytes(int C, int h, int w, int d, int disp_hw);
+int cvx_correlate_f32(const float* fix, const float* mov, int C, int h, int w, int d, int disp_hw,
+                      float* ssd, int64_t* argmin, void* workspace, size_t workspace_bytes, void* stream);
+
+/* coupled convex regularisation ---------------------------------------------------------------------
+ * replaces coupled_convex(ssd, ssd_argmin, disp_mesh_t, grid_sp, shape)  convex_adam_utils.py:93-109
+ *   mesh [3][n^3] (device); out [3][h][w][d] in coarse-voxel units */
+size_t cvx_coupled_convex_workspace_bytes(int h, int w, int d, int disp_hw);
+int cvx_coupled_convex_f32(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d,
+                           int disp_hw, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* inverse consistency -------------------------------------------------------------------------------
+ * replaces inverse_consistency(disp_field1s, disp_field2s, iter)        convex_adam_utils.py:114-129
+ *   fields [3][h][w][d], channel 0 = normalised displacement along the LAST axis (caller flips,
+ *   convex_adam_MIND.py:139); base_* = affine identity tables (device, from cvx_affine_base_host) */
+size_t cvx_inverse_consistency_workspace_bytes(int h, int w, int d);
+int cvx_inverse_consistency_f32(const float* f1, const float* f2, int h, int w, int d, int iters,
+                                const float* base_h, const float* base_w, const float* base_d, float* o1,
+                                float* o2, void* workspace, size_t workspace_bytes, void* stream);
+
+/* F.interpolate(x, size, mode='trilinear', align_corners=False)        convex_adam_MIND.py:141,153,182
+ *   in [C][h][w][d] -> out [C][H][W][D] */
+int cvx_resize_trilinear_f32(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D,
+                             void* stream);
+
+/* F.grid_sample(vol, grid, bilinear, zeros, align_corners=False)        convex_adam_utils.py:126,134
+ *   vol [C][h][w][d], grid [ho][wo][do][3] (x,y,z normalised) -> out [C][ho][wo][do] */
+int cvx_grid_sample_f32(const float* vol, int C, int h, int w, int d, const float* grid, int ho, int wo, int dd,
+                        float* out, void* stream);
+
+/* Adam instance optimisation -------------------------------------------------------------------------
+ * replaces the loop of convex_adam_MIND.py:155-182 (nn.Conv3d weight + torch.optim.Adam(lr=1)).
+ *   F2, M2 [C][h][w][d] pooled features; P [3][h][w][d] control grid (grid units), updated in place;
+ *   m, v Adam moments (caller zeroes them for a fresh run); step0 = Adam steps already taken;
+ *   cost_scale = 12 in convex_adam_MIND.py:176 (n_ch in the sweep scripts);
+ *   U [3][h][w][d] receives disp_sample of the LAST forward pass (what the reference returns, :181);
+ *   snapshot_iters (host, ascending, may be NULL): after iteration i (1-based) copy U to
+ *   snapshots[j] ([n_snap][3][h][w][d])                    self_configuring/convex_adam_MIND.py:115-139 */
+size_t cvx_adam_workspace_bytes(int C, int h, int w, int d);
+int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m,
+                     float* v, float lambda_weight, int niter, int step0, float cost_scale,
+                     const float* base_h, const float* base_w, const float* base_d, float* U, float* grad_out,
+                     const int* snapshot_iters_host, int n_snap, float* snapshots, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* whole pair ---------------------------------------------------------------------------------------
+ * replaces convex_adam_pt(...)                                       convex_adam_MIND.py:64-202
+ * (use_mask=False path; features are MIND-SSC of the two images, or caller-supplied feature
+ *  volumes when feat_fixed/feat_moving are non-NULL: convex_adam_nnUNet.py:41-159) */
+typedef struct cvx_pair_params {
+    int H, W, D;
+    int mind_r, mind_d;
+    float lambda_weight;
+    int grid_sp, disp_hw;
+    int selected_niter, selected_smooth;
+    int grid_sp_adam;
+    int ic;
+    int n_feat;          /* 0: compute MIND (12 ch) from images; >0: feat_* given with this many channels */
+    float cost_scale;    /* 12 */
+} cvx_pair_params;
+
+size_t cvx_register_pair_workspace_bytes(const cvx_pair_params* p);
+/* out_field [3][H][W][D] float32 (for ic=0 && lambda_weight<=0 the reference returns the coarse
+ * field unchanged: [3][H/gs][W/gs][D/gs], convex_adam_MIND.py:143-144; out_dims_host[3] reports it). */
+int cvx_register_pair_f32(const float* img_fixed, const float* img_moving, const float* feat_fixed,
+                          const float* feat_moving, const cvx_pair_params* p, float* out_field,
+                          int* out_dims_host, void* workspace, size_t workspace_bytes, void* stream);
+
+/* per-stage device time of the last cvx_register_pair_f32 call on this thread (hipEvents, ms).
+ * names_host receives pointers to static strings; returns the number of stages written. */
+int cvx_last_pair_profile(const char** names_host, float* ms_host, int max_stages);
+void cvx_set_profiling(int enabled);
+
+#pragma GCC visibility pop
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONVEXADAM_HIP_H */

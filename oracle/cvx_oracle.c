@@ -687,7 +687,8 @@ ORC_API void orc_adam_run(const float* F2, const float* M2, int C, int h, int w,
             const float g = t1[i];
             const float mm = fmaf(w1, g - m[i], m[i]);             /* exp_avg.lerp_(grad, 1-beta1) */
             float vv = v[i] * b2;                                   /* exp_avg_sq.mul_(beta2) */
-            vv = vv + (omb2 * g) * g;                               /* .addcmul_(grad, grad, value=1-beta2) */
+            vv = fmaf(omb2 * g, g, vv);                             /* .addcmul_(grad, grad, value=1-beta2): the ATen
+                                                                       kernel rounds (value*g) and fuses the rest */
             const float den = sqrtf(vv) / bc2s + 1e-8f;             /* (sqrt / bc2_sqrt).add_(eps) */
             P[i] = P[i] + (neg_step * mm) / den;                    /* addcdiv_(exp_avg, denom, value=-step_size) */
             m[i] = mm; v[i] = vv;

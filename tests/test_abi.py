@@ -1,0 +1,96 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads without a GPU and exports every
+symbol include/convexadam_hip.h declares; the ctypes table matches the header; argument validation and
+the no-fallback rule hold.  No kernels are launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "convexadam_hip.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(cvx_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from convexadam_amd.csrc import build
+    build.build()
+    from convexadam_amd import _lib
+    return _lib.lib()
+
+
+def test_header_declares_expected_entry_points():
+    names = header_functions()
+    for must in ("cvx_mindssc_f32", "cvx_avgpool_f32", "cvx_correlate_f32", "cvx_coupled_convex_f32",
+                 "cvx_inverse_consistency_f32", "cvx_resize_trilinear_f32", "cvx_adam_run_f32", "cvx_register_pair_f32"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(L):
+    from convexadam_amd import _lib
+    for name in header_functions():
+        assert hasattr(L, name), "libconvexadam_hip.so does not export %s" % name
+        assert name in _lib.SIGNATURES, "ctypes table lacks %s" % name
+    assert sorted(_lib.SIGNATURES) == header_functions()
+
+
+def test_version_and_device_count(L):
+    assert L.cvx_version() >= 1
+    n = L.cvx_device_count()
+    assert n >= 0
+    if not torch.cuda.is_available():
+        assert n == 0
+
+
+def test_argument_validation_without_gpu(L):
+    # invalid arguments are rejected before anything touches a device
+    assert L.cvx_mindssc_f32(None, 8, 8, 8, 1, 2, None, None, 0, None) == -1
+    assert b"null" in L.cvx_last_error()
+    assert L.cvx_correlate_f32(None, None, 12, 4, 4, 4, 2, None, None, None, 0, None) == -1
+    dummy = C.c_void_p(256)
+    assert L.cvx_correlate_f32(dummy, dummy, 12, 4, 4, 4, 9, dummy, None, dummy, 1 << 40, None) == -4   # hw > 8 unsupported
+    assert L.cvx_correlate_f32(dummy, dummy, 12, 4, 4, 4, 2, dummy, None, dummy, 16, None) == -2         # workspace too small
+    assert L.cvx_box_smooth_f32(dummy, 3, 4, 4, 4, 4, 1, C.c_void_p(512), None, 0, None) == -1           # even kernel
+    assert b"odd" in L.cvx_last_error()
+
+
+def test_workspace_queries(L):
+    from convexadam_amd._lib import PairParams
+    # OASIS-size pair: raw (K*h*w*dp) + ssd (K*v) dominate
+    p = PairParams(160, 192, 224, 1, 2, 1.25, 6, 6, 80, 0, 2, 1, 0, 12.0)
+    n = L.cvx_register_pair_workspace_bytes(C.byref(p))
+    K, v = 13 ** 3, 26 * 32 * 37
+    assert n > 4 * K * v * 2 + 2 * 12 * 160 * 192 * 224 * 4
+    assert n < 3 * 1024 ** 3
+    bad = PairParams(160, 192, 224, 1, 2, 1.25, 6, 6, 0, 0, 2, 1, 0, 12.0)       # niter 0 with lambda > 0
+    assert L.cvx_register_pair_workspace_bytes(C.byref(bad)) == 0
+    assert L.cvx_correlate_workspace_bytes(12, 26, 32, 37, 6) >= 4 * K * 26 * 32 * 40
+
+
+def test_no_cpu_fallback():
+    from convexadam_amd import convex_adam_utils as U, convex_adam_MIND as M
+    x = torch.zeros(1, 1, 8, 8, 8)
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            U.MINDSSC(x, 1, 2, device="cuda")
+    with pytest.raises(RuntimeError, match="no CPU"):
+        U.correlate(torch.zeros(1, 12, 4, 4, 4), torch.zeros(1, 12, 4, 4, 4), 2, 2, (8, 8, 8), 12)
+    with pytest.raises(RuntimeError, match="no CPU|HIP device"):
+        M.convex_adam_pt(np.zeros((16, 16, 16), np.float32), np.zeros((16, 16, 16), np.float32), device=torch.device("cpu"))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "convexadam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libcvx_oracle" not in txt, f

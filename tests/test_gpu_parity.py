@@ -1,0 +1,289 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): the HIP path, called through the C ABI, against
+  (1) the CPU oracle on the same seeded inputs -- BIT-EXACT (np.array_equal) for every operator, because the
+      kernels follow the oracle's / ATen's evaluation order and share the exp() restatement;
+  (2) the golden vectors captured from the upstream reference (tests/golden), with the tolerances of
+      tests/test_oracle_vs_golden.py (bit-exact except MKL's exp in MIND and sqrt in Adam);
+  (3) size-independent properties at BASELINE.json's full sizes (identity -> 0, translation recovery,
+      argmin consistency, inverse-consistency residual).
+Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def epe(a, b):
+    return float(np.sqrt(((a.astype(np.float64) - b.astype(np.float64)) ** 2).sum(-1)).mean())
+
+
+@pytest.fixture(scope="module")
+def U():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from convexadam_amd import convex_adam_utils
+    return convex_adam_utils
+
+
+@pytest.fixture(scope="module")
+def M():
+    from convexadam_amd import convex_adam_MIND
+    return convex_adam_MIND
+
+
+def test_library_sees_the_gpu():
+    from convexadam_amd import _lib
+    assert _lib.lib().cvx_device_count() >= 1
+
+
+# ---- (1) HIP vs oracle, bit-exact --------------------------------------------------------------------
+@pytest.mark.parametrize("shape,r,d", [((20, 18, 23), 1, 2), ((33, 40, 70), 1, 2), ((20, 18, 23), 2, 2), ((17, 9, 66), 1, 1),
+                                       ((12, 13, 14), 3, 3), ((9, 70, 8), 2, 1)])
+def test_mindssc_vs_oracle(U, orc, shape, r, d):
+    from convexadam_amd.phantom import phantom
+    img = phantom(shape, 3, 30)
+    out = host(U.MINDSSC(img[None, None].to(DEV), r, d, device=DEV))[0]
+    ref = orc.mindssc(img.numpy(), r, d)
+    assert np.array_equal(out, ref), "max |diff| %g" % np.abs(out - ref).max()
+
+
+def test_mindssc_flat_and_clamped_regions(U, orc):
+    """Zero background (mind_var = 0 -> clamped to 0.001*mean) and a bright blob: exercises both clamp bounds."""
+    img = np.zeros((24, 20, 28), np.float32)
+    img[6:18, 5:15, 8:20] = np.random.default_rng(0).normal(100, 30, (12, 10, 12)).astype(np.float32)
+    out = host(U.MINDSSC(dev(img)[None, None], 1, 2, device=DEV))[0]
+    assert np.array_equal(out, orc.mindssc(img, 1, 2))
+    assert np.all(out[:, 0, 0, 0] == 1.0)
+
+
+@pytest.mark.parametrize("g", [2, 3, 6])
+def test_avgpool_vs_oracle(U, orc, g):
+    x = np.random.default_rng(g).standard_normal((5, 13, 14, 15)).astype(np.float32)
+    assert np.array_equal(host(U.avg_pool(dev(x)[None], g))[0], orc.avgpool_stride(x, g))
+
+
+@pytest.mark.parametrize("C,shape,hw", [(12, (12, 10, 14), 2), (12, (7, 9, 11), 3), (12, (9, 8, 37), 4), (20, (7, 5, 9), 1),
+                                        (3, (5, 6, 7), 2), (33, (6, 5, 8), 2), (12, (4, 4, 4), 6), (1, (3, 3, 3), 0)])
+def test_correlate_vs_oracle(U, orc, C, shape, hw):
+    """Includes C >= 16 (ATen cascade sum), ragged inner sizes (interleaved tail rule), D not a multiple of 4,
+    search windows larger than the volume, and the degenerate hw = 0."""
+    rng = np.random.default_rng(C * 100 + hw)
+    f = rng.random((C,) + shape, dtype=np.float32)
+    m = rng.random((C,) + shape, dtype=np.float32)
+    ssd, am = U.correlate(dev(f)[None], dev(m)[None], hw, 1, shape, C)
+    rs, ra = orc.correlate(f, m, hw)
+    assert np.array_equal(host(ssd), rs), "max |diff| %g" % np.abs(host(ssd) - rs).max()
+    assert np.array_equal(host(am), ra)
+
+
+def test_argmin_ties_resolve_to_lowest_k(U):
+    f = torch.zeros(1, 12, 6, 6, 6, device=DEV)
+    ssd, am = U.correlate(f, f, 2, 1, (6, 6, 6), 12)      # every displacement costs 0 -> first index wins
+    assert int(ssd.abs().max()) == 0 and int(am.max()) == 0
+
+
+@pytest.mark.parametrize("shape,hw", [((12, 10, 14), 2), ((7, 9, 11), 3), ((9, 8, 37), 4)])
+def test_coupled_convex_vs_oracle(U, orc, shape, hw):
+    rng = np.random.default_rng(hw)
+    f = rng.random((12,) + shape, dtype=np.float32)
+    m = rng.random((12,) + shape, dtype=np.float32)
+    rs, ra = orc.correlate(f, m, hw)
+    mesh = orc.disp_mesh(hw)
+    out = U.coupled_convex(dev(rs), dev(ra), dev(mesh)[:, :, None], 1, shape)
+    assert np.array_equal(host(out)[0], orc.coupled_convex(rs, ra, mesh, hw))
+
+
+def test_inverse_consistency_vs_oracle(U, orc):
+    rng = np.random.default_rng(5)
+    a = (0.2 * rng.standard_normal((3, 9, 11, 13))).astype(np.float32)
+    b = (0.2 * rng.standard_normal((3, 9, 11, 13))).astype(np.float32)
+    for it in (1, 2, 15):
+        o1, o2 = U.inverse_consistency(dev(a)[None], dev(b)[None], iter=it)
+        r1, r2 = orc.inverse_consistency(a, b, it)
+        assert np.array_equal(host(o1)[0], r1) and np.array_equal(host(o2)[0], r2)
+
+
+@pytest.mark.parametrize("src,dst", [((9, 11, 13), (36, 30, 42)), ((36, 30, 42), (18, 15, 21)), ((5, 6, 7), (5, 12, 7)), ((26, 32, 37), (160, 192, 224))])
+def test_resize_vs_oracle(U, orc, src, dst):
+    x = np.random.default_rng(1).standard_normal((3,) + src).astype(np.float32)
+    assert np.array_equal(host(U.resize_trilinear(dev(x)[None], dst))[0], orc.resize_trilinear(x, dst))
+
+
+def test_grid_sample_vs_oracle(U, orc):
+    rng = np.random.default_rng(2)
+    vol = rng.standard_normal((4, 7, 8, 9)).astype(np.float32)
+    grid = (rng.random((5, 6, 7, 3), dtype=np.float32) * 2.6 - 1.3).astype(np.float32)   # some samples outside
+    assert np.array_equal(host(U.grid_sample(dev(vol)[None], dev(grid)[None]))[0], orc.grid_sample(vol, grid))
+
+
+@pytest.mark.parametrize("k,passes", [(3, 1), (3, 3), (5, 3)])
+def test_box_smooth_vs_oracle(U, orc, k, passes):
+    x = np.random.default_rng(k).standard_normal((3, 10, 11, 12)).astype(np.float32)
+    r = x
+    for _ in range(passes):
+        r = orc.box_zero(r, k)
+    assert np.array_equal(host(U.box_smooth(dev(x)[None], k, passes))[0], r)
+
+
+@pytest.mark.parametrize("niter", [1, 3, 10])
+def test_adam_vs_oracle(U, orc, golden, niter):
+    g = golden("adam")
+    Ud, st = U.adam_run(dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]), niter, return_state=True)
+    r = orc.adam_run(g["F2"], g["M2"], g["P0"], float(g["lam"]), niter, want_grad=True)
+    assert np.array_equal(host(Ud)[0], r["U"])
+    assert np.array_equal(host(st["G"])[0], r["G"])
+    assert np.array_equal(host(st["P"])[0], r["P"])
+    assert np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
+
+
+def test_adam_snapshots_and_resume(U, orc, golden):
+    g = golden("adam")
+    args = (dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]))
+    U8, st = U.adam_run(*args, 8, snapshot_iters=(3, 8), return_state=True)
+    assert np.array_equal(host(st["snapshots"][0]), orc.adam_run(g["F2"], g["M2"], g["P0"], float(g["lam"]), 3)["U"])
+    assert torch.equal(st["snapshots"][1], U8[0])
+    U3, s3 = U.adam_run(*args, 3, return_state=True)
+    U8b = U.adam_run(*args, 5, state=s3)
+    assert torch.equal(U8, U8b)
+
+
+@pytest.mark.parametrize("kw", [dict(lambda_weight=0, ic=True), dict(lambda_weight=0, ic=False), dict(lambda_weight=1.25, selected_niter=5, ic=True),
+                                dict(lambda_weight=1.25, selected_niter=5, ic=False), dict(lambda_weight=1.25, selected_niter=3, selected_smooth=3, ic=True)])
+def test_pipeline_vs_oracle_bit_exact(M, orc, golden, kw):
+    g = golden("pipeline")
+    base = dict(mind_r=1, mind_d=2, grid_sp=4, disp_hw=3, grid_sp_adam=2)
+    out = M.convex_adam_pt(g["fix"], g["mov"], dtype=torch.float32, device=torch.device(DEV), **base, **kw)
+    ref = orc.convex_adam_pipeline(g["fix"], g["mov"], **base, **kw)
+    assert out.shape == ref.shape and out.dtype == np.float64
+    assert np.array_equal(out, ref), "EPE %g" % epe(out, ref)
+
+
+# ---- (2) HIP vs reference goldens -----------------------------------------------------------------------
+def test_mindssc_vs_reference_golden(U, golden):
+    g = golden("mind")
+    for key, r, d in (("mind_r1d2", 1, 2), ("mind_r2d2", 2, 2), ("mind_r1d1", 1, 1)):
+        out = host(U.MINDSSC(dev(g["img"])[None, None], r, d, device=DEV))[0]
+        assert np.abs(out - g[key]).max() <= 6e-8          # 1 ulp: MKL vsExp vs the shared expf restatement
+
+
+def test_convex_stage_vs_reference_golden(U, golden):
+    g = golden("convex")
+    H, W, D, gs, hw = [int(v) for v in g["shape"]]
+    ssd, am = U.correlate(dev(g["feat_fix"])[None], dev(g["feat_mov"])[None], hw, gs, (H, W, D), 12)
+    assert np.array_equal(host(ssd), g["ssd"]) and np.array_equal(host(am), g["argmin"])
+    soft = U.coupled_convex(ssd, am, dev(g["mesh"])[:, :, None], gs, (H, W, D))
+    assert np.array_equal(host(soft)[0], g["soft"])
+    o1, o2 = U.inverse_consistency(dev(g["ic_in1"])[None], dev(g["ic_in2"])[None], iter=15)
+    assert np.array_equal(host(o1)[0], g["ic_out1"]) and np.array_equal(host(o2)[0], g["ic_out2"])
+    assert np.array_equal(host(U.resize_trilinear(dev(g["disp_hr"])[None], (H // 2, W // 2, D // 2)))[0], g["disp_lr"])
+
+
+def test_correlate_c20_vs_reference_golden(U, golden):
+    g = golden("correlate_c20")
+    ssd, am = U.correlate(dev(g["fix"])[None], dev(g["mov"])[None], 1, 1, g["fix"].shape[1:], 20)
+    assert np.array_equal(host(ssd), g["ssd"]) and np.array_equal(host(am), g["argmin"])
+
+
+def test_adam_vs_reference_golden(U, golden):
+    g = golden("adam")
+    args = (dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]))
+    U1, st = U.adam_run(*args, 1, return_state=True)
+    assert np.array_equal(host(U1)[0], g["U_1"]) and np.array_equal(host(st["G"])[0], g["G_1"])   # autograd-exact
+    assert np.abs(host(st["P"])[0] - g["P_1"]).max() <= 2.5e-7                                    # MKL sqrt, 1 ulp
+    for niter, tol in ((5, 5e-6), (20, 5e-5)):
+        assert np.abs(host(U.adam_run(*args, niter))[0] - g["U_%d" % niter]).max() <= tol
+
+
+@pytest.mark.parametrize("key,kw,tol", [("convex_only_ic", dict(lambda_weight=0, ic=True), 1e-5), ("convex_only_noic", dict(lambda_weight=0, ic=False), 1e-5),
+                                        ("adam_1", dict(selected_niter=1), 1e-5), ("adam_5", dict(selected_niter=5), 1e-4),
+                                        ("adam_20", dict(selected_niter=20), 1e-3), ("adam_5_smooth3", dict(selected_niter=5, selected_smooth=3), 1e-4),
+                                        ("adam_5_noic", dict(selected_niter=5, ic=False), 1e-4)])
+def test_pipeline_vs_reference_golden(M, golden, key, kw, tol):
+    """North-star tolerance: mean endpoint error < 1e-3 voxel against the reference's CPU float32 field."""
+    g = golden("pipeline")
+    args = dict(mind_r=1, mind_d=2, grid_sp=4, disp_hw=3, grid_sp_adam=2, lambda_weight=1.25, ic=True)
+    args.update(kw)
+    out = M.convex_adam_pt(g["fix"], g["mov"], dtype=torch.float32, device=torch.device(DEV), **args)
+    assert out.shape == g[key].shape
+    assert epe(out, g[key]) < tol
+
+
+def test_translation_known_answers(M, golden):
+    from convexadam_amd.phantom import phantom
+    g = golden("translation64")
+    fix = phantom((64, 64, 64), 2, 20)
+    for name, sh, gs in (("roll_4_0_m8_gs4", (4, 0, -8), 4), ("roll_6_m6_0_gs6", (6, -6, 0), 6)):
+        out = M.convex_adam_pt(fix, torch.roll(fix, sh, (0, 1, 2)), lambda_weight=0, grid_sp=gs, disp_hw=4, dtype=torch.float32,
+                               device=torch.device(DEV))
+        assert np.allclose(out[16:48, 16:48, 16:48].mean((0, 1, 2)), g[name], atol=1e-4)
+        assert np.abs(out[::4, ::4, ::4] - g[name + "_sub"]).max() < 1e-3
+
+
+def test_label_features_and_nnunet_path(orc, golden):
+    from convexadam_amd import convex_adam_nnUNet as N
+    g = golden("labels")
+    lf, lm = g["lab_fix"].astype(np.float32), g["lab_mov"].astype(np.float32)
+    ff, fm = N.extract_features(dev(lf), dev(lm), device=DEV)
+    rf, rm, _ = orc.label_features(lf, lm, 10.0)
+    assert np.array_equal(host(ff)[0], rf) and np.array_equal(host(fm)[0], rm)
+    assert np.allclose(host(ff)[0].reshape(ff.shape[1], -1).max(1), g["weights"], rtol=2e-6)
+    out = N.convex_adam_pt(dev(lf), dev(lm), 1.25, 4, 2, 5, 0, device=DEV)
+    assert out.shape == lf.shape + (3,) and np.isfinite(out).all()
+
+
+# ---- (3) properties at full size (BASELINE.json configs 2 and 3) ------------------------------------------
+@pytest.mark.timeout(900)
+def test_full_size_identity_and_determinism(M):
+    """160x192x224, disp_hw 6, 80 Adam iterations (config 2): registering an image to itself gives a field
+    that is exactly zero at the convex stage and stays < 0.1 voxel after Adam (reference test
+    test_convex_adam_identity, atol 0.1); two runs are bit-identical (no atomics on float data)."""
+    from convexadam_amd.phantom import phantom
+    fix = phantom((160, 192, 224), 1, 10).to(DEV)
+    conv = M.register_pair_device(fix, fix, lambda_weight=0, grid_sp=6, disp_hw=6, ic=True)
+    assert float(conv.abs().max()) == 0.0
+    a = M.register_pair_device(fix, fix, grid_sp=6, disp_hw=6, selected_niter=80)
+    b = M.register_pair_device(fix, fix, grid_sp=6, disp_hw=6, selected_niter=80)
+    assert torch.equal(a, b)
+    assert float(a.abs().max()) < 0.1
+
+
+@pytest.mark.timeout(900)
+def test_full_size_translation_recovery(M):
+    """Config 2 size, known shift: the recovered field equals the shift in the interior (reference
+    test_convex_adam_translation: > 90 % of the central voxels within 1 voxel)."""
+    from convexadam_amd.phantom import phantom
+    fix = phantom((160, 192, 224), 1, 10).to(DEV)
+    sh = (6, -4, 8)
+    mov = torch.roll(fix, sh, (0, 1, 2))
+    u = M.register_pair_device(fix, mov, grid_sp=6, disp_hw=6, selected_niter=80)
+    c = u[:, 32:128, 38:154, 45:179]
+    for a in range(3):
+        assert float(((c[a] - sh[a]).abs() < 1.0).float().mean()) > 0.9
+        assert abs(float(c[a].mean()) - sh[a]) < 0.25
+
+
+@pytest.mark.timeout(900)
+def test_large_motion_config3_argmin_consistency(U):
+    """Config 3 (224x192x224, disp_hw 8, grid_sp 6 -> 4913 x 37x32x37 cost volume): the fused argmin equals
+    torch-free re-evaluation of the minimum over the stored cost volume, and a rolled feature volume is
+    recovered exactly (zero cost at the true displacement)."""
+    rng = torch.Generator().manual_seed(0)
+    f = torch.rand(1, 12, 37, 32, 37, generator=rng).to(DEV)
+    m = torch.roll(f, (3, -5, 7), (2, 3, 4))
+    ssd, am = U.correlate(f, m, 8, 6, (224, 192, 224), 12)
+    assert ssd.shape == (4913, 37, 32, 37)
+    mins = ssd.min(0)
+    assert torch.equal(mins.indices, am)          # first-min tie rule == torch.argmin on device data
+    k = (7 + 8) * 289 + (-5 + 8) * 17 + (3 + 8)
+    inner = am[12:25, 12:20, 12:25]
+    assert int((inner == k).all()) == 1
+    assert float(ssd[k, 12:25, 12:20, 12:25].abs().max()) == 0.0

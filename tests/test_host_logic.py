@@ -1,0 +1,106 @@
+"""CPU tests of the host-side logic: table helpers against torch itself, the synthetic-data recipe, the
+API mirror's error behaviour, and the sharded multi-GPU driver over gloo (world_size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_affine_base_matches_torch_affine_grid():
+    from convexadam_amd.convex_adam_utils import affine_base
+    for S in list(range(2, 130)) + [160, 192, 224, 255, 399]:
+        g = F.affine_grid(torch.eye(3, 4).unsqueeze(0), (1, 1, 2, 2, S), align_corners=False)[0, 0, 0, :, 0].numpy()
+        assert np.array_equal(affine_base(S), g), S
+
+
+def test_disp_mesh_matches_torch_affine_grid():
+    from convexadam_amd.convex_adam_utils import disp_mesh
+    for hw in range(1, 9):
+        n = 2 * hw + 1
+        m = F.affine_grid(hw * torch.eye(3, 4).unsqueeze(0), (1, 1, n, n, n), align_corners=True).permute(0, 4, 1, 2, 3).reshape(3, -1)
+        assert np.array_equal(disp_mesh(hw), m.numpy()), hw
+    # k -> (dH, dW, dD) with the D-shift slowest
+    m = disp_mesh(2)
+    assert m[:, 3 * 25 + 1 * 5 + 4].tolist() == [2.0, -1.0, 1.0]
+
+
+def test_oracle_tables_agree_with_library(orc):
+    from convexadam_amd.convex_adam_utils import affine_base, disp_mesh
+    assert all(np.array_equal(affine_base(S), orc.affine_base(S)) for S in range(1, 300))
+    assert all(np.array_equal(disp_mesh(h), orc.disp_mesh(h)) for h in range(0, 9))
+
+
+def test_outer_sum_tail_rule_matches_torch(orc):
+    """ATen sums an outer dimension in blocks of 32 columns; the last (ncols mod 32) columns use a 4-way
+    interleaved order.  The oracle (and the HIP kernels) restate that rule."""
+    import ctypes as C
+    lib = orc.lib()
+    lib.orc_outer_sum_rows.restype = C.c_float
+    lib.orc_outer_sum_rows.argtypes = [np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_int64, C.c_int]
+    g = torch.Generator().manual_seed(0)
+    for Cn, N in ((12, 1000), (20, 333), (40, 97), (12, 64)):
+        x = torch.rand(Cn, N, generator=g)
+        t = x.sum(0).numpy()
+        xn = x.numpy()
+        tail = (N // 32) * 32
+        mine = np.array([lib.orc_outer_sum_rows(np.ascontiguousarray(xn[:, j]), Cn, int(j >= tail)) for j in range(N)], np.float32)
+        assert np.array_equal(mine, t), (Cn, N)
+
+
+def test_phantom_is_deterministic():
+    from convexadam_amd.phantom import phantom, smooth_warp, label_phantom
+    a, b = phantom((16, 12, 20), 3, 7), phantom((16, 12, 20), 3, 7)
+    assert torch.equal(a, b) and a.shape == (16, 12, 20) and a.dtype == torch.float32
+    assert not torch.equal(a, phantom((16, 12, 20), 4, 7))
+    assert smooth_warp((8, 8, 8), 1).shape == (1, 8, 8, 8, 3)
+    assert label_phantom((8, 8, 8), 5, 1).max() <= 4
+
+
+def test_validate_image_mirrors_reference_errors():
+    from convexadam_amd.convex_adam_utils import validate_image
+    assert isinstance(validate_image(np.zeros((2, 2, 2), np.float32)), torch.Tensor)
+    t = torch.zeros(2, 2, 2)
+    assert validate_image(t) is t
+    with pytest.raises(ValueError):
+        validate_image("not an image")
+
+
+def test_shard_assignment():
+    from convexadam_amd.sweep import shard_items
+    items = list(range(10))
+    assert shard_items(items, 0, 1) == items
+    parts = [shard_items(items, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == items
+    assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert shard_items([], 1, 2) == []
+
+
+def test_sweep_grid_enumeration():
+    from convexadam_amd.sweep import sweep_settings
+    s = sweep_settings()
+    assert len(s) == 256 and len({tuple(sorted(d.items())) for d in s}) == 256
+    assert all(d["disp_hw"] <= 8 and d["grid_sp"] >= 2 for d in s)
+
+
+@pytest.mark.timeout(300)
+def test_sharded_driver_gloo_world_size_2(tmp_path):
+    """The N>1 path: one process per rank, items sharded with no data-path collective, results gathered on
+    rank 0.  Runs on CPU with the gloo backend and the driver's --dry-run mode (no kernels)."""
+    out = tmp_path / "res.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", os.path.join(ROOT, "convexadam_amd", "sweep.py"), "--dry-run", "--pairs", "5", "--settings", "3",
+           "--out", str(out)]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:]
+    import json
+    res = json.loads(out.read_text())
+    assert res["world_size"] == 2 and res["n_items"] == 15
+    assert sorted(res["items_done"]) == list(range(15))
+    assert sorted(len(v) for v in res["per_rank"].values()) == [7, 8]
