@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["api.hip", "mind.hip", "pool.hip", "correlate.hip", "convex.hip", "adam.hip", "pipeline.hip"]
 LIB = os.path.join(HERE, "libconvexadam_hip.so")
 OBJDIR = os.path.join(HERE, "build")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + HERE]
 
 

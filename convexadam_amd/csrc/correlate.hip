@@ -357,11 +357,8 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
         hipLaunchKernelGGL(k_corr_tail, dim3(cdiv(ntail * g.n, 64)), dim3(64), 0, s, fix, mov, g, tail_from, ntail, raw);
 
     const size_t lds = sizeof(float) * (size_t)(b.Tz + 4) * b.wy * b.dx;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr_box), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static size_t granted = 0;
+    ensure_dynamic_lds(&k_corr_box, lds, granted);
     hipLaunchKernelGGL(k_corr_box, dim3((unsigned)K, b.nslabs), dim3(BOX_NT), lds, s, raw, b, ssd);
     int rc = check_last("correlate");
     if (rc) return rc;

@@ -28,6 +28,16 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// opt in to more than 64 KiB of dynamic LDS for `kernel` (idempotent; never leaves a sticky error)
+template <typename KernelT>
+static inline void ensure_dynamic_lds(KernelT kernel, size_t bytes, size_t& granted) {
+    if (bytes > granted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipGetLastError();
+        granted = bytes;
+    }
+}
+
 // bump allocator over the caller's workspace (256-byte aligned carves)
 struct Carver {
     char* base;
@@ -48,7 +58,9 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 // IEEE correctly rounded division / sqrt (never the fast approximations)
 __device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
-__device__ __forceinline__ float fsqrt(float a) { return __fsqrt_rn(a); }
+// NB: HIP's __fsqrt_rn() maps to the APPROXIMATE native sqrt; sqrtf() is the correctly rounded one
+// (-fhip-fp32-correctly-rounded-divide-sqrt, on by default and passed explicitly by build.py).
+__device__ __forceinline__ float fsqrt(float a) { return sqrtf(a); }
 
 // exp(): SLEEF-style expf (Cody-Waite reduction, degree-6 FMA polynomial, two-step ldexp).
 // Bit-identical to oracle/cvx_oracle.c::orc_expf; <= 1 ulp from the reference's MKL vsExp.

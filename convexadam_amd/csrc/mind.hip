@@ -84,7 +84,7 @@ __global__ void k_mind_stats_finish(MindStats* st, double count) {
 
 // ---- the tiled stencil ---------------------------------------------------------------------------
 template <int R, int PASS>
-__global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int H, int W, int D, int dil,
+__global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int H, int W, int D, int dil, int nbuf,
                                               MindStats* __restrict__ st, float* __restrict__ out) {
     constexpr int K = 2 * R + 1;
     constexpr int SZ = TZ + 2 * R, SY = TY + 2 * R, SX = TX + 2 * R;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
     constexpr MindOffsets MO{};
 #pragma unroll
     for (int c = 0; c < 12; ++c) {          // fully unrolled: res[c][] must stay in registers
-        float* sq = ssq + (c & 1) * (SZ * SY * SXP);
+        float* sq = ssq + (c & (nbuf - 1)) * (SZ * SY * SXP);
         const int a1z = MO.o1[c][0] * dil, a1y = MO.o1[c][1] * dil, a1x = MO.o1[c][2] * dil;
         const int a2z = MO.o2[c][0] * dil, a2y = MO.o2[c][1] * dil, a2x = MO.o2[c][2] * dil;
         // squared differences on the tile grown by R; the box sees the clamped POSITION (rpad2),
@@ -150,7 +150,9 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
             }
 #pragma unroll
         for (int j = 0; j < RUN; ++j) res[c][j] = fdiv(s[j], (float)(K * K * K));
-        // double-buffered sq: the next channel writes the other buffer, so one barrier per channel
+        // double-buffered sq (nbuf = 2): the next channel writes the other buffer, one barrier per channel;
+        // large radius/dilation tiles only fit one buffer and need a second barrier
+        if (nbuf == 1) __syncthreads();
     }
 
     const int gz = z0 + tz, gy = y0 + ty;     // threads of an overhanging tile still join the reduction
@@ -224,27 +226,25 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
     }
 }
 
-static size_t mind_lds_bytes(int R, int dil) {
+static size_t mind_lds_bytes(int R, int dil, int nbuf) {
     const int halo = R + dil;
     const int IZ = TZ + 2 * halo, IY = TY + 2 * halo, IX = TX + 2 * halo;
     const int SZ = TZ + 2 * R, SY = TY + 2 * R, SX = TX + 2 * R, SXP = (SX + 3) / 4 * 4 + 4;
-    return sizeof(float) * ((size_t)((IZ * IY * IX + 3) / 4) * 4 + 2 * (size_t)SZ * SY * SXP);
+    return sizeof(float) * ((size_t)((IZ * IY * IX + 3) / 4) * 4 + (size_t)nbuf * SZ * SY * SXP);
 }
 
 template <int R>
 static int mind_launch_r(const float* img, int H, int W, int D, int dil, MindStats* st, float* out, hipStream_t s) {
     const dim3 grid(cdiv(D, TX), cdiv(W, TY), cdiv(H, TZ));
-    const size_t lds = mind_lds_bytes(R, dil);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mind<R, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mind<R, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    const int nbuf = mind_lds_bytes(R, dil, 2) <= 160 * 1024 ? 2 : 1;
+    const size_t lds = mind_lds_bytes(R, dil, nbuf);
+    static size_t granted0 = 0, granted1 = 0;
+    ensure_dynamic_lds(&k_mind<R, 0>, lds, granted0);
+    ensure_dynamic_lds(&k_mind<R, 1>, lds, granted1);
     const double count = (double)H * W * D;
-    hipLaunchKernelGGL((k_mind<R, 0>), grid, dim3(NT), lds, s, img, H, W, D, dil, st, out);
+    hipLaunchKernelGGL((k_mind<R, 0>), grid, dim3(NT), lds, s, img, H, W, D, dil, nbuf, st, out);
     hipLaunchKernelGGL(k_mind_stats_finish, dim3(1), dim3(1), 0, s, st, count);
-    hipLaunchKernelGGL((k_mind<R, 1>), grid, dim3(NT), lds, s, img, H, W, D, dil, st, out);
+    hipLaunchKernelGGL((k_mind<R, 1>), grid, dim3(NT), lds, s, img, H, W, D, dil, nbuf, st, out);
     return check_last("mindssc");
 }
 
@@ -265,7 +265,7 @@ extern "C" int cvx_mindssc_f32(const float* img, int H, int W, int D, int radius
     CVX_REQUIRE(dilation >= 1 && dilation <= 4, "cvx_mindssc_f32: dilation %d not in 1..4", dilation);
     if (workspace_bytes < cvx_mindssc_workspace_bytes(H, W, D, radius, dilation))
         return fail(CVX_ERR_WORKSPACE, "cvx_mindssc_f32: workspace too small");
-    if (mind_lds_bytes(radius, dilation) > 160 * 1024)
+    if (mind_lds_bytes(radius, dilation, 1) > 160 * 1024)
         return fail(CVX_ERR_UNSUPPORTED, "cvx_mindssc_f32: radius %d dilation %d exceeds the LDS tile", radius, dilation);
     hipStream_t s = as_stream(stream);
     Carver cv(workspace, workspace_bytes);
