@@ -19,10 +19,22 @@
 
 namespace cvx {
 
-__global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2, const float* __restrict__ M2, int C, int h,
-                                                   int w, int d, const float* __restrict__ U, const float* __restrict__ bh,
-                                                   const float* __restrict__ bw, const float* __restrict__ bd, float gsc,
-                                                   float cH, float cW, float cD, float* __restrict__ gU) {
+// channel-last copies of the pooled features: [C][V] -> [V][CP] (CP = C rounded up to 4, zero filled), so that
+// one trilinear corner is CP/4 contiguous 16-byte loads instead of C scattered 4-byte loads
+__global__ __launch_bounds__(256) void k_to_channel_last(const float* __restrict__ in, int C, int CP, size_t V,
+                                                         float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V * (size_t)CP) return;
+    const int c = (int)(i % CP);
+    const size_t p = i / CP;
+    out[i] = c < C ? in[(size_t)c * V + p] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2, const float* __restrict__ M2, int C, int CP,
+                                                   int h, int w, int d, const float* __restrict__ U,
+                                                   const float* __restrict__ bh, const float* __restrict__ bw,
+                                                   const float* __restrict__ bd, float gsc, float cH, float cW, float cD,
+                                                   float* __restrict__ gU) {
     const size_t V = (size_t)h * w * d;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= V) return;
@@ -33,37 +45,56 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
     tri_setup(t, bd[x] + fdiv(uD, sc2), bw[y] + fdiv(uW, sc1), bh[z] + fdiv(uH, sc0), h, w, d);
     const int x0 = t.x0, y0 = t.y0, z0 = t.z0, x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
     const float fx0 = (float)x0, fy0 = (float)y0, fz0 = (float)z0, fx1 = (float)x1, fy1 = (float)y1, fz1 = (float)z1;
-    const bool b000 = inb3(z0, y0, x0, h, w, d), b001 = inb3(z0, y0, x1, h, w, d), b010 = inb3(z0, y1, x0, h, w, d),
-               b011 = inb3(z0, y1, x1, h, w, d), b100 = inb3(z1, y0, x0, h, w, d), b101 = inb3(z1, y0, x1, h, w, d),
-               b110 = inb3(z1, y1, x0, h, w, d), b111 = inb3(z1, y1, x1, h, w, d);
-    const size_t i000 = ((size_t)z0 * w + y0) * d + x0, i001 = i000 + 1, i010 = i000 + d, i011 = i010 + 1,
-                 i100 = i000 + (size_t)w * d, i101 = i100 + 1, i110 = i100 + d, i111 = i110 + 1;
+    bool bnd[8];
+    bnd[0] = inb3(z0, y0, x0, h, w, d); bnd[1] = inb3(z0, y0, x1, h, w, d); bnd[2] = inb3(z0, y1, x0, h, w, d);
+    bnd[3] = inb3(z0, y1, x1, h, w, d); bnd[4] = inb3(z1, y0, x0, h, w, d); bnd[5] = inb3(z1, y0, x1, h, w, d);
+    bnd[6] = inb3(z1, y1, x0, h, w, d); bnd[7] = inb3(z1, y1, x1, h, w, d);
+    // Branch-free gathers: every corner is loaded from a clamped (always valid) address and replaced by 0 when it
+    // lies outside the volume.  ATen skips such corners; adding their exact-zero products instead is bit-identical
+    // here because the features and the trilinear factors are non-negative (products are +0, never -0).
+    const int zc0 = clampi(z0, 0, h - 1), zc1 = clampi(z1, 0, h - 1), yc0 = clampi(y0, 0, w - 1), yc1 = clampi(y1, 0, w - 1),
+              xc0 = clampi(x0, 0, d - 1), xc1 = clampi(x1, 0, d - 1);
+    size_t addr[8];
+    addr[0] = ((size_t)zc0 * w + yc0) * d + xc0; addr[1] = ((size_t)zc0 * w + yc0) * d + xc1;
+    addr[2] = ((size_t)zc0 * w + yc1) * d + xc0; addr[3] = ((size_t)zc0 * w + yc1) * d + xc1;
+    addr[4] = ((size_t)zc1 * w + yc0) * d + xc0; addr[5] = ((size_t)zc1 * w + yc0) * d + xc1;
+    addr[6] = ((size_t)zc1 * w + yc1) * d + xc0; addr[7] = ((size_t)zc1 * w + yc1) * d + xc1;
+    // forward weights in ATen's corner order and the backward factor pairs per corner (GridSampler.cpp)
+    const float wgt[8] = {t.tnw, t.tne, t.tsw, t.tse, t.bnw, t.bne, t.bsw, t.bse};
+    const float ax[8] = {fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0, fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0};
+    const float bx[8] = {fz1 - t.iz, fz1 - t.iz, fz1 - t.iz, fz1 - t.iz, t.iz - fz0, t.iz - fz0, t.iz - fz0, t.iz - fz0};
+    const float ay[8] = {fx1 - t.ix, t.ix - fx0, fx1 - t.ix, t.ix - fx0, fx1 - t.ix, t.ix - fx0, fx1 - t.ix, t.ix - fx0};
+    const float bz[8] = {fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0, fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0};
     float gix = 0.f, giy = 0.f, giz = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float* mv = M2 + (size_t)c * V;
-        const float v000 = b000 ? mv[i000] : 0.f, v001 = b001 ? mv[i001] : 0.f, v010 = b010 ? mv[i010] : 0.f,
-                    v011 = b011 ? mv[i011] : 0.f, v100 = b100 ? mv[i100] : 0.f, v101 = b101 ? mv[i101] : 0.f,
-                    v110 = b110 ? mv[i110] : 0.f, v111 = b111 ? mv[i111] : 0.f;
-        // forward sample, corners accumulated in ATen order (skipped corners add nothing)
-        float wv = 0.0f;
-        if (b000) wv += v000 * t.tnw;
-        if (b001) wv += v001 * t.tne;
-        if (b010) wv += v010 * t.tsw;
-        if (b011) wv += v011 * t.tse;
-        if (b100) wv += v100 * t.bnw;
-        if (b101) wv += v101 * t.bne;
-        if (b110) wv += v110 * t.bsw;
-        if (b111) wv += v111 * t.bse;
-        const float df = wv - F2[(size_t)c * V + p];
-        const float gOut = gsc * (2.0f * df);                      // PowBackward0: grad * (2 * self)
-        if (b000) { gix -= v000 * (fy1 - t.iy) * (fz1 - t.iz) * gOut; giy -= v000 * (fx1 - t.ix) * (fz1 - t.iz) * gOut; giz -= v000 * (fx1 - t.ix) * (fy1 - t.iy) * gOut; }
-        if (b001) { gix += v001 * (fy1 - t.iy) * (fz1 - t.iz) * gOut; giy -= v001 * (t.ix - fx0) * (fz1 - t.iz) * gOut; giz -= v001 * (t.ix - fx0) * (fy1 - t.iy) * gOut; }
-        if (b010) { gix -= v010 * (t.iy - fy0) * (fz1 - t.iz) * gOut; giy += v010 * (fx1 - t.ix) * (fz1 - t.iz) * gOut; giz -= v010 * (fx1 - t.ix) * (t.iy - fy0) * gOut; }
-        if (b011) { gix += v011 * (t.iy - fy0) * (fz1 - t.iz) * gOut; giy += v011 * (t.ix - fx0) * (fz1 - t.iz) * gOut; giz -= v011 * (t.ix - fx0) * (t.iy - fy0) * gOut; }
-        if (b100) { gix -= v100 * (fy1 - t.iy) * (t.iz - fz0) * gOut; giy -= v100 * (fx1 - t.ix) * (t.iz - fz0) * gOut; giz += v100 * (fx1 - t.ix) * (fy1 - t.iy) * gOut; }
-        if (b101) { gix += v101 * (fy1 - t.iy) * (t.iz - fz0) * gOut; giy -= v101 * (t.ix - fx0) * (t.iz - fz0) * gOut; giz += v101 * (t.ix - fx0) * (fy1 - t.iy) * gOut; }
-        if (b110) { gix -= v110 * (t.iy - fy0) * (t.iz - fz0) * gOut; giy += v110 * (fx1 - t.ix) * (t.iz - fz0) * gOut; giz += v110 * (fx1 - t.ix) * (t.iy - fy0) * gOut; }
-        if (b111) { gix += v111 * (t.iy - fy0) * (t.iz - fz0) * gOut; giy += v111 * (t.ix - fx0) * (t.iz - fz0) * gOut; giz += v111 * (t.ix - fx0) * (t.iy - fy0) * gOut; }
+    const float4* Fv = reinterpret_cast<const float4*>(F2 + p * (size_t)CP);
+    for (int c4 = 0; c4 < CP / 4; ++c4) {
+        float vals[8][4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 q = *reinterpret_cast<const float4*>(M2 + addr[k] * CP + 4 * c4);
+            vals[k][0] = bnd[k] ? q.x : 0.f; vals[k][1] = bnd[k] ? q.y : 0.f;
+            vals[k][2] = bnd[k] ? q.z : 0.f; vals[k][3] = bnd[k] ? q.w : 0.f;
+        }
+        const float4 fq = Fv[c4];
+        const float fv[4] = {fq.x, fq.y, fq.z, fq.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // channels beyond C are zero-padded in both volumes: df = 0, gOut = 0, all updates are exact no-ops
+            float wv = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wv += vals[k][j] * wgt[k];
+            const float df = wv - fv[j];
+            const float gOut = gsc * (2.0f * df);                    // PowBackward0: grad * (2 * self)
+            // corner order tnw,tne,tsw,tse,bnw,bne,bsw,bse ; signs from GridSampler.cpp
+            gix -= vals[0][j] * ax[0] * bx[0] * gOut; giy -= vals[0][j] * ay[0] * bx[0] * gOut; giz -= vals[0][j] * ay[0] * bz[0] * gOut;
+            gix += vals[1][j] * ax[1] * bx[1] * gOut; giy -= vals[1][j] * ay[1] * bx[1] * gOut; giz -= vals[1][j] * ay[1] * bz[1] * gOut;
+            gix -= vals[2][j] * ax[2] * bx[2] * gOut; giy += vals[2][j] * ay[2] * bx[2] * gOut; giz -= vals[2][j] * ay[2] * bz[2] * gOut;
+            gix += vals[3][j] * ax[3] * bx[3] * gOut; giy += vals[3][j] * ay[3] * bx[3] * gOut; giz -= vals[3][j] * ay[3] * bz[3] * gOut;
+            gix -= vals[4][j] * ax[4] * bx[4] * gOut; giy -= vals[4][j] * ay[4] * bx[4] * gOut; giz += vals[4][j] * ay[4] * bz[4] * gOut;
+            gix += vals[5][j] * ax[5] * bx[5] * gOut; giy -= vals[5][j] * ay[5] * bx[5] * gOut; giz += vals[5][j] * ay[5] * bz[5] * gOut;
+            gix -= vals[6][j] * ax[6] * bx[6] * gOut; giy += vals[6][j] * ay[6] * bx[6] * gOut; giz += vals[6][j] * ay[6] * bz[6] * gOut;
+            gix += vals[7][j] * ax[7] * bx[7] * gOut; giy += vals[7][j] * ay[7] * bx[7] * gOut; giz += vals[7][j] * ay[7] * bz[7] * gOut;
+        }
     }
     // grad wrt the normalised grid (x,y,z) = (size/2)*gi ; flip ; / scale -> grad wrt U (H,W,D)
     float g[3];
@@ -86,20 +117,137 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
     }
 }
 
-__global__ __launch_bounds__(256) void k_adam_update(const float* __restrict__ G, float* __restrict__ P, float* __restrict__ m,
-                                                     float* __restrict__ v, size_t n, float w1, float b2, float omb2,
-                                                     float bc2s, float neg_step) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float g = G[i];
-    const float mo = m[i];
-    const float mm = __builtin_fmaf(w1, g - mo, mo);          // exp_avg.lerp_(grad, 1-beta1)
-    float vv = v[i] * b2;                                      // exp_avg_sq.mul_(beta2)
-    vv = __builtin_fmaf(omb2 * g, g, vv);                      // .addcmul_(grad, grad, value=1-beta2)
-    const float den = fdiv(fsqrt(vv), bc2s) + 1e-8f;           // (sqrt / bias_correction2_sqrt).add_(eps)
-    P[i] = P[i] + fdiv(neg_step * mm, den);                    // addcdiv_(exp_avg, denom, value=-step_size)
-    m[i] = mm;
-    v[i] = vv;
+// ---- three chained 3^3 box filters in one launch ---------------------------------------------------------
+// One workgroup = one channel x one 8x8x32 output tile.  The input tile (+3 halo in z,y; columns x0-4..x0+35
+// so that global loads are aligned float4) is staged in LDS; the three passes shrink the region by one voxel
+// each in z,y (14 -> 12 -> 10 -> 8 rows); along x every pass evaluates the 40 staged columns in aligned runs of
+// 4 (the outermost columns of a pass are don't-care values that never reach a needed output).  Every
+// intermediate is zero outside the VOLUME (each avg_pool3d zero-pads its own input).
+//   forward  (ATen avg_pool3d):           out = (raster sum of 27 taps) / 27            at every pass
+//   backward (ATen avg_pool3d_backward):  out = raster sum of (tap / 27): taps are divided once when they
+//                                          are staged, the last pass stores the plain sum
+// With ADAM the last backward pass applies the Adam update to P, m, v in place instead of storing G.
+// LDS column of volume coordinate x is (x - x0 + 8); row pitch 48 floats (16-byte aligned runs).
+constexpr int BT_Z = 8, BT_Y = 8, BT_X = 32, BT_NT = 512, BT_PX = 48;
+struct AdamConsts { float w1, b2, omb2, bc2s, neg_step; };
+
+// One pass.  A wavefront handles 6 rows x 10 aligned runs of 4 columns (lanes 60..63 idle): each lane issues ONE
+// conflict-free ds_read_b128 per tap row and gets the two neighbouring columns (c-1, c+4) from the adjacent
+// lanes' registers; at the ends of a row those neighbours are the don't-care columns 3 / 44.
+template <bool LAST, bool BACKWARD, bool ADAM>
+__device__ __forceinline__ void box_pass(const float* __restrict__ src, int sy, float* __restrict__ dst, int dz, int dy,
+                                         int gz0, int gy0, int x0, int h, int w, int d, float* __restrict__ gout,
+                                         float* __restrict__ P, float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
+                                         float* __restrict__ gsave) {
+    constexpr int NRUN = (BT_X + 8) / 4, RPW = 64 / NRUN;           // 10 runs per row, 6 rows per wavefront
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nrows = dz * dy, ngroups = (nrows + RPW - 1) / RPW;
+    const int xr = lane % NRUN, rsub = lane / NRUN;
+    const int col = 4 + 4 * xr;
+    for (int g = wave; g < ngroups; g += BT_NT / 64) {
+        const int rowid = g * RPW + rsub;
+        const bool active = rsub < RPW && rowid < nrows;
+        const int rid = active ? rowid : 0;
+        const int y = rid % dy, z = rid / dy;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const f32x4 q = lds_load4(src + ((z + a) * sy + (y + b)) * BT_PX + col);
+                const float lft = lane_prev(q.w), rgt = lane_next(q.x);
+                s[0] += lft; s[0] += q.x; s[0] += q.y;
+                s[1] += q.x; s[1] += q.y; s[1] += q.z;
+                s[2] += q.y; s[2] += q.z; s[2] += q.w;
+                s[3] += q.z; s[3] += q.w; s[3] += rgt;
+            }
+        if (!active) continue;
+        const int gz = gz0 + z, gy = gy0 + y, gx = x0 - 8 + col;
+        const bool rowin = gz >= 0 && gz < h && gy >= 0 && gy < w;
+        if (!LAST) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (rowin && gx + j >= 0 && gx + j < d) ? fdiv(s[j], 27.0f) : 0.0f;
+            lds_store4(dst + (z * dy + y) * BT_PX + col, f32x4{o[0], o[1], o[2], o[3]});
+        } else if (rowin && xr >= 1 && xr <= BT_X / 4) {           // columns 8..39 are the output tile
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (gx + j >= d) break;
+                const size_t i = ((size_t)gz * w + gy) * d + gx + j;
+                if (!BACKWARD) gout[i] = fdiv(s[j], 27.0f);
+                else if (!ADAM) gout[i] = s[j];
+                else {
+                    const float g = s[j];
+                    const float mo = m[i];
+                    const float mm = __builtin_fmaf(ac.w1, g - mo, mo);          // exp_avg.lerp_(grad, 1-beta1)
+                    float vv = v[i] * ac.b2;                                      // exp_avg_sq.mul_(beta2)
+                    vv = __builtin_fmaf(ac.omb2 * g, g, vv);                      // .addcmul_(grad, grad, value=1-beta2)
+                    const float den = fdiv(fsqrt(vv), ac.bc2s) + 1e-8f;           // (sqrt / bias_correction2_sqrt).add_(eps)
+                    P[i] = P[i] + fdiv(ac.neg_step * mm, den);                    // addcdiv_(exp_avg, denom, value=-step_size)
+                    m[i] = mm;
+                    v[i] = vv;
+                    if (gsave) gsave[i] = g;
+                }
+            }
+        }
+    }
+}
+
+template <bool BACKWARD, bool ADAM>
+__global__ __launch_bounds__(BT_NT) void k_box3x3(const float* __restrict__ in, float* __restrict__ out, int h, int w, int d,
+                                                  float* __restrict__ P, float* __restrict__ m, float* __restrict__ v,
+                                                  AdamConsts ac, float* __restrict__ gsave) {
+    __shared__ __attribute__((aligned(16))) float A[(BT_Z + 6) * (BT_Y + 6) * BT_PX];
+    __shared__ __attribute__((aligned(16))) float B[(BT_Z + 4) * (BT_Y + 4) * BT_PX];
+    const int ntx = (d + BT_X - 1) / BT_X, nty = (w + BT_Y - 1) / BT_Y, ntz = (h + BT_Z - 1) / BT_Z;
+    int b = blockIdx.x;
+    const int tx = b % ntx; b /= ntx;
+    const int ty = b % nty; b /= nty;
+    const int tz = b % ntz; const int c = b / ntz;
+    const int x0 = tx * BT_X, y0 = ty * BT_Y, z0 = tz * BT_Z;
+    const size_t V = (size_t)h * w * d;
+    const float* ic = in + (size_t)c * V;
+    // stage columns x0-4 .. x0+35 (LDS columns 4..43) of rows z0-3.., y0-3..; zero outside the volume
+    constexpr int AZ = BT_Z + 6, AY = BT_Y + 6, NCH = (BT_X + 8) / 4;
+    const bool vec = (d & 3) == 0;
+    for (int i = threadIdx.x; i < AZ * AY * NCH; i += BT_NT) {
+        const int ch = i % NCH, y = (i / NCH) % AY, z = i / (NCH * AY);
+        const int gz = z0 - 3 + z, gy = y0 - 3 + y, gx = x0 - 4 + 4 * ch;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gz >= 0 && gz < h && gy >= 0 && gy < w) {
+            const float* rowp = ic + ((size_t)gz * w + gy) * d;
+            if (vec && gx >= 0 && gx + 3 < d) q = *reinterpret_cast<const float4*>(rowp + gx);
+            else {
+                if (gx >= 0 && gx < d) q.x = rowp[gx];
+                if (gx + 1 >= 0 && gx + 1 < d) q.y = rowp[gx + 1];
+                if (gx + 2 >= 0 && gx + 2 < d) q.z = rowp[gx + 2];
+                if (gx + 3 >= 0 && gx + 3 < d) q.w = rowp[gx + 3];
+            }
+            if (BACKWARD) { q.x = fdiv(q.x, 27.0f); q.y = fdiv(q.y, 27.0f); q.z = fdiv(q.z, 27.0f); q.w = fdiv(q.w, 27.0f); }
+        }
+        *reinterpret_cast<float4*>(A + (z * AY + y) * BT_PX + 4 + 4 * ch) = q;
+    }
+    __syncthreads();
+    float* oc = out ? out + (size_t)c * V : nullptr;
+    float* Pc = P ? P + (size_t)c * V : nullptr;
+    float* mc = m ? m + (size_t)c * V : nullptr;
+    float* vc = v ? v + (size_t)c * V : nullptr;
+    float* gs = gsave ? gsave + (size_t)c * V : nullptr;
+    // pass 1: A (14x14 rows) -> B (12x12 rows), columns 4..43 ; pass 2: B -> A (10x10 rows) ; pass 3: A -> tile (cols 8..39)
+    box_pass<false, BACKWARD, ADAM>(A, AY, B, BT_Z + 4, BT_Y + 4, z0 - 2, y0 - 2, x0, h, w, d, nullptr, nullptr, nullptr, nullptr, ac, nullptr);
+    __syncthreads();
+    box_pass<false, BACKWARD, ADAM>(B, BT_Y + 4, A, BT_Z + 2, BT_Y + 2, z0 - 1, y0 - 1, x0, h, w, d, nullptr, nullptr, nullptr, nullptr, ac, nullptr);
+    __syncthreads();
+    box_pass<true, BACKWARD, ADAM>(A, BT_Y + 2, nullptr, BT_Z, BT_Y, z0, y0, x0, h, w, d, oc, Pc, mc, vc, ac, gs);
+}
+
+static int launch_box3x3(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
+                         AdamConsts ac, float* gsave, hipStream_t s) {
+    const int nb = cdiv(d, BT_X) * cdiv(w, BT_Y) * cdiv(h, BT_Z) * 3;
+    if (!backward) hipLaunchKernelGGL((k_box3x3<false, false>), dim3(nb), dim3(BT_NT), 0, s, in, out, h, w, d, P, m, v, ac, gsave);
+    else if (!P) hipLaunchKernelGGL((k_box3x3<true, false>), dim3(nb), dim3(BT_NT), 0, s, in, out, h, w, d, P, m, v, ac, gsave);
+    else hipLaunchKernelGGL((k_box3x3<true, true>), dim3(nb), dim3(BT_NT), 0, s, in, out, h, w, d, P, m, v, ac, gsave);
+    return check_last("box3x3");
 }
 
 }  // namespace cvx
@@ -107,8 +255,8 @@ __global__ __launch_bounds__(256) void k_adam_update(const float* __restrict__ G
 using namespace cvx;
 
 extern "C" size_t cvx_adam_workspace_bytes(int C, int h, int w, int d) {
-    (void)C;
-    return 3 * (256 + sizeof(float) * 3 * (size_t)h * w * d) + 256;
+    const size_t V = (size_t)h * w * d, CP = (size_t)(C + 3) / 4 * 4;
+    return (256 + sizeof(float) * 3 * V) + 2 * (256 + sizeof(float) * CP * V) + 256;
 }
 
 extern "C" int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
@@ -125,37 +273,37 @@ extern "C" int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, 
     hipStream_t s = as_stream(stream);
     const size_t V = (size_t)h * w * d;
     Carver cv(workspace, workspace_bytes);
-    float* t1 = cv.take<float>(3 * V);
-    float* t2 = cv.take<float>(3 * V);
     float* gU = cv.take<float>(3 * V);
+    const int CP = (C + 3) / 4 * 4;
+    float* Fcl = cv.take<float>((size_t)CP * V);
+    float* Mcl = cv.take<float>((size_t)CP * V);
+    if (niter > 0) {
+        const dim3 gt((unsigned)cdiv64((int64_t)(V * CP), 256));
+        hipLaunchKernelGGL(k_to_channel_last, gt, dim3(256), 0, s, F2, C, CP, V, Fcl);
+        hipLaunchKernelGGL(k_to_channel_last, gt, dim3(256), 0, s, M2, C, CP, V, Mcl);
+    }
 
     // MeanBackward of lambda*mean(diff^2): lambda / N_axis in float32                       (:167-169)
     const float nH = (float)((int64_t)3 * (h - 1) * w * d), nW = (float)((int64_t)3 * h * (w - 1) * d),
                 nD = (float)((int64_t)3 * h * w * (d - 1));
     const float cH = lambda_weight / nH, cW = lambda_weight / nW, cD = lambda_weight / nD;
     const float gsc = ((1.0f / (float)V) * cost_scale) / (float)C;     // MeanBackward, MulBackward, MeanBackward
-    const dim3 gv((unsigned)cdiv64((int64_t)V, 256)), g3((unsigned)cdiv64((int64_t)(3 * V), 256));
+    const dim3 gv((unsigned)cdiv64((int64_t)V, 256));
     int snap = 0;
     for (int it = 0; it < niter; ++it) {
         int rc;
-        if ((rc = launch_box_zero(P, t1, 3, h, w, d, 3, false, s))) return rc;
-        if ((rc = launch_box_zero(t1, t2, 3, h, w, d, 3, false, s))) return rc;
-        if ((rc = launch_box_zero(t2, U, 3, h, w, d, 3, false, s))) return rc;
-        hipLaunchKernelGGL(k_warp_grad, gv, dim3(256), 0, s, F2, M2, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
-        if ((rc = launch_box_zero(gU, t1, 3, h, w, d, 3, true, s))) return rc;
-        if ((rc = launch_box_zero(t1, t2, 3, h, w, d, 3, true, s))) return rc;
-        if ((rc = launch_box_zero(t2, t1, 3, h, w, d, 3, true, s))) return rc;
         const int step = step0 + it + 1;
         const double beta1 = 0.9, beta2 = 0.999;
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-        hipLaunchKernelGGL(k_adam_update, g3, dim3(256), 0, s, t1, P, m, v, 3 * V, (float)(1.0 - beta1), (float)beta2,
-                           (float)(1.0 - beta2), (float)sqrt(bc2), (float)(-(1.0 / bc1)));
+        const AdamConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)(-(1.0 / bc1))};
+        if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc;
+        hipLaunchKernelGGL(k_warp_grad, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
+        float* gsave = (grad_out && it == niter - 1) ? grad_out : nullptr;
+        if ((rc = launch_box3x3(gU, nullptr, h, w, d, true, P, m, v, ac, gsave, s))) return rc;
         while (snap < n_snap && snapshot_iters_host[snap] == it + 1) {
             (void)hipMemcpyAsync(snapshots + (size_t)snap * 3 * V, U, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice, s);
             ++snap;
         }
-        if (grad_out && it == niter - 1)
-            (void)hipMemcpyAsync(grad_out, t1, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice, s);
     }
     return check_last("adam_run");
 }

@@ -161,35 +161,35 @@ __global__ void k_corr_tail(const float* __restrict__ fix, const float* __restri
 }
 
 // ---- two box filters per (k, z-slab) in LDS ------------------------------------------------------------
-constexpr int BOX_NT = 512, BOX_MAXR = 8;
+// A wavefront handles RPW rows x rp aligned runs of 4 columns (rp = dp/4 <= 64, RPW = 64/rp, the remaining lanes
+// idle): one conflict-free ds_read_b128 per tap row per lane, the two neighbouring columns come from the
+// adjacent lanes' registers (DPP wave shift); at the two ends of a row they are the zero border.
+constexpr int BOX_NT = 512, BOX_NW = BOX_NT / 64, BOX_MAXG = 8;
 
 struct BoxGeom {
-    int h, w, d, dp;
+    int h, w, d, dp, rp, rpw;
     int Tz, nslabs;
     int wy;     // w + 2
     int dx;     // dp + 8 : element x lives at index x + 4
 };
 
-__device__ __forceinline__ void box_run(const float* __restrict__ lds, const BoxGeom& b, int p, int y, int x0, float (&s)[4]) {
-    // 27-tap raster order around (plane slot p, row y, columns x0..x0+3); taps outside the volume are stored zeros
+__device__ __forceinline__ void box_run(const float* __restrict__ lds, const BoxGeom& b, int p, int y, int xr, float (&s)[4]) {
+    // 27-tap raster order around (plane slot p, row y, columns 4*xr .. 4*xr+3); taps outside the volume are zeros
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = 0.0f;
+    const bool first = xr == 0, last = xr == b.rp - 1;
 #pragma unroll
     for (int a = -1; a <= 1; ++a)
 #pragma unroll
         for (int bb = -1; bb <= 1; ++bb) {
-            const float* row = lds + ((size_t)(p + a) * b.wy + (y + 1 + bb)) * b.dx + x0 + 3;
-            float v[6];
-            v[0] = row[0];
-            const float4 q = *reinterpret_cast<const float4*>(row + 1);
-            v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w;
-            v[5] = row[5];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s[j] += v[j];
-                s[j] += v[j + 1];
-                s[j] += v[j + 2];
-            }
+            const f32x4 q = lds_load4(lds + ((size_t)(p + a) * b.wy + (y + 1 + bb)) * b.dx + 4 * xr + 4);
+            float lft = lane_prev(q.w), rgt = lane_next(q.x);
+            lft = first ? 0.0f : lft;
+            rgt = last ? 0.0f : rgt;
+            s[0] += lft; s[0] += q.x; s[0] += q.y;
+            s[1] += q.x; s[1] += q.y; s[1] += q.z;
+            s[2] += q.y; s[2] += q.z; s[2] += q.w;
+            s[3] += q.z; s[3] += q.w; s[3] += rgt;
         }
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = fdiv(s[j], 27.0f);
@@ -197,7 +197,7 @@ __device__ __forceinline__ void box_run(const float* __restrict__ lds, const Box
 
 __global__ __launch_bounds__(BOX_NT) void k_corr_box(const float* __restrict__ raw, BoxGeom b, float* __restrict__ ssd) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = blockIdx.x, slab = blockIdx.y;
     const int z0 = slab * b.Tz;
     const int tz = min(b.Tz, b.h - z0);               // output planes of this slab
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(BOX_NT) void k_corr_box(const float* __restrict__ r
         *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     const int zlo = max(z0 - 2, 0), zhi = min(z0 + tz + 2, b.h);     // [zlo, zhi)
-    const int rp = b.dp / 4;
+    const int rp = b.rp;
     const int ncopy = (zhi - zlo) * b.w * rp;
     for (int i = tid; i < ncopy; i += BOX_NT) {
         const int xr = i % rp, y = (i / rp) % b.w, z = zlo + i / (rp * b.w);
@@ -227,32 +227,34 @@ __global__ __launch_bounds__(BOX_NT) void k_corr_box(const float* __restrict__ r
     }
     __syncthreads();
 
+    const int xr = lane % rp, rsub = lane / rp;
+    const bool lane_ok = rsub < b.rpw;
     // 2. first box on planes [z0-1, z0+tz+1) ∩ volume -> registers
     const int b1lo = max(z0 - 1, 0), b1hi = min(z0 + tz + 1, b.h);
-    const int nr1 = (b1hi - b1lo) * b.w * rp;
-    float keep[BOX_MAXR][4];
+    const int rows1 = (b1hi - b1lo) * b.w;
+    float keep[BOX_MAXG][4];
 #pragma unroll
-    for (int i = 0; i < BOX_MAXR; ++i) {
-        const int r = tid + i * BOX_NT;
-        if (r < nr1) {
-            const int xr = r % rp, y = (r / rp) % b.w, z = b1lo + r / (rp * b.w);
-            box_run(lds, b, z - (z0 - 2), y, 4 * xr, keep[i]);
+    for (int i = 0; i < BOX_MAXG; ++i) {
+        const int row = (wave + i * BOX_NW) * b.rpw + rsub;
+        if ((wave + i * BOX_NW) * b.rpw < rows1) {                       // wave-uniform: all lanes take part in the shifts
+            const int rr = (lane_ok && row < rows1) ? row : 0;
+            box_run(lds, b, b1lo + rr / b.w - (z0 - 2), rr % b.w, xr, keep[i]);
         }
     }
     __syncthreads();
     // 3. in place: the second pool sees box1 only inside the volume (zeros elsewhere)
 #pragma unroll
-    for (int i = 0; i < BOX_MAXR; ++i) {
-        const int r = tid + i * BOX_NT;
-        if (r < nr1) {
-            const int xr = r % rp, y = (r / rp) % b.w, z = b1lo + r / (rp * b.w);
+    for (int i = 0; i < BOX_MAXG; ++i) {
+        const int row = (wave + i * BOX_NW) * b.rpw + rsub;
+        if (lane_ok && row < rows1) {
+            const int y = row % b.w, z = b1lo + row / b.w;
             const int x = 4 * xr;
-            float4 v = make_float4(keep[i][0], keep[i][1], keep[i][2], keep[i][3]);
+            f32x4 v = {keep[i][0], keep[i][1], keep[i][2], keep[i][3]};
             if (x + 0 >= b.d) v.x = 0.f;
             if (x + 1 >= b.d) v.y = 0.f;
             if (x + 2 >= b.d) v.z = 0.f;
             if (x + 3 >= b.d) v.w = 0.f;
-            *reinterpret_cast<float4*>(lds + ((size_t)(z - (z0 - 2)) * b.wy + (y + 1)) * b.dx + x + 4) = v;
+            lds_store4(lds + ((size_t)(z - (z0 - 2)) * b.wy + (y + 1)) * b.dx + x + 4, v);
         }
     }
     // slots of planes z0-2 and z0+tz+1 still hold raw values, but the second box only reads
@@ -260,19 +262,23 @@ __global__ __launch_bounds__(BOX_NT) void k_corr_box(const float* __restrict__ r
     __syncthreads();
 
     // 4. second box on planes [z0, z0+tz) -> global
-    const int nr2 = tz * b.w * rp;
+    const int rows2 = tz * b.w;
     float* ok = ssd + (size_t)k * ((size_t)b.h * b.w * b.d);
 #pragma unroll
-    for (int i = 0; i < BOX_MAXR; ++i) {
-        const int r = tid + i * BOX_NT;
-        if (r < nr2) {
-            const int xr = r % rp, y = (r / rp) % b.w, z = z0 + r / (rp * b.w);
+    for (int i = 0; i < BOX_MAXG; ++i) {
+        const int row = (wave + i * BOX_NW) * b.rpw + rsub;
+        if ((wave + i * BOX_NW) * b.rpw < rows2) {
+            const bool act = lane_ok && row < rows2;
+            const int rr = act ? row : 0;
+            const int y = rr % b.w, z = z0 + rr / b.w;
             float s[4];
-            box_run(lds, b, z - (z0 - 2), y, 4 * xr, s);
-            float* dst = ok + ((size_t)z * b.w + y) * b.d + 4 * xr;
+            box_run(lds, b, z - (z0 - 2), y, xr, s);
+            if (act) {
+                float* dst = ok + ((size_t)z * b.w + y) * b.d + 4 * xr;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (4 * xr + j < b.d) dst[j] = s[j];
+                for (int j = 0; j < 4; ++j)
+                    if (4 * xr + j < b.d) dst[j] = s[j];
+            }
         }
     }
 }
@@ -280,15 +286,19 @@ __global__ __launch_bounds__(BOX_NT) void k_corr_box(const float* __restrict__ r
 static BoxGeom box_geom(int h, int w, int d) {
     BoxGeom b;
     b.h = h; b.w = w; b.d = d; b.dp = (d + 3) / 4 * 4;
+    b.rp = b.dp / 4;
     b.wy = w + 2; b.dx = b.dp + 8;
+    b.Tz = 0; b.nslabs = 0;
+    if (b.rp > 64) return b;                                           // rows longer than a wavefront: not built
+    b.rpw = 64 / b.rp;
     const size_t plane_bytes = sizeof(float) * (size_t)b.wy * b.dx;
-    const int runs_per_plane = w * (b.dp / 4);
     int tz_lds = (int)((72 * 1024) / plane_bytes) - 4;                 // two workgroups per CU
     if (tz_lds < 1) tz_lds = (int)((156 * 1024) / plane_bytes) - 4;    // large planes: one workgroup per CU
-    int tz_reg = (BOX_NT * BOX_MAXR) / runs_per_plane - 2;
+    const int max_rows = BOX_NW * BOX_MAXG * b.rpw;                    // rows of the first box one workgroup can hold
+    int tz_reg = max_rows / w - 2;
     int tzmax = tz_lds < tz_reg ? tz_lds : tz_reg;
     if (tzmax > h) tzmax = h;
-    if (tzmax < 1) { b.Tz = 0; b.nslabs = 0; return b; }               // plane too large for this kernel
+    if (tzmax < 1) return b;                                           // plane too large for this kernel
     b.nslabs = cdiv(h, tzmax);
     b.Tz = cdiv(h, b.nslabs);
     b.nslabs = cdiv(h, b.Tz);

@@ -86,6 +86,22 @@ __device__ __forceinline__ float cvx_expf(float d) {
     return u;
 }
 
+// 16-byte LDS/global vector access that the compiler must keep as ONE b128 instruction: hipcc otherwise
+// re-splits an aligned float4 LDS load into two ds_read2_b32 (4-way bank conflicts for 16-byte lane strides).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+__device__ __forceinline__ f32x4 lds_load4(const float* p) { return *(const volatile lds_f32x4*)p; }   // p must point into LDS
+__device__ __forceinline__ void lds_store4(float* p, f32x4 v) { *(volatile lds_f32x4*)p = v; }
+
+// value of the previous / next lane of the wavefront (DPP wave shift: pure VALU, no LDS traffic, and the
+// compiler folds it into the consuming v_add_f32).  Lane 0 / lane 63 receive their own value.
+__device__ __forceinline__ float lane_prev(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
 // ATen outer-dimension sum order over `n` values held in registers (see oracle outer_sum_rows):
 // plain sequential cascade (level step 16) or, for the last (ncols mod 32) columns, the 4-way
 // interleaved `row_sum` order.  n is a compile-time constant at every call site that matters.
