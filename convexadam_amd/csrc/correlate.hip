@@ -4,70 +4,73 @@
 //   ssd      = box3(box3(raw))                                 zero pad, raster-order 27-tap sums, /27
 //   k        = (dD+hw)*n^2 + (dW+hw)*n + (dH+hw),  n = 2*hw+1
 //
-// Data flow (all float32, D fastest):
-//   k_corr_prep : F -> Fp [C][h][w][dp]  (rows padded to a multiple of 4 floats)
-//                 M -> Mp [C][h+2hw][w+2hw][dq] zero border of hw voxels (no bounds checks later)
-//   k_corr_raw  : one thread = one run of 4 voxels along D x ALL n D-shifts of one (dH,dW) pair;
-//                 per channel it loads 1 float4 of F and (2*PL+4)/4 float4 of the M row and updates
-//                 4*n accumulators in registers in channel order (the reference's `.sum(0)` order,
-//                 incl. ATen's 16-wide cascade for C >= 16).  Writes raw [K][h][w][dp].
-//   k_corr_tail : re-evaluates the <= 31 trailing elements per H-shift whose channel sum ATen
-//                 evaluates in its 4-way interleaved order (see oracle outer_sum_rows).
-//   k_corr_box  : one workgroup per (k, z-slab): slab (+2 halo planes each side) staged in LDS with
-//                 zero borders, box -> registers -> LDS in place -> box -> global ssd [K][h][w][d].
-// Roofline: HBM; algorithmic bytes = K*v*4 written + 2*C*v*4 read; the raw
-// intermediate adds 2*K*v*4 of traffic that stays largely in the 256 MiB Infinity Cache.
+// Data flow (all float32, D fastest; "px" rows hold element x at index x+1, zero elsewhere):
+//   k_corr_prep : F -> Fp [C][h][w][px]        M -> Mp [C][h+2hw][w+2hw][dq]  zero border of hw voxels
+//   k_corr_raw  : one thread = one aligned run of 4 row indices x ALL n D-shifts of one (dH,dW) pair; per
+//                 channel it loads 1 float4 of F and (2*PL+4)/4 float4 of the M row and updates 4*n
+//                 accumulators in registers in channel order (the reference's `.sum(0)` order, incl. ATen's
+//                 16-wide cascade for C >= 16).  Writes raw [K][h][w][px] with exact zeros on the borders.
+//   k_corr_tail : re-evaluates the <= 31 trailing elements per H-shift whose channel sum ATen evaluates in
+//                 its 4-way interleaved order (see oracle outer_sum_rows).
+//   k_corr_box  : one workgroup per (k, y-tile) marches along z with two 4-plane LDS rings (raw, box1); one
+//                 thread per (row, pair of columns).  Each 27-tap raster sum reads 9 aligned 16-byte windows
+//                 [x-1 .. x+2] as two 8-byte halves: two packed adds + two scalar adds per tap row, no
+//                 cross-lane traffic, no bank conflicts; box1 is stored shifted by one column so that the
+//                 windows of the second box (pairs x = 2j-1, 2j) are aligned as well; division by 27 is the
+//                 exact FMA form (div_exact<27>).  No halo recomputation in z (and none in y for OASIS).
+// Roofline: HBM by bytes (K*v*4 written + 2*C*v*4 read); the reference's summation order costs
+// 2 x (26 adds + 1 division) + 36 flops per output, which makes the stage VALU-bound.
 #include "cvx_common.h"
 
 namespace cvx {
 
 struct CorrGeom {
     int C, h, w, d, hw, n;
-    int dp;     // padded F/raw row length (multiple of 4)
+    int px;     // F/raw row pitch: element x at index x+1, multiple of 4, >= d+3
     int PL;     // left pad of Mp rows (multiple of 4, >= hw)
-    int dq;     // Mp row length
+    int dq;     // Mp row pitch: element x at index x + PL + 1
     int hq, wq; // Mp plane extents (h+2hw, w+2hw)
 };
 static CorrGeom corr_geom(int C, int h, int w, int d, int hw) {
     CorrGeom g;
     g.C = C; g.h = h; g.w = w; g.d = d; g.hw = hw; g.n = 2 * hw + 1;
-    g.dp = (d + 3) / 4 * 4;
+    g.px = (d + 3 + 3) / 4 * 4;
     g.PL = (hw + 3) / 4 * 4;
-    g.dq = g.dp + 2 * g.PL;
+    g.dq = g.px + 2 * g.PL;
     g.hq = h + 2 * hw; g.wq = w + 2 * hw;
     return g;
 }
 
 __global__ __launch_bounds__(256) void k_corr_prep(const float* __restrict__ fix, const float* __restrict__ mov, CorrGeom g,
                                                    float* __restrict__ Fp, float* __restrict__ Mp) {
-    const size_t nF = (size_t)g.C * g.h * g.w * g.dp, nM = (size_t)g.C * g.hq * g.wq * g.dq;
+    const size_t nF = (size_t)g.C * g.h * g.w * g.px, nM = (size_t)g.C * g.hq * g.wq * g.dq;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nF) {
-        const int x = (int)(i % g.dp);
-        const size_t r = i / g.dp;     // (c*h + z)*w + y
-        Fp[i] = x < g.d ? fix[r * g.d + x] : 0.0f;
+        const int x = (int)(i % g.px) - 1;
+        const size_t r = i / g.px;     // (c*h + z)*w + y
+        Fp[i] = (x >= 0 && x < g.d) ? fix[r * g.d + x] : 0.0f;
     }
     if (i < nM) {
         const int xq = (int)(i % g.dq), yq = (int)((i / g.dq) % g.wq), zq = (int)((i / ((size_t)g.dq * g.wq)) % g.hq);
         const int c = (int)(i / ((size_t)g.dq * g.wq * g.hq));
-        const int x = xq - g.PL, y = yq - g.hw, z = zq - g.hw;
+        const int x = xq - g.PL - 1, y = yq - g.hw, z = zq - g.hw;
         const bool in = x >= 0 && x < g.d && y >= 0 && y < g.w && z >= 0 && z < g.h;
         Mp[i] = in ? mov[(((size_t)c * g.h + z) * g.w + y) * g.d + x] : 0.0f;
     }
 }
 
-// ---- raw SSD: register tile of 4 voxels x n D-shifts -----------------------------------------------
+// ---- raw SSD: register tile of 4 row indices x n D-shifts ---------------------------------------------
 template <int HW, bool CASCADE>
 __global__ __launch_bounds__(256) void k_corr_raw(const float* __restrict__ Fp, const float* __restrict__ Mp, CorrGeom g,
                                                   float* __restrict__ raw) {
     constexpr int N = 2 * HW + 1;
     constexpr int PL = (HW + 3) / 4 * 4;
     constexpr int NCH = (2 * PL + 4) / 4;          // float4 chunks of the M row segment
-    const int runs_per_row = g.dp / 4;
+    const int runs_per_row = g.px / 4;
     const int nruns = g.h * g.w * runs_per_row;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nruns) return;
-    const int x0 = 4 * (r % runs_per_row), y = (r / runs_per_row) % g.w, z = r / (runs_per_row * g.w);
+    const int i0 = 4 * (r % runs_per_row), y = (r / runs_per_row) % g.w, z = r / (runs_per_row * g.w);   // row index i = x + 1
     const int iH = blockIdx.y % N, iW = blockIdx.y / N;   // dH + hw, dW + hw
 
     float acc[N][4];
@@ -82,9 +85,9 @@ __global__ __launch_bounds__(256) void k_corr_raw(const float* __restrict__ Fp, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc1[k][j] = 0.0f;
     }
-    const size_t fstride = (size_t)g.h * g.w * g.dp, mstride = (size_t)g.hq * g.wq * g.dq;
-    const float* fp = Fp + ((size_t)z * g.w + y) * g.dp + x0;
-    const float* mp = Mp + ((size_t)(z + iH) * g.wq + (y + iW)) * g.dq + x0;   // covers x0-PL .. x0+PL+3
+    const size_t fstride = (size_t)g.h * g.w * g.px, mstride = (size_t)g.hq * g.wq * g.dq;
+    const float* fp = Fp + ((size_t)z * g.w + y) * g.px + i0;
+    const float* mp = Mp + ((size_t)(z + iH) * g.wq + (y + iW)) * g.dq + i0;   // Mp index of M(x+dD) = i + PL + dD
 
 #pragma unroll 1
     for (int c = 0; c < g.C; ++c) {
@@ -110,14 +113,20 @@ __global__ __launch_bounds__(256) void k_corr_raw(const float* __restrict__ Fp, 
                 for (int j = 0; j < 4; ++j) { acc1[k][j] += acc[k][j]; acc[k][j] = 0.0f; }
         }
     }
-    const size_t v = (size_t)g.h * g.w * g.dp;
+    const size_t v = (size_t)g.h * g.w * g.px;
+    bool inx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inx[j] = (i0 + j >= 1) && (i0 + j <= g.d);     // x = i - 1 in [0, d)
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = CASCADE ? acc[k][j] + acc1[k][j] : acc[k][j];
+        for (int j = 0; j < 4; ++j) {
+            const float s = CASCADE ? acc[k][j] + acc1[k][j] : acc[k][j];
+            o[j] = inx[j] ? s : 0.0f;                 // the boxes zero-pad: border columns must be exact zeros
+        }
         const size_t kk = ((size_t)k * N + iW) * N + iH;
-        *reinterpret_cast<float4*>(raw + kk * v + ((size_t)z * g.w + y) * g.dp + x0) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(raw + kk * v + ((size_t)z * g.w + y) * g.px + i0) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -157,157 +166,127 @@ __global__ void k_corr_tail(const float* __restrict__ fix, const float* __restri
     for (int i = n4 * 4; i < g.C; ++i) p[0] += sq[i];
     p[0] += p[1]; p[0] += p[2]; p[0] += p[3];
     const size_t kk = ((size_t)iD * g.n + iW) * g.n + iH;
-    raw[kk * ((size_t)g.h * g.w * g.dp) + ((size_t)z * g.w + y) * g.dp + x] = p[0];
+    raw[kk * ((size_t)g.h * g.w * g.px) + ((size_t)z * g.w + y) * g.px + x + 1] = p[0];
 }
 
-// ---- two box filters per (k, z-slab) in LDS ------------------------------------------------------------
-// A wavefront handles RPW rows x rp aligned runs of 4 columns (rp = dp/4 <= 64, RPW = 64/rp, the remaining lanes
-// idle): one conflict-free ds_read_b128 per tap row per lane, the two neighbouring columns come from the
-// adjacent lanes' registers (DPP wave shift); at the two ends of a row they are the zero border.
-constexpr int BOX_NT = 512, BOX_NW = BOX_NT / 64, BOX_MAXG = 8;
-
+// ---- two box filters, marching along z ---------------------------------------------------------------------
+// One workgroup = one displacement k x one y-tile, one thread = one (row, pair of columns).  The workgroup walks
+// the h planes once: at step t it (1) stores raw plane t (prefetched into registers during the previous step) into
+// a 4-slot LDS ring, (2) evaluates the first box for plane t-2 from ring slots t-3..t-1 into a second 4-slot ring
+// (stored shifted by one column so that the second box's windows are aligned too), (3) evaluates the second box for
+// plane t-4 and stores it to global memory; one barrier per step.  No halo recomputation in z, and none in y when
+// the whole plane fits (w + 2 <= 1024 / pairs-per-row).
 struct BoxGeom {
-    int h, w, d, dp, rp, rpw;
-    int Tz, nslabs;
-    int wy;     // w + 2
-    int dx;     // dp + 8 : element x lives at index x + 4
+    int h, w, d, px;
+    int nj;             // column pairs per row (covers row indices 0 .. 2*nj+1)
+    int Ty, nytiles;    // output rows per tile
+    int ry;             // rows handled concurrently = Ty + 2 ; workgroup = nj * ry threads
+    int nthreads;
 };
 
-__device__ __forceinline__ void box_run(const float* __restrict__ lds, const BoxGeom& b, int p, int y, int xr, float (&s)[4]) {
-    // 27-tap raster order around (plane slot p, row y, columns 4*xr .. 4*xr+3); taps outside the volume are zeros
+// raster-order partial sum over the 9 taps of ONE plane for the two outputs whose 4-wide window starts at `win`
+__device__ __forceinline__ void box9_pair(const float* __restrict__ win, int px, f32x2& s) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = 0.0f;
-    const bool first = xr == 0, last = xr == b.rp - 1;
-#pragma unroll
-    for (int a = -1; a <= 1; ++a)
-#pragma unroll
-        for (int bb = -1; bb <= 1; ++bb) {
-            const f32x4 q = lds_load4(lds + ((size_t)(p + a) * b.wy + (y + 1 + bb)) * b.dx + 4 * xr + 4);
-            float lft = lane_prev(q.w), rgt = lane_next(q.x);
-            lft = first ? 0.0f : lft;
-            rgt = last ? 0.0f : rgt;
-            s[0] += lft; s[0] += q.x; s[0] += q.y;
-            s[1] += q.x; s[1] += q.y; s[1] += q.z;
-            s[2] += q.y; s[2] += q.z; s[2] += q.w;
-            s[3] += q.z; s[3] += q.w; s[3] += rgt;
-        }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = fdiv(s[j], 27.0f);
+    for (int b = -1; b <= 1; ++b) {
+        const f32x2 lo = lds_load2(win + b * px), hi = lds_load2(win + b * px + 2);
+        s += lo;                 // s0 += t0 ; s1 += t1
+        s.x += lo.y;             // s0 += t1
+        s.y += hi.x;             // s1 += t2
+        s += hi;                 // s0 += t2 ; s1 += t3
+    }
 }
 
-__global__ __launch_bounds__(BOX_NT) void k_corr_box(const float* __restrict__ raw, BoxGeom b, float* __restrict__ ssd) {
+__global__ __launch_bounds__(1024) void k_corr_box(const float* __restrict__ raw, BoxGeom b, float* __restrict__ ssd) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = blockIdx.x, slab = blockIdx.y;
-    const int z0 = slab * b.Tz;
-    const int tz = min(b.Tz, b.h - z0);               // output planes of this slab
-    const int nplanes = b.Tz + 4;                     // slots: plane z lives in slot z - (z0 - 2)
-    const size_t plane_lds = (size_t)b.wy * b.dx;
-    const size_t vraw = (size_t)b.h * b.w * b.dp;
-    const float* rk = raw + (size_t)k * vraw;
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x, y0 = blockIdx.y * b.Ty;
+    const int ty = min(b.Ty, b.w - y0);
+    const int rows = b.Ty + 4;                         // LDS rows hold y0-2 .. y0+Ty+1
+    const int px = b.px, pp = rows * px;               // row / plane pitch in LDS
+    float* A = lds;                                    // raw ring, 4 planes (element x at index x+1)
+    float* B = lds + 4 * pp;                           // box1 ring, 4 planes (element x at index x+2)
+    const float* rk = raw + (size_t)k * ((size_t)b.h * b.w * px);
 
-    // 1. zero the whole buffer, then copy the in-volume planes (masking the padded columns x >= d)
-    for (int i = tid * 4; i < (int)(nplanes * plane_lds); i += BOX_NT * 4)
-        *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    const int zlo = max(z0 - 2, 0), zhi = min(z0 + tz + 2, b.h);     // [zlo, zhi)
-    const int rp = b.rp;
-    const int ncopy = (zhi - zlo) * b.w * rp;
-    for (int i = tid; i < ncopy; i += BOX_NT) {
-        const int xr = i % rp, y = (i / rp) % b.w, z = zlo + i / (rp * b.w);
-        float4 v = *reinterpret_cast<const float4*>(rk + ((size_t)z * b.w + y) * b.dp + 4 * xr);
-        const int x = 4 * xr;
-        if (x + 3 >= b.d) {
-            if (x + 0 >= b.d) v.x = 0.f;
-            if (x + 1 >= b.d) v.y = 0.f;
-            if (x + 2 >= b.d) v.z = 0.f;
-            v.w = 0.f;
-        }
-        *reinterpret_cast<float4*>(lds + ((size_t)(z - (z0 - 2)) * b.wy + (y + 1)) * b.dx + x + 4) = v;
-    }
-    __syncthreads();
+    for (int i = tid * 4; i < 8 * pp; i += b.nthreads * 4) *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const int xr = lane % rp, rsub = lane / rp;
-    const bool lane_ok = rsub < b.rpw;
-    // 2. first box on planes [z0-1, z0+tz+1) ∩ volume -> registers
-    const int b1lo = max(z0 - 1, 0), b1hi = min(z0 + tz + 1, b.h);
-    const int rows1 = (b1hi - b1lo) * b.w;
-    float keep[BOX_MAXG][4];
-#pragma unroll
-    for (int i = 0; i < BOX_MAXG; ++i) {
-        const int row = (wave + i * BOX_NW) * b.rpw + rsub;
-        if ((wave + i * BOX_NW) * b.rpw < rows1) {                       // wave-uniform: all lanes take part in the shifts
-            const int rr = (lane_ok && row < rows1) ? row : 0;
-            box_run(lds, b, b1lo + rr / b.w - (z0 - 2), rr % b.w, xr, keep[i]);
-        }
-    }
-    __syncthreads();
-    // 3. in place: the second pool sees box1 only inside the volume (zeros elsewhere)
-#pragma unroll
-    for (int i = 0; i < BOX_MAXG; ++i) {
-        const int row = (wave + i * BOX_NW) * b.rpw + rsub;
-        if (lane_ok && row < rows1) {
-            const int y = row % b.w, z = b1lo + row / b.w;
-            const int x = 4 * xr;
-            f32x4 v = {keep[i][0], keep[i][1], keep[i][2], keep[i][3]};
-            if (x + 0 >= b.d) v.x = 0.f;
-            if (x + 1 >= b.d) v.y = 0.f;
-            if (x + 2 >= b.d) v.z = 0.f;
-            if (x + 3 >= b.d) v.w = 0.f;
-            lds_store4(lds + ((size_t)(z - (z0 - 2)) * b.wy + (y + 1)) * b.dx + x + 4, v);
-        }
-    }
-    // slots of planes z0-2 and z0+tz+1 still hold raw values, but the second box only reads
-    // [z0-1, z0+tz]: in-volume planes there now hold box1, out-of-volume slots are still zero
-    __syncthreads();
+    // staging role: thread -> (LDS row, 16-byte chunk) of one plane
+    const int c4 = px / 4;
+    const int srow = tid / c4, scx = tid % c4;
+    const int sgy = y0 - 2 + srow;
+    const bool stager = srow < rows && sgy >= 0 && sgy < b.w;
+    const float* sp = rk + (size_t)(stager ? sgy : 0) * px + 4 * scx;
+    float* sdst = A + srow * px + 4 * scx;
+    // compute role: thread -> (row slot, column pair)
+    const int j = tid % b.nj, ry = tid / b.nj;
+    const int gy1 = y0 - 1 + ry;                       // row of the first box
+    const bool row1 = gy1 >= 0 && gy1 < b.w;
+    const bool row2 = ry < ty;                         // row y0 + ry of the second box
+    const float* wA = A + (ry + 1) * px + 2 * j;       // window x = 2j-1 .. 2j+2 -> outputs x = 2j, 2j+1
+    float* oB = B + (ry + 1) * px + 2 * j + 2;         // where those two outputs live in the shifted layout
+    const float* wB = B + (ry + 2) * px + 2 * j;       // window x = 2j-2 .. 2j+1 -> outputs x = 2j-1, 2j
+    float* ok = ssd + (size_t)k * ((size_t)b.h * b.w * b.d) + (size_t)(y0 + ry) * b.d;
+    const bool m0 = 2 * j < b.d, m1 = 2 * j + 1 < b.d;
+    const int xa = 2 * j - 1, xb = 2 * j;
 
-    // 4. second box on planes [z0, z0+tz) -> global
-    const int rows2 = tz * b.w;
-    float* ok = ssd + (size_t)k * ((size_t)b.h * b.w * b.d);
-#pragma unroll
-    for (int i = 0; i < BOX_MAXG; ++i) {
-        const int row = (wave + i * BOX_NW) * b.rpw + rsub;
-        if ((wave + i * BOX_NW) * b.rpw < rows2) {
-            const bool act = lane_ok && row < rows2;
-            const int rr = act ? row : 0;
-            const int y = rr % b.w, z = z0 + rr / b.w;
-            float s[4];
-            box_run(lds, b, z - (z0 - 2), y, xr, s);
-            if (act) {
-                float* dst = ok + ((size_t)z * b.w + y) * b.d + 4 * xr;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * xr + j < b.d) dst[j] = s[j];
+    float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (stager && b.h > 0) pre = *reinterpret_cast<const float4*>(sp);
+    __syncthreads();
+    const size_t gplane = (size_t)b.w * px;
+    for (int t = 0; t < b.h + 4; ++t) {
+        // (1) raw plane t -> ring, prefetch plane t+1
+        if (srow < rows) *reinterpret_cast<float4*>(sdst + (t & 3) * pp) = (stager && t < b.h) ? pre : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (stager && t + 1 < b.h) pre = *reinterpret_cast<const float4*>(sp + (size_t)(t + 1) * gplane);
+        // (2) first box for plane t-2 (taps in planes t-3, t-2, t-1), zero outside the volume
+        const int p1 = t - 2;
+        {
+            f32x2 s = {0.0f, 0.0f};
+            if (row1 && p1 >= 0 && p1 < b.h) {
+                box9_pair(wA + ((t - 3) & 3) * pp, px, s);
+                box9_pair(wA + ((t - 2) & 3) * pp, px, s);
+                box9_pair(wA + ((t - 1) & 3) * pp, px, s);
+                s.x = m0 ? div_exact<27>(s.x) : 0.0f;       // the second pool zero-pads box1
+                s.y = m1 ? div_exact<27>(s.y) : 0.0f;
             }
+            lds_store2(oB + (p1 & 3) * pp, s);
         }
+        // (3) second box for plane t-4 (taps in box1 planes t-5, t-4, t-3)
+        const int p2 = t - 4;
+        if (row2 && p2 >= 0) {
+            f32x2 s = {0.0f, 0.0f};
+            box9_pair(wB + ((t - 5) & 3) * pp, px, s);
+            box9_pair(wB + ((t - 4) & 3) * pp, px, s);
+            box9_pair(wB + ((t - 3) & 3) * pp, px, s);
+            float* dst = ok + (size_t)p2 * b.w * b.d;
+            if (xa >= 0 && xa < b.d) dst[xa] = div_exact<27>(s.x);
+            if (xb < b.d) dst[xb] = div_exact<27>(s.y);
+        }
+        __syncthreads();
     }
 }
 
-static BoxGeom box_geom(int h, int w, int d) {
+static BoxGeom box_geom(int h, int w, int d, int px) {
     BoxGeom b;
-    b.h = h; b.w = w; b.d = d; b.dp = (d + 3) / 4 * 4;
-    b.rp = b.dp / 4;
-    b.wy = w + 2; b.dx = b.dp + 8;
-    b.Tz = 0; b.nslabs = 0;
-    if (b.rp > 64) return b;                                           // rows longer than a wavefront: not built
-    b.rpw = 64 / b.rp;
-    const size_t plane_bytes = sizeof(float) * (size_t)b.wy * b.dx;
-    int tz_lds = (int)((72 * 1024) / plane_bytes) - 4;                 // two workgroups per CU
-    if (tz_lds < 1) tz_lds = (int)((156 * 1024) / plane_bytes) - 4;    // large planes: one workgroup per CU
-    const int max_rows = BOX_NW * BOX_MAXG * b.rpw;                    // rows of the first box one workgroup can hold
-    int tz_reg = max_rows / w - 2;
-    int tzmax = tz_lds < tz_reg ? tz_lds : tz_reg;
-    if (tzmax > h) tzmax = h;
-    if (tzmax < 1) return b;                                           // plane too large for this kernel
-    b.nslabs = cdiv(h, tzmax);
-    b.Tz = cdiv(h, b.nslabs);
-    b.nslabs = cdiv(h, b.Tz);
+    b.h = h; b.w = w; b.d = d; b.px = px;
+    b.nj = (d + 2) / 2;                                // pairs j = 0 .. d/2 reach x = d-1 in both passes
+    b.Ty = b.nytiles = b.ry = b.nthreads = 0;
+    if (b.nj > 340) return b;
+    int ry = 1024 / b.nj;                              // rows per workgroup
+    if (ry > w + 2) ry = w + 2;
+    if (ry < 3) return b;
+    b.nytiles = cdiv(w, ry - 2);
+    b.Ty = cdiv(w, b.nytiles);
+    b.nytiles = cdiv(w, b.Ty);
+    b.ry = b.Ty + 2;
+    b.nthreads = b.nj * b.ry;
+    const int stagers = (b.Ty + 4) * (px / 4);         // every LDS row needs a staging thread
+    if (b.nthreads < stagers) b.nthreads = stagers;
+    if (b.nthreads > 1024 || sizeof(float) * 8 * (size_t)(b.Ty + 4) * px > 160 * 1024) { b.nthreads = 0; return b; }
     return b;
 }
 
 template <int HW>
 static void corr_raw_dispatch(const float* Fp, const float* Mp, const CorrGeom& g, float* raw, hipStream_t s) {
-    const int nruns = g.h * g.w * (g.dp / 4);
+    const int nruns = g.h * g.w * (g.px / 4);
     const dim3 grid(cdiv(nruns, 256), g.n * g.n);
     if (g.C >= 16) hipLaunchKernelGGL((k_corr_raw<HW, true>), grid, dim3(256), 0, s, Fp, Mp, g, raw);
     else hipLaunchKernelGGL((k_corr_raw<HW, false>), grid, dim3(256), 0, s, Fp, Mp, g, raw);
@@ -321,9 +300,9 @@ extern "C" size_t cvx_correlate_workspace_bytes(int C, int h, int w, int d, int 
     const CorrGeom g = corr_geom(C, h, w, d, disp_hw);
     const size_t K = (size_t)g.n * g.n * g.n;
     size_t used = 0;
-    used = carve_size(used, sizeof(float) * (size_t)C * h * w * g.dp);            // Fp
+    used = carve_size(used, sizeof(float) * (size_t)C * h * w * g.px);            // Fp
     used = carve_size(used, sizeof(float) * (size_t)C * g.hq * g.wq * g.dq);      // Mp
-    used = carve_size(used, sizeof(float) * K * h * w * g.dp);                    // raw
+    used = carve_size(used, sizeof(float) * K * h * w * g.px);                    // raw
     used = carve_size(used, sizeof(unsigned long long) * (size_t)h * w * d);      // argmin keys
     return used + 256;
 }
@@ -339,12 +318,12 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
     hipStream_t s = as_stream(stream);
     const CorrGeom g = corr_geom(C, h, w, d, disp_hw);
     const size_t K = (size_t)g.n * g.n * g.n;
-    const BoxGeom b = box_geom(h, w, d);
-    if (b.nslabs == 0) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse plane %dx%d too large for the LDS box kernel", w, d);
+    const BoxGeom b = box_geom(h, w, d, g.px);
+    if (b.nthreads == 0) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
     Carver cv(workspace, workspace_bytes);
-    float* Fp = cv.take<float>((size_t)C * h * w * g.dp);
+    float* Fp = cv.take<float>((size_t)C * h * w * g.px);
     float* Mp = cv.take<float>((size_t)C * g.hq * g.wq * g.dq);
-    float* raw = cv.take<float>(K * h * w * g.dp);
+    float* raw = cv.take<float>(K * h * w * g.px);
     unsigned long long* keys = cv.take<unsigned long long>((size_t)h * w * d);
 
     const size_t nprep = (size_t)C * g.hq * g.wq * g.dq;   // >= nF
@@ -366,10 +345,10 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
     if (ntail > 0)
         hipLaunchKernelGGL(k_corr_tail, dim3(cdiv(ntail * g.n, 64)), dim3(64), 0, s, fix, mov, g, tail_from, ntail, raw);
 
-    const size_t lds = sizeof(float) * (size_t)(b.Tz + 4) * b.wy * b.dx;
+    const size_t lds = sizeof(float) * 8 * (size_t)(b.Ty + 4) * b.px;
     static size_t granted = 0;
     ensure_dynamic_lds(&k_corr_box, lds, granted);
-    hipLaunchKernelGGL(k_corr_box, dim3((unsigned)K, b.nslabs), dim3(BOX_NT), lds, s, raw, b, ssd);
+    hipLaunchKernelGGL(k_corr_box, dim3((unsigned)K, b.nytiles), dim3(b.nthreads), lds, s, raw, b, ssd);
     int rc = check_last("correlate");
     if (rc) return rc;
     if (argmin) return launch_argmin(ssd, nullptr, nullptr, 0.0f, false, (int)K, (size_t)h * w * d, keys, argmin, s);

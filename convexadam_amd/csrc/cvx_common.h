@@ -93,6 +93,25 @@ typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 __device__ __forceinline__ f32x4 lds_load4(const float* p) { return *(const volatile lds_f32x4*)p; }   // p must point into LDS
 __device__ __forceinline__ void lds_store4(float* p, f32x4 v) { *(volatile lds_f32x4*)p = v; }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+__device__ __forceinline__ f32x2 lds_load2(const float* p) { return *(const volatile lds_f32x2*)p; }   // one ds_read_b64
+__device__ __forceinline__ void lds_store2(float* p, f32x2 v) { *(volatile lds_f32x2*)p = v; }
+
+// Exact x / D for the divisors of the box filters and poolings (D in {8, 27, 64, 125, 343}):
+//   q = x*r ; e = fma(-D, q, x) ; q' = fma(e, r, q)      with r = RN(1/D)
+// equals the correctly rounded IEEE quotient for EVERY float x (verified exhaustively over all 2^32 bit
+// patterns, scratch/div27.c in the build log) except that -0.0 maps to +0.0, which no caller can produce:
+// the dividends are sums that start from +0.0.  3 instructions instead of the ~15 of the IEEE sequence.
+template <int D>
+__device__ __forceinline__ float div_exact(float x) {
+    static_assert(D == 8 || D == 27 || D == 64 || D == 125 || D == 343, "divisor not verified");
+    constexpr float r = 1.0f / (float)D;
+    const float q = x * r;
+    const float e = __builtin_fmaf(-(float)D, q, x);
+    return __builtin_fmaf(e, r, q);
+}
+
 // value of the previous / next lane of the wavefront (DPP wave shift: pure VALU, no LDS traffic, and the
 // compiler folds it into the consuming v_add_f32).  Lane 0 / lane 63 receive their own value.
 __device__ __forceinline__ float lane_prev(float x) {
