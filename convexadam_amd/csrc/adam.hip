@@ -30,15 +30,22 @@ __global__ __launch_bounds__(256) void k_to_channel_last(const float* __restrict
     out[i] = c < C ? in[(size_t)c * V + p] : 0.0f;
 }
 
+// NPRE > 0: all 8 x NPRE 16-byte gathers of a voxel are issued before any arithmetic (one memory round trip per
+// wavefront instead of one per 4-channel chunk); NPRE = 0: generic chunked loop for wide feature vectors.
+template <int NPRE>
 __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2, const float* __restrict__ M2, int C, int CP,
                                                    int h, int w, int d, const float* __restrict__ U,
                                                    const float* __restrict__ bh, const float* __restrict__ bw,
                                                    const float* __restrict__ bd, float gsc, float cH, float cW, float cD,
                                                    float* __restrict__ gU) {
     const size_t V = (size_t)h * w * d;
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= V) return;
-    const int x = (int)(p % d), y = (int)((p / d) % w), z = (int)(p / ((size_t)d * w));
+    // 4 x 4 x 16 voxel tile per workgroup: the 8-corner footprints of a tile overlap in L1 (each moving-feature
+    // record is fetched from L2 about 1.7x instead of 4x with a linear mapping)
+    const int ntx = (d + 15) / 16, nty = (w + 3) / 4;
+    const int tbx = blockIdx.x % ntx, tby = (blockIdx.x / ntx) % nty, tbz = blockIdx.x / (ntx * nty);
+    const int x = tbx * 16 + (threadIdx.x & 15), y = tby * 4 + ((threadIdx.x >> 4) & 3), z = tbz * 4 + (threadIdx.x >> 6);
+    if (x >= d || y >= w || z >= h) return;
+    const size_t p = ((size_t)z * w + y) * d + x;
     const float sc0 = (float)((h - 1) / 2.0), sc1 = (float)((w - 1) / 2.0), sc2 = (float)((d - 1) / 2.0);   // (:171)
     const float uH = U[p], uW = U[V + p], uD = U[2 * V + p];
     Tri t;
@@ -67,35 +74,47 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
     const float bz[8] = {fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0, fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0};
     float gix = 0.f, giy = 0.f, giz = 0.f;
     const float4* Fv = reinterpret_cast<const float4*>(F2 + p * (size_t)CP);
-    for (int c4 = 0; c4 < CP / 4; ++c4) {
-        float vals[8][4];
+    constexpr int NLOOP = NPRE > 0 ? 1 : 0;
+    const int nouter = NPRE > 0 ? 1 : CP / 4;
+    for (int c0 = 0; c0 < nouter; ++c0) {
+        constexpr int NC4 = NPRE > 0 ? NPRE : 1;
+        float vals[NC4][8][4];
+        float fv[NC4][4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float4 q = *reinterpret_cast<const float4*>(M2 + addr[k] * CP + 4 * c4);
-            vals[k][0] = bnd[k] ? q.x : 0.f; vals[k][1] = bnd[k] ? q.y : 0.f;
-            vals[k][2] = bnd[k] ? q.z : 0.f; vals[k][3] = bnd[k] ? q.w : 0.f;
+        for (int q4 = 0; q4 < NC4; ++q4) {
+            const int c4 = (NPRE > 0) ? q4 : c0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 q = *reinterpret_cast<const float4*>(M2 + addr[k] * CP + 4 * c4);
+                vals[q4][k][0] = bnd[k] ? q.x : 0.f; vals[q4][k][1] = bnd[k] ? q.y : 0.f;
+                vals[q4][k][2] = bnd[k] ? q.z : 0.f; vals[q4][k][3] = bnd[k] ? q.w : 0.f;
+            }
+            const float4 fq = Fv[c4];
+            fv[q4][0] = fq.x; fv[q4][1] = fq.y; fv[q4][2] = fq.z; fv[q4][3] = fq.w;
         }
-        const float4 fq = Fv[c4];
-        const float fv[4] = {fq.x, fq.y, fq.z, fq.w};
+#pragma unroll
+        for (int q4 = 0; q4 < NC4; ++q4)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // channels beyond C are zero-padded in both volumes: df = 0, gOut = 0, all updates are exact no-ops
             float wv = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) wv += vals[k][j] * wgt[k];
-            const float df = wv - fv[j];
+            for (int k = 0; k < 8; ++k) wv += vals[q4][k][j] * wgt[k];
+            const float df = wv - fv[q4][j];
             const float gOut = gsc * (2.0f * df);                    // PowBackward0: grad * (2 * self)
             // corner order tnw,tne,tsw,tse,bnw,bne,bsw,bse ; signs from GridSampler.cpp
-            gix -= vals[0][j] * ax[0] * bx[0] * gOut; giy -= vals[0][j] * ay[0] * bx[0] * gOut; giz -= vals[0][j] * ay[0] * bz[0] * gOut;
-            gix += vals[1][j] * ax[1] * bx[1] * gOut; giy -= vals[1][j] * ay[1] * bx[1] * gOut; giz -= vals[1][j] * ay[1] * bz[1] * gOut;
-            gix -= vals[2][j] * ax[2] * bx[2] * gOut; giy += vals[2][j] * ay[2] * bx[2] * gOut; giz -= vals[2][j] * ay[2] * bz[2] * gOut;
-            gix += vals[3][j] * ax[3] * bx[3] * gOut; giy += vals[3][j] * ay[3] * bx[3] * gOut; giz -= vals[3][j] * ay[3] * bz[3] * gOut;
-            gix -= vals[4][j] * ax[4] * bx[4] * gOut; giy -= vals[4][j] * ay[4] * bx[4] * gOut; giz += vals[4][j] * ay[4] * bz[4] * gOut;
-            gix += vals[5][j] * ax[5] * bx[5] * gOut; giy -= vals[5][j] * ay[5] * bx[5] * gOut; giz += vals[5][j] * ay[5] * bz[5] * gOut;
-            gix -= vals[6][j] * ax[6] * bx[6] * gOut; giy += vals[6][j] * ay[6] * bx[6] * gOut; giz += vals[6][j] * ay[6] * bz[6] * gOut;
-            gix += vals[7][j] * ax[7] * bx[7] * gOut; giy += vals[7][j] * ay[7] * bx[7] * gOut; giz += vals[7][j] * ay[7] * bz[7] * gOut;
+            const float (*vv)[4] = vals[q4];
+            gix -= vv[0][j] * ax[0] * bx[0] * gOut; giy -= vv[0][j] * ay[0] * bx[0] * gOut; giz -= vv[0][j] * ay[0] * bz[0] * gOut;
+            gix += vv[1][j] * ax[1] * bx[1] * gOut; giy -= vv[1][j] * ay[1] * bx[1] * gOut; giz -= vv[1][j] * ay[1] * bz[1] * gOut;
+            gix -= vv[2][j] * ax[2] * bx[2] * gOut; giy += vv[2][j] * ay[2] * bx[2] * gOut; giz -= vv[2][j] * ay[2] * bz[2] * gOut;
+            gix += vv[3][j] * ax[3] * bx[3] * gOut; giy += vv[3][j] * ay[3] * bx[3] * gOut; giz -= vv[3][j] * ay[3] * bz[3] * gOut;
+            gix -= vv[4][j] * ax[4] * bx[4] * gOut; giy -= vv[4][j] * ay[4] * bx[4] * gOut; giz += vv[4][j] * ay[4] * bz[4] * gOut;
+            gix += vv[5][j] * ax[5] * bx[5] * gOut; giy -= vv[5][j] * ay[5] * bx[5] * gOut; giz += vv[5][j] * ay[5] * bz[5] * gOut;
+            gix -= vv[6][j] * ax[6] * bx[6] * gOut; giy += vv[6][j] * ay[6] * bx[6] * gOut; giz += vv[6][j] * ay[6] * bz[6] * gOut;
+            gix += vv[7][j] * ax[7] * bx[7] * gOut; giy += vv[7][j] * ay[7] * bx[7] * gOut; giz += vv[7][j] * ay[7] * bz[7] * gOut;
         }
     }
+    (void)NLOOP;
     // grad wrt the normalised grid (x,y,z) = (size/2)*gi ; flip ; / scale -> grad wrt U (H,W,D)
     float g[3];
     g[0] = fdiv(((float)h / 2.0f) * giz, sc0);
@@ -118,66 +137,66 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
 }
 
 // ---- three chained 3^3 box filters in one launch ---------------------------------------------------------
-// One workgroup = one channel x one 8x8x32 output tile.  The input tile (+3 halo in z,y; columns x0-4..x0+35
-// so that global loads are aligned float4) is staged in LDS; the three passes shrink the region by one voxel
-// each in z,y (14 -> 12 -> 10 -> 8 rows); along x every pass evaluates the 40 staged columns in aligned runs of
-// 4 (the outermost columns of a pass are don't-care values that never reach a needed output).  Every
-// intermediate is zero outside the VOLUME (each avg_pool3d zero-pads its own input).
+// One workgroup = one channel x one 8x8x32 output tile.  The input tile (+3 halo rows/planes, columns x0-4 ..
+// x0+35, aligned float4 global loads) is staged in LDS; the passes shrink the region by one voxel each in z,y
+// (14 -> 12 -> 10 -> 8 rows) and along x (38 -> 36 -> 34 columns needed).  Every intermediate is zero outside the
+// VOLUME (each avg_pool3d zero-pads its own input).
 //   forward  (ATen avg_pool3d):           out = (raster sum of 27 taps) / 27            at every pass
 //   backward (ATen avg_pool3d_backward):  out = raster sum of (tap / 27): taps are divided once when they
 //                                          are staged, the last pass stores the plain sum
 // With ADAM the last backward pass applies the Adam update to P, m, v in place instead of storing G.
-// LDS column of volume coordinate x is (x - x0 + 8); row pitch 48 floats (16-byte aligned runs).
+// One thread evaluates a PAIR of adjacent columns from 9 aligned 16-byte windows [c-1 .. c+2], read as two
+// ds_read_b64: per tap row two packed adds + two scalar adds, no cross-lane traffic, no bank conflicts.  Each
+// pass stores its result shifted by one more index so that the next pass's windows are aligned again:
+//   "column" c = x - x0 + 8;  A holds the input at index c, B holds pass 1 at index c+1, A then pass 2 at c+2.
 constexpr int BT_Z = 8, BT_Y = 8, BT_X = 32, BT_NT = 512, BT_PX = 48;
 struct AdamConsts { float w1, b2, omb2, bc2s, neg_step; };
 
-// One pass.  A wavefront handles 6 rows x 10 aligned runs of 4 columns (lanes 60..63 idle): each lane issues ONE
-// conflict-free ds_read_b128 per tap row and gets the two neighbouring columns (c-1, c+4) from the adjacent
-// lanes' registers; at the ends of a row those neighbours are the don't-care columns 3 / 44.
-template <bool LAST, bool BACKWARD, bool ADAM>
+// PASS 1: pairs (c, c+1), c = 5 + 2p, p < 19  (needs columns 6..41)   src shift 0 -> dst shift 1
+// PASS 2: pairs (c, c+1), c = 6 + 2p, p < 18  (needs columns 7..40)   src shift 1 -> dst shift 2
+// PASS 3: pairs (c, c+1), c = 7 + 2p, p < 17  (outputs columns 8..39) src shift 2 -> global
+template <int PASS, bool BACKWARD, bool ADAM>
 __device__ __forceinline__ void box_pass(const float* __restrict__ src, int sy, float* __restrict__ dst, int dz, int dy,
                                          int gz0, int gy0, int x0, int h, int w, int d, float* __restrict__ gout,
                                          float* __restrict__ P, float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
                                          float* __restrict__ gsave) {
-    constexpr int NRUN = (BT_X + 8) / 4, RPW = 64 / NRUN;           // 10 runs per row, 6 rows per wavefront
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nrows = dz * dy, ngroups = (nrows + RPW - 1) / RPW;
-    const int xr = lane % NRUN, rsub = lane / NRUN;
-    const int col = 4 + 4 * xr;
-    for (int g = wave; g < ngroups; g += BT_NT / 64) {
-        const int rowid = g * RPW + rsub;
-        const bool active = rsub < RPW && rowid < nrows;
-        const int rid = active ? rowid : 0;
-        const int y = rid % dy, z = rid / dy;
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NP = 20 - PASS, C0 = 4 + PASS, SH = PASS - 1;         // pairs per row, first column, source shift
+    const int nr = dz * dy * NP;
+    for (int r = threadIdx.x; r < nr; r += BT_NT) {
+        const int p = r % NP, row = r / NP;
+        const int y = row % dy, z = row / dy;
+        const int c = C0 + 2 * p;                                        // outputs: columns c, c+1
+        const float* win = src + ((z + 1) * sy + (y + 1)) * BT_PX + (c - 1 + SH);   // window = columns c-1 .. c+2
+        f32x2 s = {0.0f, 0.0f};
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int a = -1; a <= 1; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const f32x4 q = lds_load4(src + ((z + a) * sy + (y + b)) * BT_PX + col);
-                const float lft = lane_prev(q.w), rgt = lane_next(q.x);
-                s[0] += lft; s[0] += q.x; s[0] += q.y;
-                s[1] += q.x; s[1] += q.y; s[1] += q.z;
-                s[2] += q.y; s[2] += q.z; s[2] += q.w;
-                s[3] += q.z; s[3] += q.w; s[3] += rgt;
+            for (int b = -1; b <= 1; ++b) {
+                const float* q = win + (a * sy + b) * BT_PX;
+                const f32x2 lo = lds_load2(q), hi = lds_load2(q + 2);
+                s += lo;                 // s0 += t0 ; s1 += t1
+                s.x += lo.y;             // s0 += t1
+                s.y += hi.x;             // s1 += t2
+                s += hi;                 // s0 += t2 ; s1 += t3
             }
-        if (!active) continue;
-        const int gz = gz0 + z, gy = gy0 + y, gx = x0 - 8 + col;
+        const int gz = gz0 + z, gy = gy0 + y, gx = x0 - 8 + c;
         const bool rowin = gz >= 0 && gz < h && gy >= 0 && gy < w;
-        if (!LAST) {
-            float o[4];
+        if (PASS < 3) {
+            f32x2 o;
+            o.x = (rowin && gx >= 0 && gx < d) ? div_exact<27>(s.x) : 0.0f;
+            o.y = (rowin && gx + 1 >= 0 && gx + 1 < d) ? div_exact<27>(s.y) : 0.0f;
+            lds_store2(dst + (z * dy + y) * BT_PX + (c + SH + 1), o);
+        } else if (rowin) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (rowin && gx + j >= 0 && gx + j < d) ? fdiv(s[j], 27.0f) : 0.0f;
-            lds_store4(dst + (z * dy + y) * BT_PX + col, f32x4{o[0], o[1], o[2], o[3]});
-        } else if (rowin && xr >= 1 && xr <= BT_X / 4) {           // columns 8..39 are the output tile
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (gx + j >= d) break;
+            for (int j = 0; j < 2; ++j) {
+                const int cc = c + j;
+                if (cc < 8 || cc > 39 || gx + j >= d) continue;           // columns 8..39 are the output tile
                 const size_t i = ((size_t)gz * w + gy) * d + gx + j;
-                if (!BACKWARD) gout[i] = fdiv(s[j], 27.0f);
-                else if (!ADAM) gout[i] = s[j];
+                const float sj = j ? s.y : s.x;
+                if (!BACKWARD) gout[i] = div_exact<27>(sj);
+                else if (!ADAM) gout[i] = sj;
                 else {
-                    const float g = s[j];
+                    const float g = sj;
                     const float mo = m[i];
                     const float mm = __builtin_fmaf(ac.w1, g - mo, mo);          // exp_avg.lerp_(grad, 1-beta1)
                     float vv = v[i] * ac.b2;                                      // exp_avg_sq.mul_(beta2)
@@ -223,6 +242,7 @@ __global__ __launch_bounds__(BT_NT) void k_box3x3(const float* __restrict__ in, 
                 if (gx + 2 >= 0 && gx + 2 < d) q.z = rowp[gx + 2];
                 if (gx + 3 >= 0 && gx + 3 < d) q.w = rowp[gx + 3];
             }
+            // backward: every tap is gradOut / 27 (the only place where the dividend may be -0.0 -> IEEE division)
             if (BACKWARD) { q.x = fdiv(q.x, 27.0f); q.y = fdiv(q.y, 27.0f); q.z = fdiv(q.z, 27.0f); q.w = fdiv(q.w, 27.0f); }
         }
         *reinterpret_cast<float4*>(A + (z * AY + y) * BT_PX + 4 + 4 * ch) = q;
@@ -233,12 +253,12 @@ __global__ __launch_bounds__(BT_NT) void k_box3x3(const float* __restrict__ in, 
     float* mc = m ? m + (size_t)c * V : nullptr;
     float* vc = v ? v + (size_t)c * V : nullptr;
     float* gs = gsave ? gsave + (size_t)c * V : nullptr;
-    // pass 1: A (14x14 rows) -> B (12x12 rows), columns 4..43 ; pass 2: B -> A (10x10 rows) ; pass 3: A -> tile (cols 8..39)
-    box_pass<false, BACKWARD, ADAM>(A, AY, B, BT_Z + 4, BT_Y + 4, z0 - 2, y0 - 2, x0, h, w, d, nullptr, nullptr, nullptr, nullptr, ac, nullptr);
+    // pass 1: A (14x14 rows) -> B (12x12 rows); pass 2: B -> A (10x10 rows); pass 3: A -> tile
+    box_pass<1, BACKWARD, ADAM>(A, AY, B, BT_Z + 4, BT_Y + 4, z0 - 2, y0 - 2, x0, h, w, d, nullptr, nullptr, nullptr, nullptr, ac, nullptr);
     __syncthreads();
-    box_pass<false, BACKWARD, ADAM>(B, BT_Y + 4, A, BT_Z + 2, BT_Y + 2, z0 - 1, y0 - 1, x0, h, w, d, nullptr, nullptr, nullptr, nullptr, ac, nullptr);
+    box_pass<2, BACKWARD, ADAM>(B, BT_Y + 4, A, BT_Z + 2, BT_Y + 2, z0 - 1, y0 - 1, x0, h, w, d, nullptr, nullptr, nullptr, nullptr, ac, nullptr);
     __syncthreads();
-    box_pass<true, BACKWARD, ADAM>(A, BT_Y + 2, nullptr, BT_Z, BT_Y, z0, y0, x0, h, w, d, oc, Pc, mc, vc, ac, gs);
+    box_pass<3, BACKWARD, ADAM>(A, BT_Y + 2, nullptr, BT_Z, BT_Y, z0, y0, x0, h, w, d, oc, Pc, mc, vc, ac, gs);
 }
 
 static int launch_box3x3(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
@@ -288,7 +308,7 @@ extern "C" int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, 
                 nD = (float)((int64_t)3 * h * w * (d - 1));
     const float cH = lambda_weight / nH, cW = lambda_weight / nW, cD = lambda_weight / nD;
     const float gsc = ((1.0f / (float)V) * cost_scale) / (float)C;     // MeanBackward, MulBackward, MeanBackward
-    const dim3 gv((unsigned)cdiv64((int64_t)V, 256));
+    const dim3 gv((unsigned)(cdiv(d, 16) * cdiv(w, 4) * cdiv(h, 4)));
     int snap = 0;
     for (int it = 0; it < niter; ++it) {
         int rc;
@@ -297,7 +317,10 @@ extern "C" int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, 
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
         const AdamConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)(-(1.0 / bc1))};
         if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc;
-        hipLaunchKernelGGL(k_warp_grad, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
+        if (false) hipLaunchKernelGGL(k_warp_grad<3>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
+        else if (CP == 4) hipLaunchKernelGGL(k_warp_grad<1>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
+        else if (false) hipLaunchKernelGGL(k_warp_grad<2>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
+        else hipLaunchKernelGGL(k_warp_grad<0>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
         float* gsave = (grad_out && it == niter - 1) ? grad_out : nullptr;
         if ((rc = launch_box3x3(gU, nullptr, h, w, d, true, P, m, v, ac, gsave, s))) return rc;
         while (snap < n_snap && snapshot_iters_host[snap] == it + 1) {
