@@ -14,7 +14,8 @@ barrier + synchronize and the slowest rank's time is used: value = N*K / T (weak
 Extra objects on the JSON line:
   roofline     the SSD correlation stage (k_corr_prep/raw/tail/box of one direction): algorithmic bytes
                (n^3*v*4 written + 2*C*v*4 read = 273.5 MB) / its mean duration measured with HIP events on the
-               launch stream inside the timed region, against 8 TB/s HBM3E peak.
+               launch stream inside the timed region, against 8 TB/s HBM3E peak; `traffic` = HBM bytes per launch
+               from the committed rocprofv3 PMC passes (profiles/pmc_hbm_traffic.json: 2*FETCH_SIZE + WRITE_SIZE).
   cpu_baseline the CPU oracle (kind "port", OpenMP over all host cores) timed on one full pair of the same
                workload, rank 0 / N=1 only.  It is the checker, timed as a baseline -- never the product.
 """
@@ -45,6 +46,15 @@ def make_pair(device, idx):
     mov = F.grid_sample(phantom(SHAPE, 1 + idx, 110 + idx)[None, None], grid, mode="bilinear", padding_mode="border",
                         align_corners=False)[0, 0]
     return fix.to(device).contiguous(), mov.to(device).contiguous()
+
+
+def pmc_traffic():
+    """HBM bytes per correlation-stage launch from the last committed rocprofv3 PMC passes (profiles/); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")) as f:
+            return float(json.load(f)["correlate_stage_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(fix, mov):
@@ -78,7 +88,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    from convexadam_amd.convex_adam_MIND import last_profile, register_pair_device
+    from convexadam_amd.convex_adam_MIND import last_profile, register_pair_device, set_profiling
 
     fix, mov = make_pair(dev, rank)
     out = torch.empty((3,) + SHAPE, dtype=torch.float32, device=dev)
@@ -90,17 +100,18 @@ def main():
         dist.barrier()
         torch.cuda.synchronize(dev)
     stage_ms = {}
+    set_profiling(2)            # stage boundaries = hipEventRecord on the launch stream, read back after the timed region
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        register_pair_device(fix, mov, out=out, profile=True, **CFG)
-        # reading the stage events waits for this pair only (the next one would start right after anyway)
-        for name, ms in last_profile():
-            stage_ms.setdefault(name, []).append(ms)
+        register_pair_device(fix, mov, out=out, **CFG)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    for name, ms in last_profile():
+        stage_ms.setdefault(name, []).append(ms)
+    set_profiling(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -133,7 +144,7 @@ def main():
                        "pairs_per_gpu_per_step": 1, "parallelism": "one pair per GPU, no collectives"},
             "roofline": {"kernel": "correlate stage = k_corr_prep + k_corr_raw + k_corr_tail + k_corr_box (one direction)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(), "algorithmic_bytes": alg_bytes,
                          "avg_launch_ms": corr_ms},
             "stages_ms": {k: sum(vs) / len(vs) for k, vs in stage_ms.items()},
         }

@@ -75,7 +75,7 @@ def extract_features(img_fixed: torch.Tensor, img_moving: torch.Tensor, mind_r: 
 
 def register_pair_device(img_fixed=None, img_moving=None, feat_fixed=None, feat_moving=None, mind_r=1, mind_d=2,
                          lambda_weight=1.25, grid_sp=6, disp_hw=4, selected_niter=80, selected_smooth=0, grid_sp_adam=2,
-                         ic=True, cost_scale=12.0, out=None, profile=False):
+                         ic=True, cost_scale=12.0, out=None, profile=None):
     """One registration, device in / device out: returns the displacement field as a (3,H',W',D') float32
     device tensor (full resolution, or the coarse grid for the reference's ic=False & lambda_weight<=0 case).
     Either two (H,W,D) images (MIND-SSC features are computed) or two (C,H,W,D) feature volumes."""
@@ -111,18 +111,24 @@ def register_pair_device(img_fixed=None, img_moving=None, feat_fixed=None, feat_
     ws = workspace(nws, dev)
     dims = (C.c_int * 3)()
     with torch.cuda.device(dev):
-        L.cvx_set_profiling(1 if profile else 0)
+        if profile is not None:
+            L.cvx_set_profiling(int(profile))
         check(L.cvx_register_pair_f32(ptr(a), ptr(b), ptr(ff), ptr(fm), C.byref(p), ptr(out), C.cast(dims, C.c_void_p), ptr(ws), nws,
                                       stream_ptr(dev)))
     assert tuple(dims) == tuple(oshape[1:]), (tuple(dims), oshape)
     return out
 
 
-def last_profile():
-    """[(stage, milliseconds)] of the last profiled register_pair_device call (hipEvent timing)."""
-    names = (C.c_char_p * 32)()
-    ms = (C.c_float * 32)()
-    n = lib().cvx_last_pair_profile(C.cast(names, C.c_void_p), C.cast(ms, C.c_void_p), 32)
+def set_profiling(mode: int):
+    """0 = off, 1 = keep the stage timings of the last call, 2 = accumulate over calls (hipEvents on the launch stream)."""
+    lib().cvx_set_profiling(int(mode))
+
+
+def last_profile(max_intervals=4096):
+    """[(stage, milliseconds)] recorded since profiling was switched on (waits for the last event)."""
+    names = (C.c_char_p * max_intervals)()
+    ms = (C.c_float * max_intervals)()
+    n = lib().cvx_last_pair_profile(C.cast(names, C.c_void_p), C.cast(ms, C.c_void_p), max_intervals)
     return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
 

@@ -112,7 +112,7 @@ static PairLayout pair_layout(const cvx_pair_params& p) {
 }
 
 // ---- optional per-stage timing -------------------------------------------------------------------------
-static thread_local bool g_profiling = false;
+static thread_local int g_profiling = 0;       // 0 off, 1 last call only, 2 accumulate over calls
 struct StageMark { const char* name; hipEvent_t ev; };
 static thread_local std::vector<StageMark> g_marks;
 static thread_local std::vector<hipEvent_t> g_pool;
@@ -153,17 +153,23 @@ static int validate(const cvx_pair_params* p) {
 
 using namespace cvx;
 
-extern "C" void cvx_set_profiling(int enabled) { g_profiling = enabled != 0; }
+extern "C" void cvx_set_profiling(int enabled) {
+    g_profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
+    g_marks.clear();
+    g_pool_used = 0;
+}
 
 extern "C" int cvx_last_pair_profile(const char** names_host, float* ms_host, int max_stages) {
     if (g_marks.size() < 2) return 0;
     (void)hipEventSynchronize(g_marks.back().ev);
     int n = 0;
-    for (size_t i = 1; i < g_marks.size() && n < max_stages; ++i, ++n) {
+    for (size_t i = 1; i < g_marks.size() && n < max_stages; ++i) {
+        if (g_marks[i].name[0] == 's' && g_marks[i].name[1] == 't' && g_marks[i].name[2] == 'a') continue;   // "start" of the next pair
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, g_marks[i - 1].ev, g_marks[i].ev);
         names_host[n] = g_marks[i].name;
         ms_host[n] = ms;
+        ++n;
     }
     return n;
 }
@@ -186,8 +192,7 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
     hipStream_t s = as_stream(stream);
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-    g_marks.clear();
-    g_pool_used = 0;
+    if (g_profiling != 2) { g_marks.clear(); g_pool_used = 0; }
     mark("start", s);
 
     // 1. features                                                              (:106-116)

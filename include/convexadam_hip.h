@@ -154,10 +154,12 @@ int cvx_register_pair_f32(const float* img_fixed, const float* img_moving, const
                           const float* feat_moving, const cvx_pair_params* p, float* out_field,
                           int* out_dims_host, void* workspace, size_t workspace_bytes, void* stream);
 
-/* per-stage device time of the last cvx_register_pair_f32 call on this thread (hipEvents, ms).
- * names_host receives pointers to static strings; returns the number of stages written. */
+/* per-stage device time of cvx_register_pair_f32 calls on this thread (hipEvents recorded on the launch
+ * stream, ms).  cvx_set_profiling(0) off, (1) keep the last call only, (2) accumulate over calls until the next
+ * cvx_set_profiling(); names_host receives pointers to static strings; returns the number of intervals written
+ * (waits for the last recorded event). */
 int cvx_last_pair_profile(const char** names_host, float* ms_host, int max_stages);
-void cvx_set_profiling(int enabled);
+void cvx_set_profiling(int mode);
 
 #pragma GCC visibility pop
 
