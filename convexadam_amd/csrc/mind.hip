@@ -111,27 +111,35 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
     const int tx0 = trun * RUN;
     float res[12][RUN];
 
+    // squared-difference stage: every thread owns NSQ fixed positions of the (tile + R) region; their clamped
+    // source index in the image tile and their destination index are the same for all 12 channels
+    constexpr int NSQ = (SZ * SY * SX + NT - 1) / NT;
+    int sq_src[NSQ], sq_dst[NSQ];
+#pragma unroll
+    for (int e = 0; e < NSQ; ++e) {
+        const int i = tid + e * NT;
+        const int sx = i % SX, sy = (i / SX) % SY, sz = i / (SX * SY);
+        // the box sees the clamped POSITION (rpad2), the shifts clamp again (rpad1): I(clamp(clamp(P)+o*d))
+        const int pz = clampi(z0 - R + sz, 0, H - 1), py = clampi(y0 - R + sy, 0, W - 1), px = clampi(x0 - R + sx, 0, D - 1);
+        sq_src[e] = ((pz - (z0 - halo)) * IY + (py - (y0 - halo))) * IX + (px - (x0 - halo));
+        sq_dst[e] = (i < SZ * SY * SX) ? (sz * SY + sy) * SXP + sx : -1;
+        if (i >= SZ * SY * SX) sq_src[e] = (halo * IY + halo) * IX + halo;      // any in-range position; never stored
+    }
+
     constexpr MindOffsets MO{};
 #pragma unroll
     for (int c = 0; c < 12; ++c) {          // fully unrolled: res[c][] must stay in registers
         float* sq = ssq + (c & (nbuf - 1)) * (SZ * SY * SXP);
-        const int a1z = MO.o1[c][0] * dil, a1y = MO.o1[c][1] * dil, a1x = MO.o1[c][2] * dil;
-        const int a2z = MO.o2[c][0] * dil, a2y = MO.o2[c][1] * dil, a2x = MO.o2[c][2] * dil;
-        // squared differences on the tile grown by R; the box sees the clamped POSITION (rpad2),
-        // the shifts clamp again (rpad1): I(clamp(clamp(P)+o*d))
-#pragma unroll 1
-        for (int i = tid; i < SZ * SY * SX; i += NT) {
-            const int sx = i % SX, sy = (i / SX) % SY, sz = i / (SX * SY);
-            const int pz = clampi(z0 - R + sz, 0, H - 1), py = clampi(y0 - R + sy, 0, W - 1),
-                      px = clampi(x0 - R + sx, 0, D - 1);
-            const int lz = pz - (z0 - halo), ly = py - (y0 - halo), lx = px - (x0 - halo);
-            const float a = simg[((lz + a1z) * IY + (ly + a1y)) * IX + (lx + a1x)];
-            const float b = simg[((lz + a2z) * IY + (ly + a2y)) * IX + (lx + a2x)];
-            const float df = a - b;
-            sq[(sz * SY + sy) * SXP + sx] = df * df;
+        const int off1 = ((MO.o1[c][0] * IY + MO.o1[c][1]) * IX + MO.o1[c][2]) * dil;
+        const int off2 = ((MO.o2[c][0] * IY + MO.o2[c][1]) * IX + MO.o2[c][2]) * dil;
+#pragma unroll
+        for (int e = 0; e < NSQ; ++e) {
+            const float df = simg[sq_src[e] + off1] - simg[sq_src[e] + off2];
+            if (sq_dst[e] >= 0) sq[sq_dst[e]] = df * df;
         }
         __syncthreads();
-        // raster-order box sum (z slowest, x fastest), one division by K^3
+        // raster-order box sums (z slowest, x fastest) for 4 adjacent outputs from aligned 8-byte LDS reads,
+        // one exact division by K^3
         float s[RUN];
 #pragma unroll
         for (int j = 0; j < RUN; ++j) s[j] = 0.0f;
@@ -142,14 +150,17 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
                 const float* row = sq + ((tz + a) * SY + (ty + b)) * SXP + tx0;
                 float rv[RUN + 2 * R];
 #pragma unroll
-                for (int j = 0; j < RUN + 2 * R; ++j) rv[j] = row[j];
+                for (int j = 0; j < (RUN + 2 * R) / 2; ++j) {
+                    const f32x2 q = lds_load2(row + 2 * j);
+                    rv[2 * j] = q.x; rv[2 * j + 1] = q.y;
+                }
 #pragma unroll
                 for (int j = 0; j < RUN; ++j)
 #pragma unroll
                     for (int cc = 0; cc < K; ++cc) s[j] += rv[j + cc];
             }
 #pragma unroll
-        for (int j = 0; j < RUN; ++j) res[c][j] = fdiv(s[j], (float)(K * K * K));
+        for (int j = 0; j < RUN; ++j) res[c][j] = div_exact<K * K * K>(s[j]);
         // double-buffered sq (nbuf = 2): the next channel writes the other buffer, one barrier per channel;
         // large radius/dilation tiles only fit one buffer and need a second barrier
         if (nbuf == 1) __syncthreads();
