@@ -119,6 +119,40 @@ def register_pair_device(img_fixed=None, img_moving=None, feat_fixed=None, feat_
     return out
 
 
+def register_pairs_device(imgs_fixed, imgs_moving, outs=None, n_streams=2, mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6,
+                          disp_hw=4, selected_niter=80, selected_smooth=0, grid_sp_adam=2, ic=True, cost_scale=12.0):
+    """Several independent pairs (lists of (H,W,D) device tensors, equal shapes) in one call: the library deals them
+    onto `n_streams` internal HIP streams so that independent pairs fill each other's idle issue slots
+    (cvx_register_pairs_f32).  Returns the list of (3,H,W,D) fields."""
+    n = len(imgs_fixed)
+    fx = [f32c(t) for t in imgs_fixed]
+    mv = [f32c(t) for t in imgs_moving]
+    H, W, D = [int(s) for s in fx[0].shape]
+    dev = fx[0].device
+    _require_hip(dev)
+    if lambda_weight > 0 and selected_niter < 1:
+        raise UnboundLocalError("local variable 'disp_sample' referenced before assignment (convex_adam_MIND.py:181)")
+    p = PairParams(H, W, D, int(mind_r), int(mind_d), float(lambda_weight), int(grid_sp), int(disp_hw), int(selected_niter),
+                   int(selected_smooth), int(grid_sp_adam), 1 if ic else 0, 0, float(cost_scale))
+    L = lib()
+    per = L.cvx_register_pair_workspace_bytes(C.byref(p))
+    if per == 0:
+        raise _lib.CvxError(_lib.CVX_ERR_INVALID_ARG, L.cvx_last_error().decode())
+    n_streams = max(1, min(int(n_streams), n, 8))
+    nws = ((per + 4095) // 4096 * 4096) * n_streams
+    full = ic or lambda_weight > 0
+    oshape = (3, H, W, D) if full else (3, H // grid_sp, W // grid_sp, D // grid_sp)
+    if outs is None:
+        outs = [torch.empty(oshape, dtype=torch.float32, device=dev) for _ in range(n)]
+    ws = workspace(nws, dev)
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    dims = (C.c_int * 3)()
+    with torch.cuda.device(dev):
+        check(L.cvx_register_pairs_f32(n, C.cast(arr(fx), C.c_void_p), C.cast(arr(mv), C.c_void_p), None, None, C.byref(p),
+                                       C.cast(arr(outs), C.c_void_p), C.cast(dims, C.c_void_p), ptr(ws), nws, n_streams, stream_ptr(dev)))
+    return outs
+
+
 def set_profiling(mode: int):
     """0 = off, 1 = keep the stage timings of the last call, 2 = accumulate over calls (hipEvents on the launch stream)."""
     lib().cvx_set_profiling(int(mode))

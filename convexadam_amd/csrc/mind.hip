@@ -57,10 +57,15 @@ __global__ __launch_bounds__(256) void k_minmax_partial(const float* __restrict_
         part[2 * blockIdx.x + 1] = mx;
     }
 }
-__global__ void k_mind_stats_init(const float* part, int nparts, double count, MindStats* st) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float mn = part[0], mx = part[1];
-    for (int i = 1; i < nparts; ++i) { mn = fminf(mn, part[2 * i]); mx = fmaxf(mx, part[2 * i + 1]); }
+__global__ __launch_bounds__(256) void k_mind_stats_init(const float* part, int nparts, double count, MindStats* st) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < nparts; i += 256) { mn = fminf(mn, part[2 * i]); mx = fmaxf(mx, part[2 * i + 1]); }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_down(mn, o)); mx = fmaxf(mx, __shfl_down(mx, o)); }
+    __shared__ float smn[4], smx[4];
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int i = 1; i < 4; ++i) { mn = fminf(mn, smn[i]); mx = fmaxf(mx, smx[i]); }
     const double range = (double)mx - (double)mn;
     double bound = range * range;
     if (!(bound > 0.0)) bound = 1e-300;
@@ -285,7 +290,7 @@ extern "C" int cvx_mindssc_f32(const float* img, int H, int W, int D, int radius
     const size_t V = (size_t)H * W * D;
     const int nb = (int)(V / 4096 + 1 < 1024 ? V / 4096 + 1 : 1024);
     hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(256), 0, s, img, V, part);
-    hipLaunchKernelGGL(k_mind_stats_init, dim3(1), dim3(1), 0, s, part, nb, (double)V, st);
+    hipLaunchKernelGGL(k_mind_stats_init, dim3(1), dim3(256), 0, s, part, nb, (double)V, st);
     switch (radius) {
         case 1: return mind_launch_r<1>(img, H, W, D, dilation, st, out, s);
         case 2: return mind_launch_r<2>(img, H, W, D, dilation, st, out, s);

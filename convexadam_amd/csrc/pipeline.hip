@@ -279,3 +279,66 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
     if (out_dims_host) { out_dims_host[0] = hh; out_dims_host[1] = hw_; out_dims_host[2] = hd; }
     return check_last("register_pair");
 }
+
+
+// ---- several pairs at once on internal streams ------------------------------------------------------------
+// The kernels of one pair are chained by data dependencies and leave issue slots idle (short grids, tails);
+// independent pairs fill them.  Pairs are dealt round-robin onto `n_streams` internal non-blocking streams
+// that fork from / join back into the caller's stream with events, so the call is still asynchronous and
+// ordered with respect to the caller's stream.  workspace = n_streams x cvx_register_pair_workspace_bytes().
+namespace cvx {
+struct StreamPool {
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;
+    hipEvent_t fork = nullptr;
+    int device = -1;
+};
+static thread_local StreamPool g_pool_streams;
+static int ensure_streams(int n) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    StreamPool& P = g_pool_streams;
+    if (P.device != dev) { P.streams.clear(); P.done.clear(); P.fork = nullptr; P.device = dev; }   // leaked on device switch (rare)
+    if (!P.fork && hipEventCreateWithFlags(&P.fork, hipEventDisableTiming) != hipSuccess) return fail(CVX_ERR_LAUNCH, "event create failed");
+    while ((int)P.streams.size() < n) {
+        hipStream_t s; hipEvent_t e;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return fail(CVX_ERR_LAUNCH, "stream create failed");
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(CVX_ERR_LAUNCH, "event create failed");
+        P.streams.push_back(s); P.done.push_back(e);
+    }
+    return CVX_OK;
+}
+}  // namespace cvx
+
+extern "C" int cvx_register_pairs_f32(int n_pairs, const float* const* img_fixed, const float* const* img_moving,
+                                      const float* const* feat_fixed, const float* const* feat_moving,
+                                      const cvx_pair_params* p, float* const* out_fields, int* out_dims_host, void* workspace,
+                                      size_t workspace_bytes, int n_streams, void* stream) {
+    CVX_REQUIRE(n_pairs >= 1 && out_fields && workspace, "cvx_register_pairs_f32: bad arguments");
+    CVX_REQUIRE(n_streams >= 1 && n_streams <= 8, "cvx_register_pairs_f32: n_streams must be 1..8");
+    if (n_streams > n_pairs) n_streams = n_pairs;
+    const size_t per = cvx_register_pair_workspace_bytes(p);
+    if (per == 0) return CVX_ERR_INVALID_ARG;
+    const size_t per_al = align_up(per, 4096);
+    if (workspace_bytes < per_al * (size_t)n_streams) return fail(CVX_ERR_WORKSPACE, "cvx_register_pairs_f32: workspace %zu < %zu", workspace_bytes, per_al * (size_t)n_streams);
+    int rc = ensure_streams(n_streams);
+    if (rc) return rc;
+    StreamPool& P = g_pool_streams;
+    hipStream_t user = as_stream(stream);
+    const int saved_prof = g_profiling;
+    g_profiling = 0;                                  // stage marks are per stream; not recorded in batch mode
+    (void)hipEventRecord(P.fork, user);
+    for (int s = 0; s < n_streams; ++s) (void)hipStreamWaitEvent(P.streams[s], P.fork, 0);
+    for (int i = 0; i < n_pairs && rc == CVX_OK; ++i) {
+        const int s = i % n_streams;
+        rc = cvx_register_pair_f32(img_fixed ? img_fixed[i] : nullptr, img_moving ? img_moving[i] : nullptr,
+                                   feat_fixed ? feat_fixed[i] : nullptr, feat_moving ? feat_moving[i] : nullptr, p, out_fields[i],
+                                   out_dims_host, static_cast<char*>(workspace) + per_al * (size_t)s, per, P.streams[s]);
+    }
+    for (int s = 0; s < n_streams; ++s) {
+        (void)hipEventRecord(P.done[s], P.streams[s]);
+        (void)hipStreamWaitEvent(user, P.done[s], 0);
+    }
+    g_profiling = saved_prof;
+    return rc;
+}

@@ -154,6 +154,15 @@ int cvx_register_pair_f32(const float* img_fixed, const float* img_moving, const
                           const float* feat_moving, const cvx_pair_params* p, float* out_field,
                           int* out_dims_host, void* workspace, size_t workspace_bytes, void* stream);
 
+/* n_pairs independent pairs with the same parameters, dealt round-robin onto n_streams (1..8) internal HIP
+ * streams that fork from / join into `stream` (the sweep scripts' loop over pairs, e.g.
+ * self_configuring/convex_run_withconfig.py:85).  Pointer arrays live on the HOST and hold device pointers;
+ * img_* or feat_* may be NULL as in cvx_register_pair_f32.  workspace = n_streams x (per-pair size rounded up to 4096). */
+int cvx_register_pairs_f32(int n_pairs, const float* const* img_fixed, const float* const* img_moving,
+                           const float* const* feat_fixed, const float* const* feat_moving, const cvx_pair_params* p,
+                           float* const* out_fields, int* out_dims_host, void* workspace, size_t workspace_bytes,
+                           int n_streams, void* stream);
+
 /* per-stage device time of cvx_register_pair_f32 calls on this thread (hipEvents recorded on the launch
  * stream, ms).  cvx_set_profiling(0) off, (1) keep the last call only, (2) accumulate over calls until the next
  * cvx_set_profiling(); names_host receives pointers to static strings; returns the number of intervals written

@@ -167,6 +167,20 @@ def test_pipeline_vs_oracle_bit_exact(M, orc, golden, kw):
     assert np.array_equal(out, ref), "EPE %g" % epe(out, ref)
 
 
+def test_batched_pairs_on_internal_streams_match_single_calls(M, golden):
+    """cvx_register_pairs_f32 (pairs dealt onto internal HIP streams) returns exactly what one call per pair returns."""
+    g = golden("pipeline")
+    fix, mov = dev(g["fix"]), dev(g["mov"])
+    kw = dict(mind_r=1, mind_d=2, grid_sp=4, disp_hw=3, grid_sp_adam=2, lambda_weight=1.25, selected_niter=4, ic=True)
+    pairs_f = [fix, mov, fix]
+    pairs_m = [mov, fix, fix]
+    single = [M.register_pair_device(f, m, **kw).clone() for f, m in zip(pairs_f, pairs_m)]
+    for ns in (1, 2, 3):
+        outs = M.register_pairs_device(pairs_f, pairs_m, n_streams=ns, **kw)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(single, outs)), ns
+
+
 # ---- (2) HIP vs reference goldens -----------------------------------------------------------------------
 def test_mindssc_vs_reference_golden(U, golden):
     g = golden("mind")
