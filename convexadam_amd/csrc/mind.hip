@@ -93,7 +93,8 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
                                               MindStats* __restrict__ st, float* __restrict__ out) {
     constexpr int K = 2 * R + 1;
     constexpr int SZ = TZ + 2 * R, SY = TY + 2 * R, SX = TX + 2 * R;
-    constexpr int SXP = (SX + 3) / 4 * 4 + 4;        // padded row (keeps rows 16-B aligned, skews banks)
+    constexpr int SXP = (SX + 3) / 4 * 4 + 2;        // row pitch = 2 (mod 4) floats: the 8-byte reads of lanes 16 B apart in
+                                                     // adjacent rows land on disjoint banks
     const int halo = R + dil;
     const int IZ = TZ + 2 * halo, IY = TY + 2 * halo, IX = TX + 2 * halo;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
 static size_t mind_lds_bytes(int R, int dil, int nbuf) {
     const int halo = R + dil;
     const int IZ = TZ + 2 * halo, IY = TY + 2 * halo, IX = TX + 2 * halo;
-    const int SZ = TZ + 2 * R, SY = TY + 2 * R, SX = TX + 2 * R, SXP = (SX + 3) / 4 * 4 + 4;
+    const int SZ = TZ + 2 * R, SY = TY + 2 * R, SX = TX + 2 * R, SXP = (SX + 3) / 4 * 4 + 2;
     return sizeof(float) * ((size_t)((IZ * IY * IX + 3) / 4) * 4 + (size_t)nbuf * SZ * SY * SXP);
 }
 
