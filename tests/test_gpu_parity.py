@@ -301,3 +301,47 @@ def test_large_motion_config3_argmin_consistency(U):
     inner = am[12:25, 12:20, 12:25]
     assert int((inner == k).all()) == 1
     assert float(ssd[k, 12:25, 12:20, 12:25].abs().max()) == 0.0
+
+
+@pytest.mark.timeout(900)
+def test_full_size_config3_pipeline(M):
+    """BASELINE configs[2] geometry without the mask: 224x192x224, disp_hw 8 (4913-way search), 20 Adam iterations.
+    Identity pair -> zero field at the convex stage; shifted pair -> shift recovered; memory for the 861 MB cost
+    volume + 930 MB intermediate is carved from one workspace."""
+    from convexadam_amd.phantom import phantom
+    fix = phantom((224, 192, 224), 4, 40).to(DEV)
+    conv = M.register_pair_device(fix, fix, lambda_weight=0, grid_sp=6, disp_hw=8, ic=True)
+    assert float(conv.abs().max()) == 0.0
+    sh = (12, -6, 18)                                   # multiples of grid_sp: exactly representable by the search mesh
+    u = M.register_pair_device(fix, torch.roll(fix, sh, (0, 1, 2)), grid_sp=6, disp_hw=8, selected_niter=20)
+    c = u[:, 60:160, 50:140, 60:160]
+    for a in range(3):       # the reference's own criterion: within 1 voxel (test_convex_adam_translation); the coarse-grid
+        assert abs(float(c[a].mean()) - sh[a]) < 1.0      # stage under-estimates by ~5 % (SURVEY app. A: 6 -> 5.73)
+
+
+@pytest.mark.timeout(900)
+def test_full_size_config4_label_features(orc):
+    """BASELINE configs[3]: multi-channel (nnUNet-style) path with C = 32 label channels on a 160x192x160 volume:
+    exercises the cascade channel sum (C >= 16), channel padding in the Adam gather and a 0.9 GB feature volume."""
+    from convexadam_amd import convex_adam_nnUNet as N
+    from convexadam_amd.phantom import label_phantom
+    lab = label_phantom((160, 192, 160), 32, 3)
+    assert int(lab.max()) == 31
+    labm = torch.roll(lab, (4, -2, 6), (0, 1, 2))
+    ff, fm = N.extract_features(lab.to(DEV), labm.to(DEV), device=DEV)
+    assert ff.shape[1] == 32
+    from convexadam_amd.convex_adam_MIND import register_pair_device
+    u = register_pair_device(feat_fixed=ff[0], feat_moving=fm[0], lambda_weight=1.25, grid_sp=4, disp_hw=4, selected_niter=10,
+                             grid_sp_adam=2, ic=True)
+    assert u.shape == (3, 160, 192, 160) and bool(torch.isfinite(u).all())
+    c = u[:, 40:120, 48:144, 40:120]
+    for a, s in enumerate((4, -2, 6)):
+        assert abs(float(c[a].mean()) - s) < 1.0
+    # small-volume bit parity of the same path against the oracle (C = 20 -> cascade + channel padding 20 -> 20)
+    rng = np.random.default_rng(0)
+    f = rng.random((20, 24, 20, 28), dtype=np.float32)
+    m = np.roll(f, (1, -1, 2), (1, 2, 3)).copy()
+    kw = dict(lambda_weight=1.25, grid_sp=4, disp_hw=2, selected_niter=3, grid_sp_adam=2, ic=True)
+    out = host(register_pair_device(feat_fixed=dev(f), feat_moving=dev(m), **kw))
+    ref = orc.convex_adam_pipeline(None, None, features=(f, m), **kw)
+    assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), ref)
