@@ -44,6 +44,9 @@ SIGNATURES = {
     "cvx_avgpool_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cvx_box_smooth_workspace_bytes": (_sz, [_i] * 5),
     "cvx_box_smooth_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "cvx_mask_erode_f32": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
+    "cvx_gather_f32": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "cvx_select_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "cvx_label_histogram_i64": (_i, [_vp, _i64, _i, _vp, _vp]),
     "cvx_label_weights_host": (_i, [_vp, _vp, _i, _vp, _vp]),
     "cvx_label_features_f32": (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp]),

@@ -39,21 +39,33 @@ def _load_mask(path):
 
 
 def _replicate_fill(img, mask, device):
-    """Masked 'replicate fill' of convex_adam_MIND.py:40-51: outside the eroded mask the image takes the
-    value of the nearest in-mask voxel (found at half resolution with scipy's EDT on the host, exactly
-    like the reference), tri-linearly up-sampled; inside it keeps its own values."""
-    import torch.nn.functional as F
+    """Masked 'replicate fill' of convex_adam_MIND.py:40-51: outside the eroded mask the image takes the value of the
+    nearest in-mask voxel (found at half resolution with scipy's Euclidean feature transform on the host, exactly like
+    the reference), tri-linearly up-sampled; inside it keeps its own values.  Erosion, gather, up-sampling and merge are
+    HIP kernels; only the EDT index search runs on the CPU."""
     from scipy.ndimage import distance_transform_edt as edt
-    H, W, D = img.shape[-3:]
-    m = F.avg_pool3d(F.pad(mask.view(1, 1, H, W, D).to(device), (1,) * 6, mode="replicate"), 3, stride=1)
-    m = (m > 0.9).float()
-    _, idx = edt((m[0, 0, ::2, ::2, ::2] == 0).squeeze().cpu().numpy(), return_indices=True)
-    idx = torch.from_numpy(idx).to(device)
+    from .convex_adam_utils import resize_trilinear
+    H, W, D = [int(s) for s in img.shape[-3:]]
+    if H % 2 or W % 2 or D % 2:
+        raise ValueError("masked feature extraction needs even extents (the reference's index expression at "
+                         "convex_adam_MIND.py:45 and its x2 up-sampling only line up for even H, W, D)")
+    L = lib()
+    im = f32c(img.to(device)).reshape(H, W, D)
+    mk = f32c(mask.to(device)).reshape(H, W, D)
+    m = torch.empty_like(mk)
+    with torch.cuda.device(device):
+        check(L.cvx_mask_erode_f32(ptr(mk), H, W, D, 0.9, ptr(m), stream_ptr(device)))
+    _, idx = edt((m[::2, ::2, ::2] == 0).cpu().numpy(), return_indices=True)
     lin = idx[0] * D // 2 * W // 2 + idx[1] * D // 2 + idx[2]          # same index expression as :45
-    half = img[::2, ::2, ::2].to(device).reshape(-1)[lin]
-    filled = F.interpolate(half.unsqueeze(0).unsqueeze(0), scale_factor=2, mode="trilinear")
-    sel = m.view(-1) != 0
-    filled.view(-1)[sel] = img.to(device).reshape(-1)[sel]
+    lin_d = torch.from_numpy(np.ascontiguousarray(lin, dtype=np.int64)).to(device)
+    half_src = im[::2, ::2, ::2].contiguous()
+    half = torch.empty((1, 1) + tuple(half_src.shape), dtype=torch.float32, device=device)
+    filled = torch.empty((1, 1, H, W, D), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        check(L.cvx_gather_f32(ptr(half_src), ptr(lin_d), lin_d.numel(), ptr(half), stream_ptr(device)))
+    up = resize_trilinear(half, (H, W, D))                              # F.interpolate(scale_factor=2, trilinear)
+    with torch.cuda.device(device):
+        check(L.cvx_select_f32(ptr(m), ptr(im), ptr(up), im.numel(), ptr(filled), stream_ptr(device)))
     return filled
 
 

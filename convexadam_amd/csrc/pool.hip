@@ -61,6 +61,32 @@ int launch_box_zero(const float* in, float* out, int C, int H, int W, int D, int
     return check_last("box_zero");
 }
 
+// ---- masked-feature helpers (convex_adam_MIND.py:36-54) ------------------------------------------------------
+// (ReplicationPad3d(1) + AvgPool3d(3, stride 1))(mask) > 0.9 : raster sum of 27 clamped taps, one exact division
+__global__ __launch_bounds__(256) void k_mask_erode(const float* __restrict__ mask, int H, int W, int D, float thr,
+                                                    float* __restrict__ out) {
+    const size_t n = (size_t)H * W * D;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)(i % D), w = (int)((i / D) % W), h = (int)(i / ((size_t)D * W));
+    float s = 0.0f;
+    for (int a = -1; a <= 1; ++a)
+        for (int b = -1; b <= 1; ++b)
+            for (int c = -1; c <= 1; ++c)
+                s += mask[((size_t)clampi(h + a, 0, H - 1) * W + clampi(w + b, 0, W - 1)) * D + clampi(d + c, 0, D - 1)];
+    out[i] = fdiv(s, 27.0f) > thr ? 1.0f : 0.0f;
+}
+__global__ __launch_bounds__(256) void k_gather_index(const float* __restrict__ src, const int64_t* __restrict__ idx, size_t n,
+                                                      float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+__global__ __launch_bounds__(256) void k_select(const float* __restrict__ m, const float* __restrict__ a, const float* __restrict__ b,
+                                                size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = m[i] != 0.0f ? a[i] : b[i];
+}
+
 // ---- trilinear resize (ATen upsample_trilinear3d, align_corners=False) ----------------------------
 //   src = max(fma(in/out, dst + 0.5, -0.5), 0); i0 = min(floor(src), in-1); l1 = clamp(src - i0, 0, 1)
 //   l0 = 1 - l1; i1 = i0 + (i0 < in-1); per level (last dim first): r = fma(v0, l0, v1 * l1)
@@ -169,6 +195,23 @@ extern "C" int cvx_avgpool_f32(const float* in, int C, int H, int W, int D, int 
     hipLaunchKernelGGL(k_avgpool, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, as_stream(stream), in, C, H, W,
                        D, g, out);
     return check_last("avgpool");
+}
+
+extern "C" int cvx_mask_erode_f32(const float* mask, int H, int W, int D, float threshold, float* out, void* stream) {
+    CVX_REQUIRE(mask && out && H > 0 && W > 0 && D > 0, "cvx_mask_erode_f32: bad arguments");
+    const size_t n = (size_t)H * W * D;
+    hipLaunchKernelGGL(k_mask_erode, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, as_stream(stream), mask, H, W, D, threshold, out);
+    return check_last("mask_erode");
+}
+extern "C" int cvx_gather_f32(const float* src, const int64_t* index, int64_t n, float* out, void* stream) {
+    CVX_REQUIRE(src && index && out && n > 0, "cvx_gather_f32: bad arguments");
+    hipLaunchKernelGGL(k_gather_index, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, as_stream(stream), src, index, (size_t)n, out);
+    return check_last("gather");
+}
+extern "C" int cvx_select_f32(const float* mask, const float* a, const float* b, int64_t n, float* out, void* stream) {
+    CVX_REQUIRE(mask && a && b && out && n > 0, "cvx_select_f32: bad arguments");
+    hipLaunchKernelGGL(k_select, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, as_stream(stream), mask, a, b, (size_t)n, out);
+    return check_last("select");
 }
 
 extern "C" size_t cvx_box_smooth_workspace_bytes(int C, int H, int W, int D, int passes) {

@@ -71,6 +71,15 @@ size_t cvx_box_smooth_workspace_bytes(int C, int H, int W, int D, int passes);
 int cvx_box_smooth_f32(const float* in, int C, int H, int W, int D, int k, int passes, float* out,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* masked feature extraction helpers                             convex_adam_MIND.py:36-54
+ *   cvx_mask_erode_f32 : out = (AvgPool3d(3)(ReplicationPad3d(1)(mask)) > threshold) ? 1 : 0      (:40,43,48)
+ *   cvx_gather_f32     : out[i] = src[index[i]]  (half-resolution nearest-in-mask gather, :45,50; the Euclidean
+ *                        feature transform itself stays scipy on the host, like the reference)
+ *   cvx_select_f32     : out[i] = mask[i] != 0 ? a[i] : b[i]                                       (:46,51) */
+int cvx_mask_erode_f32(const float* mask, int H, int W, int D, float threshold, float* out, void* stream);
+int cvx_gather_f32(const float* src, const int64_t* index, int64_t n, float* out, void* stream);
+int cvx_select_f32(const float* mask, const float* a, const float* b, int64_t n, float* out, void* stream);
+
 /* label-map features                                         convex_adam_nnUNet.py:19-38
  *   lab_* [V] float-valued integer labels in [0, max_label]; weights_host[C] and present_host[C]
  *   are computed on the host by the caller (cvx_label_weights_host) from the two histograms;

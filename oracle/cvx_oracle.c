@@ -165,6 +165,22 @@ ORC_API void orc_box_zero_backward(const float* gout, float* gin, int C, int H, 
         }
 }
 
+/* nn.Sequential(ReplicationPad3d(1), AvgPool3d(3, stride=1)) of convex_adam_MIND.py:40 : raster sum of the 27 taps
+ * of the replicate-padded volume (all taps present, clamped coordinates), one division by 27. */
+ORC_API void orc_box3_replicate(const float* in, float* out, int H, int W, int D) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w)
+            for (int d = 0; d < D; ++d) {
+                float s = 0.0f;
+                for (int a = -1; a <= 1; ++a)
+                    for (int b = -1; b <= 1; ++b)
+                        for (int c = -1; c <= 1; ++c)
+                            s += in[((size_t)clampi(h + a, 0, H - 1) * W + clampi(w + b, 0, W - 1)) * D + clampi(d + c, 0, D - 1)];
+                out[((size_t)h * W + w) * D + d] = s / 27.0f;
+            }
+}
+
 /* avg_pool3d(g, stride=g): floor output extent, raster sum of g^3 taps, one division.
  * (convex_adam_MIND.py:118-119,149-150) */
 ORC_API void orc_avgpool_stride(const float* in, float* out, int C, int H, int W, int D, int g) {

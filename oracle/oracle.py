@@ -41,6 +41,7 @@ def lib():
         L.orc_box_zero.argtypes = [_f32p, _f32p] + [C.c_int] * 5
         L.orc_box_zero_backward.argtypes = [_f32p, _f32p] + [C.c_int] * 5
         L.orc_avgpool_stride.argtypes = [_f32p, _f32p] + [C.c_int] * 5
+        L.orc_box3_replicate.argtypes = [_f32p, _f32p] + [C.c_int] * 3
         L.orc_mindssc.argtypes = [_f32p] + [C.c_int] * 5 + [_f32p, C.POINTER(C.c_float)]
         L.orc_correlate.argtypes = [_f32p, _f32p] + [C.c_int] * 5 + [_f32p, _i64p]
         L.orc_coupled_convex.argtypes = [_f32p, _i64p, _f32p] + [C.c_int] * 4 + [_f32p]
@@ -100,6 +101,25 @@ def avgpool_stride(x, g):
     x = _f(x); c, h, w, d = x.shape
     out = np.empty((c, h // g, w // g, d // g), np.float32)
     lib().orc_avgpool_stride(x.reshape(-1), out.reshape(-1), c, h, w, d, g); return out
+
+
+def box3_replicate(x):
+    x = _f(x); h, w, d = x.shape
+    out = np.empty_like(x); lib().orc_box3_replicate(x.reshape(-1), out.reshape(-1), h, w, d); return out
+
+
+def replicate_fill(img, mask):
+    """Masked replicate fill of convex_adam_MIND.py:40-51 (even extents): erode the mask (replicate box3 > 0.9), find for
+    every half-resolution voxel the nearest in-mask voxel (scipy EDT, as the reference does), gather, x2 trilinear
+    up-sample, keep the original values inside the eroded mask."""
+    from scipy.ndimage import distance_transform_edt as edt
+    img = _f(img); mask = _f(mask); H, W, D = img.shape
+    m = (box3_replicate(mask) > np.float32(0.9)).astype(np.float32)
+    _, idx = edt(m[::2, ::2, ::2] == 0, return_indices=True)
+    lin = idx[0] * D // 2 * W // 2 + idx[1] * D // 2 + idx[2]
+    half = img[::2, ::2, ::2].reshape(-1)[lin].astype(np.float32)
+    up = resize_trilinear(half[None], (2 * half.shape[0], 2 * half.shape[1], 2 * half.shape[2]))[0]
+    return np.where(m != 0, img, up).astype(np.float32), m
 
 
 def mindssc(img, radius=2, dilation=2, return_mean=False):

@@ -254,6 +254,22 @@ def test_label_features_and_nnunet_path(orc, golden):
     assert out.shape == lf.shape + (3,) and np.isfinite(out).all()
 
 
+def test_masked_feature_extraction(M, orc, golden):
+    """use_mask=True branch (BASELINE configs[2]): erosion, gather, up-sampling and merge run as HIP kernels (only the
+    EDT index search is scipy on the host, like the reference); bit-identical to the oracle, 1 ulp from the reference."""
+    g = golden("masked")
+    ff, fm = M.extract_features(torch.from_numpy(g["img_fix"]), torch.from_numpy(g["img_mov"]), 1, 2, True,
+                                torch.from_numpy(g["mask_fix"]), torch.from_numpy(g["mask_mov"]), device=torch.device(DEV),
+                                dtype=torch.float32)
+    for out, img, mask, key in ((ff, g["img_fix"], g["mask_fix"], "feat_fix"), (fm, g["img_mov"], g["mask_mov"], "feat_mov")):
+        filled, _ = orc.replicate_fill(img, mask)
+        assert np.array_equal(host(out)[0], orc.mindssc(filled, 1, 2))
+        assert np.abs(host(out)[0] - g[key]).max() <= 6e-8
+    with pytest.raises(ValueError):
+        M.extract_features(torch.zeros(9, 8, 8), torch.zeros(9, 8, 8), 1, 2, True, torch.ones(9, 8, 8), torch.ones(9, 8, 8),
+                           device=torch.device(DEV), dtype=torch.float32)
+
+
 # ---- (3) properties at full size (BASELINE.json configs 2 and 3) ------------------------------------------
 @pytest.mark.timeout(900)
 def test_full_size_identity_and_determinism(M):

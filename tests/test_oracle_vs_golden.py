@@ -163,3 +163,15 @@ def test_label_features(orc, golden):
     assert np.allclose(ff.astype(np.float64).sum((1, 2, 3)), g["feat_fix_sum"], rtol=1e-5)
     assert np.allclose(fm.astype(np.float64).sum((1, 2, 3)), g["feat_mov_sum"], rtol=1e-5)
     assert np.allclose(orc.avgpool_stride(ff, 2), g["feat_fix_pool2"], rtol=2e-6, atol=1e-7)
+
+
+def test_masked_feature_extraction(orc, golden):
+    """extract_features(use_mask=True), convex_adam_MIND.py:36-54: eroded mask, half-resolution nearest-in-mask fill
+    (scipy EDT on the host, as in the reference), x2 trilinear up-sampling, MIND-SSC of the filled image."""
+    g = golden("masked")
+    for img, mask, key in ((g["img_fix"], g["mask_fix"], "feat_fix"), (g["img_mov"], g["mask_mov"], "feat_mov")):
+        filled, m = orc.replicate_fill(img, mask)
+        assert 0.05 < m.mean() < 0.5
+        assert np.array_equal(filled[m != 0], img[m != 0])
+        out = orc.mindssc(filled, 1, 2)
+        assert np.abs(out - g[key]).max() <= 6e-8           # 1 ulp: MKL exp only
