@@ -22,6 +22,11 @@ class CvxError(RuntimeError):
         self.code = code
 
 
+class Smoother(C.Structure):
+    """struct cvx_smoother (include/convexadam_hip.h)."""
+    _fields_ = [("kind", C.c_int), ("n_boxes", C.c_int), ("box_k", C.c_int * 4), ("gauss_w", C.c_float * 5)]
+
+
 class PairParams(C.Structure):
     """struct cvx_pair_params (include/convexadam_hip.h)."""
     _fields_ = [("H", C.c_int), ("W", C.c_int), ("D", C.c_int), ("mind_r", C.c_int), ("mind_d", C.c_int),
@@ -61,6 +66,10 @@ SIGNATURES = {
     "cvx_adam_workspace_bytes": (_sz, [_i] * 4),
     "cvx_adam_run_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                               _vp, _vp, _sz, _vp]),
+    "cvx_smooth_workspace_bytes": (_sz, [_i] * 4),
+    "cvx_smooth_f32": (_i, [_vp, _i, _i, _i, _i, C.POINTER(Smoother), _i, _vp, _vp, _sz, _vp]),
+    "cvx_adam_run_smoother_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                       _vp, C.POINTER(Smoother), _vp, _sz, _vp]),
     "cvx_register_pair_workspace_bytes": (_sz, [C.POINTER(PairParams)]),
     "cvx_register_pair_f32": (_i, [_vp, _vp, _vp, _vp, C.POINTER(PairParams), _vp, _vp, _vp, _sz, _vp]),
     "cvx_register_pairs_f32": (_i, [_i, _vp, _vp, _vp, _vp, C.POINTER(PairParams), _vp, _vp, _vp, _sz, _i, _vp]),

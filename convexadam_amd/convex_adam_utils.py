@@ -180,10 +180,11 @@ def combineDeformation3d(disp_1st, disp_2nd, identity):
 
 
 def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snapshot_iters=(), return_state=False,
-             state=None):
+             state=None, smoother=None):
     """Adam instance optimisation of convex_adam_MIND.py:155-182 on pooled features (1,C,h,w,d) and an
     initial control grid P0 (1,3,h,w,d) in grid units.  Returns disp_sample of the last forward pass
-    (1,3,h,w,d) [and optionally snapshots / optimiser state]."""
+    (1,3,h,w,d) [and optionally snapshots / optimiser state].  `smoother` = a GaussianSmoothing / kovesi_spline object of
+    convexadam_amd.convexAdam_hyper_util replaces the three 3^3 boxes (adam_run_withconfig_shiftSpline.py:217)."""
     F2 = f32c(require_device_tensor(feat_fix, "feat_fix"))
     M2 = f32c(require_device_tensor(feat_mov, "feat_mov"))
     _, Cn, h, w, d = [int(s) for s in F2.shape]
@@ -204,10 +205,10 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
     nws = lib().cvx_adam_workspace_bytes(Cn, h, w, d)
     ws = workspace(nws, dev)
     with torch.cuda.device(dev):
-        check(lib().cvx_adam_run_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
-                                     int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
-                                     C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf), ptr(ws), nws,
-                                     stream_ptr(dev)))
+        check(lib().cvx_adam_run_smoother_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
+                                              int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
+                                              C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf),
+                                              C.byref(smoother.spec) if smoother is not None else None, ptr(ws), nws, stream_ptr(dev)))
     if return_state:
         return U, dict(P=P, m=m, v=v, step=step0 + int(niter), G=G, snapshots=snap_buf)
     return U

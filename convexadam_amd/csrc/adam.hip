@@ -261,6 +261,21 @@ __global__ __launch_bounds__(BT_NT) void k_box3x3(const float* __restrict__ in, 
     box_pass<3, BACKWARD, ADAM>(A, BT_Y + 2, nullptr, BT_Z, BT_Y, z0, y0, x0, h, w, d, oc, Pc, mc, vc, ac, gs);
 }
 
+__global__ __launch_bounds__(256) void k_adam_update(const float* __restrict__ G, float* __restrict__ P, float* __restrict__ m,
+                                                     float* __restrict__ v, size_t n, AdamConsts ac) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = G[i];
+    const float mo = m[i];
+    const float mm = __builtin_fmaf(ac.w1, g - mo, mo);          // exp_avg.lerp_(grad, 1-beta1)
+    float vv = v[i] * ac.b2;                                      // exp_avg_sq.mul_(beta2)
+    vv = __builtin_fmaf(ac.omb2 * g, g, vv);                      // .addcmul_(grad, grad, value=1-beta2)
+    const float den = fdiv(fsqrt(vv), ac.bc2s) + 1e-8f;           // (sqrt / bias_correction2_sqrt).add_(eps)
+    P[i] = P[i] + fdiv(ac.neg_step * mm, den);                    // addcdiv_(exp_avg, denom, value=-step_size)
+    m[i] = mm;
+    v[i] = vv;
+}
+
 static int launch_box3x3(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
                          AdamConsts ac, float* gsave, hipStream_t s) {
     const int nb = cdiv(d, BT_X) * cdiv(w, BT_Y) * cdiv(h, BT_Z) * 3;
@@ -276,7 +291,7 @@ using namespace cvx;
 
 extern "C" size_t cvx_adam_workspace_bytes(int C, int h, int w, int d) {
     const size_t V = (size_t)h * w * d, CP = (size_t)(C + 3) / 4 * 4;
-    return (256 + sizeof(float) * 3 * V) + 2 * (256 + sizeof(float) * CP * V) + 256;
+    return 3 * (256 + sizeof(float) * 3 * V) + 2 * (256 + sizeof(float) * CP * V) + 256;
 }
 
 extern "C" int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
@@ -284,6 +299,15 @@ extern "C" int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, 
                                 const float* base_w, const float* base_d, float* U, float* grad_out,
                                 const int* snapshot_iters_host, int n_snap, float* snapshots, void* workspace,
                                 size_t workspace_bytes, void* stream) {
+    return cvx_adam_run_smoother_f32(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U,
+                                     grad_out, snapshot_iters_host, n_snap, snapshots, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
+                                         float lambda_weight, int niter, int step0, float cost_scale, const float* base_h,
+                                         const float* base_w, const float* base_d, float* U, float* grad_out,
+                                         const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
     CVX_REQUIRE(F2 && M2 && P && m && v && U && base_h && base_w && base_d, "cvx_adam_run_f32: null pointer");
     CVX_REQUIRE(C > 0 && h > 1 && w > 1 && d > 1, "cvx_adam_run_f32: bad extent C=%d %dx%dx%d", C, h, w, d);
     CVX_REQUIRE(niter >= 0 && step0 >= 0, "cvx_adam_run_f32: negative iteration count");
@@ -294,6 +318,17 @@ extern "C" int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, 
     const size_t V = (size_t)h * w * d;
     Carver cv(workspace, workspace_bytes);
     float* gU = cv.take<float>(3 * V);
+    float* t1 = cv.take<float>(3 * V);
+    float* t2 = cv.take<float>(3 * V);
+    // generic smoother path unless it is the packaged chain of three 3^3 boxes (fused LDS kernels)
+    const bool fused = !sm || (sm->kind == 0 && sm->n_boxes == 3 && sm->box_k[0] == 3 && sm->box_k[1] == 3 && sm->box_k[2] == 3);
+    if (sm) {
+        CVX_REQUIRE(sm->kind == 0 || sm->kind == 1, "cvx_adam_run_smoother_f32: smoother kind must be 0 or 1");
+        if (sm->kind == 0) {
+            CVX_REQUIRE(sm->n_boxes >= 1 && sm->n_boxes <= 4, "cvx_adam_run_smoother_f32: n_boxes must be 1..4");
+            for (int i = 0; i < sm->n_boxes; ++i) CVX_REQUIRE(sm->box_k[i] >= 1 && (sm->box_k[i] & 1), "cvx_adam_run_smoother_f32: box size must be odd");
+        }
+    }
     const int CP = (C + 3) / 4 * 4;
     float* Fcl = cv.take<float>((size_t)CP * V);
     float* Mcl = cv.take<float>((size_t)CP * V);
@@ -316,13 +351,19 @@ extern "C" int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, 
         const double beta1 = 0.9, beta2 = 0.999;
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
         const AdamConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)(-(1.0 / bc1))};
-        if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc;
+        if (fused) { if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc; }
+        else if ((rc = launch_smoother(P, U, t1, 3, h, w, d, *sm, false, s))) return rc;
         if (false) hipLaunchKernelGGL(k_warp_grad<3>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
         else if (CP == 4) hipLaunchKernelGGL(k_warp_grad<1>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
         else if (false) hipLaunchKernelGGL(k_warp_grad<2>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
         else hipLaunchKernelGGL(k_warp_grad<0>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
         float* gsave = (grad_out && it == niter - 1) ? grad_out : nullptr;
-        if ((rc = launch_box3x3(gU, nullptr, h, w, d, true, P, m, v, ac, gsave, s))) return rc;
+        if (fused) { if ((rc = launch_box3x3(gU, nullptr, h, w, d, true, P, m, v, ac, gsave, s))) return rc; }
+        else {
+            if ((rc = launch_smoother(gU, t2, t1, 3, h, w, d, *sm, true, s))) return rc;
+            hipLaunchKernelGGL(k_adam_update, dim3((unsigned)cdiv64((int64_t)(3 * V), 256)), dim3(256), 0, s, t2, P, m, v, 3 * V, ac);
+            if (gsave) (void)hipMemcpyAsync(gsave, t2, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice, s);
+        }
         while (snap < n_snap && snapshot_iters_host[snap] == it + 1) {
             (void)hipMemcpyAsync(snapshots + (size_t)snap * 3 * V, U, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice, s);
             ++snap;

@@ -61,6 +61,72 @@ int launch_box_zero(const float* in, float* out, int C, int H, int W, int D, int
     return check_last("box_zero");
 }
 
+// ---- GaussianSmoothing: 5-tap convolution along one axis, replicate padding (hyper_util.py:423-437) -------------
+// forward  (oneDNN conv, pinned on torch 2.10 CPU): acc = w0*x0 ; acc = fma(w_t, x_t, acc), t = 1..4
+// backward (conv backward-data + replication_pad3d_backward): gxp[j] = w0*g[j], then t = 1..4 ascending
+//          fma(w_t, g[j-t], acc) for multi-channel tensors (a single-channel tensor takes another oneDNN kernel that
+//          rounds the products: acc + w_t*g) on the padded index range (g = 0 outside), then the pad gradient adds
+//          the border entries of gxp in ascending order into the first / last element.
+struct GaussW { float w[5]; };
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void k_gauss1d(const float* __restrict__ in, float* __restrict__ out, size_t total, int n,
+                                                 size_t stride, GaussW gw, bool fused_bwd) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int a = (int)((i / stride) % n);                 // coordinate along the filtered axis
+    const float* base = in + (i - (size_t)a * stride);     // element 0 of this line
+    if (!BACKWARD) {
+        float acc = gw.w[0] * base[(size_t)clampi(a - 2, 0, n - 1) * stride];
+#pragma unroll
+        for (int t = 1; t < 5; ++t) acc = __builtin_fmaf(gw.w[t], base[(size_t)clampi(a + t - 2, 0, n - 1) * stride], acc);
+        out[i] = acc;
+    } else {
+        float r = 0.0f;
+        const int j0 = a == 0 ? 0 : a + 2, j1 = a == n - 1 ? n + 3 : a + 2;     // padded positions that clamp onto a
+        for (int j = j0; j <= j1; ++j) {
+            float g0 = (j >= 0 && j < n) ? base[(size_t)j * stride] : 0.0f;
+            float acc = gw.w[0] * g0;
+#pragma unroll
+            for (int t = 1; t < 5; ++t) {
+                const int q = j - t;
+                const float gq = (q >= 0 && q < n) ? base[(size_t)q * stride] : 0.0f;
+                acc = fused_bwd ? __builtin_fmaf(gw.w[t], gq, acc) : acc + gw.w[t] * gq;
+            }
+            r += acc;
+        }
+        out[i] = r;
+    }
+}
+static int launch_gauss1d(const float* in, float* out, int C, int H, int W, int D, int axis, const float* w5, bool backward,
+                          hipStream_t s) {
+    const size_t total = (size_t)C * H * W * D;
+    const int n = axis == 0 ? H : (axis == 1 ? W : D);
+    const size_t stride = axis == 0 ? (size_t)W * D : (axis == 1 ? (size_t)D : 1);
+    GaussW gw;
+    for (int t = 0; t < 5; ++t) gw.w[t] = w5[t];
+    const dim3 grid((unsigned)cdiv64((int64_t)total, 256));
+    if (backward) hipLaunchKernelGGL(k_gauss1d<true>, grid, dim3(256), 0, s, in, out, total, n, stride, gw, C > 1);
+    else hipLaunchKernelGGL(k_gauss1d<false>, grid, dim3(256), 0, s, in, out, total, n, stride, gw, C > 1);
+    return check_last("gauss1d");
+}
+
+// applies a smoother (or its adjoint) with ping-pong through `tmp`; the last stage lands in `out`
+int launch_smoother(const float* in, float* out, float* tmp, int C, int H, int W, int D, const cvx_smoother& sm, bool backward,
+                    hipStream_t s) {
+    const int nst = sm.kind == 1 ? 3 : sm.n_boxes;
+    const float* src = in;
+    for (int i = 0; i < nst; ++i) {
+        float* dst = ((nst - 1 - i) & 1) ? tmp : out;
+        const int st = backward ? nst - 1 - i : i;          // the adjoint runs the stages in reverse order
+        int rc;
+        if (sm.kind == 1) rc = launch_gauss1d(src, dst, C, H, W, D, st, sm.gauss_w, backward, s);
+        else rc = launch_box_zero(src, dst, C, H, W, D, sm.box_k[st], backward, s);
+        if (rc) return rc;
+        src = dst;
+    }
+    return CVX_OK;
+}
+
 // ---- masked-feature helpers (convex_adam_MIND.py:36-54) ------------------------------------------------------
 // (ReplicationPad3d(1) + AvgPool3d(3, stride 1))(mask) > 0.9 : raster sum of 27 clamped taps, one exact division
 __global__ __launch_bounds__(256) void k_mask_erode(const float* __restrict__ mask, int H, int W, int D, float thr,
@@ -195,6 +261,28 @@ extern "C" int cvx_avgpool_f32(const float* in, int C, int H, int W, int D, int 
     hipLaunchKernelGGL(k_avgpool, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, as_stream(stream), in, C, H, W,
                        D, g, out);
     return check_last("avgpool");
+}
+
+static int check_smoother(const cvx_smoother* sm) {
+    CVX_REQUIRE(sm, "smoother: null");
+    CVX_REQUIRE(sm->kind == 0 || sm->kind == 1, "smoother: kind must be 0 (box chain) or 1 (gaussian)");
+    if (sm->kind == 0) {
+        CVX_REQUIRE(sm->n_boxes >= 1 && sm->n_boxes <= 4, "smoother: n_boxes must be 1..4");
+        for (int i = 0; i < sm->n_boxes; ++i) CVX_REQUIRE(sm->box_k[i] >= 1 && (sm->box_k[i] & 1), "smoother: box size must be odd");
+    }
+    return CVX_OK;
+}
+extern "C" size_t cvx_smooth_workspace_bytes(int C, int H, int W, int D) { return 256 + sizeof(float) * (size_t)C * H * W * D; }
+extern "C" int cvx_smooth_f32(const float* in, int C, int H, int W, int D, const cvx_smoother* sm, int backward, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    CVX_REQUIRE(in && out && in != out && workspace, "cvx_smooth_f32: bad pointers");
+    CVX_REQUIRE(C > 0 && H > 0 && W > 0 && D > 0, "cvx_smooth_f32: bad extent");
+    int rc = check_smoother(sm);
+    if (rc) return rc;
+    if (workspace_bytes < cvx_smooth_workspace_bytes(C, H, W, D)) return fail(CVX_ERR_WORKSPACE, "cvx_smooth_f32: workspace too small");
+    Carver cv(workspace, workspace_bytes);
+    float* tmp = cv.take<float>((size_t)C * H * W * D);
+    return launch_smoother(in, out, tmp, C, H, W, D, *sm, backward != 0, as_stream(stream));
 }
 
 extern "C" int cvx_mask_erode_f32(const float* mask, int H, int W, int D, float threshold, float* out, void* stream) {

@@ -125,6 +125,23 @@ int cvx_resize_trilinear_f32(const float* in, int C, int h, int w, int d, float*
 int cvx_grid_sample_f32(const float* vol, int C, int h, int w, int d, const float* grid, int ho, int wo, int dd,
                         float* out, void* stream);
 
+/* smoothers of the sweep scripts' Adam loop ---------------------------------------------
+ * replaces  kovesi_spline(sigma, n)  = chain of zero-padded AvgPool3d(k, stride 1, pad k/2), k in {3,5}
+ *                                       self_configuring/convexAdam_hyper_util.py:475-488
+ *           GaussianSmoothing(sigma) = separable 5-tap convolution, replicate padding, along H, then W, then D
+ *                                       self_configuring/convexAdam_hyper_util.py:423-473
+ * (selected by `avg_n` in adam_run_withconfig_shiftSpline.py:140-141,217).  backward = 0 applies the smoother,
+ * backward = 1 its adjoint in autograd's evaluation order.  in/out [C][H][W][D], in != out. */
+typedef struct cvx_smoother {
+    int kind;            /* 0 = box chain, 1 = gaussian */
+    int n_boxes;         /* 1..4 */
+    int box_k[4];        /* 3 or 5 (any odd size works) */
+    float gauss_w[5];    /* normalised taps, as GaussianSmoothing.weight */
+} cvx_smoother;
+size_t cvx_smooth_workspace_bytes(int C, int H, int W, int D);
+int cvx_smooth_f32(const float* in, int C, int H, int W, int D, const cvx_smoother* sm, int backward, float* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* Adam instance optimisation -------------------------------------------------------------------------
  * replaces the loop of convex_adam_MIND.py:155-182 (nn.Conv3d weight + torch.optim.Adam(lr=1)).
  *   F2, M2 [C][h][w][d] pooled features; P [3][h][w][d] control grid (grid units), updated in place;
@@ -139,6 +156,14 @@ int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, int w, int 
                      const float* base_h, const float* base_w, const float* base_d, float* U, float* grad_out,
                      const int* snapshot_iters_host, int n_snap, float* snapshots, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* same loop with a pluggable smoother instead of the three 3^3 boxes (adam_run_withconfig_shiftSpline.py:214-230);
+ * sm == NULL or the chain {3,3,3} selects the fused kernels of cvx_adam_run_f32. */
+int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m,
+                              float* v, float lambda_weight, int niter, int step0, float cost_scale,
+                              const float* base_h, const float* base_w, const float* base_d, float* U, float* grad_out,
+                              const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* whole pair ---------------------------------------------------------------------------------------
  * replaces convex_adam_pt(...)                                       convex_adam_MIND.py:64-202

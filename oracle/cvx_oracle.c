@@ -592,6 +592,61 @@ ORC_API void orc_resize_trilinear(const float* in, int C, int h, int w, int d, f
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Smoothers of the sweep scripts: kovesi_spline = chain of zero-padded box filters
+ * (self_configuring/convexAdam_hyper_util.py:475-488); GaussianSmoothing = 5-tap replicate-padded convolution along
+ * H, W, D (hyper_util.py:423-473).  Rounding order pinned against torch 2.10 CPU (oneDNN convolution):
+ *   forward  acc = w0*x0 ; acc = fma(w_t, x_t, acc)  t = 1..4
+ *   backward gxp[j] = w0*g[j] ; then t = 1..4 ascending: fma(w_t, g[j-t], acc) when the tensor has more than one
+ *            channel (oneDNN picks another kernel for a single image: there the products are rounded, acc + w_t*g),
+ *            padded index j; then replication_pad3d_backward adds the border entries in ascending order.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int kind; int n_boxes; int box_k[4]; float gauss_w[5]; } orc_smoother;
+
+static void gauss1d(const float* in, float* out, int C, int H, int W, int D, int axis, const float* w, int backward) {
+    const size_t total = (size_t)C * H * W * D;
+    const int n = axis == 0 ? H : (axis == 1 ? W : D);
+    const size_t stride = axis == 0 ? (size_t)W * D : (axis == 1 ? (size_t)D : 1);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < total; ++i) {
+        const int a = (int)((i / stride) % n);
+        const float* base = in + (i - (size_t)a * stride);
+        if (!backward) {
+            float acc = w[0] * base[(size_t)clampi(a - 2, 0, n - 1) * stride];
+            for (int t = 1; t < 5; ++t) acc = fmaf(w[t], base[(size_t)clampi(a + t - 2, 0, n - 1) * stride], acc);
+            out[i] = acc;
+        } else {
+            float r = 0.0f;
+            const int j0 = a == 0 ? 0 : a + 2, j1 = a == n - 1 ? n + 3 : a + 2;
+            for (int j = j0; j <= j1; ++j) {
+                float acc = w[0] * ((j >= 0 && j < n) ? base[(size_t)j * stride] : 0.0f);
+                for (int t = 1; t < 5; ++t) {
+                    const int q = j - t;
+                    const float gq = (q >= 0 && q < n) ? base[(size_t)q * stride] : 0.0f;
+                    acc = (C > 1) ? fmaf(w[t], gq, acc) : acc + w[t] * gq;
+                }
+                r += acc;
+            }
+            out[i] = r;
+        }
+    }
+}
+ORC_API void orc_smooth(const float* in, float* out, int C, int H, int W, int D, const orc_smoother* sm, int backward) {
+    const size_t n = (size_t)C * H * W * D;
+    float* a = (float*)malloc(sizeof(float) * n); float* b = (float*)malloc(sizeof(float) * n);
+    memcpy(a, in, sizeof(float) * n);
+    const int nst = sm->kind == 1 ? 3 : sm->n_boxes;
+    for (int i = 0; i < nst; ++i) {
+        const int st = backward ? nst - 1 - i : i;
+        if (sm->kind == 1) gauss1d(a, b, C, H, W, D, st, sm->gauss_w, backward);
+        else if (backward) orc_box_zero_backward(a, b, C, H, W, D, sm->box_k[st]);
+        else orc_box_zero(a, b, C, H, W, D, sm->box_k[st]);
+        float* t = a; a = b; b = t;
+    }
+    memcpy(out, a, sizeof(float) * n);
+    free(a); free(b);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Adam instance optimisation, convex_adam_MIND.py:155-182.
  *   P    : [3][h][w][d]   parameter (control grid, grid units)   -- updated in place
  *   m, v : Adam moments (zero-initialised by the caller for a fresh run)
@@ -606,9 +661,19 @@ ORC_API void orc_resize_trilinear(const float* in, int C, int h, int w, int d, f
  *   loss = mean_x( mean_c((Wc-Fc)^2) * 12 )                                       (:176-177)
  *   backward (autograd accumulation order restated below), Adam step             (:178-179)
  * ---------------------------------------------------------------------------------------------- */
+ORC_API void orc_adam_run_smoother(const float* F2, const float* M2, int C, int h, int w, int d, float* P,
+                          float* m, float* v, float lambda_weight, int niter, int step0, float cost_scale,
+                          float* U, float* G, float* loss_out, const orc_smoother* sm);
 ORC_API void orc_adam_run(const float* F2, const float* M2, int C, int h, int w, int d, float* P,
                           float* m, float* v, float lambda_weight, int niter, int step0, float cost_scale,
                           float* U, float* G, float* loss_out) {
+    orc_adam_run_smoother(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, U, G, loss_out, NULL);
+}
+ORC_API void orc_adam_run_smoother(const float* F2, const float* M2, int C, int h, int w, int d, float* P,
+                          float* m, float* v, float lambda_weight, int niter, int step0, float cost_scale,
+                          float* U, float* G, float* loss_out, const orc_smoother* sm) {
+    const orc_smoother dflt = {0, 3, {3, 3, 3, 0}, {0, 0, 0, 0, 0}};       /* box3(box3(box3(.))), MIND:166 */
+    if (!sm) sm = &dflt;
     const size_t V = (size_t)h * w * d;
     float* t1 = (float*)malloc(sizeof(float) * 3 * V);
     float* t2 = (float*)malloc(sizeof(float) * 3 * V);
@@ -626,9 +691,7 @@ ORC_API void orc_adam_run(const float* F2, const float* M2, int C, int h, int w,
     const float gmx = (float)d / 2.0f, gmy = (float)w / 2.0f, gmz = (float)h / 2.0f;
 
     for (int it = 0; it < niter; ++it) {
-        orc_box_zero(P, t1, 3, h, w, d, 3);
-        orc_box_zero(t1, t2, 3, h, w, d, 3);
-        orc_box_zero(t2, U, 3, h, w, d, 3);
+        orc_smooth(P, U, 3, h, w, d, sm, 0);
         double lsum = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : lsum)
         for (size_t p = 0; p < V; ++p) {
@@ -686,9 +749,7 @@ ORC_API void orc_adam_run(const float* F2, const float* M2, int C, int h, int w,
         }
         if (loss_out) loss_out[it] = (float)(lsum * (double)cost_scale / (double)C / (double)V);
         /* adjoint of the three box filters (symmetric operator, ATen backward order) */
-        orc_box_zero_backward(gU, t1, 3, h, w, d, 3);
-        orc_box_zero_backward(t1, t2, 3, h, w, d, 3);
-        orc_box_zero_backward(t2, t1, 3, h, w, d, 3);
+        orc_smooth(gU, t1, 3, h, w, d, sm, 1);
         if (G) memcpy(G, t1, sizeof(float) * 3 * V);
         /* torch.optim.Adam (single-tensor path), lr=1, betas=(0.9,0.999), eps=1e-8 */
         const int step = step0 + it + 1;

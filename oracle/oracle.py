@@ -14,6 +14,24 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libcvx_oracle.so")
 _lib = None
 
+
+class Smoother(C.Structure):
+    _fields_ = [("kind", C.c_int), ("n_boxes", C.c_int), ("box_k", C.c_int * 4), ("gauss_w", C.c_float * 5)]
+
+
+def make_smoother(boxes=None, gauss_w=None):
+    sm = Smoother()
+    if gauss_w is not None:
+        sm.kind = 1
+        for i in range(5):
+            sm.gauss_w[i] = float(gauss_w[i])
+    else:
+        sm.kind = 0
+        sm.n_boxes = len(boxes)
+        for i, k in enumerate(boxes):
+            sm.box_k[i] = int(k)
+    return sm
+
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -50,6 +68,9 @@ def lib():
         L.orc_resize_trilinear.argtypes = [_f32p] + [C.c_int] * 4 + [_f32p] + [C.c_int] * 3
         L.orc_adam_run.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [_f32p, _f32p, _f32p, C.c_float, C.c_int,
                                                                    C.c_int, C.c_float, _f32p, C.c_void_p, C.c_void_p]
+        L.orc_smooth.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [C.POINTER(Smoother), C.c_int]
+        L.orc_adam_run_smoother.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [_f32p, _f32p, _f32p, C.c_float, C.c_int,
+                                                                            C.c_int, C.c_float, _f32p, C.c_void_p, C.c_void_p, C.POINTER(Smoother)]
         L.orc_label_features.argtypes = [_f32p, _f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_label_features.restype = C.c_int
         L.orc_mind_tables.argtypes = [_i32p, _i32p, _i32p]
@@ -167,14 +188,22 @@ def resize_trilinear(x, size):
     lib().orc_resize_trilinear(x.reshape(-1), c, h, w, d, out.reshape(-1), H, W, D); return out
 
 
-def adam_run(F2, M2, P, lambda_weight, niter, m=None, v=None, step0=0, cost_scale=12.0, want_grad=False):
+def smooth(x, smoother, backward=False):
+    x = _f(x); c, h, w, d = x.shape
+    out = np.empty_like(x)
+    lib().orc_smooth(x.reshape(-1), out.reshape(-1), c, h, w, d, C.byref(smoother), 1 if backward else 0)
+    return out
+
+
+def adam_run(F2, M2, P, lambda_weight, niter, m=None, v=None, step0=0, cost_scale=12.0, want_grad=False, smoother=None):
     """Runs `niter` Adam iterations in place on copies; returns dict(P, m, v, U, G, loss)."""
     F2 = _f(F2); M2 = _f(M2); c, h, w, d = F2.shape
     P = _f(P).copy(); m = np.zeros_like(P) if m is None else _f(m).copy(); v = np.zeros_like(P) if v is None else _f(v).copy()
     U = np.zeros_like(P); G = np.zeros_like(P) if want_grad else None; loss = np.zeros(max(niter, 1), np.float32)
-    lib().orc_adam_run(F2.reshape(-1), M2.reshape(-1), c, h, w, d, P.reshape(-1), m.reshape(-1), v.reshape(-1),
-                       float(lambda_weight), int(niter), int(step0), float(cost_scale), U.reshape(-1),
-                       G.ctypes.data_as(C.c_void_p) if G is not None else None, loss.ctypes.data_as(C.c_void_p))
+    lib().orc_adam_run_smoother(F2.reshape(-1), M2.reshape(-1), c, h, w, d, P.reshape(-1), m.reshape(-1), v.reshape(-1),
+                                float(lambda_weight), int(niter), int(step0), float(cost_scale), U.reshape(-1),
+                                G.ctypes.data_as(C.c_void_p) if G is not None else None, loss.ctypes.data_as(C.c_void_p),
+                                C.byref(smoother) if smoother is not None else None)
     return dict(P=P, m=m, v=v, U=U, G=G, loss=loss[:niter])
 
 

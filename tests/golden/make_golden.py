@@ -153,5 +153,59 @@ def main():
         torch.Tensor.cuda, torch.Tensor.half = _cuda, _half
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--smoothers" not in sys.argv:
     main()
+    smoother_goldens_later = True
+
+
+def smoother_goldens():
+    """Row P: GaussianSmoothing / kovesi_spline of self_configuring/convexAdam_hyper_util.py inside the sweep's Adam loop
+    (adam_run_withconfig_shiftSpline.py:214-230).  cupy is stubbed (only the metrics of that module need it)."""
+    import types
+    for m in ("cupy", "cupyx", "cupyx.scipy", "cupyx.scipy.ndimage"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.path.insert(0, os.path.join(os.environ.get("CONVEXADAM_REFERENCE", "/root/reference"), "self_configuring"))
+    import convexAdam_hyper_util as HU
+    torch.manual_seed(77)
+    x = torch.randn(1, 3, 11, 12, 13)
+    go = torch.randn(1, 3, 11, 12, 13)
+    out = dict(x=x[0].numpy(), go=go[0].numpy())
+    specs = {"gauss07": HU.GaussianSmoothing(0.7), "gauss10": HU.GaussianSmoothing(1.0), "kov16": HU.kovesi_spline(1.6, 4),
+             "kov19": HU.kovesi_spline(1.9, 4), "kov28": HU.kovesi_spline(2.8, 4)}
+    for k, sm in specs.items():
+        xr = x.clone().requires_grad_(True)
+        y = sm(xr)
+        y.backward(go)
+        out[k + "_fwd"] = y.detach()[0].numpy()
+        out[k + "_bwd"] = xr.grad[0].numpy()
+    out["gauss07_w"] = specs["gauss07"].weight.numpy()
+    out["gauss10_w"] = specs["gauss10"].weight.numpy()
+    # a few Adam iterations with two of the smoothers, n_ch cost scale (adam_run_withconfig_shiftSpline.py:227)
+    a = dict(np.load(os.path.join(HERE, "adam.npz")))
+    pf, pm = torch.from_numpy(a["F2"])[None], torch.from_numpy(a["M2"])[None]
+    h, w, d = pf.shape[2:]
+    lam = 0.8
+    for k in ("gauss07", "kov19"):
+        net = nn.Sequential(nn.Conv3d(3, 1, (h, w, d), bias=False))
+        net[0].weight.data[:] = torch.from_numpy(a["P0"])[None]
+        opt = torch.optim.Adam(net.parameters(), lr=1)
+        grid0 = F.affine_grid(torch.eye(3, 4).unsqueeze(0), (1, 1, h, w, d), align_corners=False)
+        for it in range(3):
+            opt.zero_grad()
+            ds = specs[k](net[0].weight).permute(0, 2, 3, 4, 1)
+            reg = lam * ((ds[0, :, 1:, :] - ds[0, :, :-1, :]) ** 2).mean() + lam * ((ds[0, 1:, :, :] - ds[0, :-1, :, :]) ** 2).mean() + lam * ((ds[0, :, :, 1:] - ds[0, :, :, :-1]) ** 2).mean()
+            sc = torch.tensor([(h - 1) / 2, (w - 1) / 2, (d - 1) / 2]).unsqueeze(0)
+            gd = grid0.view(-1, 3).float() + ((ds.view(-1, 3)) / sc).flip(1).float()
+            pms = F.grid_sample(pm.float(), gd.view(1, h, w, d, 3), align_corners=False, mode="bilinear")
+            loss = ((pms - pf).pow(2).mean(1) * 12).mean()
+            (loss + reg).backward()
+            if it == 0:
+                out[k + "_adam_U1"] = ds.detach().permute(0, 4, 1, 2, 3)[0].numpy().copy()
+                out[k + "_adam_G1"] = net[0].weight.grad[0].numpy().copy()
+            opt.step()
+        out[k + "_adam_U3"] = ds.detach().permute(0, 4, 1, 2, 3)[0].numpy().copy()
+    save("smoothers", **out)
+
+
+if __name__ == "__main__":
+    smoother_goldens()

@@ -270,6 +270,31 @@ def test_masked_feature_extraction(M, orc, golden):
                            device=torch.device(DEV), dtype=torch.float32)
 
 
+def test_sweep_smoothers(orc, golden):
+    """Row P on the GPU: forward and adjoint of every smoother of the sweep bit-identical to the oracle and to the
+    reference goldens; the autograd wrapper gives the same adjoint; the fused Adam loop accepts them."""
+    from convexadam_amd import convexAdam_hyper_util as HU
+    from convexadam_amd import convex_adam_utils as U
+    g, a = golden("smoothers"), golden("adam")
+    mods = {"gauss07": HU.GaussianSmoothing(0.7), "gauss10": HU.GaussianSmoothing(1.0), "kov16": HU.kovesi_spline(1.6, 4),
+            "kov19": HU.kovesi_spline(1.9, 4), "kov28": HU.kovesi_spline(2.8, 4)}
+    assert np.array_equal(np.array(list(mods["gauss07"].spec.gauss_w), np.float32), g["gauss07_w"])
+    for k, mod in mods.items():
+        x = dev(g["x"])[None].requires_grad_(True)
+        y = mod(x)
+        y.backward(dev(g["go"])[None])
+        assert np.array_equal(host(y)[0], g[k + "_fwd"]), k
+        assert np.array_equal(host(x.grad)[0], g[k + "_bwd"]), k
+    for k in ("gauss07", "kov19", "kov28"):
+        sm = orc.make_smoother(gauss_w=g["gauss07_w"]) if k == "gauss07" else orc.make_smoother(mods[k].sizes)
+        Ud, st = U.adam_run(dev(a["F2"])[None], dev(a["M2"])[None], dev(a["P0"])[None], 0.8, 4, smoother=mods[k], return_state=True)
+        r = orc.adam_run(a["F2"], a["M2"], a["P0"], 0.8, 4, want_grad=True, smoother=sm)
+        assert np.array_equal(host(Ud)[0], r["U"]) and np.array_equal(host(st["G"])[0], r["G"]) and np.array_equal(host(st["P"])[0], r["P"]), k
+    # the packaged chain [3,3,3] given as a smoother takes the fused kernels and equals the default loop
+    U3 = U.adam_run(dev(a["F2"])[None], dev(a["M2"])[None], dev(a["P0"])[None], 1.25, 3, smoother=HU.kovesi_spline(1.3, 4))
+    assert torch.equal(U3, U.adam_run(dev(a["F2"])[None], dev(a["M2"])[None], dev(a["P0"])[None], 1.25, 3))
+
+
 # ---- (3) properties at full size (BASELINE.json configs 2 and 3) ------------------------------------------
 @pytest.mark.timeout(900)
 def test_full_size_identity_and_determinism(M):

@@ -175,3 +175,28 @@ def test_masked_feature_extraction(orc, golden):
         assert np.array_equal(filled[m != 0], img[m != 0])
         out = orc.mindssc(filled, 1, 2)
         assert np.abs(out - g[key]).max() <= 6e-8           # 1 ulp: MKL exp only
+
+
+def _smoother_specs(orc, g):
+    return {"gauss07": orc.make_smoother(gauss_w=g["gauss07_w"]), "gauss10": orc.make_smoother(gauss_w=g["gauss10_w"]),
+            "kov16": orc.make_smoother([3, 3, 3, 3]), "kov19": orc.make_smoother([3, 3, 3, 5]), "kov28": orc.make_smoother([5, 5, 5, 5])}
+
+
+def test_sweep_smoothers_forward_and_adjoint_bit_exact(orc, golden):
+    """GaussianSmoothing / kovesi_spline of self_configuring/convexAdam_hyper_util.py:454-488 and
+    their autograd adjoints (oneDNN convolution / avg_pool3d_backward evaluation order)."""
+    g = golden("smoothers")
+    for k, sm in _smoother_specs(orc, g).items():
+        assert np.array_equal(orc.smooth(g["x"], sm), g[k + "_fwd"]), k
+        assert np.array_equal(orc.smooth(g["go"], sm, backward=True), g[k + "_bwd"]), k
+
+
+def test_adam_with_sweep_smoothers(orc, golden):
+    """adam_run_withconfig_shiftSpline.py:214-230 with avgs[avg_n] instead of the three 3^3 boxes."""
+    g, a = golden("smoothers"), golden("adam")
+    specs = _smoother_specs(orc, g)
+    for k in ("gauss07", "kov19"):
+        r = orc.adam_run(a["F2"], a["M2"], a["P0"], 0.8, 1, want_grad=True, smoother=specs[k])
+        assert np.array_equal(r["U"], g[k + "_adam_U1"]) and np.array_equal(r["G"], g[k + "_adam_G1"])
+        r3 = orc.adam_run(a["F2"], a["M2"], a["P0"], 0.8, 3, smoother=specs[k])
+        assert np.abs(r3["U"] - g[k + "_adam_U3"]).max() < 1e-6          # MKL sqrt in the optimiser step
