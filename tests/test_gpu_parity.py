@@ -181,6 +181,24 @@ def test_batched_pairs_on_internal_streams_match_single_calls(M, golden):
         assert all(torch.equal(a, b) for a, b in zip(single, outs)), ns
 
 
+@pytest.mark.parametrize("shape,kw", [
+    ((33, 29, 37), dict(mind_r=1, mind_d=2, grid_sp=5, disp_hw=2, grid_sp_adam=3, lambda_weight=0.7, selected_niter=4, ic=True)),
+    ((26, 41, 30), dict(mind_r=2, mind_d=1, grid_sp=3, disp_hw=4, grid_sp_adam=1, lambda_weight=1.5, selected_niter=2, ic=True, selected_smooth=5)),
+    ((24, 24, 50), dict(mind_r=1, mind_d=3, grid_sp=4, disp_hw=5, grid_sp_adam=2, lambda_weight=1.0, selected_niter=3, ic=False)),
+    ((40, 20, 23), dict(mind_r=1, mind_d=1, grid_sp=2, disp_hw=1, grid_sp_adam=4, lambda_weight=2.0, selected_niter=2, ic=True)),
+])
+def test_pipeline_ragged_shapes_vs_oracle_bit_exact(M, orc, shape, kw):
+    """Extents that are not multiples of the grid spacings (floor pooling drops the remainder), every mind_r/mind_d,
+    grid_sp_adam 1..4, odd widths (row padding / tail rules): the whole pipeline stays bit-identical to the oracle."""
+    from convexadam_amd.phantom import phantom
+    fix = phantom(shape, 11, 21)
+    mov = torch.roll(phantom(shape, 11, 22), (1, -1, 2), (0, 1, 2))
+    out = M.convex_adam_pt(fix, mov, dtype=torch.float32, device=torch.device(DEV), **kw)
+    ref = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), **kw)
+    assert out.shape == ref.shape
+    assert np.array_equal(out, ref), "EPE %g" % epe(out, ref)
+
+
 # ---- (2) HIP vs reference goldens -----------------------------------------------------------------------
 def test_mindssc_vs_reference_golden(U, golden):
     g = golden("mind")
