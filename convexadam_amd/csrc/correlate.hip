@@ -91,16 +91,17 @@ __global__ __launch_bounds__(256) void k_corr_raw(const float* __restrict__ Fp, 
     const float* fp = Fp + ((size_t)z * g.w + y) * g.px + i0;
     const float* mp = Mp + ((size_t)(z + iH) * g.wq + (y + iW)) * g.dq + i0;   // Mp index of M(x+dD) = i + PL + dD
 
-#pragma unroll 1
-    for (int c = 0; c < g.C; ++c) {
-        const float4 f4 = *reinterpret_cast<const float4*>(fp + (size_t)c * fstride);
+    // software pipeline over channels: the loads of channel c+1 are issued before the arithmetic of channel c
+    float4 fq[2];
+    float4 mq[2][NCH];
+    fq[0] = *reinterpret_cast<const float4*>(fp);
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) mq[0][q] = *reinterpret_cast<const float4*>(mp + 4 * q);
+    auto consume = [&](const float4& f4, const float4 (&mv)[NCH], int c) {
         const float f[4] = {f4.x, f4.y, f4.z, f4.w};
         float m[4 * NCH];
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(mp + (size_t)c * mstride + 4 * q);
-            m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
-        }
+        for (int q = 0; q < NCH; ++q) { m[4 * q] = mv[q].x; m[4 * q + 1] = mv[q].y; m[4 * q + 2] = mv[q].z; m[4 * q + 3] = mv[q].w; }
 #pragma unroll
         for (int k = 0; k < N; ++k)
 #pragma unroll
@@ -113,6 +114,23 @@ __global__ __launch_bounds__(256) void k_corr_raw(const float* __restrict__ Fp, 
             for (int k = 0; k < N; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc1[k][j] += acc[k][j]; acc[k][j] = 0.0f; }
+        }
+    };
+#pragma unroll 1
+    for (int c = 0; c < g.C; c += 2) {
+        if (c + 1 < g.C) {
+            fq[1] = *reinterpret_cast<const float4*>(fp + (size_t)(c + 1) * fstride);
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) mq[1][q] = *reinterpret_cast<const float4*>(mp + (size_t)(c + 1) * mstride + 4 * q);
+        }
+        consume(fq[0], mq[0], c);
+        if (c + 1 < g.C) {
+            if (c + 2 < g.C) {
+                fq[0] = *reinterpret_cast<const float4*>(fp + (size_t)(c + 2) * fstride);
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) mq[0][q] = *reinterpret_cast<const float4*>(mp + (size_t)(c + 2) * mstride + 4 * q);
+            }
+            consume(fq[1], mq[1], c + 1);
         }
     }
     const size_t v = (size_t)g.h * g.w * g.px;
