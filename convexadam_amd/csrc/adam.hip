@@ -120,18 +120,28 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
     g[0] = fdiv(((float)h / 2.0f) * giz, sc0);
     g[1] = fdiv(((float)w / 2.0f) * giy, sc1);
     g[2] = fdiv(((float)d / 2.0f) * gix, sc2);
+    // Diffusion regulariser: the 18 neighbour values are fetched in one batch from clamped (always valid) addresses
+    // and the one-sided terms are selected afterwards -- one memory round trip instead of 18 dependent ones.
     const size_t sH = (size_t)w * d;
+    const size_t pxp = x < d - 1 ? p + 1 : p, pxm = x > 0 ? p - 1 : p, pzp = z < h - 1 ? p + sH : p, pzm = z > 0 ? p - sH : p,
+                 pyp = y < w - 1 ? p + d : p, pym = y > 0 ? p - d : p;
+    float nb[3][6];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float* Ua = U + (size_t)a * V;
-        const float uc = Ua[p];
-        float acc = g[a];
-        if (x < d - 1) acc += -(cD * (2.0f * (Ua[p + 1] - uc)));
-        if (x > 0)     acc +=  (cD * (2.0f * (uc - Ua[p - 1])));
-        if (z < h - 1) acc += -(cH * (2.0f * (Ua[p + sH] - uc)));
-        if (z > 0)     acc +=  (cH * (2.0f * (uc - Ua[p - sH])));
-        if (y < w - 1) acc += -(cW * (2.0f * (Ua[p + d] - uc)));
-        if (y > 0)     acc +=  (cW * (2.0f * (uc - Ua[p - d])));
+        nb[a][0] = Ua[pxp]; nb[a][1] = Ua[pxm]; nb[a][2] = Ua[pzp]; nb[a][3] = Ua[pzm]; nb[a][4] = Ua[pyp]; nb[a][5] = Ua[pym];
+    }
+    const float uc3[3] = {uH, uW, uD};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float uc = uc3[a];
+        float acc = g[a], t;
+        t = acc + -(cD * (2.0f * (nb[a][0] - uc))); acc = x < d - 1 ? t : acc;
+        t = acc +  (cD * (2.0f * (uc - nb[a][1]))); acc = x > 0 ? t : acc;
+        t = acc + -(cH * (2.0f * (nb[a][2] - uc))); acc = z < h - 1 ? t : acc;
+        t = acc +  (cH * (2.0f * (uc - nb[a][3]))); acc = z > 0 ? t : acc;
+        t = acc + -(cW * (2.0f * (nb[a][4] - uc))); acc = y < w - 1 ? t : acc;
+        t = acc +  (cW * (2.0f * (uc - nb[a][5]))); acc = y > 0 ? t : acc;
         gU[(size_t)a * V + p] = acc;
     }
 }
