@@ -19,133 +19,6 @@
 
 namespace cvx {
 
-// channel-last copies of the pooled features: [C][V] -> [V][CP] (CP = C rounded up to 4, zero filled), so that
-// one trilinear corner is CP/4 contiguous 16-byte loads instead of C scattered 4-byte loads
-__global__ __launch_bounds__(256) void k_to_channel_last(const float* __restrict__ in, int C, int CP, size_t V,
-                                                         float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V * (size_t)CP) return;
-    const int c = (int)(i % CP);
-    const size_t p = i / CP;
-    out[i] = c < C ? in[(size_t)c * V + p] : 0.0f;
-}
-
-// NPRE > 0: all 8 x NPRE 16-byte gathers of a voxel are issued before any arithmetic (one memory round trip per
-// wavefront instead of one per 4-channel chunk); NPRE = 0: generic chunked loop for wide feature vectors.
-template <int NPRE>
-__global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2, const float* __restrict__ M2, int C, int CP,
-                                                   int h, int w, int d, const float* __restrict__ U,
-                                                   const float* __restrict__ bh, const float* __restrict__ bw,
-                                                   const float* __restrict__ bd, float gsc, float cH, float cW, float cD,
-                                                   float* __restrict__ gU) {
-    const size_t V = (size_t)h * w * d;
-    // 4 x 4 x 16 voxel tile per workgroup: the 8-corner footprints of a tile overlap in L1 (each moving-feature
-    // record is fetched from L2 about 1.7x instead of 4x with a linear mapping)
-    const int ntx = (d + 15) / 16, nty = (w + 3) / 4;
-    const int tbx = blockIdx.x % ntx, tby = (blockIdx.x / ntx) % nty, tbz = blockIdx.x / (ntx * nty);
-    const int x = tbx * 16 + (threadIdx.x & 15), y = tby * 4 + ((threadIdx.x >> 4) & 3), z = tbz * 4 + (threadIdx.x >> 6);
-    if (x >= d || y >= w || z >= h) return;
-    const size_t p = ((size_t)z * w + y) * d + x;
-    const float sc0 = (float)((h - 1) / 2.0), sc1 = (float)((w - 1) / 2.0), sc2 = (float)((d - 1) / 2.0);   // (:171)
-    const float uH = U[p], uW = U[V + p], uD = U[2 * V + p];
-    Tri t;
-    tri_setup(t, bd[x] + fdiv(uD, sc2), bw[y] + fdiv(uW, sc1), bh[z] + fdiv(uH, sc0), h, w, d);
-    const int x0 = t.x0, y0 = t.y0, z0 = t.z0, x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
-    const float fx0 = (float)x0, fy0 = (float)y0, fz0 = (float)z0, fx1 = (float)x1, fy1 = (float)y1, fz1 = (float)z1;
-    bool bnd[8];
-    bnd[0] = inb3(z0, y0, x0, h, w, d); bnd[1] = inb3(z0, y0, x1, h, w, d); bnd[2] = inb3(z0, y1, x0, h, w, d);
-    bnd[3] = inb3(z0, y1, x1, h, w, d); bnd[4] = inb3(z1, y0, x0, h, w, d); bnd[5] = inb3(z1, y0, x1, h, w, d);
-    bnd[6] = inb3(z1, y1, x0, h, w, d); bnd[7] = inb3(z1, y1, x1, h, w, d);
-    // Branch-free gathers: every corner is loaded from a clamped (always valid) address and replaced by 0 when it
-    // lies outside the volume.  ATen skips such corners; adding their exact-zero products instead is bit-identical
-    // here because the features and the trilinear factors are non-negative (products are +0, never -0).
-    const int zc0 = clampi(z0, 0, h - 1), zc1 = clampi(z1, 0, h - 1), yc0 = clampi(y0, 0, w - 1), yc1 = clampi(y1, 0, w - 1),
-              xc0 = clampi(x0, 0, d - 1), xc1 = clampi(x1, 0, d - 1);
-    size_t addr[8];
-    addr[0] = ((size_t)zc0 * w + yc0) * d + xc0; addr[1] = ((size_t)zc0 * w + yc0) * d + xc1;
-    addr[2] = ((size_t)zc0 * w + yc1) * d + xc0; addr[3] = ((size_t)zc0 * w + yc1) * d + xc1;
-    addr[4] = ((size_t)zc1 * w + yc0) * d + xc0; addr[5] = ((size_t)zc1 * w + yc0) * d + xc1;
-    addr[6] = ((size_t)zc1 * w + yc1) * d + xc0; addr[7] = ((size_t)zc1 * w + yc1) * d + xc1;
-    // forward weights in ATen's corner order and the backward factor pairs per corner (GridSampler.cpp)
-    const float wgt[8] = {t.tnw, t.tne, t.tsw, t.tse, t.bnw, t.bne, t.bsw, t.bse};
-    const float ax[8] = {fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0, fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0};
-    const float bx[8] = {fz1 - t.iz, fz1 - t.iz, fz1 - t.iz, fz1 - t.iz, t.iz - fz0, t.iz - fz0, t.iz - fz0, t.iz - fz0};
-    const float ay[8] = {fx1 - t.ix, t.ix - fx0, fx1 - t.ix, t.ix - fx0, fx1 - t.ix, t.ix - fx0, fx1 - t.ix, t.ix - fx0};
-    const float bz[8] = {fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0, fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0};
-    float gix = 0.f, giy = 0.f, giz = 0.f;
-    const float4* Fv = reinterpret_cast<const float4*>(F2 + p * (size_t)CP);
-    constexpr int NLOOP = NPRE > 0 ? 1 : 0;
-    const int nouter = NPRE > 0 ? 1 : CP / 4;
-    for (int c0 = 0; c0 < nouter; ++c0) {
-        constexpr int NC4 = NPRE > 0 ? NPRE : 1;
-        float vals[NC4][8][4];
-        float fv[NC4][4];
-#pragma unroll
-        for (int q4 = 0; q4 < NC4; ++q4) {
-            const int c4 = (NPRE > 0) ? q4 : c0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float4 q = *reinterpret_cast<const float4*>(M2 + addr[k] * CP + 4 * c4);
-                vals[q4][k][0] = bnd[k] ? q.x : 0.f; vals[q4][k][1] = bnd[k] ? q.y : 0.f;
-                vals[q4][k][2] = bnd[k] ? q.z : 0.f; vals[q4][k][3] = bnd[k] ? q.w : 0.f;
-            }
-            const float4 fq = Fv[c4];
-            fv[q4][0] = fq.x; fv[q4][1] = fq.y; fv[q4][2] = fq.z; fv[q4][3] = fq.w;
-        }
-#pragma unroll
-        for (int q4 = 0; q4 < NC4; ++q4)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // channels beyond C are zero-padded in both volumes: df = 0, gOut = 0, all updates are exact no-ops
-            float wv = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) wv += vals[q4][k][j] * wgt[k];
-            const float df = wv - fv[q4][j];
-            const float gOut = gsc * (2.0f * df);                    // PowBackward0: grad * (2 * self)
-            // corner order tnw,tne,tsw,tse,bnw,bne,bsw,bse ; signs from GridSampler.cpp
-            const float (*vv)[4] = vals[q4];
-            gix -= vv[0][j] * ax[0] * bx[0] * gOut; giy -= vv[0][j] * ay[0] * bx[0] * gOut; giz -= vv[0][j] * ay[0] * bz[0] * gOut;
-            gix += vv[1][j] * ax[1] * bx[1] * gOut; giy -= vv[1][j] * ay[1] * bx[1] * gOut; giz -= vv[1][j] * ay[1] * bz[1] * gOut;
-            gix -= vv[2][j] * ax[2] * bx[2] * gOut; giy += vv[2][j] * ay[2] * bx[2] * gOut; giz -= vv[2][j] * ay[2] * bz[2] * gOut;
-            gix += vv[3][j] * ax[3] * bx[3] * gOut; giy += vv[3][j] * ay[3] * bx[3] * gOut; giz -= vv[3][j] * ay[3] * bz[3] * gOut;
-            gix -= vv[4][j] * ax[4] * bx[4] * gOut; giy -= vv[4][j] * ay[4] * bx[4] * gOut; giz += vv[4][j] * ay[4] * bz[4] * gOut;
-            gix += vv[5][j] * ax[5] * bx[5] * gOut; giy -= vv[5][j] * ay[5] * bx[5] * gOut; giz += vv[5][j] * ay[5] * bz[5] * gOut;
-            gix -= vv[6][j] * ax[6] * bx[6] * gOut; giy += vv[6][j] * ay[6] * bx[6] * gOut; giz += vv[6][j] * ay[6] * bz[6] * gOut;
-            gix += vv[7][j] * ax[7] * bx[7] * gOut; giy += vv[7][j] * ay[7] * bx[7] * gOut; giz += vv[7][j] * ay[7] * bz[7] * gOut;
-        }
-    }
-    (void)NLOOP;
-    // grad wrt the normalised grid (x,y,z) = (size/2)*gi ; flip ; / scale -> grad wrt U (H,W,D)
-    float g[3];
-    g[0] = fdiv(((float)h / 2.0f) * giz, sc0);
-    g[1] = fdiv(((float)w / 2.0f) * giy, sc1);
-    g[2] = fdiv(((float)d / 2.0f) * gix, sc2);
-    // Diffusion regulariser: the 18 neighbour values are fetched in one batch from clamped (always valid) addresses
-    // and the one-sided terms are selected afterwards -- one memory round trip instead of 18 dependent ones.
-    const size_t sH = (size_t)w * d;
-    const size_t pxp = x < d - 1 ? p + 1 : p, pxm = x > 0 ? p - 1 : p, pzp = z < h - 1 ? p + sH : p, pzm = z > 0 ? p - sH : p,
-                 pyp = y < w - 1 ? p + d : p, pym = y > 0 ? p - d : p;
-    float nb[3][6];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float* Ua = U + (size_t)a * V;
-        nb[a][0] = Ua[pxp]; nb[a][1] = Ua[pxm]; nb[a][2] = Ua[pzp]; nb[a][3] = Ua[pzm]; nb[a][4] = Ua[pyp]; nb[a][5] = Ua[pym];
-    }
-    const float uc3[3] = {uH, uW, uD};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float uc = uc3[a];
-        float acc = g[a], t;
-        t = acc + -(cD * (2.0f * (nb[a][0] - uc))); acc = x < d - 1 ? t : acc;
-        t = acc +  (cD * (2.0f * (uc - nb[a][1]))); acc = x > 0 ? t : acc;
-        t = acc + -(cH * (2.0f * (nb[a][2] - uc))); acc = z < h - 1 ? t : acc;
-        t = acc +  (cH * (2.0f * (uc - nb[a][3]))); acc = z > 0 ? t : acc;
-        t = acc + -(cW * (2.0f * (nb[a][4] - uc))); acc = y < w - 1 ? t : acc;
-        t = acc +  (cW * (2.0f * (uc - nb[a][5]))); acc = y > 0 ? t : acc;
-        gU[(size_t)a * V + p] = acc;
-    }
-}
-
 // ---- three chained 3^3 box filters in one launch ---------------------------------------------------------
 // One workgroup = one channel x one 8x8x32 output tile.  The input tile (+3 halo rows/planes, columns x0-4 ..
 // x0+35, aligned float4 global loads) is staged in LDS; the passes shrink the region by one voxel each in z,y
@@ -301,7 +174,7 @@ using namespace cvx;
 
 extern "C" size_t cvx_adam_workspace_bytes(int C, int h, int w, int d) {
     const size_t V = (size_t)h * w * d, CP = (size_t)(C + 3) / 4 * 4;
-    return 3 * (256 + sizeof(float) * 3 * V) + 2 * (256 + sizeof(float) * CP * V) + 256;
+    return 3 * (256 + sizeof(float) * 3 * V) + 2 * (256 + sizeof(float) * CP * (V + 1)) + 256;
 }
 
 extern "C" int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
@@ -340,12 +213,11 @@ extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C
         }
     }
     const int CP = (C + 3) / 4 * 4;
-    float* Fcl = cv.take<float>((size_t)CP * V);
-    float* Mcl = cv.take<float>((size_t)CP * V);
+    float* Fcl = cv.take<float>((size_t)CP * (V + 1));
+    float* Mcl = cv.take<float>((size_t)CP * (V + 1));
     if (niter > 0) {
-        const dim3 gt((unsigned)cdiv64((int64_t)(V * CP), 256));
-        hipLaunchKernelGGL(k_to_channel_last, gt, dim3(256), 0, s, F2, C, CP, V, Fcl);
-        hipLaunchKernelGGL(k_to_channel_last, gt, dim3(256), 0, s, M2, C, CP, V, Mcl);
+        int rc;
+        if ((rc = launch_to_chunked(F2, C, V, Fcl, s)) || (rc = launch_to_chunked(M2, C, V, Mcl, s))) return rc;
     }
 
     // MeanBackward of lambda*mean(diff^2): lambda / N_axis in float32                       (:167-169)
@@ -353,7 +225,6 @@ extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C
                 nD = (float)((int64_t)3 * h * w * (d - 1));
     const float cH = lambda_weight / nH, cW = lambda_weight / nW, cD = lambda_weight / nD;
     const float gsc = ((1.0f / (float)V) * cost_scale) / (float)C;     // MeanBackward, MulBackward, MeanBackward
-    const dim3 gv((unsigned)(cdiv(d, 16) * cdiv(w, 4) * cdiv(h, 4)));
     int snap = 0;
     for (int it = 0; it < niter; ++it) {
         int rc;
@@ -363,10 +234,7 @@ extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C
         const AdamConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)(-(1.0 / bc1))};
         if (fused) { if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc; }
         else if ((rc = launch_smoother(P, U, t1, 3, h, w, d, *sm, false, s))) return rc;
-        if (false) hipLaunchKernelGGL(k_warp_grad<3>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
-        else if (CP == 4) hipLaunchKernelGGL(k_warp_grad<1>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
-        else if (false) hipLaunchKernelGGL(k_warp_grad<2>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
-        else hipLaunchKernelGGL(k_warp_grad<0>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU);
+        if ((rc = launch_warp_grad(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, s))) return rc;
         float* gsave = (grad_out && it == niter - 1) ? grad_out : nullptr;
         if (fused) { if ((rc = launch_box3x3(gU, nullptr, h, w, d, true, P, m, v, ac, gsave, s))) return rc; }
         else {

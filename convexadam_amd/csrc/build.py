@@ -11,7 +11,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["api.hip", "mind.hip", "pool.hip", "correlate.hip", "convex.hip", "adam.hip", "pipeline.hip"]
+SOURCES = ["api.hip", "mind.hip", "pool.hip", "correlate.hip", "convex.hip", "adam.hip", "warp.hip", "pipeline.hip"]
+PER_FILE_FLAGS = {"warp.hip": ["-fno-slp-vectorize"]}     # see the header of warp.hip
 LIB = os.path.join(HERE, "libconvexadam_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-fvisibility=hidden",
@@ -40,7 +41,7 @@ def build(force=False, verbose=False):
         s = os.path.join(HERE, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc()] + FLAGS + ["-DCVX_BUILDING=1", "-c", s, "-o", o])
+            jobs.append([hipcc()] + FLAGS + PER_FILE_FLAGS.get(src, []) + ["-DCVX_BUILDING=1", "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -217,5 +217,9 @@ int launch_argmin(const float* ssd, const float* mesh, const float* u, float coe
 // out = interp(in * pre_mul) / post_div   (pre_mul, post_div = 1 -> plain F.interpolate)
 int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D, float pre_mul,
                   float post_div, hipStream_t s);
+// warp.hip: [C][V] -> [CP/4][V][4] feature copies and the warp + data-term gradient of one Adam iteration
+int launch_to_chunked(const float* in, int C, size_t V, float* out, hipStream_t s);
+int launch_warp_grad(const float* Fcl, const float* Mcl, int C, int h, int w, int d, const float* U, const float* bh,
+                     const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s);
 
 }  // namespace cvx
