@@ -33,7 +33,6 @@ namespace cvx {
 // pass stores its result shifted by one more index so that the next pass's windows are aligned again:
 //   "column" c = x - x0 + 8;  A holds the input at index c, B holds pass 1 at index c+1, A then pass 2 at c+2.
 constexpr int BT_Z = 8, BT_Y = 8, BT_X = 32, BT_NT = 512, BT_PX = 48;
-struct AdamConsts { float w1, b2, omb2, bc2s, neg_step; };
 
 // PASS 1: pairs (c, c+1), c = 5 + 2p, p < 19  (needs columns 6..41)   src shift 0 -> dst shift 1
 // PASS 2: pairs (c, c+1), c = 6 + 2p, p < 18  (needs columns 7..40)   src shift 1 -> dst shift 2
@@ -161,6 +160,9 @@ __global__ __launch_bounds__(256) void k_adam_update(const float* __restrict__ G
 
 static int launch_box3x3(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
                          AdamConsts ac, float* gsave, hipStream_t s) {
+    // rows of up to 126 voxels: z-marching pipeline (boxmarch.hip); longer rows: the tiled kernel below
+    static const bool force_tiled = getenv("CVX_BOX_TILED") != nullptr;
+    if (!force_tiled && box3_march_supported(d)) return launch_box3_march(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
     const int nb = cdiv(d, BT_X) * cdiv(w, BT_Y) * cdiv(h, BT_Z) * 3;
     if (!backward) hipLaunchKernelGGL((k_box3x3<false, false>), dim3(nb), dim3(BT_NT), 0, s, in, out, h, w, d, P, m, v, ac, gsave);
     else if (!P) hipLaunchKernelGGL((k_box3x3<true, false>), dim3(nb), dim3(BT_NT), 0, s, in, out, h, w, d, P, m, v, ac, gsave);

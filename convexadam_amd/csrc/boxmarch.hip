@@ -1,0 +1,266 @@
+// boxmarch.hip -- three chained 3^3 box filters of the Adam control grid as ONE z-marching kernel
+// (reference: the three F.avg_pool3d(.,3,stride=1,padding=1) of convex_adam_MIND.py:166 and their autograd adjoint).
+//
+// A workgroup owns one channel, 8 rows (y) x the full row length (x) x a chunk of planes (z) and marches along z.
+// The three passes run CONCURRENTLY as a skewed pipeline on specialised wavefronts: at step t the loader stages input
+// plane zlo+t, the pass-1 waves produce plane zlo+t-2 of stage 1, the pass-2 waves plane zlo+t-4 of stage 2 and the
+// pass-3 waves the output plane zlo+t-6; one barrier per step.  LDS holds only the NEWEST plane of every stage
+// (double buffered, 39 KB for 126-voxel rows): a thread keeps the 3 rows x 6 columns windows of the two previous
+// planes of its 4 output columns in registers, so every stage value is read from LDS 3 times instead of 27 and the
+// 27-tap raster-order sums run from registers (108 adds + 4 exact divisions per 4 outputs, ~135 instructions).
+// Rows are stored with a per-stage shift (stage 0: column c at index c+7, stage 1: c+6, stage 2: c+5) so that
+// every window read is one aligned ds_read_b128 + ds_read_b64 at the same index 4q+4 and every stage write one
+// aligned ds_write_b128; pass k evaluates columns 4q-3+k .. 4q+k, the last pass lands on 16-byte aligned rows of
+// the output (and of P, m, v for the fused Adam update).  No halo along x (the row pads are the zero padding of
+// avg_pool3d), 3 rows of halo along y, 3 planes (+ pipeline fill) along z.
+//   forward  (ATen avg_pool3d):           out = (raster sum of 27 taps) / 27            at every pass
+//   backward (ATen avg_pool3d_backward):  out = raster sum of (tap / 27): taps are divided when they are staged
+//                                          (IEEE division, the dividend may be -0.0), the last pass stores the sum
+#include "cvx_common.h"
+
+namespace cvx {
+
+constexpr int BM_YT = 8;
+
+template <int QPR>
+struct BMGeom {
+    static constexpr int RPW = 64 / QPR;                                   // rows per wavefront
+    static constexpr int ROWS0 = BM_YT + 6, ROWS1 = BM_YT + 4, ROWS2 = BM_YT + 2, ROWS3 = BM_YT;
+    static constexpr int NW1 = (ROWS1 + RPW - 1) / RPW, NW2 = (ROWS2 + RPW - 1) / RPW, NW3 = (ROWS3 + RPW - 1) / RPW;
+    static constexpr int NT = 64 * (NW1 + NW2 + NW3);
+    static constexpr int RS = 4 * QPR + 8;                                 // LDS row stride in floats
+};
+
+// per-workgroup constants shared by the three roles
+struct BMCtx {
+    const float* ic;                       // input channel
+    float *oc, *Pc, *mc, *vc, *gs;          // output channel / Adam state / saved gradient (may be null)
+    float *S0, *S1, *S2;
+    int h, w, d, z0, y0, zn, nsteps;
+    bool vec;
+    AdamConsts ac;
+};
+
+// loader state of one thread: columns 4lq .. 4lq+3 of input row lgy, one plane per step, register staged
+struct BMLoader {
+    bool ldr, lrow;
+    int lgy, lq;
+    float* lds0;
+    float4 reg;
+};
+
+template <bool BACKWARD>
+__device__ __forceinline__ void bm_issue(const BMCtx& c, BMLoader& L, int gz) {
+    L.reg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (L.lrow && gz >= 0 && gz < c.h) {
+        const float* rowp = c.ic + ((size_t)gz * c.w + L.lgy) * c.d + 4 * L.lq;
+        if (c.vec) L.reg = *reinterpret_cast<const float4*>(rowp);
+        else {
+            L.reg.x = rowp[0];
+            if (4 * L.lq + 1 < c.d) L.reg.y = rowp[1];
+            if (4 * L.lq + 2 < c.d) L.reg.z = rowp[2];
+            if (4 * L.lq + 3 < c.d) L.reg.w = rowp[3];
+        }
+        // backward: every tap is gradOut / 27 (the only place where the dividend may be -0.0 -> IEEE division)
+        if (BACKWARD) { L.reg.x = fdiv(L.reg.x, 27.0f); L.reg.y = fdiv(L.reg.y, 27.0f); L.reg.z = fdiv(L.reg.z, 27.0f); L.reg.w = fdiv(L.reg.w, 27.0f); }
+    }
+}
+
+// loader part of step t: publish the plane fetched during the previous step, start fetching the next one
+template <int SLOT0, bool BACKWARD>
+__device__ __forceinline__ void bm_load_step(const BMCtx& c, BMLoader& L, int t) {
+    if (L.ldr && t <= c.zn + 5) {
+        float* p = L.lds0 + (t & 1) * SLOT0;                         // indices 4lq+7 .. 4lq+10: b32 + b64 + b32
+        p[0] = L.reg.x;
+        const f32x2 mid = {L.reg.y, L.reg.z};
+        lds_store2(p + 1, mid);
+        p[3] = L.reg.w;
+        if (t + 1 <= c.zn + 5) bm_issue<BACKWARD>(c, L, c.z0 - 3 + t + 1);
+    }
+}
+
+// The whole march of one role.  Every role executes exactly nsteps barriers.  Lanes beyond the role's last row
+// compute on a clamped row and only their stores are masked, so that the window registers never pass through a
+// divergent merge (no register copies).
+template <int K, int QPR, bool BACKWARD, bool ADAM>
+__device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int lane) {
+    using G = BMGeom<QPR>;
+    constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
+    constexpr int ROWS = BM_YT + 6 - 2 * K;
+    constexpr int SRC_SLOT = K == 1 ? SLOT0 : (K == 2 ? SLOT1 : SLOT2), DST_SLOT = K == 1 ? SLOT1 : SLOT2;
+    const int r_raw = wk * G::RPW + lane / QPR, q = lane % QPR;
+    const bool active = r_raw < ROWS;
+    const int r = active ? r_raw : ROWS - 1;
+    const int c0 = 4 * q - 3 + K;
+    const int gy = c.y0 - 3 + K + r;
+    const bool rowok = active && gy >= 0 && gy < c.w;
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ok[j] = rowok && c0 + j >= 0 && c0 + j < c.d;
+    const float* src = (K == 1 ? c.S0 : (K == 2 ? c.S1 : c.S2)) + r * G::RS + 4 * q + 4;
+    float* dst = (K == 1 ? c.S1 : c.S2) + r * G::RS + 4 * q + 4;
+    const int ncol = c.d - 4 * q;                                        // pass 3: valid columns of this quad
+    const size_t rowbase = (size_t)(gy < 0 ? 0 : gy) * c.d + 4 * q;
+    const int tlast = c.zn + 5 + K;
+
+    float win[3][3][6];
+    auto load_win = [&](auto rot, int t) {
+        constexpr int ROT = decltype(rot)::value;
+        const float* sp = src + ((t - 1) & 1) * SRC_SLOT;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4 a = lds_load4(sp + i * G::RS);
+            const f32x2 b = lds_load2(sp + i * G::RS + 4);
+            win[ROT][i][0] = a.x; win[ROT][i][1] = a.y; win[ROT][i][2] = a.z; win[ROT][i][3] = a.w;
+            win[ROT][i][4] = b.x; win[ROT][i][5] = b.y;
+        }
+    };
+    auto full = [&](auto rot, int t) {
+        constexpr int ROT = decltype(rot)::value;
+        bm_load_step<SLOT0, BACKWARD>(c, L, t);
+        load_win(rot, t);
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int pl = 1; pl <= 3; ++pl) {                   // planes z-1, z, z+1 = register slots ROT+1, ROT+2, ROT (mod 3)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s[j] += win[(ROT + pl) % 3][i][j];
+                    s[j] += win[(ROT + pl) % 3][i][j + 1];
+                    s[j] += win[(ROT + pl) % 3][i][j + 2];
+                }
+        }
+        const int gz = c.z0 - (2 * K + 3) + t;
+        const bool planeok = gz >= 0 && gz < c.h;
+        if (K < 3) {
+            f32x4 o;
+            o.x = (planeok && ok[0]) ? div_exact<27>(s[0]) : 0.0f;
+            o.y = (planeok && ok[1]) ? div_exact<27>(s[1]) : 0.0f;
+            o.z = (planeok && ok[2]) ? div_exact<27>(s[2]) : 0.0f;
+            o.w = (planeok && ok[3]) ? div_exact<27>(s[3]) : 0.0f;
+            if (active) lds_store4(dst + (t & 1) * DST_SLOT, o);
+        } else if (planeok && rowok && ncol > 0) {
+            const size_t gidx = (size_t)gz * c.w * c.d + rowbase;
+            float g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = BACKWARD ? s[j] : div_exact<27>(s[j]);
+            if (!ADAM) {
+                if (c.vec) *reinterpret_cast<float4*>(c.oc + gidx) = make_float4(g[0], g[1], g[2], g[3]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (j < ncol) c.oc[gidx + j] = g[j];
+                }
+            } else if (c.vec) {
+                float4 p4 = *reinterpret_cast<float4*>(c.Pc + gidx), m4 = *reinterpret_cast<float4*>(c.mc + gidx),
+                       v4 = *reinterpret_cast<float4*>(c.vc + gidx);
+                adam_update(g[0], p4.x, m4.x, v4.x, c.ac); adam_update(g[1], p4.y, m4.y, v4.y, c.ac);
+                adam_update(g[2], p4.z, m4.z, v4.z, c.ac); adam_update(g[3], p4.w, m4.w, v4.w, c.ac);
+                *reinterpret_cast<float4*>(c.Pc + gidx) = p4; *reinterpret_cast<float4*>(c.mc + gidx) = m4;
+                *reinterpret_cast<float4*>(c.vc + gidx) = v4;
+                if (c.gs) *reinterpret_cast<float4*>(c.gs + gidx) = make_float4(g[0], g[1], g[2], g[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < ncol) {
+                        float pp = c.Pc[gidx + j], mm = c.mc[gidx + j], vv = c.vc[gidx + j];
+                        adam_update(g[j], pp, mm, vv, c.ac);
+                        c.Pc[gidx + j] = pp; c.mc[gidx + j] = mm; c.vc[gidx + j] = vv;
+                        if (c.gs) c.gs[gidx + j] = g[j];
+                    }
+            }
+        }
+        __syncthreads();
+    };
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
+    int t = 0;
+    for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD>(c, L, t); __syncthreads(); }
+    bm_load_step<SLOT0, BACKWARD>(c, L, t); load_win(R1{}, t); __syncthreads(); ++t;        // t = 3K-2: slot 1
+    bm_load_step<SLOT0, BACKWARD>(c, L, t); load_win(R2{}, t); __syncthreads(); ++t;        // t = 3K-1: slot 2
+    for (; t + 2 <= tlast; t += 3) { full(R0{}, t); full(R1{}, t + 1); full(R2{}, t + 2); }  // t = 3K ..: slot 0, 1, 2
+    if (t <= tlast) { full(R0{}, t); ++t; }
+    if (t <= tlast) { full(R1{}, t); ++t; }
+    for (; t < c.nsteps; ++t) { bm_load_step<SLOT0, BACKWARD>(c, L, t); __syncthreads(); }
+}
+
+template <int QPR, bool BACKWARD, bool ADAM>
+__global__ __launch_bounds__(BMGeom<QPR>::NT) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
+                                                                int w, int d, int zc, int nzc, int nyt, float* __restrict__ P,
+                                                                float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
+                                                                float* __restrict__ gsave, int vec_ok) {
+    using G = BMGeom<QPR>;
+    constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
+    __shared__ __attribute__((aligned(16))) float S0[2 * SLOT0];
+    __shared__ __attribute__((aligned(16))) float S1[2 * SLOT1];
+    __shared__ __attribute__((aligned(16))) float S2[2 * SLOT2];
+    // XCD-aware order: XCD q (workgroups q, q+8, ..) takes the q-th contiguous run of (channel, y tile, z chunk) triples
+    const int nblk = 3 * nyt * nzc;
+    const int b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (b >= nblk) return;
+    const int zi = b % nzc, yi = (b / nzc) % nyt, ch = b / (nzc * nyt);
+    const size_t V = (size_t)h * w * d;
+    BMCtx c;
+    c.ic = in + (size_t)ch * V;
+    c.oc = out ? out + (size_t)ch * V : nullptr;
+    c.Pc = P ? P + (size_t)ch * V : nullptr;
+    c.mc = m ? m + (size_t)ch * V : nullptr;
+    c.vc = v ? v + (size_t)ch * V : nullptr;
+    c.gs = gsave ? gsave + (size_t)ch * V : nullptr;
+    c.S0 = S0; c.S1 = S1; c.S2 = S2;
+    c.h = h; c.w = w; c.d = d; c.z0 = zi * zc; c.y0 = yi * BM_YT;
+    c.zn = min(zc, h - c.z0);
+    c.nsteps = c.zn + 9;
+    c.vec = vec_ok != 0;
+    c.ac = ac;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * SLOT0; i += G::NT) S0[i] = 0.0f;
+    for (int i = tid; i < 2 * SLOT1; i += G::NT) S1[i] = 0.0f;
+    for (int i = tid; i < 2 * SLOT2; i += G::NT) S2[i] = 0.0f;
+
+    BMLoader L;
+    L.ldr = tid < G::ROWS0 * QPR;
+    const int lr = tid / QPR;
+    L.lq = tid % QPR;
+    L.lgy = c.y0 - 3 + lr;
+    L.lrow = L.ldr && L.lgy >= 0 && L.lgy < w && 4 * L.lq < d;
+    L.lds0 = S0 + lr * G::RS + 4 * L.lq + 7;
+    bm_issue<BACKWARD>(c, L, c.z0 - 3);
+    __syncthreads();
+
+    // role of this wavefront (wave-uniform, kept in a scalar register)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    if (wave < G::NW1) bm_run<1, QPR, BACKWARD, ADAM>(c, L, wave, lane);
+    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, BACKWARD, ADAM>(c, L, wave - G::NW1, lane);
+    else bm_run<3, QPR, BACKWARD, ADAM>(c, L, wave - G::NW1 - G::NW2, lane);
+}
+
+bool box3_march_supported(int d) { return d <= 126; }
+
+template <int QPR>
+static int launch_qpr(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
+                      AdamConsts ac, float* gsave, hipStream_t s) {
+    using G = BMGeom<QPR>;
+    const int nyt = cdiv(w, BM_YT);
+    const int nz_target = 256 / (3 * nyt) > 0 ? 256 / (3 * nyt) : 1;         // about one workgroup per CU
+    int zc = cdiv(h, nz_target);
+    if (zc < 4) zc = 4;
+    const int nzc = cdiv(h, zc);
+    const unsigned grid = (unsigned)((3 * nyt * nzc + 7) / 8 * 8);
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int vec = (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave);
+    if (!backward) hipLaunchKernelGGL((k_box3_march<QPR, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
+    else if (!P) hipLaunchKernelGGL((k_box3_march<QPR, true, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
+    else hipLaunchKernelGGL((k_box3_march<QPR, true, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
+    return check_last("box3_march");
+}
+
+int launch_box3_march(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
+                      AdamConsts ac, float* gsave, hipStream_t s) {
+    if (d <= 30) return launch_qpr<8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+    if (d <= 62) return launch_qpr<16>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+    return launch_qpr<32>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+}
+
+}  // namespace cvx

@@ -217,6 +217,21 @@ int launch_argmin(const float* ssd, const float* mesh, const float* u, float coe
 // out = interp(in * pre_mul) / post_div   (pre_mul, post_div = 1 -> plain F.interpolate)
 int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D, float pre_mul,
                   float post_div, hipStream_t s);
+// Adam step constants of one iteration (torch.optim.Adam, lr = 1, eps = 1e-8) and the in-place update of one element
+struct AdamConsts { float w1, b2, omb2, bc2s, neg_step; };
+__device__ __forceinline__ void adam_update(float g, float& P, float& m, float& v, const AdamConsts& ac) {
+    const float mm = __builtin_fmaf(ac.w1, g - m, m);            // exp_avg.lerp_(grad, 1-beta1)
+    float vv = v * ac.b2;                                         // exp_avg_sq.mul_(beta2)
+    vv = __builtin_fmaf(ac.omb2 * g, g, vv);                      // .addcmul_(grad, grad, value=1-beta2)
+    const float den = fdiv(fsqrt(vv), ac.bc2s) + 1e-8f;           // (sqrt / bias_correction2_sqrt).add_(eps)
+    P = P + fdiv(ac.neg_step * mm, den);                          // addcdiv_(exp_avg, denom, value=-step_size)
+    m = mm;
+    v = vv;
+}
+// boxmarch.hip: three chained 3^3 boxes (forward / adjoint / adjoint + Adam) for rows of at most 126 voxels
+bool box3_march_supported(int d);
+int launch_box3_march(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
+                      AdamConsts ac, float* gsave, hipStream_t s);
 // warp.hip: [C][V] -> [CP/4][V][4] feature copies and the warp + data-term gradient of one Adam iteration
 int launch_to_chunked(const float* in, int C, size_t V, float* out, hipStream_t s);
 int launch_warp_grad(const float* Fcl, const float* Mcl, int C, int h, int w, int d, const float* U, const float* bh,
