@@ -35,8 +35,9 @@ struct BMGeom {
 struct BMCtx {
     const float* ic;                       // input channel
     float *oc, *Pc, *mc, *vc, *gs;          // output channel / Adam state / saved gradient (may be null)
-    float *S0, *S1, *S2;
+    float *S0, *S1, *S2, *S3;               // S3: plain adjoint sums of the newest output plane (Adam variant only)
     int h, w, d, z0, y0, zn, nsteps;
+    int e_row[2], e_col[2];                 // Adam variant: the (row, column) of the <= 2 plane elements this thread updates
     bool vec;
     AdamConsts ac;
 };
@@ -48,6 +49,9 @@ struct BMLoader {
     float* lds0;
     float4 reg;
 };
+
+// x / 27 correctly rounded for every float including -0.0 (IEEE: -0.0 / 27 = -0.0)
+__device__ __forceinline__ float div27_signed(float x) { return x == 0.0f ? x : div_exact<27>(x); }
 
 template <bool BACKWARD>
 __device__ __forceinline__ void bm_issue(const BMCtx& c, BMLoader& L, int gz) {
@@ -61,8 +65,8 @@ __device__ __forceinline__ void bm_issue(const BMCtx& c, BMLoader& L, int gz) {
             if (4 * L.lq + 2 < c.d) L.reg.z = rowp[2];
             if (4 * L.lq + 3 < c.d) L.reg.w = rowp[3];
         }
-        // backward: every tap is gradOut / 27 (the only place where the dividend may be -0.0 -> IEEE division)
-        if (BACKWARD) { L.reg.x = fdiv(L.reg.x, 27.0f); L.reg.y = fdiv(L.reg.y, 27.0f); L.reg.z = fdiv(L.reg.z, 27.0f); L.reg.w = fdiv(L.reg.w, 27.0f); }
+        // backward: every tap is gradOut / 27; the dividend may be -0.0 here, which div_exact maps to +0.0 -> sign fix
+        if (BACKWARD) { L.reg.x = div27_signed(L.reg.x); L.reg.y = div27_signed(L.reg.y); L.reg.z = div27_signed(L.reg.z); L.reg.w = div27_signed(L.reg.w); }
     }
 }
 
@@ -76,6 +80,45 @@ __device__ __forceinline__ void bm_load_step(const BMCtx& c, BMLoader& L, int t)
         lds_store2(p + 1, mid);
         p[3] = L.reg.w;
         if (t + 1 <= c.zn + 5) bm_issue<BACKWARD>(c, L, c.z0 - 3 + t + 1);
+    }
+}
+
+// Adam variant, every thread: update the elements (e_row, e_col) of the plane that the pass-3 waves published in S3
+// during the previous step (plane index z0 + t - 10).  Spreading the update over all wavefronts keeps the
+// per-step work of the roles balanced; P, m, v of a plane are fetched one step ahead so that their latency is
+// not on the critical path of the step barrier.
+struct BMAdamPre { float p[2], m[2], v[2]; };
+
+template <int QPR>
+__device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int t) {
+    using G = BMGeom<QPR>;
+    constexpr int SLOT3 = G::ROWS3 * G::RS;
+    if (t >= 10 && t <= c.zn + 9) {
+        const int gz = c.z0 + t - 10;
+        const float* sp = c.S3 + ((t - 1) & 1) * SLOT3;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = c.e_row[k], col = c.e_col[k], gy = c.y0 + row;
+            if (row < BM_YT && gy < c.w) {
+                const float g = sp[row * G::RS + col + 4];
+                const size_t i = ((size_t)gz * c.w + gy) * c.d + col;
+                float pp = pre.p[k], mm = pre.m[k], vv = pre.v[k];
+                adam_update(g, pp, mm, vv, c.ac);
+                c.Pc[i] = pp; c.mc[i] = mm; c.vc[i] = vv;
+                if (c.gs) c.gs[i] = g;
+            }
+        }
+    }
+    if (t + 1 >= 10 && t + 1 <= c.zn + 9) {
+        const int gz = c.z0 + t + 1 - 10;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = c.e_row[k], col = c.e_col[k], gy = c.y0 + row;
+            if (row < BM_YT && gy < c.w) {
+                const size_t i = ((size_t)gz * c.w + gy) * c.d + col;
+                pre.p[k] = c.Pc[i]; pre.m[k] = c.mc[i]; pre.v[k] = c.vc[i];
+            }
+        }
     }
 }
 
@@ -103,6 +146,7 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     const size_t rowbase = (size_t)(gy < 0 ? 0 : gy) * c.d + 4 * q;
     const int tlast = c.zn + 5 + K;
 
+    BMAdamPre pre = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     float win[3][3][6];
     auto load_win = [&](auto rot, int t) {
         constexpr int ROT = decltype(rot)::value;
@@ -140,49 +184,41 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
             o.z = (planeok && ok[2]) ? div_exact<27>(s[2]) : 0.0f;
             o.w = (planeok && ok[3]) ? div_exact<27>(s[3]) : 0.0f;
             if (active) lds_store4(dst + (t & 1) * DST_SLOT, o);
+        } else if (ADAM) {
+            // plain adjoint sums of this plane -> S3 (index = column + 4); consumed by bm_adam_step of the next step
+            const f32x4 o = {s[0], s[1], s[2], s[3]};
+            if (active) lds_store4(c.S3 + (t & 1) * (G::ROWS3 * G::RS) + r * G::RS + 4 * q + 4, o);
         } else if (planeok && rowok && ncol > 0) {
             const size_t gidx = (size_t)gz * c.w * c.d + rowbase;
             float g[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = BACKWARD ? s[j] : div_exact<27>(s[j]);
-            if (!ADAM) {
+            {
                 if (c.vec) *reinterpret_cast<float4*>(c.oc + gidx) = make_float4(g[0], g[1], g[2], g[3]);
                 else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (j < ncol) c.oc[gidx + j] = g[j];
                 }
-            } else if (c.vec) {
-                float4 p4 = *reinterpret_cast<float4*>(c.Pc + gidx), m4 = *reinterpret_cast<float4*>(c.mc + gidx),
-                       v4 = *reinterpret_cast<float4*>(c.vc + gidx);
-                adam_update(g[0], p4.x, m4.x, v4.x, c.ac); adam_update(g[1], p4.y, m4.y, v4.y, c.ac);
-                adam_update(g[2], p4.z, m4.z, v4.z, c.ac); adam_update(g[3], p4.w, m4.w, v4.w, c.ac);
-                *reinterpret_cast<float4*>(c.Pc + gidx) = p4; *reinterpret_cast<float4*>(c.mc + gidx) = m4;
-                *reinterpret_cast<float4*>(c.vc + gidx) = v4;
-                if (c.gs) *reinterpret_cast<float4*>(c.gs + gidx) = make_float4(g[0], g[1], g[2], g[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < ncol) {
-                        float pp = c.Pc[gidx + j], mm = c.mc[gidx + j], vv = c.vc[gidx + j];
-                        adam_update(g[j], pp, mm, vv, c.ac);
-                        c.Pc[gidx + j] = pp; c.mc[gidx + j] = mm; c.vc[gidx + j] = vv;
-                        if (c.gs) c.gs[gidx + j] = g[j];
-                    }
             }
         }
+        if (ADAM) bm_adam_step<QPR>(c, pre, t);
         __syncthreads();
     };
     using R0 = std::integral_constant<int, 0>;
     using R1 = std::integral_constant<int, 1>;
     using R2 = std::integral_constant<int, 2>;
     int t = 0;
-    for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD>(c, L, t); __syncthreads(); }
+    for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD>(c, L, t); __syncthreads(); }                    // (Adam starts at t = 10)
     bm_load_step<SLOT0, BACKWARD>(c, L, t); load_win(R1{}, t); __syncthreads(); ++t;        // t = 3K-2: slot 1
     bm_load_step<SLOT0, BACKWARD>(c, L, t); load_win(R2{}, t); __syncthreads(); ++t;        // t = 3K-1: slot 2
     for (; t + 2 <= tlast; t += 3) { full(R0{}, t); full(R1{}, t + 1); full(R2{}, t + 2); }  // t = 3K ..: slot 0, 1, 2
     if (t <= tlast) { full(R0{}, t); ++t; }
     if (t <= tlast) { full(R1{}, t); ++t; }
-    for (; t < c.nsteps; ++t) { bm_load_step<SLOT0, BACKWARD>(c, L, t); __syncthreads(); }
+    for (; t < c.nsteps; ++t) {
+        bm_load_step<SLOT0, BACKWARD>(c, L, t);
+        if (ADAM) bm_adam_step<QPR>(c, pre, t);
+        __syncthreads();
+    }
 }
 
 template <int QPR, bool BACKWARD, bool ADAM>
@@ -195,6 +231,7 @@ __global__ __launch_bounds__(BMGeom<QPR>::NT) void k_box3_march(const float* __r
     __shared__ __attribute__((aligned(16))) float S0[2 * SLOT0];
     __shared__ __attribute__((aligned(16))) float S1[2 * SLOT1];
     __shared__ __attribute__((aligned(16))) float S2[2 * SLOT2];
+    __shared__ __attribute__((aligned(16))) float S3[ADAM ? 2 * G::ROWS3 * G::RS : 4];
     // XCD-aware order: XCD q (workgroups q, q+8, ..) takes the q-th contiguous run of (channel, y tile, z chunk) triples
     const int nblk = 3 * nyt * nzc;
     const int b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
@@ -208,17 +245,26 @@ __global__ __launch_bounds__(BMGeom<QPR>::NT) void k_box3_march(const float* __r
     c.mc = m ? m + (size_t)ch * V : nullptr;
     c.vc = v ? v + (size_t)ch * V : nullptr;
     c.gs = gsave ? gsave + (size_t)ch * V : nullptr;
-    c.S0 = S0; c.S1 = S1; c.S2 = S2;
+    c.S0 = S0; c.S1 = S1; c.S2 = S2; c.S3 = S3;
     c.h = h; c.w = w; c.d = d; c.z0 = zi * zc; c.y0 = yi * BM_YT;
     c.zn = min(zc, h - c.z0);
-    c.nsteps = c.zn + 9;
+    c.nsteps = c.zn + (ADAM ? 10 : 9);
     c.vec = vec_ok != 0;
     c.ac = ac;
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * SLOT0; i += G::NT) S0[i] = 0.0f;
     for (int i = tid; i < 2 * SLOT1; i += G::NT) S1[i] = 0.0f;
     for (int i = tid; i < 2 * SLOT2; i += G::NT) S2[i] = 0.0f;
+    if (ADAM) for (int i = tid; i < 2 * G::ROWS3 * G::RS; i += G::NT) S3[i] = 0.0f;
 
+    if (ADAM) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * G::NT;                           // 8 rows x d columns <= 1008 elements <= 2 per thread
+            c.e_row[k] = e / d;
+            c.e_col[k] = e - c.e_row[k] * d;
+        }
+    }
     BMLoader L;
     L.ldr = tid < G::ROWS0 * QPR;
     const int lr = tid / QPR;
