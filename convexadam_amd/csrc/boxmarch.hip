@@ -37,7 +37,9 @@ struct BMCtx {
     float *oc, *Pc, *mc, *vc, *gs;          // output channel / Adam state / saved gradient (may be null)
     float *S0, *S1, *S2, *S3;               // S3: plain adjoint sums of the newest output plane (Adam variant only)
     int h, w, d, z0, y0, zn, nsteps;
-    int e_row[2], e_col[2];                 // Adam variant: the (row, column) of the <= 2 plane elements this thread updates
+    size_t wd;                              // plane stride w*d
+    unsigned e_off[2];                      // Adam variant: offset (y0+row)*d + col inside a plane of the <= 2 elements this thread updates
+    unsigned e_lds[2];                      //               and their index in an S3 slot; 0xffffffff = none
     bool vec;
     AdamConsts ac;
 };
@@ -45,7 +47,8 @@ struct BMCtx {
 // loader state of one thread: columns 4lq .. 4lq+3 of input row lgy, one plane per step, register staged
 struct BMLoader {
     bool ldr, lrow;
-    int lgy, lq;
+    int lq;
+    unsigned loff;                          // lgy*d + 4lq
     float* lds0;
     float4 reg;
 };
@@ -57,7 +60,7 @@ template <bool BACKWARD>
 __device__ __forceinline__ void bm_issue(const BMCtx& c, BMLoader& L, int gz) {
     L.reg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (L.lrow && gz >= 0 && gz < c.h) {
-        const float* rowp = c.ic + ((size_t)gz * c.w + L.lgy) * c.d + 4 * L.lq;
+        const float* rowp = c.ic + (size_t)gz * c.wd + L.loff;
         if (c.vec) L.reg = *reinterpret_cast<const float4*>(rowp);
         else {
             L.reg.x = rowp[0];
@@ -94,31 +97,25 @@ __device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int
     using G = BMGeom<QPR>;
     constexpr int SLOT3 = G::ROWS3 * G::RS;
     if (t >= 10 && t <= c.zn + 9) {
-        const int gz = c.z0 + t - 10;
+        const size_t po = (size_t)(c.z0 + t - 10) * c.wd;             // uniform plane offset
+        float *Pz = c.Pc + po, *mz = c.mc + po, *vz = c.vc + po;
         const float* sp = c.S3 + ((t - 1) & 1) * SLOT3;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int row = c.e_row[k], col = c.e_col[k], gy = c.y0 + row;
-            if (row < BM_YT && gy < c.w) {
-                const float g = sp[row * G::RS + col + 4];
-                const size_t i = ((size_t)gz * c.w + gy) * c.d + col;
+        for (int k = 0; k < 2; ++k)
+            if (c.e_lds[k] != 0xffffffffu) {
+                const float g = sp[c.e_lds[k]];
                 float pp = pre.p[k], mm = pre.m[k], vv = pre.v[k];
                 adam_update(g, pp, mm, vv, c.ac);
-                c.Pc[i] = pp; c.mc[i] = mm; c.vc[i] = vv;
-                if (c.gs) c.gs[i] = g;
+                Pz[c.e_off[k]] = pp; mz[c.e_off[k]] = mm; vz[c.e_off[k]] = vv;
+                if (c.gs) (c.gs + po)[c.e_off[k]] = g;
             }
-        }
     }
     if (t + 1 >= 10 && t + 1 <= c.zn + 9) {
-        const int gz = c.z0 + t + 1 - 10;
+        const size_t po = (size_t)(c.z0 + t + 1 - 10) * c.wd;
+        const float *Pz = c.Pc + po, *mz = c.mc + po, *vz = c.vc + po;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int row = c.e_row[k], col = c.e_col[k], gy = c.y0 + row;
-            if (row < BM_YT && gy < c.w) {
-                const size_t i = ((size_t)gz * c.w + gy) * c.d + col;
-                pre.p[k] = c.Pc[i]; pre.m[k] = c.mc[i]; pre.v[k] = c.vc[i];
-            }
-        }
+        for (int k = 0; k < 2; ++k)
+            if (c.e_lds[k] != 0xffffffffu) { pre.p[k] = Pz[c.e_off[k]]; pre.m[k] = mz[c.e_off[k]]; pre.v[k] = vz[c.e_off[k]]; }
     }
 }
 
@@ -143,7 +140,7 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     const float* src = (K == 1 ? c.S0 : (K == 2 ? c.S1 : c.S2)) + r * G::RS + 4 * q + 4;
     float* dst = (K == 1 ? c.S1 : c.S2) + r * G::RS + 4 * q + 4;
     const int ncol = c.d - 4 * q;                                        // pass 3: valid columns of this quad
-    const size_t rowbase = (size_t)(gy < 0 ? 0 : gy) * c.d + 4 * q;
+    const unsigned rowbase = (unsigned)((gy < 0 ? 0 : gy) * c.d + 4 * q);
     const int tlast = c.zn + 5 + K;
 
     BMAdamPre pre = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -189,15 +186,15 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
             const f32x4 o = {s[0], s[1], s[2], s[3]};
             if (active) lds_store4(c.S3 + (t & 1) * (G::ROWS3 * G::RS) + r * G::RS + 4 * q + 4, o);
         } else if (planeok && rowok && ncol > 0) {
-            const size_t gidx = (size_t)gz * c.w * c.d + rowbase;
+            float* oz = c.oc + (size_t)gz * c.wd;
             float g[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = BACKWARD ? s[j] : div_exact<27>(s[j]);
             {
-                if (c.vec) *reinterpret_cast<float4*>(c.oc + gidx) = make_float4(g[0], g[1], g[2], g[3]);
+                if (c.vec) *reinterpret_cast<float4*>(oz + rowbase) = make_float4(g[0], g[1], g[2], g[3]);
                 else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (j < ncol) c.oc[gidx + j] = g[j];
+                    for (int j = 0; j < 4; ++j) if (j < ncol) oz[rowbase + j] = g[j];
                 }
             }
         }
@@ -246,6 +243,7 @@ __global__ __launch_bounds__(BMGeom<QPR>::NT) void k_box3_march(const float* __r
     c.vc = v ? v + (size_t)ch * V : nullptr;
     c.gs = gsave ? gsave + (size_t)ch * V : nullptr;
     c.S0 = S0; c.S1 = S1; c.S2 = S2; c.S3 = S3;
+    c.wd = (size_t)w * d;
     c.h = h; c.w = w; c.d = d; c.z0 = zi * zc; c.y0 = yi * BM_YT;
     c.zn = min(zc, h - c.z0);
     c.nsteps = c.zn + (ADAM ? 10 : 9);
@@ -261,16 +259,19 @@ __global__ __launch_bounds__(BMGeom<QPR>::NT) void k_box3_march(const float* __r
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int e = tid + k * G::NT;                           // 8 rows x d columns <= 1008 elements <= 2 per thread
-            c.e_row[k] = e / d;
-            c.e_col[k] = e - c.e_row[k] * d;
+            const int row = e / d, col = e - row * d;
+            const bool have = row < BM_YT && c.y0 + row < w;
+            c.e_off[k] = (unsigned)((c.y0 + row) * d + col);
+            c.e_lds[k] = have ? (unsigned)(row * G::RS + col + 4) : 0xffffffffu;
         }
     }
     BMLoader L;
     L.ldr = tid < G::ROWS0 * QPR;
     const int lr = tid / QPR;
     L.lq = tid % QPR;
-    L.lgy = c.y0 - 3 + lr;
-    L.lrow = L.ldr && L.lgy >= 0 && L.lgy < w && 4 * L.lq < d;
+    const int lgy = c.y0 - 3 + lr;
+    L.lrow = L.ldr && lgy >= 0 && lgy < w && 4 * L.lq < d;
+    L.loff = (unsigned)((lgy < 0 ? 0 : lgy) * d + 4 * L.lq);
     L.lds0 = S0 + lr * G::RS + 4 * L.lq + 7;
     bm_issue<BACKWARD>(c, L, c.z0 - 3);
     __syncthreads();
