@@ -368,7 +368,8 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
     const CorrGeom g = corr_geom(C, h, w, d, disp_hw);
     const size_t K = (size_t)g.n * g.n * g.n;
     const BoxGeom b = box_geom(h, w, d, g.px);
-    if (b.nthreads == 0) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
+    if (b.nthreads == 0 && !corr_box2_supported(h, w, d, g.px))
+        return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
     Carver cv(workspace, workspace_bytes);
     float* Fp = cv.take<float>((size_t)C * h * w * g.px);
     float* Mp = cv.take<float>((size_t)C * g.hq * g.wq * g.dq);
@@ -394,11 +395,17 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
     if (ntail > 0)
         hipLaunchKernelGGL(k_corr_tail, dim3(cdiv(ntail * g.n, 64)), dim3(64), 0, s, fix, mov, g, tail_from, ntail, raw);
 
-    const size_t lds = sizeof(float) * 8 * (size_t)(b.Ty + 4) * b.px;
-    static size_t granted = 0;
-    ensure_dynamic_lds(&k_corr_box, lds, granted);
-    hipLaunchKernelGGL(k_corr_box, dim3((unsigned)K, b.nytiles), dim3(b.nthreads), lds, s, raw, b, ssd);
-    int rc = check_last("correlate");
+    static const bool old_box = getenv("CVX_CORR_BOX_V1") != nullptr;
+    int rc;
+    if (!old_box && corr_box2_supported(h, w, d, g.px)) rc = launch_corr_box2(raw, (int)K, h, w, d, g.px, ssd, s);
+    else {
+        if (b.nthreads == 0) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
+        const size_t lds = sizeof(float) * 8 * (size_t)(b.Ty + 4) * b.px;
+        static size_t granted = 0;
+        ensure_dynamic_lds(&k_corr_box, lds, granted);
+        hipLaunchKernelGGL(k_corr_box, dim3((unsigned)K, b.nytiles), dim3(b.nthreads), lds, s, raw, b, ssd);
+        rc = check_last("correlate");
+    }
     if (rc) return rc;
     if (argmin) return launch_argmin(ssd, nullptr, nullptr, 0.0f, false, (int)K, (size_t)h * w * d, keys, argmin, s);
     return CVX_OK;

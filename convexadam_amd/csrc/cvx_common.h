@@ -228,6 +228,9 @@ __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& 
     m = mm;
     v = vv;
 }
+// corrbox.hip: the two box filters of the SSD volume (z-marching pipeline); raw [K][h][w][px] -> ssd [K][h][w][d]
+bool corr_box2_supported(int h, int w, int d, int px);
+int launch_corr_box2(const float* raw, int K, int h, int w, int d, int px, float* ssd, hipStream_t s);
 // boxmarch.hip: three chained 3^3 boxes (forward / adjoint / adjoint + Adam) for rows of at most 126 voxels
 bool box3_march_supported(int d);
 int launch_box3_march(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
