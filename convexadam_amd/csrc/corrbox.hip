@@ -12,7 +12,6 @@
 // 4q .. 4q+3 and stores them at index 4q+4, box 2 evaluates columns 4q-3 .. 4q: every window is one aligned
 // ds_read_b128 + ds_read_b64, every stage write one aligned ds_write_b128.  Values outside the volume are exact zeros
 // in every stage (each avg_pool3d zero-pads its own input).
-#include <stdio.h>
 #include <stdlib.h>
 
 #include "cvx_common.h"
@@ -202,11 +201,14 @@ static CB2Geom cb2_geom(int h, int w, int d, int px) {
     CB2Geom b;
     b.h = h; b.w = w; b.d = d; b.px = px;
     b.lpr = px / 4;
-    b.RS = px + 8;
+    // row stride: >= px + 8 floats, and (RS/4) = lpr (mod 8) so that the 16-byte window reads of consecutive lanes stay
+    // on distinct bank groups across a row boundary (lane -> (row, quad) is row-major with lpr quads per row)
+    int rs4 = b.lpr + 2;
+    while ((rs4 & 7) != (b.lpr & 7)) ++rs4;
+    b.RS = 4 * rs4;
     b.nthreads = 0;
     // largest y tile whose two roles (and the loader rows) fit 1024 threads
-    static const int ty_env = getenv("CVX_CB2_TY") ? atoi(getenv("CVX_CB2_TY")) : 0;
-    int Ty = (ty_env > 0 && ty_env < w) ? ty_env : w;
+    int Ty = w;
     for (;; --Ty) {
         if (Ty < 1) return b;
         const int nw1 = cdiv((Ty + 2) * b.lpr, 64), nw2 = cdiv(Ty * b.lpr, 64);
@@ -235,8 +237,6 @@ int launch_corr_box2(const float* raw, int K, int h, int w, int d, int px, float
     if (b.nthreads == 0) return fail(CVX_ERR_UNSUPPORTED, "correlate: rows of %d voxels are too long for the LDS box kernel", d);
     static size_t granted = 0;
     ensure_dynamic_lds(&k_corr_box2, b.lds_bytes, granted);
-    if (getenv("CVX_DEBUG_OCC")) { int nb = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_corr_box2, b.nthreads, b.lds_bytes); fprintf(stderr, "corr_box2: %d threads, %zu B LDS, occupancy %d WG/CU\n", b.nthreads, b.lds_bytes, nb); }
-    if (getenv("CVX_DEBUG_K")) K = atoi(getenv("CVX_DEBUG_K"));
     hipLaunchKernelGGL(k_corr_box2, dim3((unsigned)K, b.nyt), dim3(b.nthreads), b.lds_bytes, s, raw, b, ssd);
     return check_last("corr_box2");
 }
