@@ -29,6 +29,36 @@ __global__ __launch_bounds__(256) void k_avgpool(const float* __restrict__ in, i
     out[i] = fdiv(s, (float)(g * g * g));
 }
 
+// Same result with the window size known at compile time: the G rows of one z-slice are fetched as 8-byte loads
+// before they are added (G*G/2.. loads in flight per thread instead of one), which is what this HBM-bound pass needs.
+// Requires even G and even D (8-byte aligned row segments).
+template <int G>
+__global__ __launch_bounds__(256) void k_avgpool_even(const float* __restrict__ in, int C, int H, int W, int D,
+                                                      float* __restrict__ out) {
+    static_assert(G % 2 == 0, "even windows only");
+    const int Ho = H / G, Wo = W / G, Do = D / G;
+    const size_t n = (size_t)C * Ho * Wo * Do;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)(i % Do), w = (int)((i / Do) % Wo), h = (int)((i / ((size_t)Do * Wo)) % Ho);
+    const int c = (int)(i / ((size_t)Do * Wo * Ho));
+    const float* base = in + (((size_t)c * H + (size_t)h * G) * W + (size_t)w * G) * D + (size_t)d * G;
+    float s = 0.0f;
+#pragma unroll
+    for (int z = 0; z < G; ++z) {
+        float2 v[G][G / 2];
+#pragma unroll
+        for (int y = 0; y < G; ++y)
+#pragma unroll
+            for (int x = 0; x < G / 2; ++x) v[y][x] = *reinterpret_cast<const float2*>(base + ((size_t)z * W + y) * D + 2 * x);
+#pragma unroll
+        for (int y = 0; y < G; ++y)
+#pragma unroll
+            for (int x = 0; x < G / 2; ++x) { s += v[y][x].x; s += v[y][x].y; }
+    }
+    out[i] = fdiv(s, (float)(G * G * G));
+}
+
 // ---- avg_pool3d(k, stride 1, pad k/2), forward and ATen-ordered backward (global-memory version)
 template <bool BACKWARD>
 __global__ __launch_bounds__(256) void k_box_zero(const float* __restrict__ in, float* __restrict__ out, int C, int H,
@@ -258,8 +288,13 @@ extern "C" int cvx_avgpool_f32(const float* in, int C, int H, int W, int D, int 
     CVX_REQUIRE(C > 0 && H > 0 && W > 0 && D > 0 && g > 0, "cvx_avgpool_f32: bad arguments");
     CVX_REQUIRE(H / g > 0 && W / g > 0 && D / g > 0, "cvx_avgpool_f32: pooling window %d larger than the volume", g);
     const size_t n = (size_t)C * (H / g) * (W / g) * (D / g);
-    hipLaunchKernelGGL(k_avgpool, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, as_stream(stream), in, C, H, W,
-                       D, g, out);
+    const dim3 grid((unsigned)cdiv64((int64_t)n, 256));
+    const bool even = (D % 2 == 0) && (reinterpret_cast<uintptr_t>(in) & 7) == 0;
+    if (even && g == 2) hipLaunchKernelGGL(k_avgpool_even<2>, grid, dim3(256), 0, as_stream(stream), in, C, H, W, D, out);
+    else if (even && g == 4) hipLaunchKernelGGL(k_avgpool_even<4>, grid, dim3(256), 0, as_stream(stream), in, C, H, W, D, out);
+    else if (even && g == 6) hipLaunchKernelGGL(k_avgpool_even<6>, grid, dim3(256), 0, as_stream(stream), in, C, H, W, D, out);
+    else if (even && g == 8) hipLaunchKernelGGL(k_avgpool_even<8>, grid, dim3(256), 0, as_stream(stream), in, C, H, W, D, out);
+    else hipLaunchKernelGGL(k_avgpool, grid, dim3(256), 0, as_stream(stream), in, C, H, W, D, g, out);
     return check_last("avgpool");
 }
 
