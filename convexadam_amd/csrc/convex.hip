@@ -98,17 +98,22 @@ __global__ __launch_bounds__(256) void k_index64_to_32(const int64_t* __restrict
 }
 
 // u_a(x) = avg_pool3d(mesh[a, idx], 3, padding=1)  -- raster-order 27-tap sum of the in-range taps, / 27
-__global__ __launch_bounds__(256) void k_gather_box3(const int* __restrict__ idx, const float* __restrict__ mesh, int K,
-                                                     int h, int w, int d, float* __restrict__ out) {
+// The index comes either from an int32 map or from the low word of the 64-bit argmin keys of the previous pass;
+// `reset` (optional) is a key buffer that this launch re-arms to all ones for a later pass.
+template <typename IndexT>
+__global__ __launch_bounds__(256) void k_gather_box3(const IndexT* __restrict__ idx, const float* __restrict__ mesh, int K,
+                                                     int h, int w, int d, float* __restrict__ out,
+                                                     unsigned long long* __restrict__ reset) {
     const size_t v = (size_t)h * w * d;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v) return;
+    if (reset) reset[i] = ~0ull;
     const int x = (int)(i % d), y = (int)((i / d) % w), z = (int)(i / ((size_t)d * w));
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int a = max(z - 1, 0); a <= min(z + 1, h - 1); ++a)
         for (int b = max(y - 1, 0); b <= min(y + 1, w - 1); ++b)
             for (int c = max(x - 1, 0); c <= min(x + 1, d - 1); ++c) {
-                const int k = idx[((size_t)a * w + b) * d + c];
+                const int k = (int)(unsigned)idx[((size_t)a * w + b) * d + c];     // low 32 bits of a key = displacement index
                 s0 += mesh[k];
                 s1 += mesh[K + k];
                 s2 += mesh[2 * K + k];
@@ -119,8 +124,8 @@ __global__ __launch_bounds__(256) void k_gather_box3(const int* __restrict__ idx
 }
 
 static int argmin_pass(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
-                       unsigned long long* keys, hipStream_t s) {
-    if (hipMemsetAsync(keys, 0xff, sizeof(unsigned long long) * v, s) != hipSuccess)
+                       unsigned long long* keys, bool arm, hipStream_t s) {
+    if (arm && hipMemsetAsync(keys, 0xff, sizeof(unsigned long long) * v, s) != hipSuccess)
         return fail(CVX_ERR_LAUNCH, "argmin: memset failed");
     const bool vec4 = (v % 4 == 0) && ((reinterpret_cast<uintptr_t>(ssd) | reinterpret_cast<uintptr_t>(u)) & 15) == 0;
     const int xb = (int)cdiv64((int64_t)(vec4 ? v / 4 : v), 256);
@@ -140,7 +145,7 @@ static int argmin_pass(const float* ssd, const float* mesh, const float* u, floa
 
 int launch_argmin(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
                   unsigned long long* keys, int64_t* argmin_out, hipStream_t s) {
-    int rc = argmin_pass(ssd, mesh, u, coef, coupled, K, v, keys, s);
+    int rc = argmin_pass(ssd, mesh, u, coef, coupled, K, v, keys, true, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_keys_to_index, dim3((unsigned)cdiv64((int64_t)v, 256)), dim3(256), 0, s, keys, v, (int*)nullptr,
                        argmin_out);
@@ -174,7 +179,7 @@ extern "C" size_t cvx_coupled_convex_workspace_bytes(int h, int w, int d, int di
     (void)disp_hw;
     const size_t v = (size_t)h * w * d;
     size_t used = 0;
-    used = carve_size(used, sizeof(unsigned long long) * v);
+    for (int i = 0; i < 3; ++i) used = carve_size(used, sizeof(unsigned long long) * v);
     used = carve_size(used, sizeof(int) * v);
     return used + 256;
 }
@@ -189,17 +194,20 @@ extern "C" int cvx_coupled_convex_f32(const float* ssd, const int64_t* argmin, c
     const int n = 2 * disp_hw + 1, K = n * n * n;
     const size_t v = (size_t)h * w * d;
     Carver cv(workspace, workspace_bytes);
-    unsigned long long* keys = cv.take<unsigned long long>(v);
+    // three key buffers in rotation: pass p mins into keys[p % 3]; the gather that consumes pass p re-arms keys[(p+2) % 3]
+    unsigned long long* keys[3];
+    for (int i = 0; i < 3; ++i) keys[i] = cv.take<unsigned long long>(v);
     int* idx = cv.take<int>(v);
     const dim3 gv((unsigned)cdiv64((int64_t)v, 256));
     hipLaunchKernelGGL(k_index64_to_32, gv, dim3(256), 0, s, argmin, v, idx);
+    if (hipMemsetAsync(keys[0], 0xff, sizeof(unsigned long long) * v, s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
+    hipLaunchKernelGGL(k_gather_box3<int>, gv, dim3(256), 0, s, idx, mesh, K, h, w, d, out, keys[1]);
     static const float coeffs[6] = {0.003f, 0.01f, 0.03f, 0.1f, 0.3f, 1.0f};   // torch.tensor([...]) float32 (:98)
-    for (int it = 0; it <= 6; ++it) {
-        hipLaunchKernelGGL(k_gather_box3, gv, dim3(256), 0, s, idx, mesh, K, h, w, d, out);
-        if (it == 6) break;
-        int rc = argmin_pass(ssd, mesh, out, coeffs[it], true, K, v, keys, s);
+    for (int it = 0; it < 6; ++it) {
+        int rc = argmin_pass(ssd, mesh, out, coeffs[it], true, K, v, keys[it % 3], false, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_keys_to_index, gv, dim3(256), 0, s, keys, v, idx, (int64_t*)nullptr);
+        hipLaunchKernelGGL(k_gather_box3<unsigned long long>, gv, dim3(256), 0, s, keys[it % 3], mesh, K, h, w, d, out,
+                           it < 4 ? keys[(it + 2) % 3] : nullptr);
     }
     return check_last("coupled_convex");
 }

@@ -194,17 +194,28 @@ __device__ __forceinline__ void tri_setup(Tri& t, float gx, float gy, float gz, 
 __device__ __forceinline__ bool inb3(int z, int y, int x, int h, int w, int d) {
     return z >= 0 && z < h && y >= 0 && y < w && x >= 0 && x < d;
 }
+// ATen adds the products of the in-range corners only, in corner order.  Branch-free form: all 8 corners are loaded
+// at once from clamped addresses (one memory round trip instead of up to 8 dependent ones) and an out-of-range corner
+// leaves the accumulator untouched through a select -- bit-identical to skipping the addition.
 __device__ __forceinline__ float tri_sample(const Tri& t, const float* __restrict__ vol, int h, int w, int d) {
     const int x0 = t.x0, y0 = t.y0, z0 = t.z0, x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
-    float o = 0.0f;
-    if (inb3(z0, y0, x0, h, w, d)) o += vol[((size_t)z0 * w + y0) * d + x0] * t.tnw;
-    if (inb3(z0, y0, x1, h, w, d)) o += vol[((size_t)z0 * w + y0) * d + x1] * t.tne;
-    if (inb3(z0, y1, x0, h, w, d)) o += vol[((size_t)z0 * w + y1) * d + x0] * t.tsw;
-    if (inb3(z0, y1, x1, h, w, d)) o += vol[((size_t)z0 * w + y1) * d + x1] * t.tse;
-    if (inb3(z1, y0, x0, h, w, d)) o += vol[((size_t)z1 * w + y0) * d + x0] * t.bnw;
-    if (inb3(z1, y0, x1, h, w, d)) o += vol[((size_t)z1 * w + y0) * d + x1] * t.bne;
-    if (inb3(z1, y1, x0, h, w, d)) o += vol[((size_t)z1 * w + y1) * d + x0] * t.bsw;
-    if (inb3(z1, y1, x1, h, w, d)) o += vol[((size_t)z1 * w + y1) * d + x1] * t.bse;
+    const bool zi0 = (unsigned)z0 < (unsigned)h, zi1 = (unsigned)z1 < (unsigned)h, yi0 = (unsigned)y0 < (unsigned)w,
+               yi1 = (unsigned)y1 < (unsigned)w, xi0 = (unsigned)x0 < (unsigned)d, xi1 = (unsigned)x1 < (unsigned)d;
+    const int zc0 = clampi(z0, 0, h - 1), zc1 = clampi(z1, 0, h - 1), yc0 = clampi(y0, 0, w - 1), yc1 = clampi(y1, 0, w - 1),
+              xc0 = clampi(x0, 0, d - 1), xc1 = clampi(x1, 0, d - 1);
+    const size_t r00 = ((size_t)zc0 * w + yc0) * d, r01 = ((size_t)zc0 * w + yc1) * d, r10 = ((size_t)zc1 * w + yc0) * d,
+                 r11 = ((size_t)zc1 * w + yc1) * d;
+    const float v0 = vol[r00 + xc0], v1 = vol[r00 + xc1], v2 = vol[r01 + xc0], v3 = vol[r01 + xc1], v4 = vol[r10 + xc0],
+                v5 = vol[r10 + xc1], v6 = vol[r11 + xc0], v7 = vol[r11 + xc1];
+    float o = 0.0f, n;
+    n = o + v0 * t.tnw; o = (zi0 && yi0 && xi0) ? n : o;
+    n = o + v1 * t.tne; o = (zi0 && yi0 && xi1) ? n : o;
+    n = o + v2 * t.tsw; o = (zi0 && yi1 && xi0) ? n : o;
+    n = o + v3 * t.tse; o = (zi0 && yi1 && xi1) ? n : o;
+    n = o + v4 * t.bnw; o = (zi1 && yi0 && xi0) ? n : o;
+    n = o + v5 * t.bne; o = (zi1 && yi0 && xi1) ? n : o;
+    n = o + v6 * t.bsw; o = (zi1 && yi1 && xi0) ? n : o;
+    n = o + v7 * t.bse; o = (zi1 && yi1 && xi1) ? n : o;
     return o;
 }
 
