@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Turns the output of tools/profile_round.sh (gpurun_out/round) into the committed files under profiles/:
+   python tools/make_profiles.py gpurun_out/round r01_v4
+ - <tag>_bench_kernel_stats.txt   per-kernel durations of `bench.py --steps 5 --warmup 1` (rocprofv3 --kernel-trace --stats)
+ - <tag>_pmc_hbm_traffic.txt      FETCH_SIZE / WRITE_SIZE per kernel and the corrected HBM bytes per launch
+ - <tag>_pmc_sq_counters.txt      SQ counters per kernel
+ - pmc_hbm_traffic.json           bytes per launch of the correlation stage (read by bench.py for roofline.traffic)
+ - <tag>_bench_line.json          the bench line of the same box
+FETCH_SIZE counts half of the bytes of a streamed read on gfx950 (calibrated on k_argmin: 270.5 MB streamed), WRITE_SIZE
+is exact; both are in KiB: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
+import collections
+import csv
+import glob
+import io
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def pmc(d):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k][r["Counter_Name"]] += 1
+    return acc, cnt
+
+
+def main(src, tag):
+    prof = os.path.join(ROOT, "profiles")
+    db = glob.glob(src + "/stats/**/*_results.db", recursive=True)
+    if db:
+        out = subprocess.run([sys.executable, os.path.join(HERE, "rocpd_stats.py"), db[0]], stdout=subprocess.PIPE, text=True).stdout
+        with open(os.path.join(prof, tag + "_bench_kernel_stats.txt"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-batched   (6 pairs)\n" + out)
+    fa, fc = pmc(src + "/fetch")
+    wa, wc = pmc(src + "/write")
+    rows = []
+    for k in sorted(set(fa) | set(wa)):
+        n = max(fc[k].get("FETCH_SIZE", 0), wc[k].get("WRITE_SIZE", 0))
+        fe = fa[k].get("FETCH_SIZE", 0.0) / max(fc[k].get("FETCH_SIZE", 1), 1)
+        wr = wa[k].get("WRITE_SIZE", 0.0) / max(wc[k].get("WRITE_SIZE", 1), 1)
+        rows.append((k, n, fe, wr, (2 * fe + wr) * 1024 / 1e6))
+    rows.sort(key=lambda r: -r[4] * r[1])
+    buf = io.StringIO()
+    buf.write("# HBM traffic per launch from rocprofv3 PMC counters (two separate passes, MI355X_MICROARCH.md section HBM):\n"
+              "#   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched\n"
+              "#   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched\n"
+              "# Counters are in KiB; WRITE_SIZE is exact, FETCH_SIZE reads 1/2 of a streamed read on gfx950 -> bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.\n")
+    buf.write("%-44s %6s %14s %14s %18s\n" % ("kernel", "calls", "FETCH_KiB/call", "WRITE_KiB/call", "corrected_MB/call"))
+    for k, n, fe, wr, mb in rows:
+        buf.write("%-44s %6d %14.1f %14.1f %18.1f\n" % (k[-44:], n, fe, wr, mb))
+    open(os.path.join(prof, tag + "_pmc_hbm_traffic.txt"), "w").write(buf.getvalue())
+    stage = [r for r in rows if any(s in r[0] for s in ("k_corr_prep", "k_corr_raw", "k_corr_tail", "k_corr_box"))]
+    total = sum(r[4] for r in stage) * 1e6
+    json.dump({"correlate_stage_bytes_per_launch": total, "source": "profiles/%s_pmc_hbm_traffic.txt" % tag,
+               "kernels": {r[0]: r[4] * 1e6 for r in stage},
+               "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 summed over k_corr_prep, k_corr_raw, (k_corr_tail,) k_corr_box2"},
+              open(os.path.join(prof, "pmc_hbm_traffic.json"), "w"), indent=1)
+    sa, sc = pmc(src + "/sq")
+    names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT"]
+    with open(os.path.join(prof, tag + "_pmc_sq_counters.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc %s -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched\n" % " ".join(names))
+        f.write("# per-dispatch averages (SQ cycle counters are in quad-cycles)\n")
+        f.write("%-44s %6s " % ("kernel", "calls") + " ".join("%13s" % n[3:].lower()[:13] for n in names) + "\n")
+        for k in sorted(sa, key=lambda k: -sa[k].get("SQ_WAVE_CYCLES", 0)):
+            f.write("%-44s %6d " % (k[-44:], sc[k].get("SQ_WAVES", 0)) + " ".join("%13.0f" % (sa[k].get(n, 0) / max(sc[k].get(n, 1), 1)) for n in names) + "\n")
+    for name, dst in (("bench_line.json", tag + "_bench_line.json"), ("bench_under_rocprof.json", tag + "_bench_line_under_rocprofv3.json")):
+        p = os.path.join(src, name)
+        if os.path.exists(p) and os.path.getsize(p):
+            open(os.path.join(prof, dst), "w").write(open(p).read())
+    print("correlation stage HBM bytes per launch: %.1f MB" % (total / 1e6))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
