@@ -71,6 +71,25 @@ def test_avgpool_vs_oracle(U, orc, g):
     assert np.array_equal(host(U.avg_pool(dev(x)[None], g))[0], orc.avgpool_stride(x, g))
 
 
+@pytest.mark.parametrize("g,shape", [(2, (3, 12, 12, 16)), (4, (3, 12, 8, 16)), (6, (2, 12, 18, 24)), (8, (2, 16, 8, 24)), (6, (1, 13, 12, 14))])
+def test_avgpool_even_windows_vs_oracle(U, orc, g, shape):
+    """Even D selects the compile-time-window kernels (8-byte row loads); remainders of H, W, D are ignored."""
+    x = np.random.default_rng(g + shape[1]).standard_normal(shape).astype(np.float32)
+    assert np.array_equal(host(U.avg_pool(dev(x)[None], g))[0], orc.avgpool_stride(x, g))
+
+
+@pytest.mark.parametrize("C,shape,hw", [(3, (5, 60, 37), 1), (2, (4, 30, 61), 1), (2, (3, 70, 9), 2)])
+def test_correlate_tiled_rows_vs_oracle(U, orc, C, shape, hw):
+    """Planes too large for one workgroup of the marching box kernel: y tiles with recomputed halo rows."""
+    rng = np.random.default_rng(C * 10 + hw)
+    f = rng.random((C,) + shape, dtype=np.float32)
+    m = rng.random((C,) + shape, dtype=np.float32)
+    ssd, am = U.correlate(dev(f)[None], dev(m)[None], hw, 1, shape, C)
+    rs, ra = orc.correlate(f, m, hw)
+    assert np.array_equal(host(ssd), rs), "max |diff| %g" % np.abs(host(ssd) - rs).max()
+    assert np.array_equal(host(am), ra)
+
+
 @pytest.mark.parametrize("C,shape,hw", [(12, (12, 10, 14), 2), (12, (7, 9, 11), 3), (12, (9, 8, 37), 4), (20, (7, 5, 9), 1),
                                         (3, (5, 6, 7), 2), (33, (6, 5, 8), 2), (12, (4, 4, 4), 6), (1, (3, 3, 3), 0)])
 def test_correlate_vs_oracle(U, orc, C, shape, hw):
@@ -139,6 +158,25 @@ def test_adam_vs_oracle(U, orc, golden, niter):
     g = golden("adam")
     Ud, st = U.adam_run(dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]), niter, return_state=True)
     r = orc.adam_run(g["F2"], g["M2"], g["P0"], float(g["lam"]), niter, want_grad=True)
+    assert np.array_equal(host(Ud)[0], r["U"])
+    assert np.array_equal(host(st["G"])[0], r["G"])
+    assert np.array_equal(host(st["P"])[0], r["P"])
+    assert np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
+
+
+@pytest.mark.parametrize("shape", [(6, 9, 30), (5, 10, 28), (7, 9, 61), (6, 17, 60), (5, 9, 124), (4, 9, 126), (4, 8, 130), (14, 8, 12), (3, 3, 5)])
+def test_adam_grid_shapes_vs_oracle(U, orc, shape):
+    """Control grids that select every variant of the three-box kernels: 8 / 16 / 32 quads per row, rows that are /
+    are not multiples of 4 voxels (16-byte vs scalar global access), two Adam elements per thread (8 x 124 > 960),
+    rows longer than 126 voxels (tiled LDS kernel), several z chunks, a grid smaller than one tile.  C = 5 pads the
+    feature chunks with zero channels."""
+    rng = np.random.default_rng(sum(shape))
+    C = 5
+    F2 = rng.random((C,) + shape, dtype=np.float32)
+    M2 = rng.random((C,) + shape, dtype=np.float32)
+    P0 = (0.7 * rng.standard_normal((3,) + shape)).astype(np.float32)
+    Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.25, 3, return_state=True)
+    r = orc.adam_run(F2, M2, P0, 1.25, 3, want_grad=True)
     assert np.array_equal(host(Ud)[0], r["U"])
     assert np.array_equal(host(st["G"])[0], r["G"])
     assert np.array_equal(host(st["P"])[0], r["P"])
