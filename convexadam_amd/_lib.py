@@ -75,6 +75,11 @@ SIGNATURES = {
     "cvx_register_pairs_f32": (_i, [_i, _vp, _vp, _vp, _vp, C.POINTER(PairParams), _vp, _vp, _vp, _sz, _i, _vp]),
     "cvx_last_pair_profile": (_i, [_vp, _vp, _i]),
     "cvx_set_profiling": (None, [_i]),
+    "cvx_jacobian_det_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "cvx_jacobian_stats_f64": (_i, [_vp, _i64, _vp, _vp]),
+    "cvx_warp_labels_nearest_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cvx_label_overlap_i64": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "cvx_map_coordinates_linear_f64": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

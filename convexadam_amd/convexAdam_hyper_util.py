@@ -9,8 +9,15 @@ scripts import: convex_run_withconfig.py:13-16, adam_run_withconfig_shiftSpline.
 The two smoothers are callables on (1,C,H,W,D) device tensors AND differentiable (torch.autograd.Function whose
 backward is the adjoint HIP kernel), so the sweep scripts' inline autograd Adam loop
 (adam_run_withconfig_shiftSpline.py:214-230) can keep calling `avgs[avg_n](net[0].weight)`; they also serve as the
-`smoother=` argument of convexadam_amd.convex_adam_utils.adam_run (fused loop).  Evaluation metrics of that file
-(dice_coeff, cupy_hd95, jacobian_determinant_3d, sort_rank) are out of scope.
+`smoother=` argument of convexadam_amd.convex_adam_utils.adam_run (fused loop).
+
+Evaluation operators of that file, on the device:
+    jacobian_determinant_3d(dense_flow, convert1=True)   :86-108
+    dice_coeff(outputs, labels, max_label)               :53-60
+    sort_rank(value)                                     :28-31   (host)
+plus the three call sequences the sweep scripts write inline (convex_run_withconfig.py:141,148-150,
+convex_run_paired_mind.py:167-173): warp_labels_nearest, jacobian_log_std_and_folding, tre_at_keypoints.
+cupy_hd95 (:32-52) needs a Euclidean distance transform and stays out of scope.
 """
 import ctypes as C
 
@@ -110,3 +117,92 @@ def kovesi_spline(sigma, n=4):
     if not 1 <= len(sizes) <= 4:
         raise ValueError("kovesi_spline: %d boxes not supported" % len(sizes))
     return _BoxChain(sizes)
+
+
+# ---- evaluation operators -----------------------------------------------------------------------------
+def jacobian_determinant_3d(dense_flow, convert1=True):
+    """hyper_util.py:86-108.  dense_flow (1,3,H,W,D) device tensor -> (H-4, W-4, D-4) float32 device tensor."""
+    x = f32c(require_device_tensor(dense_flow, "dense_flow"))
+    B, ch, H, W, D = [int(v) for v in x.shape]
+    if B != 1 or ch != 3:
+        raise ValueError("jacobian_determinant_3d: expected a (1,3,H,W,D) field")
+    out = torch.empty((H - 4, W - 4, D - 4), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().cvx_jacobian_det_f32(ptr(x), H, W, D, 1 if convert1 else 0, ptr(out), stream_ptr(x.device)))
+    return out
+
+
+def jacobian_log_std_and_folding(jac_det):
+    """convex_run_withconfig.py:148-150: (jac_det.add(3).clamp_(1e-9, 1e9).log().std(), (jac_det < 0).float().mean()) as
+    Python floats; accumulated in float64 on the device."""
+    j = f32c(require_device_tensor(jac_det, "jac_det")).reshape(-1)
+    n = int(j.numel())
+    acc = torch.empty(3, dtype=torch.float64, device=j.device)
+    with torch.cuda.device(j.device):
+        check(lib().cvx_jacobian_stats_f64(ptr(j), n, ptr(acc), stream_ptr(j.device)))
+    s, s2, neg = [float(v) for v in acc.cpu()]
+    var = max(s2 - s * s / n, 0.0) / max(n - 1, 1)
+    return var ** 0.5, neg / n
+
+
+def warp_labels_nearest(seg_moving, disp_hr):
+    """convex_run_withconfig.py:96,135,141: F.grid_sample(seg.view(1,1,H,W,D), grid0 + disp_hr.permute(0,2,3,4,1).flip(-1)
+    .div(scale1), mode='nearest').squeeze().  seg (H,W,D), disp_hr (1,3,H,W,D) in voxels -> (H,W,D) float32."""
+    from .convex_adam_utils import _base_tables
+    seg = f32c(require_device_tensor(seg_moving, "seg_moving"))
+    d = f32c(require_device_tensor(disp_hr, "disp_hr"))
+    H, W, D = [int(v) for v in seg.shape[-3:]]
+    if tuple(d.shape[-4:]) != (3, H, W, D):
+        raise ValueError("warp_labels_nearest: disp_hr must be (1,3,H,W,D) matching the label map")
+    bh, bw, bd = _base_tables(H, W, D, seg.device)
+    out = torch.empty((H, W, D), dtype=torch.float32, device=seg.device)
+    with torch.cuda.device(seg.device):
+        check(lib().cvx_warp_labels_nearest_f32(ptr(seg), ptr(d), H, W, D, ptr(bh), ptr(bw), ptr(bd), ptr(out), stream_ptr(seg.device)))
+    return out
+
+
+def dice_coeff(outputs, labels, max_label):
+    """hyper_util.py:53-60: per-label Dice for labels 1 .. max_label-1 (FloatTensor on the host, like the reference).
+    The device returns exact voxel counts; the float32 means and the quotient follow the reference's expression."""
+    a = f32c(require_device_tensor(outputs, "outputs")).reshape(-1)
+    b = f32c(require_device_tensor(labels, "labels")).reshape(-1)
+    if a.numel() != b.numel():
+        raise ValueError("dice_coeff: label maps differ in size")
+    n = int(a.numel())
+    counts = torch.empty((3, int(max_label)), dtype=torch.int64, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib().cvx_label_overlap_i64(ptr(a), ptr(b), n, int(max_label), ptr(counts), stream_ptr(a.device)))
+    c = counts.cpu().numpy()
+    nf = np.float32(n)
+    dice = np.zeros(int(max_label) - 1, np.float32)
+    for lab in range(1, int(max_label)):
+        inter = np.float32(c[2, lab]) / nf
+        dice[lab - 1] = (np.float32(2.0) * inter) / ((np.float32(1e-8) + np.float32(c[0, lab]) / nf) + np.float32(c[1, lab]) / nf)
+    return torch.from_numpy(dice)
+
+
+def tre_at_keypoints(disp_hr, key_fixed, key_moving):
+    """convex_run_paired_mind.py:165-173: disp_sampled = grid_sample(disp_hr, key_fixed.flip(1)/scale1 - 1) (trilinear),
+    TRE = |key_fixed - key_moving + disp_sampled|.  Key points (n,3) in voxels (H,W,D order); returns (TRE (n,), disp_sampled (n,3))
+    on the host like the reference."""
+    from .convex_adam_utils import grid_sample
+    d = f32c(require_device_tensor(disp_hr, "disp_hr"))
+    H, W, D = [int(v) for v in d.shape[-3:]]
+    kf = torch.as_tensor(key_fixed, dtype=torch.float32).cpu()
+    km = torch.as_tensor(key_moving, dtype=torch.float32).cpu()
+    scale1 = torch.tensor([D - 1, W - 1, H - 1], dtype=torch.float32) / 2
+    lms = (kf.flip(1) / scale1 - 1).view(1, -1, 1, 1, 3).to(d.device)
+    samp = grid_sample(d.view(1, 3, H, W, D), lms).reshape(3, -1).t().cpu()
+    return (kf - km + samp).square().sum(-1).sqrt(), samp
+
+
+def sort_rank(value):
+    """hyper_util.py:28-31 (host)."""
+    value = torch.as_tensor(value)
+    rank1 = torch.ones_like(value)
+    rank1[value.sort().indices] = torch.linspace(1, .1, len(value)).to(value.device)
+    return rank1
+
+
+def cupy_hd95(*args, **kwargs):
+    raise NotImplementedError("cupy_hd95 (hyper_util.py:32-52) needs a Euclidean distance transform; out of scope (SURVEY 8(f).1)")

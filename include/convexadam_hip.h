@@ -204,6 +204,23 @@ int cvx_register_pairs_f32(int n_pairs, const float* const* img_fixed, const flo
 int cvx_last_pair_profile(const char** names_host, float* ms_host, int max_stages);
 void cvx_set_profiling(int mode);
 
+/* ---- evaluation operators of the self-configuring sweep and apply_convex --------------
+ *   cvx_jacobian_det_f32        self_configuring/convexAdam_hyper_util.py:86-108 jacobian_determinant_3d(dense_flow, convert1):
+ *                               flow [3][H][W][D] -> out [(H-4)][(W-4)][(D-4)]; convert1 != 0 scales by (size-1)/2 first
+ *   cvx_jacobian_stats_f64      convex_run_withconfig.py:148-150: acc3 (device) = { sum (l-l0), sum (l-l0)^2, #(jac < 0) } with
+ *                               l = log(clamp(jac + 3, 1e-9, 1e9)) in float64, l0 = l of element 0 (std, folding fraction: host)
+ *   cvx_warp_labels_nearest_f32 convex_run_withconfig.py:96,135,141: F.grid_sample(seg, grid0 + disp.flip/scale1, mode='nearest');
+ *                               disp [3][H][W][D] in voxels, base_* = cvx_affine_base_host(H/W/D) uploaded
+ *   cvx_label_overlap_i64       hyper_util:53-60 dice_coeff: counts (device) [3][num_labels] = |a==l|, |b==l|, |a==l & b==l|
+ *   cvx_map_coordinates_linear_f64  src/convexAdam/apply_convex.py:13-24 apply_convex: scipy map_coordinates(order=1,
+ *                               mode='constant'); moving [H][W][D] float64, disp [H][W][D][3] float64 (voxels), out float64 */
+int cvx_jacobian_det_f32(const float* flow, int H, int W, int D, int convert1, float* out, void* stream);
+int cvx_jacobian_stats_f64(const float* jac, int64_t n, double* acc3, void* stream);
+int cvx_warp_labels_nearest_f32(const float* seg, const float* disp, int H, int W, int D, const float* base_h,
+                                const float* base_w, const float* base_d, float* out, void* stream);
+int cvx_label_overlap_i64(const float* a, const float* b, int64_t n, int num_labels, int64_t* counts, void* stream);
+int cvx_map_coordinates_linear_f64(const double* moving, const double* disp, int H, int W, int D, double* out, void* stream);
+
 #pragma GCC visibility pop
 
 #ifdef __cplusplus

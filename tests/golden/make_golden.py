@@ -153,7 +153,7 @@ def main():
         torch.Tensor.cuda, torch.Tensor.half = _cuda, _half
 
 
-if __name__ == "__main__" and "--smoothers" not in sys.argv:
+if __name__ == "__main__" and "--smoothers" not in sys.argv and "--metrics" not in sys.argv:
     main()
     smoother_goldens_later = True
 
@@ -207,5 +207,60 @@ def smoother_goldens():
     save("smoothers", **out)
 
 
+def metrics_goldens():
+    """evaluation operators of the sweep scripts (convex_run_withconfig.py:136-150,
+    convex_run_paired_mind.py:167-173) and apply_convex (apply_convex.py:13-24), captured from the reference on CPU."""
+    import types
+    for m in ("cupy", "cupyx", "cupyx.scipy", "cupyx.scipy.ndimage"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    from _ref_import import import_reference
+    import_reference()
+    import importlib
+    AC = importlib.import_module("convexAdam.apply_convex")
+    sys.path.insert(0, os.path.join(os.environ.get("CONVEXADAM_REFERENCE", "/root/reference"), "self_configuring"))
+    import convexAdam_hyper_util as HU
+    g = torch.Generator().manual_seed(123)
+    H, W, D = 22, 26, 30
+    # smooth displacement field in voxels with a few folds, channel order (H, W, D) like disp_hr
+    disp = F.interpolate(torch.randn(1, 3, 4, 5, 6, generator=g) * 3.0, size=(H, W, D), mode="trilinear", align_corners=False)
+    out = dict(disp=disp[0].numpy())
+    out["jac_vox"] = HU.jacobian_determinant_3d(disp, False).numpy()                       # convex_run_withconfig.py:137
+    norm = disp / (torch.tensor([H - 1, W - 1, D - 1]) / 2).view(1, 3, 1, 1, 1)
+    out["disp_norm"] = norm[0].numpy()
+    out["jac_norm"] = HU.jacobian_determinant_3d(norm, True).numpy()
+    jd = torch.from_numpy(out["jac_vox"])
+    jl = jd.add(3).clamp_(0.000000001, 1000000000).log()                                   # :148
+    out["jac_log_std"] = np.float32(jl.std().item())
+    out["jac_neg_frac"] = np.float32((jd < 0).float().mean().item())
+    # label maps, nearest-neighbour warp, Dice                                              (:96, :141-142)
+    lab = torch.randn(1, 7, 5, 6, 7, generator=g)
+    seg_m = F.interpolate(lab, size=(H, W, D), mode="trilinear", align_corners=False).argmax(1)[0].float()
+    seg_f = torch.roll(seg_m, (1, -2, 1), (0, 1, 2))
+    grid0 = F.affine_grid(torch.eye(3, 4).unsqueeze(0), (1, 1, H, W, D), align_corners=False)
+    scale1 = torch.tensor([D - 1, W - 1, H - 1]) / 2
+    seg_w = F.grid_sample(seg_m.view(1, 1, H, W, D), grid0 + disp.permute(0, 2, 3, 4, 1).flip(-1).div(scale1), mode="nearest").squeeze()
+    out.update(seg_moving=seg_m.numpy(), seg_fixed=seg_f.numpy(), seg_warped=seg_w.numpy())
+    out["dice"] = HU.dice_coeff(seg_f, seg_w, 7).numpy()
+    # key-point TRE                                                                          (convex_run_paired_mind.py:167-173)
+    key_f = torch.rand(40, 3, generator=g) * torch.tensor([H - 1.0, W - 1.0, D - 1.0])
+    key_f[:4] = torch.tensor([[0.0, 0.0, 0.0], [H - 1.0, W - 1.0, D - 1.0], [0.5, 25.0, 29.0], [21.0, 0.0, 14.5]])
+    key_m = key_f + torch.randn(40, 3, generator=g)
+    lms = (key_f.flip(1) / scale1 - 1).view(1, -1, 1, 1, 3)
+    samp = F.grid_sample(disp.float(), lms).squeeze().t()
+    out.update(key_fixed=key_f.numpy(), key_moving=key_m.numpy(), disp_sampled=samp.numpy(),
+               tre=(key_f - key_m + samp).square().sum(-1).sqrt().numpy())
+    # rank aggregation helper                                                                (hyper_util:28-31)
+    vals = torch.rand(17, generator=g)
+    out.update(rank_in=vals.numpy(), rank_out=HU.sort_rank(vals).numpy())
+    # apply_convex: scipy map_coordinates, order 1                                           (apply_convex.py:13-24)
+    moving = torch.rand(H, W, D, generator=g).numpy().astype(np.float32)
+    dd = disp[0].permute(1, 2, 3, 0).numpy().astype(np.float64)                              # (H, W, D, 3) float64 like convex_adam_pt's result
+    out.update(moving=moving, warped=AC.apply_convex(dd, moving))
+    save("metrics", **out)
+
+
 if __name__ == "__main__":
-    smoother_goldens()
+    if "--metrics" in sys.argv:
+        metrics_goldens()
+    else:
+        smoother_goldens()

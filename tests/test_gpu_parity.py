@@ -442,3 +442,88 @@ def test_full_size_config4_label_features(orc):
     out = host(register_pair_device(feat_fixed=dev(f), feat_moving=dev(m), **kw))
     ref = orc.convex_adam_pipeline(None, None, features=(f, m), **kw)
     assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), ref)
+
+
+# ---- (4) evaluation operators of the sweep and apply_convex ------------------------------------
+@pytest.fixture(scope="module")
+def HU():
+    from convexadam_amd import convexAdam_hyper_util
+    return convexAdam_hyper_util
+
+
+@pytest.fixture(scope="module")
+def morc():
+    from oracle import metrics_oracle
+    return metrics_oracle
+
+
+@pytest.mark.parametrize("shape,convert1", [((9, 10, 11), False), ((9, 10, 11), True), ((5, 6, 37), False), ((40, 33, 29), True)])
+def test_jacobian_determinant_vs_oracle(HU, morc, shape, convert1):
+    rng = np.random.default_rng(sum(shape))
+    flow = (rng.standard_normal((3,) + shape) * (0.1 if convert1 else 2.0)).astype(np.float32)
+    assert np.array_equal(host(HU.jacobian_determinant_3d(dev(flow)[None], convert1)), morc.jacobian_determinant_3d(flow, convert1))
+
+
+def test_metrics_vs_reference_golden(HU, morc, golden):
+    g = golden("metrics")
+    disp = dev(g["disp"])[None]
+    jac = HU.jacobian_determinant_3d(disp, False)
+    assert np.array_equal(host(jac), g["jac_vox"])
+    assert np.array_equal(host(HU.jacobian_determinant_3d(dev(g["disp_norm"])[None], True)), g["jac_norm"])
+    std, neg = HU.jacobian_log_std_and_folding(jac)
+    assert abs(std - float(g["jac_log_std"])) <= 1e-5 * float(g["jac_log_std"])      # torch's float32 log / std are not restated
+    assert abs(neg - float(g["jac_neg_frac"])) <= 1e-6
+    warped = HU.warp_labels_nearest(dev(g["seg_moving"]), disp)
+    assert np.array_equal(host(warped), g["seg_warped"])
+    assert np.array_equal(HU.dice_coeff(dev(g["seg_fixed"]), warped, 7).numpy(), g["dice"])
+    tre, samp = HU.tre_at_keypoints(disp, g["key_fixed"], g["key_moving"])
+    assert np.array_equal(samp.numpy(), g["disp_sampled"])
+    assert np.allclose(tre.numpy(), g["tre"], rtol=2e-7, atol=0)                       # MKL sqrt of the reference: <= 1 ulp
+    assert np.array_equal(HU.sort_rank(torch.from_numpy(g["rank_in"])).numpy(), g["rank_out"])
+
+
+@pytest.mark.parametrize("shape", [(22, 26, 30), (7, 5, 9)])
+def test_warp_labels_and_dice_vs_oracle(HU, morc, shape):
+    rng = np.random.default_rng(shape[0])
+    seg = rng.integers(0, 9, shape).astype(np.float32)
+    seg2 = np.roll(seg, (1, 0, -1), (0, 1, 2))
+    disp = (rng.standard_normal((3,) + shape) * 2.5).astype(np.float32)                # many samples leave the volume
+    w = HU.warp_labels_nearest(dev(seg), dev(disp)[None])
+    assert np.array_equal(host(w), morc.warp_labels_nearest(seg, disp))
+    assert np.array_equal(HU.dice_coeff(dev(seg2), w, 9).numpy(), morc.dice_coeff(seg2, host(w), 9))
+
+
+def test_apply_convex_vs_scipy_and_golden(morc, golden):
+    from scipy.ndimage import map_coordinates
+    from convexadam_amd.apply_convex import apply_convex
+    g = golden("metrics")
+    dd = g["disp"].transpose(1, 2, 3, 0).astype(np.float64)
+    out = apply_convex(dd, g["moving"])
+    assert out.dtype == np.float64 and np.array_equal(out, g["warped"])                # captured from the reference
+    assert np.array_equal(out, morc.apply_convex(dd, g["moving"]))
+    rng = np.random.default_rng(3)
+    mov = rng.random((13, 9, 17))
+    d2 = rng.standard_normal((13, 9, 17, 3)) * 3.0
+    idn = np.meshgrid(np.arange(13), np.arange(9), np.arange(17), indexing="ij")
+    assert np.array_equal(apply_convex(d2, mov), map_coordinates(mov, d2.transpose(3, 0, 1, 2) + idn, order=1))   # scipy itself
+    t32 = apply_convex(torch.from_numpy(d2), torch.from_numpy(mov.astype(np.float32)))
+    assert t32.dtype == np.float32
+
+
+def test_full_size_metrics_properties(HU):
+    """BASELINE-size field: identity -> det 1 everywhere, no folding, Dice 1; a constant shift moves the labels by whole voxels."""
+    H, W, D = 160, 192, 224
+    zero = torch.zeros(1, 3, H, W, D, device=DEV)
+    jac = HU.jacobian_determinant_3d(zero, False)
+    assert float(jac.min()) == 1.0 and float(jac.max()) == 1.0
+    std, neg = HU.jacobian_log_std_and_folding(jac)
+    assert std == 0.0 and neg == 0.0
+    seg = torch.randint(0, 14, (H, W, D), device=DEV).float()
+    assert torch.equal(HU.warp_labels_nearest(seg, zero), seg)
+    d = HU.dice_coeff(seg, seg, 14).numpy()
+    assert d.shape == (13,) and np.all(d > 0.999999) and np.all(d <= 1.0)      # 2x / (1e-8 + 2x) in float32
+    shift = zero.clone()
+    shift[0, 0] = 3.0
+    shift[0, 2] = -2.0
+    w = HU.warp_labels_nearest(seg, shift)
+    assert torch.equal(w[:-3, :, 2:], seg[3:, :, :-2]) and float(w[-3:].abs().max()) == 0.0

@@ -200,3 +200,42 @@ def test_adam_with_sweep_smoothers(orc, golden):
         assert np.array_equal(r["U"], g[k + "_adam_U1"]) and np.array_equal(r["G"], g[k + "_adam_G1"])
         r3 = orc.adam_run(a["F2"], a["M2"], a["P0"], 0.8, 3, smoother=specs[k])
         assert np.abs(r3["U"] - g[k + "_adam_U3"]).max() < 1e-6          # MKL sqrt in the optimiser step
+
+
+# ---- evaluation operators of the sweep / apply_convex: metrics_oracle vs reference goldens ----
+def test_metrics_oracle_vs_reference_golden(golden):
+    from oracle import metrics_oracle as mo
+    g = golden("metrics")
+    assert np.array_equal(mo.jacobian_determinant_3d(g["disp"], False), g["jac_vox"])
+    assert np.array_equal(mo.jacobian_determinant_3d(g["disp_norm"], True), g["jac_norm"])
+    std, neg = mo.jacobian_stats(g["jac_vox"])
+    assert abs(std - float(g["jac_log_std"])) <= 1e-5 * float(g["jac_log_std"]) and abs(neg - float(g["jac_neg_frac"])) <= 1e-6
+    warped = mo.warp_labels_nearest(g["seg_moving"], g["disp"])
+    assert np.array_equal(warped, g["seg_warped"])
+    assert np.array_equal(mo.dice_coeff(g["seg_fixed"], warped, 7), g["dice"])
+    samp = mo.sample_field_at_points(g["disp"], g["key_fixed"])
+    assert np.array_equal(samp, g["disp_sampled"])
+    # the reference's sqrt is MKL's (<= 1 ulp, same non-restatable site as in torch.optim.Adam)
+    assert np.allclose(mo.tre(g["key_fixed"], g["key_moving"], samp), g["tre"], rtol=2e-7, atol=0)
+    assert np.array_equal(mo.sort_rank(g["rank_in"]), g["rank_out"])
+
+
+def test_apply_convex_oracle_vs_reference_golden_and_scipy(golden):
+    from scipy.ndimage import map_coordinates
+    from oracle import metrics_oracle as mo
+    g = golden("metrics")
+    dd = g["disp"].transpose(1, 2, 3, 0).astype(np.float64)
+    assert np.array_equal(mo.apply_convex(dd, g["moving"]), g["warped"])
+    rng = np.random.default_rng(5)
+    mov = rng.random((9, 8, 11))
+    d2 = rng.standard_normal((9, 8, 11, 3)) * 4.0
+    idn = np.meshgrid(np.arange(9), np.arange(8), np.arange(11), indexing="ij")
+    assert np.array_equal(mo.apply_convex(d2, mov), map_coordinates(mov, d2.transpose(3, 0, 1, 2) + idn, order=1))
+
+
+def test_torch_linspace_restatement():
+    import torch
+    from oracle import metrics_oracle as mo
+    for n in (2, 3, 17, 64, 255):
+        for a, b in ((1.0, 0.1), (-3.5, 2.25)):
+            assert np.array_equal(mo.linspace(a, b, n), torch.linspace(a, b, n).numpy())
