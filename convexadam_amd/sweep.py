@@ -7,7 +7,13 @@ Counterpart of the reference's manual scheme -- one OS process per GPU started b
 for the start barrier and the final gather of per-item results on rank 0 (RCCL on GPUs, gloo on CPU).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        convexadam_amd/sweep.py --pairs 4 --settings 256 --shape 160 192 224 --out sweep.json
+        convexadam_amd/sweep.py --pairs 4 --settings 256 --shape 160 192 224 --evaluate --out sweep.json
+
+With --evaluate every item is scored on the device the way the reference's sweep scripts do it
+(convex_run_withconfig.py:136-150, convex_run_paired_mind.py:165-177): Jacobian log-std and folding fraction,
+nearest-neighbour warp of the moving label map and Dice against the fixed one, key-point TRE; only those scalars
+return to the host, and rank 0 aggregates the per-setting means into the reference's geometric-mean rank
+(convex_run_withconfig.py:160-168, sort_rank of hyper_util:28-31).
 """
 import argparse
 import itertools
@@ -41,11 +47,57 @@ def sweep_settings():
     return out
 
 
+SHIFT = (2, -1, 3)          # moving = fixed content rolled by SHIFT voxels: the field to recover is +SHIFT
+
+
 def _make_pair(shape, idx, device):
     from convexadam_amd.phantom import phantom
     fix = phantom(shape, 100 + idx, 200 + idx)
-    mov = torch.roll(phantom(shape, 100 + idx, 300 + idx), (2, -1, 3), (0, 1, 2))
+    mov = torch.roll(phantom(shape, 100 + idx, 300 + idx), SHIFT, (0, 1, 2))
     return fix.to(device), mov.to(device)
+
+
+def _make_labels(shape, idx, device, num_labels=13):
+    """Synthetic anatomy: argmax over smooth random fields, moving = rolled copy; 32 key points."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(500 + idx)
+    lab = F.interpolate(torch.randn(1, num_labels + 1, *[max(2, s // 8) for s in shape], generator=g), size=shape, mode="trilinear",
+                        align_corners=False).argmax(1)[0].float()
+    key_f = torch.rand(32, 3, generator=g) * (torch.tensor([float(s - 9) for s in shape])) + 4.0
+    key_m = key_f + torch.tensor([float(v) for v in SHIFT])
+    return lab.to(device), torch.roll(lab, SHIFT, (0, 1, 2)).to(device), key_f, key_m, num_labels
+
+
+def evaluate_item(disp, seg_fixed, seg_moving, key_fixed, key_moving, num_labels):
+    """disp (3,H,W,D) device field in voxels -> dict of the reference's evaluation scalars (computed on the device)."""
+    from convexadam_amd import convexAdam_hyper_util as HU
+    d = disp[None]
+    jac = HU.jacobian_determinant_3d(d, False)                                             # convex_run_withconfig.py:137
+    jstd, fold = HU.jacobian_log_std_and_folding(jac)                                      # :148-150
+    warped = HU.warp_labels_nearest(seg_moving, d)                                         # :141
+    dice = HU.dice_coeff(seg_fixed, warped, num_labels + 1)                                # :142
+    dice0 = HU.dice_coeff(seg_fixed, seg_moving, num_labels + 1)
+    tre, _ = HU.tre_at_keypoints(d, key_fixed, key_moving)                                 # convex_run_paired_mind.py:165-173
+    tre0 = (key_fixed - key_moving).square().sum(-1).sqrt()
+    return dict(dice=float(dice.mean()), dice_before=float(dice0.mean()), jstd=jstd, folding=fold, tre=float(tre.mean()),
+                tre_before=float(tre0.mean()))
+
+
+def aggregate_ranks(results, n_settings):
+    """Per-setting means over pairs and the reference's rank: prod(sort_rank(metric)) ** (1/n) (convex_run_withconfig.py:160-168)."""
+    from convexadam_amd.convexAdam_hyper_util import sort_rank
+    acc = {k: torch.zeros(n_settings) for k in ("dice", "jstd", "tre")}
+    cnt = torch.zeros(n_settings)
+    for r in results:
+        if "dice" not in r:
+            continue
+        for k in acc:
+            acc[k][r["setting"]] += r[k]
+        cnt[r["setting"]] += 1
+    cnt = cnt.clamp(min=1)
+    dice, jstd, tre = acc["dice"] / cnt, acc["jstd"] / cnt, acc["tre"] / cnt
+    rank = (sort_rank(-dice) * sort_rank(tre) * sort_rank(jstd)).pow(1 / 3)
+    return dict(dice=dice.tolist(), jstd=jstd.tolist(), tre=tre.tolist(), rank=rank.tolist(), best_setting=int(rank.argmax()))
 
 
 def main(argv=None):
@@ -56,6 +108,7 @@ def main(argv=None):
     ap.add_argument("--niter", type=int, default=None, help="override selected_niter")
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercises sharding + gather only (CPU/gloo)")
+    ap.add_argument("--evaluate", action="store_true", help="score every item on the device (Dice, Jacobian, TRE) and rank the settings")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", 0))
@@ -74,6 +127,7 @@ def main(argv=None):
 
     results = []
     pair_cache = {}
+    label_cache = {}
     if world > 1:
         dist.barrier()
     t0 = time.time()
@@ -92,8 +146,12 @@ def main(argv=None):
         t1 = time.time()
         disp = register_pair_device(fix, mov, **cfg)
         torch.cuda.synchronize(device)
-        results.append(dict(item=item_id, setting=s, pair=p, rank=rank, ms=(time.time() - t1) * 1e3,
-                            mean_abs_disp=float(disp.abs().mean())))
+        res = dict(item=item_id, setting=s, pair=p, rank=rank, ms=(time.time() - t1) * 1e3, mean_abs_disp=float(disp.abs().mean()))
+        if a.evaluate:
+            if p not in label_cache:
+                label_cache[p] = _make_labels(tuple(a.shape), p, device)
+            res.update(evaluate_item(disp, *label_cache[p]))
+        results.append(res)
     if use_gpu:
         torch.cuda.synchronize(device)
     elapsed = time.time() - t0
@@ -109,6 +167,8 @@ def main(argv=None):
         summary = dict(world_size=world, n_items=len(items), items_done=[r["item"] for r in allres],
                        per_rank={str(g["rank"]): [r["item"] for r in g["results"]] for g in gathered},
                        wall_s=wall, items_per_s=(len(items) / wall if wall > 0 else None), results=allres)
+        if a.evaluate and not a.dry_run:
+            summary["ranking"] = aggregate_ranks(allres, len(settings))
         txt = json.dumps(summary)
         if a.out:
             with open(a.out, "w") as f:

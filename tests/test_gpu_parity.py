@@ -527,3 +527,16 @@ def test_full_size_metrics_properties(HU):
     shift[0, 2] = -2.0
     w = HU.warp_labels_nearest(seg, shift)
     assert torch.equal(w[:-3, :, 2:], seg[3:, :, :-2]) and float(w[-3:].abs().max()) == 0.0
+
+
+def test_sweep_driver_scores_items_on_the_device(tmp_path):
+    """Single-process run of the sharded driver with --evaluate: the registration recovers the known roll, so Dice rises,
+    TRE falls and no voxel folds."""
+    import json
+    from convexadam_amd import sweep
+    out = tmp_path / "sweep.json"
+    assert sweep.main(["--pairs", "1", "--settings", "2", "--shape", "48", "48", "48", "--niter", "10", "--evaluate", "--out", str(out)]) == 0
+    s = json.loads(out.read_text())
+    assert s["n_items"] == 2 and len(s["results"]) == 2 and len(s["ranking"]["rank"]) == 2
+    for r in s["results"]:
+        assert r["dice"] > r["dice_before"] + 0.1 and r["tre"] < 0.5 * r["tre_before"] and r["folding"] == 0.0
