@@ -20,12 +20,10 @@
 
 namespace cvx {
 
-constexpr int BM_YT = 8;
-
-template <int QPR>
-struct BMGeom {
+template <int QPR, int YT>
+struct BMGeomT {
     static constexpr int RPW = 64 / QPR;                                   // rows per wavefront
-    static constexpr int ROWS0 = BM_YT + 6, ROWS1 = BM_YT + 4, ROWS2 = BM_YT + 2, ROWS3 = BM_YT;
+    static constexpr int ROWS0 = YT + 6, ROWS1 = YT + 4, ROWS2 = YT + 2, ROWS3 = YT;
     static constexpr int NW1 = (ROWS1 + RPW - 1) / RPW, NW2 = (ROWS2 + RPW - 1) / RPW, NW3 = (ROWS3 + RPW - 1) / RPW;
     static constexpr int NT = 64 * (NW1 + NW2 + NW3);
     static constexpr int RS = 4 * QPR + 8;                                 // LDS row stride in floats
@@ -92,9 +90,9 @@ __device__ __forceinline__ void bm_load_step(const BMCtx& c, BMLoader& L, int t)
 // not on the critical path of the step barrier.
 struct BMAdamPre { float p[2], m[2], v[2]; };
 
-template <int QPR>
+template <int QPR, int YT>
 __device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int t) {
-    using G = BMGeom<QPR>;
+    using G = BMGeomT<QPR, YT>;
     constexpr int SLOT3 = G::ROWS3 * G::RS;
     if (t >= 10 && t <= c.zn + 9) {
         const size_t po = (size_t)(c.z0 + t - 10) * c.wd;             // uniform plane offset
@@ -122,11 +120,11 @@ __device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int
 // The whole march of one role.  Every role executes exactly nsteps barriers.  Lanes beyond the role's last row
 // compute on a clamped row and only their stores are masked, so that the window registers never pass through a
 // divergent merge (no register copies).
-template <int K, int QPR, bool BACKWARD, bool ADAM>
+template <int K, int QPR, int YT, bool BACKWARD, bool ADAM>
 __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int lane) {
-    using G = BMGeom<QPR>;
+    using G = BMGeomT<QPR, YT>;
     constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
-    constexpr int ROWS = BM_YT + 6 - 2 * K;
+    constexpr int ROWS = YT + 6 - 2 * K;
     constexpr int SRC_SLOT = K == 1 ? SLOT0 : (K == 2 ? SLOT1 : SLOT2), DST_SLOT = K == 1 ? SLOT1 : SLOT2;
     const int r_raw = wk * G::RPW + lane / QPR, q = lane % QPR;
     const bool active = r_raw < ROWS;
@@ -143,54 +141,69 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     const unsigned rowbase = (unsigned)((gy < 0 ? 0 : gy) * c.d + 4 * q);
     const int tlast = c.zn + 5 + K;
 
-    BMAdamPre pre = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    float win[3][3][6];
-    auto load_win = [&](auto rot, int t) {
-        constexpr int ROT = decltype(rot)::value;
+    BMAdamPre apre = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    // Register state: the windows of the two newest input planes (win[n % 2]) and, instead of the window of the oldest one,
+    // its finished raster-order prefix: the 27-tap sum of plane z starts with the 9 taps of plane z-1 added to +0.0, which
+    // depends on plane z-1 alone and is evaluated when that plane arrives (pre[n % 2], consumed two steps later).
+    float win[2][3][6], pre[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[a][j] = 0.0f;
+    // one step; n = t - (3K-2) counts the input planes of this role, PAR = n % 2; EMIT: n >= 2, an output plane is due
+    auto step = [&](auto par, auto emit, int t) {
+        constexpr int PAR = decltype(par)::value;
+        constexpr bool EMIT = decltype(emit)::value;
+        bm_load_step<SLOT0, BACKWARD>(c, L, t);
         const float* sp = src + ((t - 1) & 1) * SRC_SLOT;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const f32x4 a = lds_load4(sp + i * G::RS);
             const f32x2 b = lds_load2(sp + i * G::RS + 4);
-            win[ROT][i][0] = a.x; win[ROT][i][1] = a.y; win[ROT][i][2] = a.z; win[ROT][i][3] = a.w;
-            win[ROT][i][4] = b.x; win[ROT][i][5] = b.y;
+            win[PAR][i][0] = a.x; win[PAR][i][1] = a.y; win[PAR][i][2] = a.z; win[PAR][i][3] = a.w;
+            win[PAR][i][4] = b.x; win[PAR][i][5] = b.y;
         }
-    };
-    auto full = [&](auto rot, int t) {
-        constexpr int ROT = decltype(rot)::value;
-        bm_load_step<SLOT0, BACKWARD>(c, L, t);
-        load_win(rot, t);
-        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float s[4];
 #pragma unroll
-        for (int pl = 1; pl <= 3; ++pl) {                   // planes z-1, z, z+1 = register slots ROT+1, ROT+2, ROT (mod 3)
+        for (int j = 0; j < 4; ++j) s[j] = pre[PAR][j];                  // prefix of plane n-2
+        if (EMIT) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int pl = 0; pl < 2; ++pl)                               // planes n-1, n
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s[j] += win[(ROT + pl) % 3][i][j];
-                    s[j] += win[(ROT + pl) % 3][i][j + 1];
-                    s[j] += win[(ROT + pl) % 3][i][j + 2];
-                }
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s[j] += win[(PAR + 1 + pl) % 2][i][j];
+                        s[j] += win[(PAR + 1 + pl) % 2][i][j + 1];
+                        s[j] += win[(PAR + 1 + pl) % 2][i][j + 2];
+                    }
         }
-        const int gz = c.z0 - (2 * K + 3) + t;
-        const bool planeok = gz >= 0 && gz < c.h;
-        if (K < 3) {
-            f32x4 o;
-            o.x = (planeok && ok[0]) ? div_exact<27>(s[0]) : 0.0f;
-            o.y = (planeok && ok[1]) ? div_exact<27>(s[1]) : 0.0f;
-            o.z = (planeok && ok[2]) ? div_exact<27>(s[2]) : 0.0f;
-            o.w = (planeok && ok[3]) ? div_exact<27>(s[3]) : 0.0f;
-            if (active) lds_store4(dst + (t & 1) * DST_SLOT, o);
-        } else if (ADAM) {
-            // plain adjoint sums of this plane -> S3 (index = column + 4); consumed by bm_adam_step of the next step
-            const f32x4 o = {s[0], s[1], s[2], s[3]};
-            if (active) lds_store4(c.S3 + (t & 1) * (G::ROWS3 * G::RS) + r * G::RS + 4 * q + 4, o);
-        } else if (planeok && rowok && ncol > 0) {
-            float* oz = c.oc + (size_t)gz * c.wd;
-            float g[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = BACKWARD ? s[j] : div_exact<27>(s[j]);
-            {
+        for (int j = 0; j < 4; ++j) {                                    // prefix of plane n
+            float pj = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { pj += win[PAR][i][j]; pj += win[PAR][i][j + 1]; pj += win[PAR][i][j + 2]; }
+            pre[PAR][j] = pj;
+        }
+        if (EMIT) {
+            const int gz = c.z0 - (2 * K + 3) + t;
+            const bool planeok = gz >= 0 && gz < c.h;
+            if (K < 3) {
+                f32x4 o;
+                o.x = (planeok && ok[0]) ? div_exact<27>(s[0]) : 0.0f;
+                o.y = (planeok && ok[1]) ? div_exact<27>(s[1]) : 0.0f;
+                o.z = (planeok && ok[2]) ? div_exact<27>(s[2]) : 0.0f;
+                o.w = (planeok && ok[3]) ? div_exact<27>(s[3]) : 0.0f;
+                if (active) lds_store4(dst + (t & 1) * DST_SLOT, o);
+            } else if (ADAM) {
+                // plain adjoint sums of this plane -> S3 (index = column + 4); consumed by bm_adam_step of the next step
+                const f32x4 o = {s[0], s[1], s[2], s[3]};
+                if (active) lds_store4(c.S3 + (t & 1) * (G::ROWS3 * G::RS) + r * G::RS + 4 * q + 4, o);
+            } else if (planeok && rowok && ncol > 0) {
+                float* oz = c.oc + (size_t)gz * c.wd;
+                float g[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = BACKWARD ? s[j] : div_exact<27>(s[j]);
                 if (c.vec) *reinterpret_cast<float4*>(oz + rowbase) = make_float4(g[0], g[1], g[2], g[3]);
                 else {
 #pragma unroll
@@ -198,32 +211,32 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
                 }
             }
         }
-        if (ADAM) bm_adam_step<QPR>(c, pre, t);
+        if (ADAM) bm_adam_step<QPR, YT>(c, apre, t);
         __syncthreads();
     };
-    using R0 = std::integral_constant<int, 0>;
-    using R1 = std::integral_constant<int, 1>;
-    using R2 = std::integral_constant<int, 2>;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
     int t = 0;
     for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD>(c, L, t); __syncthreads(); }                    // (Adam starts at t = 10)
-    bm_load_step<SLOT0, BACKWARD>(c, L, t); load_win(R1{}, t); __syncthreads(); ++t;        // t = 3K-2: slot 1
-    bm_load_step<SLOT0, BACKWARD>(c, L, t); load_win(R2{}, t); __syncthreads(); ++t;        // t = 3K-1: slot 2
-    for (; t + 2 <= tlast; t += 3) { full(R0{}, t); full(R1{}, t + 1); full(R2{}, t + 2); }  // t = 3K ..: slot 0, 1, 2
-    if (t <= tlast) { full(R0{}, t); ++t; }
-    if (t <= tlast) { full(R1{}, t); ++t; }
+    step(P0{}, No{}, t); ++t;                                 // t = 3K-2: input plane 0
+    step(P1{}, No{}, t); ++t;                                 // t = 3K-1: input plane 1
+    for (; t + 1 <= tlast; t += 2) { step(P0{}, Yes{}, t); step(P1{}, Yes{}, t + 1); }       // t = 3K ..: output planes
+    if (t <= tlast) { step(P0{}, Yes{}, t); ++t; }
     for (; t < c.nsteps; ++t) {
         bm_load_step<SLOT0, BACKWARD>(c, L, t);
-        if (ADAM) bm_adam_step<QPR>(c, pre, t);
+        if (ADAM) bm_adam_step<QPR, YT>(c, apre, t);
         __syncthreads();
     }
 }
 
-template <int QPR, bool BACKWARD, bool ADAM>
-__global__ __launch_bounds__(BMGeom<QPR>::NT) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
+template <int QPR, int YT, bool BACKWARD, bool ADAM>
+__global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
                                                                 int w, int d, int zc, int nzc, int nyt, float* __restrict__ P,
                                                                 float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
                                                                 float* __restrict__ gsave, int vec_ok) {
-    using G = BMGeom<QPR>;
+    using G = BMGeomT<QPR, YT>;
     constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
     __shared__ __attribute__((aligned(16))) float S0[2 * SLOT0];
     __shared__ __attribute__((aligned(16))) float S1[2 * SLOT1];
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(BMGeom<QPR>::NT) void k_box3_march(const float* __r
     c.gs = gsave ? gsave + (size_t)ch * V : nullptr;
     c.S0 = S0; c.S1 = S1; c.S2 = S2; c.S3 = S3;
     c.wd = (size_t)w * d;
-    c.h = h; c.w = w; c.d = d; c.z0 = zi * zc; c.y0 = yi * BM_YT;
+    c.h = h; c.w = w; c.d = d; c.z0 = zi * zc; c.y0 = yi * YT;
     c.zn = min(zc, h - c.z0);
     c.nsteps = c.zn + (ADAM ? 10 : 9);
     c.vec = vec_ok != 0;
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(BMGeom<QPR>::NT) void k_box3_march(const float* __r
         for (int k = 0; k < 2; ++k) {
             const int e = tid + k * G::NT;                           // 8 rows x d columns <= 1008 elements <= 2 per thread
             const int row = e / d, col = e - row * d;
-            const bool have = row < BM_YT && c.y0 + row < w;
+            const bool have = row < YT && c.y0 + row < w;
             c.e_off[k] = (unsigned)((c.y0 + row) * d + col);
             c.e_lds[k] = have ? (unsigned)(row * G::RS + col + 4) : 0xffffffffu;
         }
@@ -278,36 +291,37 @@ __global__ __launch_bounds__(BMGeom<QPR>::NT) void k_box3_march(const float* __r
 
     // role of this wavefront (wave-uniform, kept in a scalar register)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    if (wave < G::NW1) bm_run<1, QPR, BACKWARD, ADAM>(c, L, wave, lane);
-    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, BACKWARD, ADAM>(c, L, wave - G::NW1, lane);
-    else bm_run<3, QPR, BACKWARD, ADAM>(c, L, wave - G::NW1 - G::NW2, lane);
+    if (wave < G::NW1) bm_run<1, QPR, YT, BACKWARD, ADAM>(c, L, wave, lane);
+    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, BACKWARD, ADAM>(c, L, wave - G::NW1, lane);
+    else bm_run<3, QPR, YT, BACKWARD, ADAM>(c, L, wave - G::NW1 - G::NW2, lane);
 }
 
 bool box3_march_supported(int d) { return d <= 126; }
 
-template <int QPR>
+template <int QPR, int YT>
 static int launch_qpr(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
                       AdamConsts ac, float* gsave, hipStream_t s) {
-    using G = BMGeom<QPR>;
-    const int nyt = cdiv(w, BM_YT);
-    const int nz_target = 256 / (3 * nyt) > 0 ? 256 / (3 * nyt) : 1;         // about one workgroup per CU
+    using G = BMGeomT<QPR, YT>;
+    const int nyt = cdiv(w, YT);
+    const int nz_target = 256 / (3 * nyt) > 0 ? 256 / (3 * nyt) : 1;         // about one workgroup per CU (4-row tiles with two
+                                                                             // workgroups per CU were measured slower: 22 vs 20 us)
     int zc = cdiv(h, nz_target);
     if (zc < 4) zc = 4;
     const int nzc = cdiv(h, zc);
     const unsigned grid = (unsigned)((3 * nyt * nzc + 7) / 8 * 8);
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec = (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave);
-    if (!backward) hipLaunchKernelGGL((k_box3_march<QPR, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
-    else if (!P) hipLaunchKernelGGL((k_box3_march<QPR, true, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
-    else hipLaunchKernelGGL((k_box3_march<QPR, true, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
+    if (!backward) hipLaunchKernelGGL((k_box3_march<QPR, YT, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
+    else if (!P) hipLaunchKernelGGL((k_box3_march<QPR, YT, true, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
+    else hipLaunchKernelGGL((k_box3_march<QPR, YT, true, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
     return check_last("box3_march");
 }
 
 int launch_box3_march(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
                       AdamConsts ac, float* gsave, hipStream_t s) {
-    if (d <= 30) return launch_qpr<8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
-    if (d <= 62) return launch_qpr<16>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
-    return launch_qpr<32>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+    if (d <= 30) return launch_qpr<8, 8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+    if (d <= 62) return launch_qpr<16, 8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+    return launch_qpr<32, 8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
 }
 
 }  // namespace cvx
