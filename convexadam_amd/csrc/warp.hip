@@ -101,9 +101,10 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
     g[2] = fdiv(((float)d / 2.0f) * gix, sc2);
     // Diffusion regulariser: the 18 neighbour values are fetched in one batch from clamped (always valid) addresses
     // and the one-sided terms are selected afterwards -- one memory round trip instead of 18 dependent ones.
-    const size_t sH = (size_t)w * d;
-    const size_t pxp = x < d - 1 ? p + 1 : p, pxm = x > 0 ? p - 1 : p, pzp = z < h - 1 ? p + sH : p, pzm = z > 0 ? p - sH : p,
-                 pyp = y < w - 1 ? p + d : p, pym = y > 0 ? p - d : p;
+    // (32-bit element offsets from the uniform channel base: the launcher guarantees 16 * (V + 1) < 2^32)
+    const unsigned sH = (unsigned)(w * d);
+    const unsigned pxp = x < d - 1 ? p + 1 : p, pxm = x > 0 ? p - 1 : p, pzp = z < h - 1 ? p + sH : p, pzm = z > 0 ? p - sH : p,
+                   pyp = y < w - 1 ? p + (unsigned)d : p, pym = y > 0 ? p - (unsigned)d : p;
     float nb[3][6];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
         t = acc +  (cH * (2.0f * (uc - nb[a][3]))); acc = z > 0 ? t : acc;
         t = acc + -(cW * (2.0f * (nb[a][4] - uc))); acc = y < w - 1 ? t : acc;
         t = acc +  (cW * (2.0f * (uc - nb[a][5]))); acc = y > 0 ? t : acc;
-        gU[(size_t)a * V + p] = acc;
+        (gU + (size_t)a * V)[p] = acc;
     }
 }
 
