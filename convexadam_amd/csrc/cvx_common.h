@@ -239,6 +239,10 @@ __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& 
     m = mm;
     v = vv;
 }
+// mind.hip: MIND-SSC delivered only through its stride poolings (pipeline path, no full-resolution descriptor)
+bool mind_pooled_supported(int H, int W, int D, int g1, int g2);
+int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int dilation, int g1, float* out1, int g2, float* out2,
+                       float* raw, void* workspace, size_t workspace_bytes, hipStream_t s);
 // corrbox.hip: the two box filters of the SSD volume (z-marching pipeline); raw [K][h][w][px] -> ssd [K][h][w][d]
 bool corr_box2_supported(int h, int w, int d, int px);
 int launch_corr_box2(const float* raw, int K, int h, int w, int d, int px, float* ssd, hipStream_t s);

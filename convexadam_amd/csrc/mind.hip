@@ -233,7 +233,23 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
     }
 }
 
-// out_c(x) = exp(-(D_c - min_c D) / clamp(mean_c(D - min), lo, hi)) in place; NV voxels per thread (4 = 16-byte access).
+// the 12 raw patch SSDs of one voxel (pre-permutation channel order) -> descriptor values, in place:
+//   exp(-(D_c - min_c D) / clamp(mean_c(D - min), lo, hi)); `tail` selects ATen's interleaved order of the channel sum
+__device__ __forceinline__ void mind_normalise(float (&r)[12], float lo, float hi, bool tail) {
+    float mn = r[0];
+#pragma unroll
+    for (int c = 1; c < 12; ++c) mn = fminf(mn, r[c]);
+#pragma unroll
+    for (int c = 0; c < 12; ++c) r[c] = r[c] - mn;
+    const float sum = tail ? outer_sum_ilp<12>(r) : cascade_seq<12>(r);
+    float var = fdiv(sum, 12.0f);
+    var = var < lo ? lo : var;
+    var = var > hi ? hi : var;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) r[c] = cvx_expf(-fdiv(r[c], var));
+}
+
+// out_c(x) in place; NV voxels per thread (4 = 16-byte access).
 // The channel mean runs over the reference's PRE-permutation channel order (the permutation is applied last, :66).
 template <int NV>
 __global__ __launch_bounds__(256) void k_mind_finish(float* __restrict__ out, size_t V, const MindStats* __restrict__ st) {
@@ -241,35 +257,103 @@ __global__ __launch_bounds__(256) void k_mind_finish(float* __restrict__ out, si
     if (x >= V) return;
     const float lo = st->lo, hi = st->hi;
     const size_t tail_from = (V / 32) * 32;
-    float r[12][NV];
+    float r[NV][12];
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
         const float* src = out + (size_t)MIND_INV[c] * V + x;
         if (NV == 4) {
             const float4 q = *reinterpret_cast<const float4*>(src);
-            r[c][0] = q.x; r[c][1 % NV] = q.y; r[c][2 % NV] = q.z; r[c][3 % NV] = q.w;
-        } else r[c][0] = src[0];
+            r[0][c] = q.x; r[1 % NV][c] = q.y; r[2 % NV][c] = q.z; r[3 % NV][c] = q.w;
+        } else r[0][c] = src[0];
     }
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        float mc[12];
-        float mn = r[0][j];
-#pragma unroll
-        for (int c = 1; c < 12; ++c) mn = fminf(mn, r[c][j]);
-#pragma unroll
-        for (int c = 0; c < 12; ++c) mc[c] = r[c][j] - mn;
-        const float sum = (x + j >= tail_from) ? outer_sum_ilp<12>(mc) : cascade_seq<12>(mc);
-        float var = fdiv(sum, 12.0f);
-        var = var < lo ? lo : var;
-        var = var > hi ? hi : var;
-#pragma unroll
-        for (int c = 0; c < 12; ++c) r[c][j] = cvx_expf(-fdiv(mc[c], var));
-    }
+    for (int j = 0; j < NV; ++j) mind_normalise(r[j], lo, hi, x + j >= tail_from);
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
         float* dst = out + (size_t)MIND_INV[c] * V + x;
-        if (NV == 4) *reinterpret_cast<float4*>(dst) = make_float4(r[c][0], r[c][1 % NV], r[c][2 % NV], r[c][3 % NV]);
-        else dst[0] = r[c][0];
+        if (NV == 4) *reinterpret_cast<float4*>(dst) = make_float4(r[0][c], r[1 % NV][c], r[2 % NV][c], r[3 % NV][c]);
+        else dst[0] = r[0][c];
+    }
+}
+
+// ---- pipeline variant: normalise + exp + BOTH stride poolings in one pass over the raw SSDs -----------------------------
+// The registration pipeline consumes the descriptor only through avg_pool3d(g, stride g) (convex_adam_MIND.py:118-119,
+// 149-150), so the full-resolution descriptor is never written: a workgroup normalises a T x T x 24 voxel tile (T = the
+// larger window, a multiple of the smaller one) into LDS and evaluates the pooling windows of both sizes from there in
+// ATen's raster order (sum of g^3 taps, one division).  HBM: 12*V*4 B read + the pooled outputs, instead of
+// 2 x 12*V*4 (finish) + 2 x 12*V*4 (two pooling passes).
+constexpr int MP_TX = 24, MP_NT = 512;
+
+// raster-order window sum of G^3 taps from the LDS tile and its store; (c, wz, wy, wx) = window inside the tile
+template <int T, int G>
+__device__ __forceinline__ void mp_window(const float* __restrict__ E, int c, int wz, int wy, int wx, int z0, int y0, int x0, int H,
+                                          int W, int D, float* __restrict__ out) {
+    const int Ho = H / G, Wo = W / G, Do = D / G;
+    const int oz = z0 / G + wz, oy = y0 / G + wy, ox = x0 / G + wx;
+    if (oz >= Ho || oy >= Wo || ox >= Do) return;
+    const float* base = E + ((c * T + wz * G) * T + wy * G) * MP_TX + wx * G;
+    float s = 0.0f;
+#pragma unroll
+    for (int z = 0; z < G; ++z)
+#pragma unroll
+        for (int y = 0; y < G; ++y) {
+            const float* row = base + (z * T + y) * MP_TX;
+            if (G % 2 == 0) {
+#pragma unroll
+                for (int x = 0; x < G; x += 2) { const f32x2 v = lds_load2(row + x); s += v.x; s += v.y; }
+            } else {
+#pragma unroll
+                for (int x = 0; x < G; ++x) s += row[x];
+            }
+        }
+    out[(size_t)c * Ho * Wo * Do + ((size_t)oz * Wo + oy) * Do + ox] = fdiv(s, (float)(G * G * G));
+}
+
+// T = GA >= GB, GB divides GA; out2 may be null (single pooling).  512 threads: phase 1 gives every thread 2 adjacent voxels
+// (12 x 8-byte loads, normalise, 12 x 8-byte LDS stores); in phase 2 the first wavefronts evaluate the few large windows
+// (one long sequential sum each) while the others sweep the many small ones.
+template <int GA, int GB>
+__global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restrict__ raw, int H, int W, int D,
+                                                            const MindStats* __restrict__ st, float* __restrict__ out1,
+                                                            float* __restrict__ out2) {
+    constexpr int T = GA;
+    __shared__ __attribute__((aligned(16))) float E[12 * T * T * MP_TX];          // [c][z][y][x], final channel order
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * MP_TX, y0 = blockIdx.y * T, z0 = blockIdx.z * T;
+    const size_t V = (size_t)H * W * D;
+    const float lo = st->lo, hi = st->hi;
+    const size_t tail_from = (V / 32) * 32;
+    constexpr int NP = MP_TX / 2;
+    for (int i = tid; i < T * T * NP; i += MP_NT) {
+        const int xp = i % NP, y = (i / NP) % T, z = i / (NP * T);
+        const int gz = z0 + z, gy = y0 + y, gx = x0 + 2 * xp;
+        if (gz >= H || gy >= W || gx + 1 >= D) continue;                           // (D is even) no complete window reaches these voxels
+        const size_t lin = ((size_t)gz * W + gy) * D + gx;
+        float r[2][12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            const float2 q = *reinterpret_cast<const float2*>(raw + (size_t)MIND_INV[c] * V + lin);
+            r[0][c] = q.x; r[1][c] = q.y;
+        }
+        mind_normalise(r[0], lo, hi, lin >= tail_from);
+        mind_normalise(r[1], lo, hi, lin + 1 >= tail_from);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            const f32x2 v = {r[0][c], r[1][c]};
+            lds_store2(E + ((MIND_INV[c] * T + z) * T + y) * MP_TX + 2 * xp, v);
+        }
+    }
+    __syncthreads();
+    constexpr int NA = 12 * (MP_TX / GA);                                          // large windows of the tile (T / GA = 1)
+    constexpr int WA = (NA + 63) / 64 * 64;                                        // threads reserved for them (whole wavefronts)
+    if (tid < WA) {
+        if (tid < NA) mp_window<T, GA>(E, tid / (MP_TX / GA), 0, 0, tid % (MP_TX / GA), z0, y0, x0, H, W, D, out1);
+    } else if (out2) {
+        constexpr int nb = T / GB, nx = MP_TX / GB;
+        for (int i = tid - WA; i < 12 * nb * nb * nx; i += MP_NT - WA) {
+            const int wx = i % nx, wy = (i / nx) % nb, wz = (i / (nx * nb)) % nb, c = i / (nx * nb * nb);
+            mp_window<T, GB>(E, c, wz, wy, wx, z0, y0, x0, H, W, D, out2);
+        }
     }
 }
 
@@ -287,15 +371,77 @@ static int mind_launch_r(const float* img, int H, int W, int D, int dil, MindSta
     const size_t lds = mind_lds_bytes(R, dil, nbuf);
     static size_t granted0 = 0;
     ensure_dynamic_lds(&k_mind<R>, lds, granted0);
-    const double count = (double)H * W * D;
-    const size_t V = (size_t)H * W * D;
     hipLaunchKernelGGL((k_mind<R>), grid, dim3(NT), lds, s, img, H, W, D, dil, nbuf, st, out);
-    hipLaunchKernelGGL(k_mind_stats_finish, dim3(1), dim3(1), 0, s, st, count);
-    if (V % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
-        hipLaunchKernelGGL(k_mind_finish<4>, dim3((unsigned)cdiv64((int64_t)(V / 4), 256)), dim3(256), 0, s, out, V, st);
-    else
-        hipLaunchKernelGGL(k_mind_finish<1>, dim3((unsigned)cdiv64((int64_t)V, 256)), dim3(256), 0, s, out, V, st);
+    hipLaunchKernelGGL(k_mind_stats_finish, dim3(1), dim3(1), 0, s, st, (double)H * W * D);
     return check_last("mindssc");
+}
+
+// min/max -> split grids -> stencil pass: raw patch SSDs in `raw` [12][V] (final channel order), statistics in *st
+static int mind_stencil(const float* img, int H, int W, int D, int radius, int dilation, float* raw, void* workspace,
+                        size_t workspace_bytes, MindStats** st_out, hipStream_t s) {
+    Carver cv(workspace, workspace_bytes);
+    float* part = cv.take<float>(2 * 1024);
+    MindStats* st = cv.take<MindStats>(1);
+    *st_out = st;
+    const size_t V = (size_t)H * W * D;
+    const int nb = (int)(V / 4096 + 1 < 1024 ? V / 4096 + 1 : 1024);
+    hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(256), 0, s, img, V, part);
+    hipLaunchKernelGGL(k_mind_stats_init, dim3(1), dim3(256), 0, s, part, nb, (double)V, st);
+    switch (radius) {
+        case 1: return mind_launch_r<1>(img, H, W, D, dilation, st, raw, s);
+        case 2: return mind_launch_r<2>(img, H, W, D, dilation, st, raw, s);
+        default: return mind_launch_r<3>(img, H, W, D, dilation, st, raw, s);
+    }
+}
+
+static int mind_check(const float* img, const float* out, const void* workspace, int H, int W, int D, int radius, int dilation,
+                      size_t workspace_bytes) {
+    CVX_REQUIRE(img && out && workspace, "cvx_mindssc_f32: null pointer");
+    CVX_REQUIRE(H > 0 && W > 0 && D > 0, "cvx_mindssc_f32: bad extent %dx%dx%d", H, W, D);
+    CVX_REQUIRE(radius >= 1 && radius <= 3, "cvx_mindssc_f32: radius %d not in 1..3", radius);
+    CVX_REQUIRE(dilation >= 1 && dilation <= 4, "cvx_mindssc_f32: dilation %d not in 1..4", dilation);
+    if (workspace_bytes < cvx_mindssc_workspace_bytes(H, W, D, radius, dilation))
+        return fail(CVX_ERR_WORKSPACE, "cvx_mindssc_f32: workspace too small");
+    if (mind_lds_bytes(radius, dilation, 1) > 160 * 1024)
+        return fail(CVX_ERR_UNSUPPORTED, "cvx_mindssc_f32: radius %d dilation %d exceeds the LDS tile", radius, dilation);
+    return CVX_OK;
+}
+
+// tile edge of the fused finish + pooling pass for window sizes (g1, g2), 0 if it does not apply
+static int mind_pool_tile(int H, int W, int D, int g1, int g2) {
+    const int T = g1 > g2 ? g1 : g2, g = g1 > g2 ? g2 : g1;
+    (void)H; (void)W;
+    if ((D & 1) != 0) return 0;                                       // 8-byte row segments
+    const bool ok = (T == 6 && (g == 2 || g == 3 || g == 6)) || (T == 4 && (g == 2 || g == 4)) || (T == 2 && g == 2);
+    return ok ? T : 0;                                                // 12 * T * T * 24 floats of LDS: 41 KB for T = 6
+}
+bool mind_pooled_supported(int H, int W, int D, int g1, int g2) { return mind_pool_tile(H, W, D, g1, g2 > 0 ? g2 : g1) != 0; }
+
+// MIND-SSC of `img` delivered only as avg_pool3d(., g1, stride g1) -> out1 and (g2 > 0) avg_pool3d(., g2, stride g2) -> out2;
+// `raw` is a 12*V float scratch (the raw patch SSDs).  Same values as cvx_mindssc_f32 followed by cvx_avgpool_f32.
+int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int dilation, int g1, float* out1, int g2, float* out2,
+                       float* raw, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    int rc = mind_check(img, raw, workspace, H, W, D, radius, dilation, workspace_bytes);
+    if (rc) return rc;
+    const int T = mind_pool_tile(H, W, D, g1, g2 > 0 ? g2 : g1);
+    if (T == 0 || !out1) return fail(CVX_ERR_UNSUPPORTED, "mind_pooled: window sizes %d, %d do not tile", g1, g2);
+    MindStats* st = nullptr;
+    if ((rc = mind_stencil(img, H, W, D, radius, dilation, raw, workspace, workspace_bytes, &st, s))) return rc;
+    const dim3 grid(cdiv(D, MP_TX), cdiv(W, T), cdiv(H, T));
+    // (ga, gb) = (larger, smaller) window; the larger one goes to the matching output
+    const bool swap = g2 > g1;
+    const int ga = swap ? g2 : g1, gb = g2 > 0 ? (swap ? g1 : g2) : g1;
+    float* oa = swap ? out2 : out1;
+    float* ob = g2 > 0 ? (swap ? out1 : out2) : nullptr;
+#define CVX_MP(GA, GB) hipLaunchKernelGGL((k_mind_finish_pool<GA, GB>), grid, dim3(MP_NT), 0, s, raw, H, W, D, st, oa, ob)
+    if (ga == 6 && gb == 2) CVX_MP(6, 2);
+    else if (ga == 6 && gb == 3) CVX_MP(6, 3);
+    else if (ga == 6 && gb == 6) CVX_MP(6, 6);
+    else if (ga == 4 && gb == 2) CVX_MP(4, 2);
+    else if (ga == 4 && gb == 4) CVX_MP(4, 4);
+    else CVX_MP(2, 2);
+#undef CVX_MP
+    return check_last("mind_finish_pool");
 }
 
 }  // namespace cvx
@@ -309,25 +455,15 @@ extern "C" size_t cvx_mindssc_workspace_bytes(int H, int W, int D, int radius, i
 
 extern "C" int cvx_mindssc_f32(const float* img, int H, int W, int D, int radius, int dilation, float* out,
                                void* workspace, size_t workspace_bytes, void* stream) {
-    CVX_REQUIRE(img && out && workspace, "cvx_mindssc_f32: null pointer");
-    CVX_REQUIRE(H > 0 && W > 0 && D > 0, "cvx_mindssc_f32: bad extent %dx%dx%d", H, W, D);
-    CVX_REQUIRE(radius >= 1 && radius <= 3, "cvx_mindssc_f32: radius %d not in 1..3", radius);
-    CVX_REQUIRE(dilation >= 1 && dilation <= 4, "cvx_mindssc_f32: dilation %d not in 1..4", dilation);
-    if (workspace_bytes < cvx_mindssc_workspace_bytes(H, W, D, radius, dilation))
-        return fail(CVX_ERR_WORKSPACE, "cvx_mindssc_f32: workspace too small");
-    if (mind_lds_bytes(radius, dilation, 1) > 160 * 1024)
-        return fail(CVX_ERR_UNSUPPORTED, "cvx_mindssc_f32: radius %d dilation %d exceeds the LDS tile", radius, dilation);
+    int rc = mind_check(img, out, workspace, H, W, D, radius, dilation, workspace_bytes);
+    if (rc) return rc;
     hipStream_t s = as_stream(stream);
-    Carver cv(workspace, workspace_bytes);
-    float* part = cv.take<float>(2 * 1024);
-    MindStats* st = cv.take<MindStats>(1);
+    MindStats* st = nullptr;
+    if ((rc = mind_stencil(img, H, W, D, radius, dilation, out, workspace, workspace_bytes, &st, s))) return rc;
     const size_t V = (size_t)H * W * D;
-    const int nb = (int)(V / 4096 + 1 < 1024 ? V / 4096 + 1 : 1024);
-    hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(256), 0, s, img, V, part);
-    hipLaunchKernelGGL(k_mind_stats_init, dim3(1), dim3(256), 0, s, part, nb, (double)V, st);
-    switch (radius) {
-        case 1: return mind_launch_r<1>(img, H, W, D, dilation, st, out, s);
-        case 2: return mind_launch_r<2>(img, H, W, D, dilation, st, out, s);
-        default: return mind_launch_r<3>(img, H, W, D, dilation, st, out, s);
-    }
+    if (V % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+        hipLaunchKernelGGL(k_mind_finish<4>, dim3((unsigned)cdiv64((int64_t)(V / 4), 256)), dim3(256), 0, s, out, V, st);
+    else
+        hipLaunchKernelGGL(k_mind_finish<1>, dim3((unsigned)cdiv64((int64_t)V, 256)), dim3(256), 0, s, out, V, st);
+    return check_last("mind_finish");
 }

@@ -197,16 +197,30 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
 
     // 1. features                                                              (:106-116)
     const float *featF = feat_fixed, *featM = feat_moving;
+    // MIND path: the descriptor is consumed only through its two stride poolings, so when the window sizes tile it is never
+    // written at full resolution (launch_mind_pooled: raw patch SSDs -> normalise + exp + both poolings in one pass)
+    const bool adam = p->lambda_weight > 0;
+    const bool pooled_mind = p->n_feat == 0 && mind_pooled_supported(p->H, p->W, p->D, p->grid_sp, adam ? p->grid_sp_adam : 0);
     if (p->n_feat == 0) {
         const size_t mws = cvx_mindssc_workspace_bytes(p->H, p->W, p->D, p->mind_r, p->mind_d);
-        if ((rc = cvx_mindssc_f32(img_fixed, p->H, p->W, p->D, p->mind_r, p->mind_d, F(L.featF), ws + L.mind_ws, mws, stream))) return rc;
-        if ((rc = cvx_mindssc_f32(img_moving, p->H, p->W, p->D, p->mind_r, p->mind_d, F(L.featM), ws + L.mind_ws, mws, stream))) return rc;
+        if (pooled_mind) {
+            const int g2 = adam ? p->grid_sp_adam : 0;
+            if ((rc = launch_mind_pooled(img_fixed, p->H, p->W, p->D, p->mind_r, p->mind_d, p->grid_sp, F(L.fs), g2, adam ? F(L.F2) : nullptr,
+                                         F(L.featF), ws + L.mind_ws, mws, s))) return rc;
+            if ((rc = launch_mind_pooled(img_moving, p->H, p->W, p->D, p->mind_r, p->mind_d, p->grid_sp, F(L.ms), g2, adam ? F(L.M2) : nullptr,
+                                         F(L.featM), ws + L.mind_ws, mws, s))) return rc;
+        } else {
+            if ((rc = cvx_mindssc_f32(img_fixed, p->H, p->W, p->D, p->mind_r, p->mind_d, F(L.featF), ws + L.mind_ws, mws, stream))) return rc;
+            if ((rc = cvx_mindssc_f32(img_moving, p->H, p->W, p->D, p->mind_r, p->mind_d, F(L.featM), ws + L.mind_ws, mws, stream))) return rc;
+        }
         featF = F(L.featF); featM = F(L.featM);
     }
     mark("mind", s);
     // 2. coarse features                                                       (:118-119)
-    if ((rc = cvx_avgpool_f32(featF, L.C, p->H, p->W, p->D, p->grid_sp, F(L.fs), stream))) return rc;
-    if ((rc = cvx_avgpool_f32(featM, L.C, p->H, p->W, p->D, p->grid_sp, F(L.ms), stream))) return rc;
+    if (!pooled_mind) {
+        if ((rc = cvx_avgpool_f32(featF, L.C, p->H, p->W, p->D, p->grid_sp, F(L.fs), stream))) return rc;
+        if ((rc = cvx_avgpool_f32(featM, L.C, p->H, p->W, p->D, p->grid_sp, F(L.ms), stream))) return rc;
+    }
     hipLaunchKernelGGL(k_disp_mesh, dim3(cdiv(L.K, 256)), dim3(256), 0, s, p->disp_hw, F(L.mesh));
     hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.h, 64)), dim3(64), 0, s, L.h, F(L.bh));
     hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.w, 64)), dim3(64), 0, s, L.w, F(L.bw));
@@ -246,8 +260,10 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
     }
 
     if (p->lambda_weight > 0) {                 // (:147-191)
-        if ((rc = cvx_avgpool_f32(featF, L.C, p->H, p->W, p->D, p->grid_sp_adam, F(L.F2), stream))) return rc;
-        if ((rc = cvx_avgpool_f32(featM, L.C, p->H, p->W, p->D, p->grid_sp_adam, F(L.M2), stream))) return rc;
+        if (!pooled_mind) {
+            if ((rc = cvx_avgpool_f32(featF, L.C, p->H, p->W, p->D, p->grid_sp_adam, F(L.F2), stream))) return rc;
+            if ((rc = cvx_avgpool_f32(featM, L.C, p->H, p->W, p->D, p->grid_sp_adam, F(L.M2), stream))) return rc;
+        }
         hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.h2, 64)), dim3(64), 0, s, L.h2, F(L.bh2));
         hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.w2, 64)), dim3(64), 0, s, L.w2, F(L.bw2));
         hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.d2, 64)), dim3(64), 0, s, L.d2, F(L.bd2));
