@@ -294,18 +294,30 @@ __device__ __forceinline__ void mp_window(const float* __restrict__ E, int c, in
     const float* base = E + ((c * T + wz * G) * T + wy * G) * MP_TX + wx * G;
     float s = 0.0f;
 #pragma unroll
-    for (int z = 0; z < G; ++z)
+    for (int z = 0; z < G; ++z) {
+        // all loads of a z-slice are issued before its adds: the sequential sum then waits for LDS once per slice
+        if (G % 2 == 0) {
+            f32x2 v[G][G / 2];
 #pragma unroll
-        for (int y = 0; y < G; ++y) {
-            const float* row = base + (z * T + y) * MP_TX;
-            if (G % 2 == 0) {
+            for (int y = 0; y < G; ++y)
 #pragma unroll
-                for (int x = 0; x < G; x += 2) { const f32x2 v = lds_load2(row + x); s += v.x; s += v.y; }
-            } else {
+                for (int x = 0; x < G / 2; ++x) v[y][x] = lds_load2(base + (z * T + y) * MP_TX + 2 * x);
 #pragma unroll
-                for (int x = 0; x < G; ++x) s += row[x];
-            }
+            for (int y = 0; y < G; ++y)
+#pragma unroll
+                for (int x = 0; x < G / 2; ++x) { s += v[y][x].x; s += v[y][x].y; }
+        } else {
+            float v[G][G];
+#pragma unroll
+            for (int y = 0; y < G; ++y)
+#pragma unroll
+                for (int x = 0; x < G; ++x) v[y][x] = base[(z * T + y) * MP_TX + x];
+#pragma unroll
+            for (int y = 0; y < G; ++y)
+#pragma unroll
+                for (int x = 0; x < G; ++x) s += v[y][x];
         }
+    }
     out[(size_t)c * Ho * Wo * Do + ((size_t)oz * Wo + oy) * Do + ox] = fdiv(s, (float)(G * G * G));
 }
 
