@@ -224,6 +224,14 @@ def test_batched_pairs_on_internal_streams_match_single_calls(M, golden):
     ((26, 41, 30), dict(mind_r=2, mind_d=1, grid_sp=3, disp_hw=4, grid_sp_adam=1, lambda_weight=1.5, selected_niter=2, ic=True, selected_smooth=5)),
     ((24, 24, 50), dict(mind_r=1, mind_d=3, grid_sp=4, disp_hw=5, grid_sp_adam=2, lambda_weight=1.0, selected_niter=3, ic=False)),
     ((40, 20, 23), dict(mind_r=1, mind_d=1, grid_sp=2, disp_hw=1, grid_sp_adam=4, lambda_weight=2.0, selected_niter=2, ic=True)),
+    # even D and window sizes that tile: MIND is delivered only through the fused normalise + pooling pass
+    ((38, 27, 52), dict(mind_r=1, mind_d=2, grid_sp=6, disp_hw=2, grid_sp_adam=2, lambda_weight=1.25, selected_niter=3, ic=True)),
+    ((25, 31, 26), dict(mind_r=1, mind_d=2, grid_sp=2, disp_hw=1, grid_sp_adam=4, lambda_weight=1.0, selected_niter=2, ic=False)),
+    ((31, 26, 44), dict(mind_r=2, mind_d=2, grid_sp=6, disp_hw=2, grid_sp_adam=3, lambda_weight=0.5, selected_niter=2, ic=True)),
+    ((24, 25, 30), dict(mind_r=1, mind_d=1, grid_sp=6, disp_hw=1, grid_sp_adam=6, lambda_weight=1.0, selected_niter=2, ic=True)),
+    ((21, 22, 26), dict(mind_r=1, mind_d=2, grid_sp=4, disp_hw=2, grid_sp_adam=4, lambda_weight=1.0, selected_niter=2, ic=True)),
+    ((17, 18, 22), dict(mind_r=1, mind_d=2, grid_sp=2, disp_hw=2, grid_sp_adam=2, lambda_weight=1.0, selected_niter=2, ic=True)),
+    ((26, 27, 30), dict(mind_r=1, mind_d=2, grid_sp=6, disp_hw=2, lambda_weight=0, ic=True)),
 ])
 def test_pipeline_ragged_shapes_vs_oracle_bit_exact(M, orc, shape, kw):
     """Extents that are not multiples of the grid spacings (floor pooling drops the remainder), every mind_r/mind_d,
