@@ -61,6 +61,13 @@ def test_argument_validation_without_gpu(L):
     assert L.cvx_correlate_f32(dummy, dummy, 12, 4, 4, 4, 2, dummy, None, dummy, 16, None) == -2         # workspace too small
     assert L.cvx_box_smooth_f32(dummy, 3, 4, 4, 4, 4, 1, C.c_void_p(512), None, 0, None) == -1           # even kernel
     assert b"odd" in L.cvx_last_error()
+    # evaluation operators: null pointers and degenerate extents
+    assert L.cvx_jacobian_det_f32(None, 8, 8, 8, 0, None, None) == -1
+    assert L.cvx_jacobian_det_f32(dummy, 4, 8, 8, 0, dummy, None) == -1 and b"crop" in L.cvx_last_error()
+    assert L.cvx_jacobian_stats_f64(dummy, 0, dummy, None) == -1
+    assert L.cvx_warp_labels_nearest_f32(dummy, dummy, 8, 8, 8, dummy, dummy, dummy, dummy, None) == -1   # in place
+    assert L.cvx_label_overlap_i64(dummy, dummy, 10, 0, dummy, None) == -1 and b"num_labels" in L.cvx_last_error()
+    assert L.cvx_map_coordinates_linear_f64(dummy, dummy, 4, 4, 0, C.c_void_p(512), None) == -1
 
 
 def test_workspace_queries(L):
