@@ -80,6 +80,9 @@ SIGNATURES = {
     "cvx_warp_labels_nearest_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cvx_label_overlap_i64": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "cvx_map_coordinates_linear_f64": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "cvx_feature_transform_workspace_bytes": (_sz, [_i, _i, _i]),
+    "cvx_feature_transform_i32": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "cvx_feature_flat_index_i64": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

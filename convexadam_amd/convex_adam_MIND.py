@@ -38,12 +38,25 @@ def _load_mask(path):
     return torch.from_numpy(nib.load(path).get_fdata()).float()
 
 
+def feature_transform(obj):
+    """Device counterpart of scipy.ndimage.distance_transform_edt(obj, return_indices=True)[1] for a (H,W,D) device tensor:
+    (3,H,W,D) int32 coordinates of the nearest ZERO voxel, scipy's tie-breaking included (csrc/edt.hip)."""
+    o = f32c(obj)
+    H, W, D = [int(s) for s in o.shape[-3:]]
+    L = lib()
+    feat = torch.empty((3, H, W, D), dtype=torch.int32, device=o.device)
+    nws = L.cvx_feature_transform_workspace_bytes(H, W, D)
+    ws = workspace(nws, o.device)
+    with torch.cuda.device(o.device):
+        check(L.cvx_feature_transform_i32(ptr(o), H, W, D, ptr(feat), ptr(ws), nws, stream_ptr(o.device)))
+    return feat
+
+
 def _replicate_fill(img, mask, device):
     """Masked 'replicate fill' of convex_adam_MIND.py:40-51: outside the eroded mask the image takes the value of the
-    nearest in-mask voxel (found at half resolution with scipy's Euclidean feature transform on the host, exactly like
-    the reference), tri-linearly up-sampled; inside it keeps its own values.  Erosion, gather, up-sampling and merge are
-    HIP kernels; only the EDT index search runs on the CPU."""
-    from scipy.ndimage import distance_transform_edt as edt
+    nearest in-mask voxel (found at half resolution with the Euclidean feature transform, tie-breaking as scipy's, which
+    the reference calls on the host), tri-linearly up-sampled; inside it keeps its own values.  Everything runs in HIP
+    kernels: erosion, feature transform, index expression of :45, gather, up-sampling, merge."""
     from .convex_adam_utils import resize_trilinear
     H, W, D = [int(s) for s in img.shape[-3:]]
     if H % 2 or W % 2 or D % 2:
@@ -55,9 +68,13 @@ def _replicate_fill(img, mask, device):
     m = torch.empty_like(mk)
     with torch.cuda.device(device):
         check(L.cvx_mask_erode_f32(ptr(mk), H, W, D, 0.9, ptr(m), stream_ptr(device)))
-    _, idx = edt((m[::2, ::2, ::2] == 0).cpu().numpy(), return_indices=True)
-    lin = idx[0] * D // 2 * W // 2 + idx[1] * D // 2 + idx[2]          # same index expression as :45
-    lin_d = torch.from_numpy(np.ascontiguousarray(lin, dtype=np.int64)).to(device)
+    # edt((m[::2,::2,::2] == 0), return_indices=True): the "objects" are the voxels OUTSIDE the eroded mask
+    outside = (m[::2, ::2, ::2] == 0).to(torch.float32).contiguous()
+    feat = feature_transform(outside)
+    h2, w2, d2 = [int(s) for s in outside.shape]
+    lin_d = torch.empty((h2, w2, d2), dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        check(L.cvx_feature_flat_index_i64(ptr(feat), h2, w2, d2, W, D, ptr(lin_d), stream_ptr(device)))   # same expression as :45
     half_src = im[::2, ::2, ::2].contiguous()
     half = torch.empty((1, 1) + tuple(half_src.shape), dtype=torch.float32, device=device)
     filled = torch.empty((1, 1, H, W, D), dtype=torch.float32, device=device)

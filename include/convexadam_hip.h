@@ -221,6 +221,17 @@ int cvx_warp_labels_nearest_f32(const float* seg, const float* disp, int H, int 
 int cvx_label_overlap_i64(const float* a, const float* b, int64_t n, int num_labels, int64_t* counts, void* stream);
 int cvx_map_coordinates_linear_f64(const double* moving, const double* disp, int H, int W, int D, double* out, void* stream);
 
+/* ---- Euclidean feature transform: the nearest-in-mask search of the masked feature path -------------
+ *   convex_adam_MIND.py:44,49: scipy.ndimage.distance_transform_edt(mask == 0, return_indices=True)[1]
+ *   cvx_feature_transform_i32  : obj [H][W][D] (non-zero = voxel that looks for its nearest ZERO voxel) ->
+ *                                feat [3][H][W][D] int32 coordinates of that voxel, scipy's tie-breaking included
+ *   cvx_feature_flat_index_i64 : the reference's index expression idx[0]*D//2*W//2 + idx[1]*D//2 + idx[2] (:45,50) with the
+ *                                full-resolution W_full, D_full -> out [H][W][D] int64 (input of cvx_gather_f32) */
+size_t cvx_feature_transform_workspace_bytes(int H, int W, int D);
+int cvx_feature_transform_i32(const float* obj, int H, int W, int D, int* feat, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int cvx_feature_flat_index_i64(const int* feat, int H, int W, int D, int W_full, int D_full, int64_t* out, void* stream);
+
 #pragma GCC visibility pop
 
 #ifdef __cplusplus

@@ -802,3 +802,85 @@ ORC_API int orc_label_features(const float* lab_fix, const float* lab_mov, int64
     free(cf); free(cm); free(present); free(wt);
     return C;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Euclidean feature transform (index of the nearest zero element), used by the masked feature path:
+ * convex_adam_MIND.py:44,49 calls scipy.ndimage.distance_transform_edt(..., return_indices=True).
+ * scipy is a third-party dependency of the reference (not vendored; 1.15.3 in this image); its exact transform is the
+ * dimension-by-dimension Voronoi algorithm of Maurer, Qi & Raghavan (IEEE TPAMI 25(2), 2003) as implemented in
+ * scipy/ndimage/src/ni_measure.c (_VoronoiFT / _ComputeFT).  Ties between equidistant sites are resolved by the
+ * order of that construction (`<= 0` keeps the older site when a site is removed, `delta1 <= delta2` keeps the
+ * lower site when scanning), which this restatement reproduces: tests/test_oracle_vs_golden.py compares it with scipy
+ * itself on random and tie-heavy masks.
+ *   obj  [H][W][D] : non-zero = object voxel (needs its nearest zero), zero = site
+ *   feat [3][H][W][D] int32 : coordinates of the nearest site along axes 0, 1, 2
+ * ---------------------------------------------------------------------------------------------- */
+static void orc_voronoi_ft(int32_t* pf, int len, const int* coor, int d, int64_t stride, int64_t cstride, int (*f)[3], int* g) {
+    int l = -1, maxl;
+    for (int ii = 0; ii < len; ii++) for (int jj = 0; jj < 3; jj++) f[ii][jj] = pf[ii * stride + cstride * jj];
+    for (int ii = 0; ii < len; ii++) {
+        if (pf[ii * stride] < 0) continue;
+        double fd = f[ii][d], wR = 0.0;
+        for (int jj = 0; jj < 3; jj++) if (jj != d) { const double tw = f[ii][jj] - coor[jj]; wR += tw * tw; }
+        while (l >= 1) {
+            const int idx1 = g[l], idx2 = g[l - 1];
+            const double f1 = f[idx1][d], a = f1 - f[idx2][d], b = fd - f1, c = a + b;
+            double uR = 0.0, vR = 0.0;
+            for (int jj = 0; jj < 3; jj++) if (jj != d) {
+                const double cc = coor[jj], tu = f[idx2][jj] - cc, tv = f[idx1][jj] - cc;
+                uR += tu * tu; vR += tv * tv;
+            }
+            if (c * vR - b * uR - a * wR - a * b * c <= 0.0) break;
+            --l;
+        }
+        g[++l] = ii;
+    }
+    maxl = l;
+    if (maxl < 0) return;
+    l = 0;
+    for (int ii = 0; ii < len; ii++) {
+        double delta1 = 0.0;
+        for (int jj = 0; jj < 3; jj++) { const double t = jj == d ? f[g[l]][jj] - ii : f[g[l]][jj] - coor[jj]; delta1 += t * t; }
+        while (l < maxl) {
+            double delta2 = 0.0;
+            for (int jj = 0; jj < 3; jj++) { const double t = jj == d ? f[g[l + 1]][jj] - ii : f[g[l + 1]][jj] - coor[jj]; delta2 += t * t; }
+            if (delta1 <= delta2) break;
+            delta1 = delta2;
+            ++l;
+        }
+        for (int jj = 0; jj < 3; jj++) pf[ii * stride + jj * cstride] = f[g[l]][jj];
+    }
+}
+ORC_API void orc_feature_transform(const float* obj, int H, int W, int D, int32_t* feat) {
+    const int64_t V = (int64_t)H * W * D;
+    int maxlen = H > W ? H : W;
+    if (D > maxlen) maxlen = D;
+#pragma omp parallel
+    {
+        int (*f)[3] = malloc(sizeof(int[3]) * (size_t)maxlen);
+        int* g = malloc(sizeof(int) * (size_t)maxlen);
+        int coor[3];
+#pragma omp for collapse(2) schedule(static)
+        for (int y = 0; y < W; y++) for (int x = 0; x < D; x++) {                 /* axis 0 */
+            coor[0] = 0; coor[1] = y; coor[2] = x;
+            int32_t* pf = feat + (int64_t)y * D + x;
+            for (int z = 0; z < H; z++) {
+                int32_t* q = pf + (int64_t)z * W * D;
+                if (obj[((int64_t)z * W + y) * D + x] != 0.0f) { q[0] = -1; q[V] = -1; q[2 * V] = -1; }
+                else { q[0] = z; q[V] = y; q[2 * V] = x; }
+            }
+            orc_voronoi_ft(pf, H, coor, 0, (int64_t)W * D, V, f, g);
+        }
+#pragma omp for collapse(2) schedule(static)
+        for (int z = 0; z < H; z++) for (int x = 0; x < D; x++) {                 /* axis 1 */
+            coor[0] = z; coor[1] = 0; coor[2] = x;
+            orc_voronoi_ft(feat + (int64_t)z * W * D + x, W, coor, 1, D, V, f, g);
+        }
+#pragma omp for collapse(2) schedule(static)
+        for (int z = 0; z < H; z++) for (int y = 0; y < W; y++) {                 /* axis 2 */
+            coor[0] = z; coor[1] = y; coor[2] = 0;
+            orc_voronoi_ft(feat + ((int64_t)z * W + y) * D, D, coor, 2, 1, V, f, g);
+        }
+        free(f); free(g);
+    }
+}

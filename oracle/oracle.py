@@ -73,6 +73,7 @@ def lib():
                                                                             C.c_int, C.c_float, _f32p, C.c_void_p, C.c_void_p, C.POINTER(Smoother)]
         L.orc_label_features.argtypes = [_f32p, _f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_label_features.restype = C.c_int
+        L.orc_feature_transform.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_mind_tables.argtypes = [_i32p, _i32p, _i32p]
         _lib = L
     return _lib
@@ -129,14 +130,23 @@ def box3_replicate(x):
     out = np.empty_like(x); lib().orc_box3_replicate(x.reshape(-1), out.reshape(-1), h, w, d); return out
 
 
+def feature_transform(obj):
+    """Index of the nearest ZERO element of `obj` for every voxel, (3,H,W,D) int32: restatement of
+    scipy.ndimage.distance_transform_edt(obj, return_indices=True)[1] including its tie-breaking (cvx_oracle.c)."""
+    o = _f(np.asarray(obj) != 0)
+    H, W, D = o.shape
+    feat = np.empty((3, H, W, D), np.int32)
+    lib().orc_feature_transform(o, H, W, D, feat.ctypes.data_as(C.c_void_p))
+    return feat
+
+
 def replicate_fill(img, mask):
     """Masked replicate fill of convex_adam_MIND.py:40-51 (even extents): erode the mask (replicate box3 > 0.9), find for
-    every half-resolution voxel the nearest in-mask voxel (scipy EDT, as the reference does), gather, x2 trilinear
-    up-sample, keep the original values inside the eroded mask."""
-    from scipy.ndimage import distance_transform_edt as edt
+    every half-resolution voxel the nearest in-mask voxel (Euclidean feature transform with scipy's tie-breaking), gather,
+    x2 trilinear up-sample, keep the original values inside the eroded mask."""
     img = _f(img); mask = _f(mask); H, W, D = img.shape
     m = (box3_replicate(mask) > np.float32(0.9)).astype(np.float32)
-    _, idx = edt(m[::2, ::2, ::2] == 0, return_indices=True)
+    idx = feature_transform(m[::2, ::2, ::2] == 0).astype(np.int64)
     lin = idx[0] * D // 2 * W // 2 + idx[1] * D // 2 + idx[2]
     half = img[::2, ::2, ::2].reshape(-1)[lin].astype(np.float32)
     up = resize_trilinear(half[None], (2 * half.shape[0], 2 * half.shape[1], 2 * half.shape[2]))[0]

@@ -548,3 +548,34 @@ def test_sweep_driver_scores_items_on_the_device(tmp_path):
     assert s["n_items"] == 2 and len(s["results"]) == 2 and len(s["ranking"]["rank"]) == 2
     for r in s["results"]:
         assert r["dice"] > r["dice_before"] + 0.1 and r["tre"] < 0.5 * r["tre_before"] and r["folding"] == 0.0
+
+
+# ---- (5) Euclidean feature transform of the masked path ------------------------------------------------
+def test_feature_transform_vs_scipy_and_oracle(M, orc):
+    """Device EDT indices == scipy.ndimage.distance_transform_edt(return_indices=True) (the call of convex_adam_MIND.py:44),
+    tie-breaking included: random masks of every density, a lattice whose cell centres are all ties, single sites."""
+    from scipy.ndimage import distance_transform_edt as edt
+    rng = np.random.default_rng(1)
+    cases = []
+    for _ in range(40):
+        shape = tuple(int(v) for v in rng.integers(2, 20, 3))
+        m = rng.random(shape) < rng.choice([0.02, 0.1, 0.3, 0.6, 0.9])
+        if m.all():
+            m.flat[int(rng.integers(m.size))] = False
+        cases.append(m)
+    for shape in ((9, 9, 9), (16, 16, 16), (40, 48, 56)):
+        m = np.ones(shape, bool); m[::4, ::4, ::4] = False; cases.append(m)
+        m = np.ones(shape, bool); m[0, 0, 0] = m[-1, -1, -1] = m[0, -1, 0] = False; cases.append(m)
+    for m in cases:
+        got = host(M.feature_transform(dev(m.astype(np.float32))))
+        assert np.array_equal(got, edt(m, return_indices=True)[1]), m.shape
+        assert np.array_equal(got, orc.feature_transform(m))
+
+
+def test_feature_transform_half_resolution_oasis_size(M):
+    """80 x 96 x 112 (the half-resolution grid of the masked path at BASELINE size), ellipsoid mask: equals scipy."""
+    from scipy.ndimage import distance_transform_edt as edt
+    z, y, x = np.meshgrid(np.linspace(-1, 1, 80), np.linspace(-1, 1, 96), np.linspace(-1, 1, 112), indexing="ij")
+    outside = (z / 0.7) ** 2 + (y / 0.7) ** 2 + (x / 0.7) ** 2 > 1.0
+    got = host(M.feature_transform(dev(outside.astype(np.float32))))
+    assert np.array_equal(got, edt(outside, return_indices=True)[1])

@@ -239,3 +239,23 @@ def test_torch_linspace_restatement():
     for n in (2, 3, 17, 64, 255):
         for a, b in ((1.0, 0.1), (-3.5, 2.25)):
             assert np.array_equal(mo.linspace(a, b, n), torch.linspace(a, b, n).numpy())
+
+
+def test_feature_transform_restatement_vs_scipy(orc):
+    """The masked path's nearest-in-mask search: scipy.ndimage.distance_transform_edt(return_indices=True) (a third-party
+    dependency of the reference) restated with its tie-breaking; compared with scipy itself on random and tie-heavy masks."""
+    from scipy.ndimage import distance_transform_edt as edt
+    rng = np.random.default_rng(0)
+    for trial in range(120):
+        shape = tuple(int(v) for v in rng.integers(2, 15, 3))
+        m = rng.random(shape) < rng.choice([0.02, 0.1, 0.3, 0.6, 0.9])
+        if m.all():
+            m.flat[int(rng.integers(m.size))] = False
+        assert np.array_equal(orc.feature_transform(m), edt(m, return_indices=True)[1]), (trial, shape)
+    for shape in ((9, 9, 9), (8, 10, 12), (16, 16, 16), (40, 48, 56)):
+        m = np.ones(shape, bool)
+        m[::4, ::4, ::4] = False                                      # lattice of sites: every cell centre is a tie
+        assert np.array_equal(orc.feature_transform(m), edt(m, return_indices=True)[1])
+        m = np.ones(shape, bool)
+        m[0, 0, 0] = m[-1, -1, -1] = m[0, -1, 0] = False
+        assert np.array_equal(orc.feature_transform(m), edt(m, return_indices=True)[1])
