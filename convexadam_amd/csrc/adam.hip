@@ -193,6 +193,17 @@ extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C
                                          const float* base_w, const float* base_d, float* U, float* grad_out,
                                          const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
                                          void* workspace, size_t workspace_bytes, void* stream) {
+    return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
+                              snapshot_iters_host, n_snap, snapshots, sm, true, workspace, workspace_bytes, stream);
+}
+
+// keep_state = false (whole-pair pipeline): P, m, v are scratch there and the result is U of the LAST forward pass
+// (convex_adam_MIND.py:181), so the gradient and the Adam step of the final iteration are never observed and are skipped.
+int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
+                       float lambda_weight, int niter, int step0, float cost_scale, const float* base_h, const float* base_w,
+                       const float* base_d, float* U, float* grad_out, const int* snapshot_iters_host, int n_snap,
+                       float* snapshots, const cvx_smoother* sm, bool keep_state, void* workspace, size_t workspace_bytes,
+                       void* stream) {
     CVX_REQUIRE(F2 && M2 && P && m && v && U && base_h && base_w && base_d, "cvx_adam_run_f32: null pointer");
     CVX_REQUIRE(C > 0 && h > 1 && w > 1 && d > 1, "cvx_adam_run_f32: bad extent C=%d %dx%dx%d", C, h, w, d);
     CVX_REQUIRE(niter >= 0 && step0 >= 0, "cvx_adam_run_f32: negative iteration count");
@@ -236,6 +247,8 @@ extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C
         const AdamConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)(-(1.0 / bc1))};
         if (fused) { if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc; }
         else if ((rc = launch_smoother(P, U, t1, 3, h, w, d, *sm, false, s))) return rc;
+        const bool last = it == niter - 1;
+        if (!(last && !keep_state && !grad_out)) {
         if ((rc = launch_warp_grad(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, s))) return rc;
         float* gsave = (grad_out && it == niter - 1) ? grad_out : nullptr;
         if (fused) { if ((rc = launch_box3x3(gU, nullptr, h, w, d, true, P, m, v, ac, gsave, s))) return rc; }
@@ -243,6 +256,7 @@ extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C
             if ((rc = launch_smoother(gU, t2, t1, 3, h, w, d, *sm, true, s))) return rc;
             hipLaunchKernelGGL(k_adam_update, dim3((unsigned)cdiv64((int64_t)(3 * V), 256)), dim3(256), 0, s, t2, P, m, v, 3 * V, ac);
             if (gsave) (void)hipMemcpyAsync(gsave, t2, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice, s);
+        }
         }
         while (snap < n_snap && snapshot_iters_host[snap] == it + 1) {
             (void)hipMemcpyAsync(snapshots + (size_t)snap * 3 * V, U, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice, s);

@@ -239,6 +239,12 @@ __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& 
     m = mm;
     v = vv;
 }
+// adam.hip: the Adam loop behind cvx_adam_run_f32 / cvx_adam_run_smoother_f32; keep_state = false lets the whole-pair pipeline
+// drop the final (unobserved) gradient + update
+int adam_run_impl(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v, float lambda_weight,
+                  int niter, int step0, float cost_scale, const float* base_h, const float* base_w, const float* base_d, float* U,
+                  float* grad_out, const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
+                  bool keep_state, void* workspace, size_t workspace_bytes, void* stream);
 // mind.hip: MIND-SSC delivered only through its stride poolings (pipeline path, no full-resolution descriptor)
 bool mind_pooled_supported(int H, int W, int D, int g1, int g2);
 int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int dilation, int g1, float* out1, int g2, float* out2,

@@ -272,9 +272,10 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
         (void)hipMemsetAsync(F(L.m), 0, sizeof(float) * 3 * L.V2, s);
         (void)hipMemsetAsync(F(L.v_), 0, sizeof(float) * 3 * L.V2, s);
         mark("adam_setup", s);
-        if ((rc = cvx_adam_run_f32(F(L.F2), F(L.M2), L.C, L.h2, L.w2, L.d2, F(L.P), F(L.m), F(L.v_), p->lambda_weight,
-                                   p->selected_niter, 0, p->cost_scale, F(L.bh2), F(L.bw2), F(L.bd2), F(L.U), nullptr, nullptr, 0,
-                                   nullptr, ws + L.adam_ws, cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2), stream))) return rc;
+        if ((rc = adam_run_impl(F(L.F2), F(L.M2), L.C, L.h2, L.w2, L.d2, F(L.P), F(L.m), F(L.v_), p->lambda_weight,
+                                p->selected_niter, 0, p->cost_scale, F(L.bh2), F(L.bw2), F(L.bd2), F(L.U), nullptr, nullptr, 0,
+                                nullptr, nullptr, /*keep_state=*/false, ws + L.adam_ws,
+                                cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2), stream))) return rc;
         mark("adam", s);
         // disp_hr = interpolate(fitted_grid * grid_sp_adam, (H,W,D))                            (:182)
         if (p->selected_smooth > 0) {
