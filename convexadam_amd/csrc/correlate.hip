@@ -12,15 +12,9 @@
 //                 16-wide cascade for C >= 16).  Writes raw [K][h][w][px] with exact zeros on the borders.
 //   k_corr_tail : re-evaluates the <= 31 trailing elements per H-shift whose channel sum ATen evaluates in
 //                 its 4-way interleaved order (see oracle outer_sum_rows).
-//   k_corr_box  : one workgroup per (k, y-tile) marches along z with two 4-plane LDS rings (raw, box1); one
-//                 thread per (row, pair of columns).  Each 27-tap raster sum reads 9 aligned 16-byte windows
-//                 [x-1 .. x+2] as two 8-byte halves: two packed adds + two scalar adds per tap row, no
-//                 cross-lane traffic, no bank conflicts; box1 is stored shifted by one column so that the
-//                 windows of the second box (pairs x = 2j-1, 2j) are aligned as well; division by 27 is the
-//                 exact FMA form (div_exact<27>).  No halo recomputation in z (and none in y for OASIS).
+//   k_corr_box2 : (corrbox.hip) the two zero-padded box filters as a z-marching pipeline, raw -> ssd.
 // Roofline: HBM by bytes (K*v*4 written + 2*C*v*4 read); the reference's summation order costs
 // 2 x (26 adds + 1 division) + 36 flops per output, which makes the stage VALU-bound.
-#include <stdlib.h>
 
 #include "cvx_common.h"
 
@@ -189,150 +183,6 @@ __global__ void k_corr_tail(const float* __restrict__ fix, const float* __restri
     raw[kk * ((size_t)g.h * g.w * g.px) + ((size_t)z * g.w + y) * g.px + x + 1] = p[0];
 }
 
-// ---- two box filters, marching along z ---------------------------------------------------------------------
-// One workgroup = one displacement k x one y-tile, one thread = one (row, pair of columns).  The workgroup walks
-// the h planes once: at step t it (1) stores raw plane t (prefetched into registers during the previous step) into
-// a 4-slot LDS ring, (2) evaluates the first box for plane t-2 from ring slots t-3..t-1 into a second 4-slot ring
-// (stored shifted by one column so that the second box's windows are aligned too), (3) evaluates the second box for
-// plane t-4 and stores it to global memory; one barrier per step.  No halo recomputation in z, and none in y when
-// the whole plane fits (w + 2 <= 1024 / pairs-per-row).
-struct BoxGeom {
-    int h, w, d, px;
-    int nj;             // column pairs per row (covers row indices 0 .. 2*nj+1)
-    int Ty, nytiles;    // output rows per tile
-    int ry;             // rows handled concurrently = Ty + 2 ; workgroup = nj * ry threads
-    int nthreads;
-};
-
-// raster-order partial sum over the 9 taps of ONE plane for the two outputs whose 4-wide window starts at `win`
-// (plain scalar adds: on gfx950 v_pk_add_f32 issues at half the rate of v_add_f32 -- 5.0 vs 2.5 cycles per
-// wave-instruction measured -- so packing buys nothing and its v_pk_mov shuffles cost extra)
-__device__ __forceinline__ void box9_pair(const float* __restrict__ win, int px, float& s0, float& s1) {
-    f32x2 lo[3], hi[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) { lo[b] = lds_load2(win + (b - 1) * px); hi[b] = lds_load2(win + (b - 1) * px + 2); }   // 6 loads in flight
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        s0 += lo[b].x; s1 += lo[b].y;     // taps x-1 | x
-        s0 += lo[b].y; s1 += hi[b].x;     // taps x   | x+1
-        s0 += hi[b].x; s1 += hi[b].y;     // taps x+1 | x+2
-    }
-}
-
-// one marching step with compile-time ring slots (S = t mod 4): all LDS offsets are scalar constants x plane pitch.
-// (Keeping the two older planes of each sum in registers instead of re-reading them from LDS was measured slower:
-//  141 VGPRs halve the number of resident workgroups.)
-template <int S>
-__device__ __forceinline__ void box_step(int t, const BoxGeom& b, int pp, int px, bool stage_row, bool stager, float4& pre,
-                                         const float* __restrict__& sp, size_t gplane, float* __restrict__ sdst,
-                                         bool row1, bool row2, const float* __restrict__ wA, float* __restrict__ oB,
-                                         const float* __restrict__ wB, float* __restrict__& dst, bool m0, bool m1, int xa, int xb) {
-    constexpr int S1 = (S + 1) & 3, S2 = (S + 2) & 3, S3 = (S + 3) & 3;      // slots of planes t-3, t-2, t-1 (= t+1, t+2, t+3 mod 4)
-    // (1) raw plane t -> ring slot S, prefetch plane t+1
-    if (stage_row) *reinterpret_cast<float4*>(sdst + S * pp) = (stager && t < b.h) ? pre : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (stager && t + 1 < b.h) { sp += gplane; pre = *reinterpret_cast<const float4*>(sp); }
-    // (2) first box for plane t-2 (taps in planes t-3, t-2, t-1), zero outside the volume
-    {
-        float s0 = 0.0f, s1 = 0.0f;
-        if (row1 && t >= 2 && t - 2 < b.h) {
-            box9_pair(wA + S1 * pp, px, s0, s1);
-            box9_pair(wA + S2 * pp, px, s0, s1);
-            box9_pair(wA + S3 * pp, px, s0, s1);
-            s0 = m0 ? div_exact<27>(s0) : 0.0f;       // the second pool zero-pads box1
-            s1 = m1 ? div_exact<27>(s1) : 0.0f;
-        }
-        lds_store2(oB + S2 * pp, f32x2{s0, s1});     // box1 plane t-2 lives in slot (t-2) mod 4
-    }
-    // (3) second box for plane t-4 (taps in box1 planes t-5, t-4, t-3 = slots S3, S, S1)
-    if (t >= 4) {
-        if (row2) {
-            float s0 = 0.0f, s1 = 0.0f;
-            box9_pair(wB + S3 * pp, px, s0, s1);
-            box9_pair(wB + S * pp, px, s0, s1);
-            box9_pair(wB + S1 * pp, px, s0, s1);
-            if (xa >= 0 && xa < b.d) dst[xa] = div_exact<27>(s0);
-            if (xb < b.d) dst[xb] = div_exact<27>(s1);
-        }
-        dst += (size_t)b.w * b.d;
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(1024) void k_corr_box(const float* __restrict__ raw, BoxGeom b, float* __restrict__ ssd) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    const int k = blockIdx.x, y0 = blockIdx.y * b.Ty;
-    const int ty = min(b.Ty, b.w - y0);
-    const int rows = b.Ty + 4;                         // LDS rows hold y0-2 .. y0+Ty+1
-    const int px = b.px, pp = rows * px;               // row / plane pitch in LDS
-    float* A = lds;                                    // raw ring, 4 planes (element x at index x+1)
-    float* B = lds + 4 * pp;                           // box1 ring, 4 planes (element x at index x+2)
-    const float* rk = raw + (size_t)k * ((size_t)b.h * b.w * px);
-
-    for (int i = tid * 4; i < 8 * pp; i += b.nthreads * 4) *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // staging role: thread -> (LDS row, 16-byte chunk) of one plane
-    const int c4 = px / 4;
-    const int srow = tid / c4, scx = tid % c4;
-    const int sgy = y0 - 2 + srow;
-    const bool stage_row = srow < rows;
-    const bool stager = stage_row && sgy >= 0 && sgy < b.w;
-    const float* sp = rk + (size_t)(stager ? sgy : 0) * px + 4 * scx;
-    float* sdst = A + srow * px + 4 * scx;
-    // compute role: px/2 lanes per row, so that lane l reads LDS dwords 2l .. 2l+3 relative to lane 0: the 8-byte
-    // accesses of a wavefront are contiguous and bank-conflict free (19 lanes per 40-float row were 2-way conflicted:
-    // 45 % of the LDS cycles in the PMC profile); the last lane(s) of a row are dummies
-    const int lpr = px / 2;
-    const int j = tid % lpr, ry = tid / lpr;
-    const int gy1 = y0 - 1 + ry;                       // row of the first box
-    const bool row1 = gy1 >= 0 && gy1 < b.w && j < b.nj && ry < b.ry;
-    const bool row2 = ry < ty && j < b.nj;            // row y0 + ry of the second box
-    const float* wA = A + (ry + 1) * px + 2 * j;       // window x = 2j-1 .. 2j+2 -> outputs x = 2j, 2j+1
-    float* oB = B + (ry + 1) * px + 2 * j + 2;         // where those two outputs live in the shifted layout
-    const float* wB = B + (ry + 2) * px + 2 * j;       // window x = 2j-2 .. 2j+1 -> outputs x = 2j-1, 2j
-    float* dst = ssd + (size_t)k * ((size_t)b.h * b.w * b.d) + (size_t)(y0 + ry) * b.d;
-    const bool m0 = 2 * j < b.d, m1 = 2 * j + 1 < b.d;
-    const int xa = 2 * j - 1, xb = 2 * j;
-
-    float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (stager && b.h > 0) pre = *reinterpret_cast<const float4*>(sp);
-    __syncthreads();
-    const size_t gplane = (size_t)b.w * px;
-    const int nsteps = b.h + 4;
-    for (int t = 0; t < nsteps; t += 4) {
-        box_step<0>(t, b, pp, px, stage_row, stager, pre, sp, gplane, sdst, row1, row2, wA, oB, wB, dst, m0, m1, xa, xb);
-        if (t + 1 < nsteps) box_step<1>(t + 1, b, pp, px, stage_row, stager, pre, sp, gplane, sdst, row1, row2, wA, oB, wB, dst, m0, m1, xa, xb);
-        if (t + 2 < nsteps) box_step<2>(t + 2, b, pp, px, stage_row, stager, pre, sp, gplane, sdst, row1, row2, wA, oB, wB, dst, m0, m1, xa, xb);
-        if (t + 3 < nsteps) box_step<3>(t + 3, b, pp, px, stage_row, stager, pre, sp, gplane, sdst, row1, row2, wA, oB, wB, dst, m0, m1, xa, xb);
-    }
-}
-
-static BoxGeom box_geom(int h, int w, int d, int px) {
-    BoxGeom b;
-    b.h = h; b.w = w; b.d = d; b.px = px;
-    b.nj = (d + 2) / 2;                                // pairs j = 0 .. d/2 reach x = d-1 in both passes
-    b.Ty = b.nytiles = b.ry = b.nthreads = 0;
-    if (b.nj > 340) return b;
-    static int max_threads = 0;
-    if (max_threads == 0) {
-        const char* e = getenv("CVX_BOX_THREADS");
-        max_threads = e ? atoi(e) : 1024;
-        if (max_threads < 64 || max_threads > 1024) max_threads = 1024;
-    }
-    int ry = max_threads / (px / 2);                   // rows per workgroup (px/2 lanes per row)
-    if (ry > w + 2) ry = w + 2;
-    if (ry < 3) return b;
-    b.nytiles = cdiv(w, ry - 2);
-    b.Ty = cdiv(w, b.nytiles);
-    b.nytiles = cdiv(w, b.Ty);
-    b.ry = b.Ty + 2;
-    b.nthreads = (px / 2) * b.ry;
-    const int stagers = (b.Ty + 4) * (px / 4);         // every LDS row needs a staging thread
-    if (b.nthreads < stagers) b.nthreads = stagers;
-    if (b.nthreads > 1024 || sizeof(float) * 8 * (size_t)(b.Ty + 4) * px > 160 * 1024) { b.nthreads = 0; return b; }
-    return b;
-}
-
 template <int HW>
 static void corr_raw_dispatch(const float* Fp, const float* Mp, const CorrGeom& g, float* raw, hipStream_t s) {
     const int nruns = g.h * g.w * (g.px / 4);
@@ -367,8 +217,7 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
     hipStream_t s = as_stream(stream);
     const CorrGeom g = corr_geom(C, h, w, d, disp_hw);
     const size_t K = (size_t)g.n * g.n * g.n;
-    const BoxGeom b = box_geom(h, w, d, g.px);
-    if (b.nthreads == 0 && !corr_box2_supported(h, w, d, g.px))
+    if (!corr_box2_supported(h, w, d, g.px))
         return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
     Carver cv(workspace, workspace_bytes);
     float* Fp = cv.take<float>((size_t)C * h * w * g.px);
@@ -395,17 +244,7 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
     if (ntail > 0)
         hipLaunchKernelGGL(k_corr_tail, dim3(cdiv(ntail * g.n, 64)), dim3(64), 0, s, fix, mov, g, tail_from, ntail, raw);
 
-    static const bool old_box = getenv("CVX_CORR_BOX_V1") != nullptr;
-    int rc;
-    if (!old_box && corr_box2_supported(h, w, d, g.px)) rc = launch_corr_box2(raw, (int)K, h, w, d, g.px, ssd, s);
-    else {
-        if (b.nthreads == 0) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
-        const size_t lds = sizeof(float) * 8 * (size_t)(b.Ty + 4) * b.px;
-        static size_t granted = 0;
-        ensure_dynamic_lds(&k_corr_box, lds, granted);
-        hipLaunchKernelGGL(k_corr_box, dim3((unsigned)K, b.nytiles), dim3(b.nthreads), lds, s, raw, b, ssd);
-        rc = check_last("correlate");
-    }
+    int rc = launch_corr_box2(raw, (int)K, h, w, d, g.px, ssd, s);
     if (rc) return rc;
     if (argmin) return launch_argmin(ssd, nullptr, nullptr, 0.0f, false, (int)K, (size_t)h * w * d, keys, argmin, s);
     return CVX_OK;
