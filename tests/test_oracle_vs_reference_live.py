@@ -1,0 +1,60 @@
+"""Live cross-check of the CPU oracle against the upstream reference itself, on inputs that are NOT in the golden files.
+Runs only where the reference tree is mounted (the build container: /root/reference); skipped everywhere else, and never
+part of the `-m gpu` selection -- nothing that runs on the GPU box reads the reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from _ref_import import import_reference, reference_available  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not reference_available(), reason="upstream reference not mounted")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return import_reference()
+
+
+def test_operators_on_fresh_inputs(ref, orc):
+    utils, _ = ref
+    g = torch.Generator().manual_seed(4242)
+    # correlate -> coupled_convex -> inverse_consistency on random features (hw 3, ragged extents)
+    shape, hw, C = (7, 9, 10), 3, 12
+    f = torch.rand(1, C, *shape, generator=g)
+    m = torch.rand(1, C, *shape, generator=g)
+    ssd, am = utils.correlate(f, m, hw, 1, shape, C)
+    os_, oa = orc.correlate(f[0].numpy(), m[0].numpy(), hw)
+    assert np.array_equal(ssd.numpy(), os_) and np.array_equal(am.numpy(), oa)
+    n = 2 * hw + 1
+    mesh_t = torch.nn.functional.affine_grid(hw * torch.eye(3, 4).unsqueeze(0), (1, 1, n, n, n), align_corners=True).permute(0, 4, 1, 2, 3).reshape(3, -1, 1)
+    soft = utils.coupled_convex(ssd, am, mesh_t, 1, shape)
+    assert np.array_equal(soft[0].numpy(), orc.coupled_convex(os_, oa, orc.disp_mesh(hw), hw))
+    a = 0.3 * torch.randn(1, 3, *shape, generator=g)
+    b = 0.3 * torch.randn(1, 3, *shape, generator=g)
+    r1, r2 = utils.inverse_consistency(a, b, iter=7)
+    o1, o2 = orc.inverse_consistency(a[0].numpy(), b[0].numpy(), 7)
+    assert np.array_equal(r1[0].numpy(), o1) and np.array_equal(r2[0].numpy(), o2)
+
+
+def test_mindssc_on_fresh_input(ref, orc):
+    utils, _ = ref
+    img = torch.randn(1, 1, 14, 15, 33, generator=torch.Generator().manual_seed(77))
+    out = utils.MINDSSC(img, 1, 2, device="cpu")[0].numpy()
+    mine = orc.mindssc(img[0, 0].numpy(), 1, 2)
+    assert np.abs(out - mine).max() <= 6e-8          # MKL vsExp vs the expf restatement: <= 1 ulp
+
+
+def test_whole_pipeline_convex_stage_on_fresh_pair(ref, orc):
+    _, mind = ref
+    from convexadam_amd.phantom import phantom
+    fix = phantom((36, 32, 40), 31, 41)
+    mov = torch.roll(phantom((36, 32, 40), 31, 42), (2, -2, 1), (0, 1, 2))
+    kw = dict(mind_r=1, mind_d=2, lambda_weight=0, grid_sp=4, disp_hw=3, ic=True)
+    out = mind.convex_adam_pt(fix, mov, dtype=torch.float32, device=torch.device("cpu"), **kw)
+    mine = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), **kw)
+    epe = float(np.sqrt(((out - mine) ** 2).sum(-1)).mean())
+    assert epe <= 1e-5, epe                          # exp differs by <= 1 ulp; everything downstream is restated exactly
