@@ -68,6 +68,8 @@ def _replicate_fill(img, mask, device):
     m = torch.empty_like(mk)
     with torch.cuda.device(device):
         check(L.cvx_mask_erode_f32(ptr(mk), H, W, D, 0.9, ptr(m), stream_ptr(device)))
+    if float(m[::2, ::2, ::2].max()) == 0.0:
+        raise ValueError("masked feature extraction: the eroded mask is empty at half resolution (no voxel to replicate from)")
     # edt((m[::2,::2,::2] == 0), return_indices=True): the "objects" are the voxels OUTSIDE the eroded mask
     outside = (m[::2, ::2, ::2] == 0).to(torch.float32).contiguous()
     feat = feature_transform(outside)
