@@ -579,3 +579,32 @@ def test_feature_transform_half_resolution_oasis_size(M):
     outside = (z / 0.7) ** 2 + (y / 0.7) ** 2 + (x / 0.7) ** 2 > 1.0
     got = host(M.feature_transform(dev(outside.astype(np.float32))))
     assert np.array_equal(got, edt(outside, return_indices=True)[1])
+
+
+# ---- (6) randomised configurations -------------------------------------------------------------------------------------------
+def test_fuzz_pipeline_and_adam_vs_oracle_bit_exact(M, U, orc):
+    """40 random small pairs (extents, MIND radius / dilation, both grid spacings, search width, lambda, iterations, ic, final
+    smoothing) and 16 random control grids (row lengths around every kernel-variant boundary): bit-identical to the oracle."""
+    from convexadam_amd.phantom import phantom
+    rng = np.random.default_rng(20260928)
+    for trial in range(40):
+        gs, gsa, hw = int(rng.choice([2, 3, 4, 5, 6])), int(rng.choice([1, 2, 3, 4])), int(rng.integers(1, 5))
+        shape = tuple(int(max(2 * gs, 2 * gsa, 8) + rng.integers(0, 30)) for _ in range(3))
+        kw = dict(mind_r=int(rng.choice([1, 2])), mind_d=int(rng.choice([1, 2, 3])), grid_sp=gs, disp_hw=hw, grid_sp_adam=gsa,
+                  lambda_weight=float(rng.choice([0.0, 0.7, 1.25])), selected_niter=int(rng.integers(1, 4)), ic=bool(rng.integers(0, 2)),
+                  selected_smooth=int(rng.choice([0, 0, 3])))
+        fix = phantom(shape, 100 + trial, 200 + trial)
+        mov = torch.roll(phantom(shape, 100 + trial, 300 + trial), (1, -1, 1), (0, 1, 2))
+        out = M.convex_adam_pt(fix, mov, dtype=torch.float32, device=torch.device(DEV), **kw)
+        ref = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), **kw)
+        assert out.shape == ref.shape and np.array_equal(out, ref), (shape, kw)
+    for trial in range(16):
+        shape = tuple(int(rng.integers(3, 40)) for _ in range(2)) + (int(rng.choice([5, 17, 29, 30, 31, 45, 61, 62, 63, 90, 125, 126, 127, 140])),)
+        C = int(rng.choice([1, 4, 5, 12]))
+        F2 = rng.random((C,) + shape, dtype=np.float32)
+        M2 = rng.random((C,) + shape, dtype=np.float32)
+        P0 = (0.7 * rng.standard_normal((3,) + shape)).astype(np.float32)
+        Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.0, 2, return_state=True)
+        r = orc.adam_run(F2, M2, P0, 1.0, 2, want_grad=True)
+        assert np.array_equal(host(Ud)[0], r["U"]) and np.array_equal(host(st["P"])[0], r["P"]), (shape, C)
+        assert np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"]), (shape, C)
