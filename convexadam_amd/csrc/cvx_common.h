@@ -112,15 +112,6 @@ __device__ __forceinline__ float div_exact(float x) {
     return __builtin_fmaf(e, r, q);
 }
 
-// value of the previous / next lane of the wavefront (DPP wave shift: pure VALU, no LDS traffic, and the
-// compiler folds it into the consuming v_add_f32).  Lane 0 / lane 63 receive their own value.
-__device__ __forceinline__ float lane_prev(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane_next(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
-}
-
 // ATen outer-dimension sum order over `n` values held in registers (see oracle outer_sum_rows):
 // plain sequential cascade (level step 16) or, for the last (ncols mod 32) columns, the 4-way
 // interleaved `row_sum` order.  n is a compile-time constant at every call site that matters.
