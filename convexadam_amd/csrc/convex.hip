@@ -9,6 +9,8 @@
 // (cost bits << 32 | k) key -- ties resolve to the lowest k, like ATen's CPU argmin.
 // The coupled variant adds coef * sum_a (mesh[a,k] - u[a,x])^2 in the reference's evaluation order.
 // HBM-bound: K*v*4 bytes per pass, 1 + 6 passes per direction.
+#include <stdlib.h>
+
 #include "cvx_common.h"
 
 namespace cvx {
@@ -84,6 +86,151 @@ __global__ __launch_bounds__(256) void k_argmin4(const float* __restrict__ ssd, 
         if (bi[j] >= 0) atomicMin(&keys[x + j], pack_min_key(best[j], (unsigned)bi[j]));
 }
 
+// ---- coupled pass with exact pruning (branch and bound) ----------------------------------------------------------------------
+// For voxel x let smin = min_k ssd[k,x] (known from the plain argmin) and B = the reference cost of ANY displacement under this
+// pass's (coef, u) -- here the previous pass's winner.  Rounding is monotonic and ssd[k,x] >= smin, so
+// cost_k = fl(ssd[k,x] + p_k) >= fl(smin + p_k) with p_k = fl(coef * q_k): a displacement with fl(smin + p_k) > B costs strictly
+// more than B >= the minimum and can neither win nor tie -- its cost-volume entry is never read.  p_k needs no memory access.
+// Only displacements inside the axis-aligned box around the admissible ball
+//     |delta - u|^2 <= ((B - smin) + 2^-22 |B|) / coef * (1 + 1e-5)
+// are visited (the margins make the box a superset of everything that passes the exact test; inside the box the exact test and
+// the reference's cost expression decide).  After the first box filter u sits on the previous winner for most voxels: on the
+// benchmark pair the median box holds ONE displacement, the mean 13 (coef 0.003) .. 1.1 (coef 1); a few voxels in flat cost
+// regions keep the whole window.  Two kernels: k_argmin_voxel -- one thread per voxel for boxes of at most `limit`
+// displacements, larger ones are appended to a list; k_argmin_wave -- one wavefront per listed voxel, the lanes scan the box
+// in parallel and merge with a 64-bit min on the (cost, index) key (lowest index among equal costs, like ATen's argmin).
+// The result is the reference's argmin bit for bit; the worst case (every voxel listed) degrades to a scan of the whole volume.
+// mesh[0][k] belongs to the fastest index of k = (a*n + b)*n + c, mesh[2][k] to the slowest; delta_i ~= i - hw.
+struct CandBox {
+    float uc, ub, ua, sm, bound;
+    int kp, c_lo, c_hi, b_lo, b_hi, a_lo, a_hi;
+    long long vol;
+    bool degenerate;
+};
+template <typename PrevT>
+__device__ __forceinline__ CandBox cand_box(const float* __restrict__ ssd, const float* __restrict__ mesh, const float* __restrict__ u,
+                                            float coef, int K, int n, size_t v, const float* __restrict__ smin,
+                                            const PrevT* __restrict__ kprev, size_t x) {
+    CandBox c;
+    c.uc = u[x]; c.ub = u[v + x]; c.ua = u[2 * v + x]; c.sm = smin[x];
+    c.kp = (int)(unsigned)kprev[x];                                     // low 32 bits of a key = displacement index
+    const float e0 = mesh[c.kp] - c.uc, e1 = mesh[K + c.kp] - c.ub, e2 = mesh[2 * K + c.kp] - c.ua;
+    float q = e0 * e0;
+    q += e1 * e1;
+    q += e2 * e2;
+    c.bound = ssd[(size_t)c.kp * v + x] + coef * q;                     // the reference cost of the previous winner
+    const float hwf = (float)((n - 1) / 2);
+    const float qmax = fdiv((c.bound - c.sm) + fabsf(c.bound) * 2.384185791015625e-07f, coef) * 1.00001f;
+    const float R = fsqrt(fmaxf(qmax, 0.0f)) * 1.00001f + 1.0e-4f;
+    c.c_lo = max((int)ceilf(c.uc - R + hwf), 0); c.c_hi = min((int)floorf(c.uc + R + hwf), n - 1);
+    c.b_lo = max((int)ceilf(c.ub - R + hwf), 0); c.b_hi = min((int)floorf(c.ub + R + hwf), n - 1);
+    c.a_lo = max((int)ceilf(c.ua - R + hwf), 0); c.a_hi = min((int)floorf(c.ua + R + hwf), n - 1);
+    c.vol = (long long)max(c.c_hi - c.c_lo + 1, 0) * max(c.b_hi - c.b_lo + 1, 0) * max(c.a_hi - c.a_lo + 1, 0);
+    c.degenerate = !(coef > 0.0f) || !(R == R) || c.vol <= 0;           // no usable bound: scan the whole window
+    if (c.degenerate) { c.c_lo = c.b_lo = c.a_lo = 0; c.c_hi = c.b_hi = c.a_hi = n - 1; c.vol = (long long)n * n * n; }
+    return c;
+}
+
+template <typename PrevT>
+__global__ __launch_bounds__(64) void k_argmin_voxel(const float* __restrict__ ssd, const float* __restrict__ mesh,
+                                                     const float* __restrict__ u, float coef, int K, int n, size_t v,
+                                                     const float* __restrict__ smin, const PrevT* __restrict__ kprev, int limit,
+                                                     unsigned long long* __restrict__ list, int* __restrict__ list_count,
+                                                     unsigned long long* __restrict__ keys) {
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= v) return;
+    const CandBox c = cand_box(ssd, mesh, u, coef, K, n, v, smin, kprev, x);
+    if (c.vol > limit) {                // hand the box over in chunks of 256 displacements: (voxel << 8 | chunk) work items
+        const int nchunks = (int)((c.vol + 255) >> 8);
+        const int at = atomicAdd(list_count, nchunks);
+        for (int i = 0; i < nchunks; ++i) list[at + i] = ((unsigned long long)x << 8) | (unsigned)i;
+        keys[x] = ~0ull;                // merged by the wavefronts with atomicMin
+        return;
+    }
+    float best = 0.0f;                  // the previous winner lies inside the box and is simply visited again in index order,
+    int bi = -1;                        // which keeps the reference's first-minimum rule
+    for (int ia = c.a_lo; ia <= c.a_hi; ++ia)
+        for (int ib = c.b_lo; ib <= c.b_hi; ++ib)
+            for (int ic = c.c_lo; ic <= c.c_hi; ++ic) {
+                const int k = (ia * n + ib) * n + ic;
+                const float e0 = mesh[k] - c.uc, e1 = mesh[K + k] - c.ub, e2 = mesh[2 * K + k] - c.ua;
+                float q = e0 * e0;      // (..).pow(2).sum(0): sequential over the 3 components
+                q += e1 * e1;
+                q += e2 * e2;
+                const float pen = coef * q;                            // coeffs[j]*(...)                     (:104)
+                const float lower = c.sm + pen;                        // <= cost_k
+                if (lower > c.bound || (bi >= 0 && lower >= best)) continue;
+                const float cost = ssd[(size_t)k * v + x] + pen;       // ssd + coeffs[j]*(...)
+                if (bi < 0 || cost < best) { best = cost; bi = k; }
+            }
+    if (bi < 0) { best = c.bound; bi = c.kp; }   // cannot happen (kp passes its own test); keeps the output defined
+    keys[x] = pack_min_key(best, (unsigned)bi);
+}
+
+template <typename PrevT>
+__global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ ssd, const float* __restrict__ mesh,
+                                                     const float* __restrict__ u, float coef, int K, int n, size_t v,
+                                                     const float* __restrict__ smin, const PrevT* __restrict__ kprev,
+                                                     const unsigned long long* __restrict__ list, const int* __restrict__ list_count,
+                                                     unsigned long long* __restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    const int cnt = *list_count;
+    for (int e = wave; e < cnt; e += nwaves) {
+        const unsigned long long item = list[e];
+        const size_t x = (size_t)(item >> 8);
+        const long long first = (long long)(item & 255) << 8;              // 256 displacements of the box: 4 per lane
+        const CandBox c = cand_box(ssd, mesh, u, coef, K, n, v, smin, kprev, x);
+        const int nc = c.c_hi - c.c_lo + 1, nb = c.b_hi - c.b_lo + 1;
+        int kk[4];
+        float pen[4];
+        bool need[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                       // all four loads of a lane are in flight together
+            const long long i = first + lane + 64 * j;
+            need[j] = i < c.vol;
+            const long long ii = need[j] ? i : 0;
+            const int ic = c.c_lo + (int)(ii % nc), ib = c.b_lo + (int)((ii / nc) % nb), ia = c.a_lo + (int)(ii / ((long long)nc * nb));
+            kk[j] = (ia * n + ib) * n + ic;
+            const float e0 = mesh[kk[j]] - c.uc, e1 = mesh[K + kk[j]] - c.ub, e2 = mesh[2 * K + kk[j]] - c.ua;
+            float q = e0 * e0;
+            q += e1 * e1;
+            q += e2 * e2;
+            pen[j] = coef * q;
+            need[j] = need[j] && (c.degenerate || !(c.sm + pen[j] > c.bound));
+        }
+        float val[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[j] = need[j] ? ssd[(size_t)kk[j] * v + x] : 0.0f;
+        unsigned long long key = ~0ull;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long cand = need[j] ? pack_min_key(val[j] + pen[j], (unsigned)kk[j]) : ~0ull;
+            key = cand < key ? cand : key;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_down(key, o);
+            key = other < key ? other : key;
+        }
+        if (lane == 0 && key != ~0ull) atomicMin(&keys[x], key);
+    }
+}
+
+// smin[x] from the (cost, index) keys of a plain argmin pass (inverse of pack_min_key's order-preserving map)
+__global__ __launch_bounds__(256) void k_keys_to_min(const unsigned long long* __restrict__ keys, size_t v, float* __restrict__ smin) {
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= v) return;
+    const unsigned b = (unsigned)(keys[x] >> 32);
+    smin[x] = __uint_as_float((b & 0x80000000u) ? (b & 0x7fffffffu) : ~b);
+}
+
+// smin[x] = ssd[argmin[x], x]: the exact minimum over the search window (argmin is the plain argmin of the same volume)
+__global__ __launch_bounds__(256) void k_gather_min(const float* __restrict__ ssd, const int* __restrict__ idx, size_t v,
+                                                    float* __restrict__ smin) {
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < v) smin[x] = ssd[(size_t)idx[x] * v + x];
+}
+
 __global__ __launch_bounds__(256) void k_keys_to_index(const unsigned long long* __restrict__ keys, size_t v,
                                                        int* __restrict__ idx32, int64_t* __restrict__ idx64) {
     const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,9 +250,10 @@ __global__ __launch_bounds__(256) void k_index64_to_32(const int64_t* __restrict
 template <typename IndexT>
 __global__ __launch_bounds__(256) void k_gather_box3(const IndexT* __restrict__ idx, const float* __restrict__ mesh, int K,
                                                      int h, int w, int d, float* __restrict__ out,
-                                                     unsigned long long* __restrict__ reset) {
+                                                     unsigned long long* __restrict__ reset, int* __restrict__ clear_count) {
     const size_t v = (size_t)h * w * d;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && clear_count) *clear_count = 0;            // list length of the pruned pass that follows
     if (i >= v) return;
     if (reset) reset[i] = ~0ull;
     const int x = (int)(i % d), y = (int)((i / d) % w), z = (int)(i / ((size_t)d * w));
@@ -143,6 +291,19 @@ static int argmin_pass(const float* ssd, const float* mesh, const float* u, floa
     return check_last("argmin");
 }
 
+// pruned coupled pass: per-voxel candidate boxes, then one wavefront per voxel with a large box; kprev = int32 indices (first
+// pass) or the key buffer of the previous pass; *list_count must be zero on entry (the preceding gather kernel clears it)
+template <typename PrevT>
+static int argmin_pass_pruned(const float* ssd, const float* mesh, const float* u, float coef, int K, int n, size_t v,
+                              const float* smin, const PrevT* kprev, unsigned long long* list, int* list_count,
+                              unsigned long long* keys, hipStream_t s) {
+    hipLaunchKernelGGL((k_argmin_voxel<PrevT>), dim3((unsigned)cdiv64((int64_t)v, 64)), dim3(64), 0, s, ssd, mesh, u, coef, K, n, v, smin,
+                       kprev, 8, list, list_count, keys);
+    hipLaunchKernelGGL((k_argmin_wave<PrevT>), dim3(512), dim3(256), 0, s, ssd, mesh, u, coef, K, n, v, smin, kprev, list, list_count,
+                       keys);
+    return check_last("argmin_pruned");
+}
+
 int launch_argmin(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
                   unsigned long long* keys, int64_t* argmin_out, hipStream_t s) {
     int rc = argmin_pass(ssd, mesh, u, coef, coupled, K, v, keys, true, s);
@@ -176,16 +337,27 @@ __global__ __launch_bounds__(256) void k_ic_step(const float* __restrict__ a1, c
 using namespace cvx;
 
 extern "C" size_t cvx_coupled_convex_workspace_bytes(int h, int w, int d, int disp_hw) {
-    (void)disp_hw;
+    const int n = 2 * disp_hw + 1;
     const size_t v = (size_t)h * w * d;
     size_t used = 0;
     for (int i = 0; i < 3; ++i) used = carve_size(used, sizeof(unsigned long long) * v);
     used = carve_size(used, sizeof(int) * v);
+    used = carve_size(used, sizeof(float) * v);       // smin
+    used = carve_size(used, sizeof(unsigned long long) * ((size_t)((n * n * n + 255) / 256) * v + 8));   // work items of the pruned passes + count
     return used + 256;
 }
 
 extern "C" int cvx_coupled_convex_f32(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d,
                                       int disp_hw, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    // the caller's `argmin` only seeds the first smoothing step (as in the reference); the lower bound of the pruned
+    // passes is taken from the volume itself
+    return cvx::coupled_convex_impl(ssd, argmin, mesh, h, w, d, disp_hw, out, /*argmin_is_exact=*/false, workspace, workspace_bytes, stream);
+}
+
+// argmin_is_exact: `argmin` is the plain argmin of `ssd` (the whole-pair pipeline computes it itself), so ssd[argmin] is the
+// per-voxel minimum and the extra streaming pass that determines it can be skipped.
+int cvx::coupled_convex_impl(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
+                             bool argmin_is_exact, void* workspace, size_t workspace_bytes, void* stream) {
     CVX_REQUIRE(ssd && argmin && mesh && out && workspace, "cvx_coupled_convex_f32: null pointer");
     CVX_REQUIRE(h > 0 && w > 0 && d > 0 && disp_hw >= 0, "cvx_coupled_convex_f32: bad arguments");
     if (workspace_bytes < cvx_coupled_convex_workspace_bytes(h, w, d, disp_hw))
@@ -198,16 +370,32 @@ extern "C" int cvx_coupled_convex_f32(const float* ssd, const int64_t* argmin, c
     unsigned long long* keys[3];
     for (int i = 0; i < 3; ++i) keys[i] = cv.take<unsigned long long>(v);
     int* idx = cv.take<int>(v);
+    float* smin = cv.take<float>(v);
+    const size_t list_cap = (size_t)((K + 255) / 256) * v;
+    unsigned long long* list = cv.take<unsigned long long>(list_cap + 8);
+    int* list_count = reinterpret_cast<int*>(list + list_cap);
     const dim3 gv((unsigned)cdiv64((int64_t)v, 256));
     hipLaunchKernelGGL(k_index64_to_32, gv, dim3(256), 0, s, argmin, v, idx);
-    if (hipMemsetAsync(keys[0], 0xff, sizeof(unsigned long long) * v, s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
-    hipLaunchKernelGGL(k_gather_box3<int>, gv, dim3(256), 0, s, idx, mesh, K, h, w, d, out, keys[1]);
+    // exact pruning needs smin[x] = min_k ssd[k,x].  CVX_NO_PRUNE=1 streams every pass instead.
+    static const bool no_prune = getenv("CVX_NO_PRUNE") != nullptr;
+    const bool prune = !no_prune;
+    if (prune && argmin_is_exact) hipLaunchKernelGGL(k_gather_min, gv, dim3(256), 0, s, ssd, idx, v, smin);
+    else if (prune) {
+        int rc = argmin_pass(ssd, nullptr, nullptr, 0.0f, false, K, v, keys[0], true, s);       // per-voxel minimum of the volume
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_keys_to_min, gv, dim3(256), 0, s, keys[0], v, smin);
+    } else if (hipMemsetAsync(keys[0], 0xff, sizeof(unsigned long long) * v, s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
+    hipLaunchKernelGGL(k_gather_box3<int>, gv, dim3(256), 0, s, idx, mesh, K, h, w, d, out, prune ? nullptr : keys[1], list_count);
     static const float coeffs[6] = {0.003f, 0.01f, 0.03f, 0.1f, 0.3f, 1.0f};   // torch.tensor([...]) float32 (:98)
     for (int it = 0; it < 6; ++it) {
-        int rc = argmin_pass(ssd, mesh, out, coeffs[it], true, K, v, keys[it % 3], false, s);
+        int rc;
+        if (!prune) rc = argmin_pass(ssd, mesh, out, coeffs[it], true, K, v, keys[it % 3], false, s);
+        else if (it == 0) rc = argmin_pass_pruned<int>(ssd, mesh, out, coeffs[it], K, n, v, smin, idx, list, list_count, keys[it % 3], s);
+        else rc = argmin_pass_pruned<unsigned long long>(ssd, mesh, out, coeffs[it], K, n, v, smin, keys[(it - 1) % 3], list, list_count, keys[it % 3], s);
         if (rc) return rc;
+        // the streamed passes need their key buffer re-armed two passes ahead; the pruned ones overwrite every key
         hipLaunchKernelGGL(k_gather_box3<unsigned long long>, gv, dim3(256), 0, s, keys[it % 3], mesh, K, h, w, d, out,
-                           it < 4 ? keys[(it + 2) % 3] : nullptr);
+                           (!prune && it < 4) ? keys[(it + 2) % 3] : nullptr, list_count);
     }
     return check_last("coupled_convex");
 }

@@ -235,7 +235,7 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
     mark("correlate", s);
     if ((rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s))) return rc;
     mark("argmin", s);
-    if ((rc = cvx_coupled_convex_f32(F(L.ssd), am, F(L.mesh), L.h, L.w, L.d, p->disp_hw, F(L.soft), ws + L.conv_ws, vws, stream))) return rc;
+    if ((rc = coupled_convex_impl(F(L.ssd), am, F(L.mesh), L.h, L.w, L.d, p->disp_hw, F(L.soft), true, ws + L.conv_ws, vws, stream))) return rc;
     mark("coupled_convex", s);
 
     const float* disp_hr = F(L.soft);          // ic=False: coarse field, coarse units (:143-144)
@@ -245,7 +245,7 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
         mark("correlate_rev", s);
         if ((rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s))) return rc;
         mark("argmin_rev", s);
-        if ((rc = cvx_coupled_convex_f32(F(L.ssd), am, F(L.mesh), L.h, L.w, L.d, p->disp_hw, F(L.soft2), ws + L.conv_ws, vws, stream))) return rc;
+        if ((rc = coupled_convex_impl(F(L.ssd), am, F(L.mesh), L.h, L.w, L.d, p->disp_hw, F(L.soft2), true, ws + L.conv_ws, vws, stream))) return rc;
         mark("coupled_convex_rev", s);
         const dim3 gv((unsigned)cdiv64((int64_t)L.v, 256));
         hipLaunchKernelGGL(k_ic_prepare, gv, dim3(256), 0, s, F(L.soft), L.h, L.w, L.d, F(L.in1));

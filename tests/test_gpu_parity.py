@@ -121,6 +121,32 @@ def test_coupled_convex_vs_oracle(U, orc, shape, hw):
     assert np.array_equal(host(out)[0], orc.coupled_convex(rs, ra, mesh, hw))
 
 
+@pytest.mark.parametrize("kind", ["foreign_argmin", "flat", "plateaus", "hw0"])
+def test_coupled_convex_pruning_edge_cases(U, orc, kind):
+    """The pruned (branch-and-bound) passes must return the reference's argmin for inputs that defeat the bound: an `argmin`
+    argument that is not the argmin of the volume (the lower bound then comes from a streaming pass), a completely flat
+    volume (every displacement ties: lowest index wins, every voxel keeps its whole window), plateaus of equal cost, and the
+    single-displacement window."""
+    rng = np.random.default_rng(7)
+    shape, hw = (6, 8, 12), 3
+    if kind == "hw0":
+        hw = 0
+    n = 2 * hw + 1
+    K = n ** 3
+    if kind == "flat":
+        ssd = np.full((K,) + shape, 0.75, np.float32)
+    elif kind == "plateaus":
+        ssd = (rng.integers(0, 3, (K,) + shape) * 0.5).astype(np.float32)
+    else:
+        ssd = rng.random((K,) + shape, dtype=np.float32)
+    am = ssd.reshape(K, -1).argmin(0).reshape(shape).astype(np.int64)
+    if kind == "foreign_argmin":
+        am = rng.integers(0, K, shape).astype(np.int64)
+    mesh = orc.disp_mesh(hw)
+    out = U.coupled_convex(dev(ssd), dev(am), dev(mesh)[:, :, None], 1, shape)
+    assert np.array_equal(host(out)[0], orc.coupled_convex(ssd, am, mesh, hw))
+
+
 def test_inverse_consistency_vs_oracle(U, orc):
     rng = np.random.default_rng(5)
     a = (0.2 * rng.standard_normal((3, 9, 11, 13))).astype(np.float32)
