@@ -16,9 +16,13 @@ __device__ __forceinline__ float linspace_pm1_at(int S, int i) {
     const float step = fdiv(1.0f - (-1.0f), (float)(S - 1));
     return (i < S / 2) ? __builtin_fmaf(step, (float)i, -1.0f) : __builtin_fmaf(-step, (float)(S - 1 - i), 1.0f);
 }
-__global__ void k_affine_base(int S, float* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < S) out[i] = fdiv(linspace_pm1_at(S, i) * (float)(S - 1), (float)S);
+// all six identity tables of a pair in one launch: (extent, destination) x 6, one workgroup row per table
+struct BaseTables { int S[6]; float* out[6]; };
+__global__ void k_affine_bases(BaseTables t) {
+    const int S = t.S[blockIdx.y];
+    float* out = t.out[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; out && i < S; i += gridDim.x * blockDim.x)
+        out[i] = fdiv(linspace_pm1_at(S, i) * (float)(S - 1), (float)S);
 }
 __global__ void k_disp_mesh(int hw, float* out) {
     const int n = 2 * hw + 1, K = n * n * n;
@@ -222,9 +226,12 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
         if ((rc = cvx_avgpool_f32(featM, L.C, p->H, p->W, p->D, p->grid_sp, F(L.ms), stream))) return rc;
     }
     hipLaunchKernelGGL(k_disp_mesh, dim3(cdiv(L.K, 256)), dim3(256), 0, s, p->disp_hw, F(L.mesh));
-    hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.h, 64)), dim3(64), 0, s, L.h, F(L.bh));
-    hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.w, 64)), dim3(64), 0, s, L.w, F(L.bw));
-    hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.d, 64)), dim3(64), 0, s, L.d, F(L.bd));
+    {
+        const bool adam_tables = p->lambda_weight > 0;
+        BaseTables t = {{L.h, L.w, L.d, L.h2, L.w2, L.d2},
+                        {F(L.bh), F(L.bw), F(L.bd), adam_tables ? F(L.bh2) : nullptr, adam_tables ? F(L.bw2) : nullptr, adam_tables ? F(L.bd2) : nullptr}};
+        hipLaunchKernelGGL(k_affine_bases, dim3(4, 6), dim3(64), 0, s, t);
+    }
     mark("pool", s);
     // 3. forward correlation + coupled convex                                  (:124-130)
     const size_t cws = cvx_correlate_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);
@@ -264,9 +271,6 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
             if ((rc = cvx_avgpool_f32(featF, L.C, p->H, p->W, p->D, p->grid_sp_adam, F(L.F2), stream))) return rc;
             if ((rc = cvx_avgpool_f32(featM, L.C, p->H, p->W, p->D, p->grid_sp_adam, F(L.M2), stream))) return rc;
         }
-        hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.h2, 64)), dim3(64), 0, s, L.h2, F(L.bh2));
-        hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.w2, 64)), dim3(64), 0, s, L.w2, F(L.bw2));
-        hipLaunchKernelGGL(k_affine_base, dim3(cdiv(L.d2, 64)), dim3(64), 0, s, L.d2, F(L.bd2));
         // disp_lr = interpolate(disp_hr, (H2,W2,D2)); weight = disp_lr / grid_sp_adam       (:153,156)
         if ((rc = launch_resize(disp_hr, 3, hh, hw_, hd, F(L.P), L.h2, L.w2, L.d2, 1.0f, (float)p->grid_sp_adam, s))) return rc;
         (void)hipMemsetAsync(F(L.m), 0, sizeof(float) * 3 * L.V2, s);
