@@ -101,6 +101,26 @@ __global__ __launch_bounds__(256) void k_argmin4(const float* __restrict__ ssd, 
 // in parallel and merge with a 64-bit min on the (cost, index) key (lowest index among equal costs, like ATen's argmin).
 // The result is the reference's argmin bit for bit; the worst case (every voxel listed) degrades to a scan of the whole volume.
 // mesh[0][k] belongs to the fastest index of k = (a*n + b)*n + c, mesh[2][k] to the slowest; delta_i ~= i - hw.
+// u_a(x) = avg_pool3d(mesh[a, idx], 3, padding=1)(x): raster-order sum of the in-range taps of the 3^3 window, / 27
+// (convex_adam_utils.py:96,107).  idx holds displacement indices (int32) or (cost, index) keys (low word = index).
+template <typename IndexT>
+__device__ __forceinline__ void smooth_winner(const IndexT* __restrict__ idx, const float* __restrict__ mesh, int K, int h, int w,
+                                              int d, size_t i, float& o0, float& o1, float& o2) {
+    const int x = (int)(i % d), y = (int)((i / d) % w), z = (int)(i / ((size_t)d * w));
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int a = max(z - 1, 0); a <= min(z + 1, h - 1); ++a)
+        for (int b = max(y - 1, 0); b <= min(y + 1, w - 1); ++b)
+            for (int c = max(x - 1, 0); c <= min(x + 1, d - 1); ++c) {
+                const int k = (int)(unsigned)idx[((size_t)a * w + b) * d + c];
+                s0 += mesh[k];
+                s1 += mesh[K + k];
+                s2 += mesh[2 * K + k];
+            }
+    o0 = fdiv(s0, 27.0f);
+    o1 = fdiv(s1, 27.0f);
+    o2 = fdiv(s2, 27.0f);
+}
+
 struct CandBox {
     float uc, ub, ua, sm, bound;
     int kp, c_lo, c_hi, b_lo, b_hi, a_lo, a_hi;
@@ -108,11 +128,11 @@ struct CandBox {
     bool degenerate;
 };
 template <typename PrevT>
-__device__ __forceinline__ CandBox cand_box(const float* __restrict__ ssd, const float* __restrict__ mesh, const float* __restrict__ u,
+__device__ __forceinline__ CandBox cand_box(const float* __restrict__ ssd, const float* __restrict__ mesh, float uc, float ub, float ua,
                                             float coef, int K, int n, size_t v, const float* __restrict__ smin,
                                             const PrevT* __restrict__ kprev, size_t x) {
     CandBox c;
-    c.uc = u[x]; c.ub = u[v + x]; c.ua = u[2 * v + x]; c.sm = smin[x];
+    c.uc = uc; c.ub = ub; c.ua = ua; c.sm = smin[x];
     c.kp = (int)(unsigned)kprev[x];                                     // low 32 bits of a key = displacement index
     const float e0 = mesh[c.kp] - c.uc, e1 = mesh[K + c.kp] - c.ub, e2 = mesh[2 * K + c.kp] - c.ua;
     float q = e0 * e0;
@@ -131,15 +151,22 @@ __device__ __forceinline__ CandBox cand_box(const float* __restrict__ ssd, const
     return c;
 }
 
+// (the kernel first evaluates u = box3(mesh[previous winners]) for its voxel -- the reference's smoothing step between two
+// passes -- and stores it for the wavefront kernel and as the running result)
 template <typename PrevT>
 __global__ __launch_bounds__(64) void k_argmin_voxel(const float* __restrict__ ssd, const float* __restrict__ mesh,
-                                                     const float* __restrict__ u, float coef, int K, int n, size_t v,
+                                                     float* __restrict__ u, float coef, int K, int n, int h, int w, int d,
                                                      const float* __restrict__ smin, const PrevT* __restrict__ kprev, int limit,
                                                      unsigned long long* __restrict__ list, int* __restrict__ list_count,
-                                                     unsigned long long* __restrict__ keys) {
+                                                     int* __restrict__ next_count, unsigned long long* __restrict__ keys) {
+    const size_t v = (size_t)h * w * d;
     const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x == 0) *next_count = 0;                            // list length of the NEXT pass (the two counters alternate)
     if (x >= v) return;
-    const CandBox c = cand_box(ssd, mesh, u, coef, K, n, v, smin, kprev, x);
+    float uc, ub, ua;
+    smooth_winner(kprev, mesh, K, h, w, d, x, uc, ub, ua);
+    u[x] = uc; u[v + x] = ub; u[2 * v + x] = ua;
+    const CandBox c = cand_box(ssd, mesh, uc, ub, ua, coef, K, n, v, smin, kprev, x);
     if (c.vol > limit) {                // hand the box over in chunks of 256 displacements: (voxel << 8 | chunk) work items
         const int nchunks = (int)((c.vol + 255) >> 8);
         const int at = atomicAdd(list_count, nchunks);
@@ -180,7 +207,7 @@ __global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ s
         const unsigned long long item = list[e];
         const size_t x = (size_t)(item >> 8);
         const long long first = (long long)(item & 255) << 8;              // 256 displacements of the box: 4 per lane
-        const CandBox c = cand_box(ssd, mesh, u, coef, K, n, v, smin, kprev, x);
+        const CandBox c = cand_box(ssd, mesh, u[x], u[v + x], u[2 * v + x], coef, K, n, v, smin, kprev, x);
         const int nc = c.c_hi - c.c_lo + 1, nb = c.b_hi - c.b_lo + 1;
         int kk[4];
         float pen[4];
@@ -244,9 +271,7 @@ __global__ __launch_bounds__(256) void k_index64_to_32(const int64_t* __restrict
     if (x < v) out[x] = (int)in[x];
 }
 
-// u_a(x) = avg_pool3d(mesh[a, idx], 3, padding=1)  -- raster-order 27-tap sum of the in-range taps, / 27
-// The index comes either from an int32 map or from the low word of the 64-bit argmin keys of the previous pass;
-// `reset` (optional) is a key buffer that this launch re-arms to all ones for a later pass.
+// stand-alone smoothing step; `reset` (optional) is a key buffer that this launch re-arms to all ones for a later pass
 template <typename IndexT>
 __global__ __launch_bounds__(256) void k_gather_box3(const IndexT* __restrict__ idx, const float* __restrict__ mesh, int K,
                                                      int h, int w, int d, float* __restrict__ out,
@@ -256,19 +281,11 @@ __global__ __launch_bounds__(256) void k_gather_box3(const IndexT* __restrict__ 
     if (i == 0 && clear_count) *clear_count = 0;            // list length of the pruned pass that follows
     if (i >= v) return;
     if (reset) reset[i] = ~0ull;
-    const int x = (int)(i % d), y = (int)((i / d) % w), z = (int)(i / ((size_t)d * w));
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int a = max(z - 1, 0); a <= min(z + 1, h - 1); ++a)
-        for (int b = max(y - 1, 0); b <= min(y + 1, w - 1); ++b)
-            for (int c = max(x - 1, 0); c <= min(x + 1, d - 1); ++c) {
-                const int k = (int)(unsigned)idx[((size_t)a * w + b) * d + c];     // low 32 bits of a key = displacement index
-                s0 += mesh[k];
-                s1 += mesh[K + k];
-                s2 += mesh[2 * K + k];
-            }
-    out[i] = fdiv(s0, 27.0f);
-    out[v + i] = fdiv(s1, 27.0f);
-    out[2 * v + i] = fdiv(s2, 27.0f);
+    float o0, o1, o2;
+    smooth_winner(idx, mesh, K, h, w, d, i, o0, o1, o2);
+    out[i] = o0;
+    out[v + i] = o1;
+    out[2 * v + i] = o2;
 }
 
 static int argmin_pass(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
@@ -291,14 +308,16 @@ static int argmin_pass(const float* ssd, const float* mesh, const float* u, floa
     return check_last("argmin");
 }
 
-// pruned coupled pass: per-voxel candidate boxes, then one wavefront per voxel with a large box; kprev = int32 indices (first
-// pass) or the key buffer of the previous pass; *list_count must be zero on entry (the preceding gather kernel clears it)
+// pruned coupled pass (smoothing step included): per-voxel candidate boxes, then one wavefront per 256-displacement chunk of the
+// large boxes; kprev = int32 indices (first pass) or the key buffer of the previous pass; *list_count must be zero on entry
+// (the previous pass's voxel kernel clears it through next_count; the two counters alternate)
 template <typename PrevT>
-static int argmin_pass_pruned(const float* ssd, const float* mesh, const float* u, float coef, int K, int n, size_t v,
-                              const float* smin, const PrevT* kprev, unsigned long long* list, int* list_count,
+static int argmin_pass_pruned(const float* ssd, const float* mesh, float* u, float coef, int K, int n, int h, int w, int d,
+                              const float* smin, const PrevT* kprev, unsigned long long* list, int* list_count, int* next_count,
                               unsigned long long* keys, hipStream_t s) {
-    hipLaunchKernelGGL((k_argmin_voxel<PrevT>), dim3((unsigned)cdiv64((int64_t)v, 64)), dim3(64), 0, s, ssd, mesh, u, coef, K, n, v, smin,
-                       kprev, 8, list, list_count, keys);
+    const size_t v = (size_t)h * w * d;
+    hipLaunchKernelGGL((k_argmin_voxel<PrevT>), dim3((unsigned)cdiv64((int64_t)v, 64)), dim3(64), 0, s, ssd, mesh, u, coef, K, n, h, w, d,
+                       smin, kprev, 8, list, list_count, next_count, keys);
     hipLaunchKernelGGL((k_argmin_wave<PrevT>), dim3(512), dim3(256), 0, s, ssd, mesh, u, coef, K, n, v, smin, kprev, list, list_count,
                        keys);
     return check_last("argmin_pruned");
@@ -379,23 +398,36 @@ int cvx::coupled_convex_impl(const float* ssd, const int64_t* argmin, const floa
     // exact pruning needs smin[x] = min_k ssd[k,x].  CVX_NO_PRUNE=1 streams every pass instead.
     static const bool no_prune = getenv("CVX_NO_PRUNE") != nullptr;
     const bool prune = !no_prune;
-    if (prune && argmin_is_exact) hipLaunchKernelGGL(k_gather_min, gv, dim3(256), 0, s, ssd, idx, v, smin);
-    else if (prune) {
-        int rc = argmin_pass(ssd, nullptr, nullptr, 0.0f, false, K, v, keys[0], true, s);       // per-voxel minimum of the volume
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_keys_to_min, gv, dim3(256), 0, s, keys[0], v, smin);
-    } else if (hipMemsetAsync(keys[0], 0xff, sizeof(unsigned long long) * v, s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
-    hipLaunchKernelGGL(k_gather_box3<int>, gv, dim3(256), 0, s, idx, mesh, K, h, w, d, out, prune ? nullptr : keys[1], list_count);
+    if (prune) {
+        int* counts = list_count;                                       // two alternating list lengths
+        if (hipMemsetAsync(counts, 0, 2 * sizeof(int), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
+        if (argmin_is_exact) hipLaunchKernelGGL(k_gather_min, gv, dim3(256), 0, s, ssd, idx, v, smin);
+        else {
+            int rc = argmin_pass(ssd, nullptr, nullptr, 0.0f, false, K, v, keys[0], true, s);   // per-voxel minimum of the volume
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_keys_to_min, gv, dim3(256), 0, s, keys[0], v, smin);
+        }
+        static const float coeffs[6] = {0.003f, 0.01f, 0.03f, 0.1f, 0.3f, 1.0f};   // torch.tensor([...]) float32 (:98)
+        for (int it = 0; it < 6; ++it) {
+            // smoothing of the previous winners + pruned argmin; keys[1], keys[2] alternate (keys[0] may hold the minimum pass)
+            unsigned long long* kc = keys[1 + (it & 1)];
+            int rc;
+            if (it == 0) rc = argmin_pass_pruned<int>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, idx, list, counts + (it & 1), counts + ((it + 1) & 1), kc, s);
+            else rc = argmin_pass_pruned<unsigned long long>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, keys[1 + ((it - 1) & 1)], list, counts + (it & 1), counts + ((it + 1) & 1), kc, s);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_gather_box3<unsigned long long>, gv, dim3(256), 0, s, keys[1 + (5 & 1)], mesh, K, h, w, d, out, (unsigned long long*)nullptr, (int*)nullptr);
+        return check_last("coupled_convex");
+    }
+    if (hipMemsetAsync(keys[0], 0xff, sizeof(unsigned long long) * v, s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
+    hipLaunchKernelGGL(k_gather_box3<int>, gv, dim3(256), 0, s, idx, mesh, K, h, w, d, out, keys[1], (int*)nullptr);
     static const float coeffs[6] = {0.003f, 0.01f, 0.03f, 0.1f, 0.3f, 1.0f};   // torch.tensor([...]) float32 (:98)
     for (int it = 0; it < 6; ++it) {
-        int rc;
-        if (!prune) rc = argmin_pass(ssd, mesh, out, coeffs[it], true, K, v, keys[it % 3], false, s);
-        else if (it == 0) rc = argmin_pass_pruned<int>(ssd, mesh, out, coeffs[it], K, n, v, smin, idx, list, list_count, keys[it % 3], s);
-        else rc = argmin_pass_pruned<unsigned long long>(ssd, mesh, out, coeffs[it], K, n, v, smin, keys[(it - 1) % 3], list, list_count, keys[it % 3], s);
+        int rc = argmin_pass(ssd, mesh, out, coeffs[it], true, K, v, keys[it % 3], false, s);
         if (rc) return rc;
-        // the streamed passes need their key buffer re-armed two passes ahead; the pruned ones overwrite every key
+        // the streamed passes need their key buffer re-armed two passes ahead
         hipLaunchKernelGGL(k_gather_box3<unsigned long long>, gv, dim3(256), 0, s, keys[it % 3], mesh, K, h, w, d, out,
-                           (!prune && it < 4) ? keys[(it + 2) % 3] : nullptr, list_count);
+                           it < 4 ? keys[(it + 2) % 3] : nullptr, (int*)nullptr);
     }
     return check_last("coupled_convex");
 }
