@@ -17,7 +17,7 @@ Evaluation operators of that file, on the device:
     sort_rank(value)                                     :28-31   (host)
 plus the three call sequences the sweep scripts write inline (convex_run_withconfig.py:141,148-150,
 convex_run_paired_mind.py:167-173): warp_labels_nearest, jacobian_log_std_and_folding, tre_at_keypoints.
-cupy_hd95 (:32-52) needs a Euclidean distance transform and stays out of scope.
+cupy_hd95(fixed, moving, num_labels, precision=1)    :32-51   (device feature transforms + histogram percentile)
 """
 import ctypes as C
 
@@ -204,5 +204,100 @@ def sort_rank(value):
     return rank1
 
 
-def cupy_hd95(*args, **kwargs):
-    raise NotImplementedError("cupy_hd95 (hyper_util.py:32-52) needs a Euclidean distance transform; out of scope (SURVEY 8(f).1)")
+def percentile_neighbours(n, q):
+    """numpy.percentile (method 'linear') on n float32 samples: indices of the two order statistics it interpolates and the
+    weight, in numpy's own arithmetic -- for a float32 array the quantile q/100 and the virtual index (n-1)*q/100 are float32
+    (numpy/lib/_function_base_impl.py: percentile, _get_indexes, _get_gamma)."""
+    quant = np.true_divide(q, np.float32(100))
+    virt = np.asanyarray((n - 1) * quant)
+    if virt >= n - 1:
+        return n - 1, n - 1, np.float32(virt - (-1))
+    k0 = int(np.floor(virt))
+    return k0, k0 + 1, np.float32(np.float64(virt) - k0)
+
+
+def percentile_linear_from_sorted_pair(a, b, gamma):
+    """numpy's _lerp on float32 operands: a + (b-a)*gamma, or b - (b-a)*(1-gamma) for gamma >= 0.5."""
+    a32, b32, t = np.float32(a), np.float32(b), np.float32(gamma)
+    diff = np.subtract(b32, a32)
+    if t >= 0.5:
+        return np.subtract(b32, diff * (np.float32(1) - t))
+    return np.add(a32, diff * t)
+
+
+def _surface_percentile(a_in2, a_out2, b_in2, nbins, q=95):
+    """np.percentile(dist_a[surf_b], q) with dist_a = sqrt(a_in2 + a_out2) in float32 and surf_b = (b_in2 == 1)   (:48)"""
+    L = lib()
+    dev = a_in2.device
+    n = int(a_in2.numel())
+    hist = torch.empty(nbins, dtype=torch.int64, device=dev)
+    flag = torch.empty(1, dtype=torch.int32, device=dev)
+    out3 = torch.empty(3, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(L.cvx_surface_hist_i64(ptr(a_in2), ptr(a_out2), ptr(b_in2), n, nbins, ptr(hist), ptr(flag), stream_ptr(dev)))
+        check(L.cvx_hist_order_stats_i64(ptr(hist), nbins, -1, -1, ptr(out3), stream_ptr(dev)))
+        cnt = int(out3.cpu()[2])
+        if int(flag.cpu()[0]) != 0:
+            raise RuntimeError("cupy_hd95: squared distance exceeds the histogram range")
+        if cnt == 0:
+            return float("nan")                        # numpy: percentile of an empty selection
+        k0, k1, gamma = percentile_neighbours(cnt, q)
+        check(L.cvx_hist_order_stats_i64(ptr(hist), nbins, k0, k1, ptr(out3), stream_ptr(dev)))
+    o = out3.cpu().numpy()
+    # float32 distances (float64_distances=False, :40): correctly rounded square roots of exact integers
+    a = np.sqrt(np.float64(o[0])).astype(np.float32)
+    b = np.sqrt(np.float64(o[1])).astype(np.float32)
+    return float(percentile_linear_from_sorted_pair(a, b, gamma))
+
+
+def cupy_hd95(fixed, moving, num_labels, precision=1):
+    """hyper_util.py:32-51: 95th-percentile symmetric surface distance for labels 1 .. num_labels (30 where a label is absent from
+    either map), float64 tensor on the device of `fixed`.  Per label on the device: masks on the nearest-upsampled grid, exact
+    Euclidean feature transforms of the mask and of its complement (csrc/edt.hip), integer squared distances, histogram of
+    dist_a over the surface of b (edt == 1); the percentile is read from the histogram (two order statistics), so no sort and no
+    host copy of a volume.  `precision` must be a positive integer (the reference's call sites use the default 1)."""
+    from .convex_adam_MIND import feature_transform
+    if int(precision) != precision or precision < 1:
+        raise NotImplementedError("cupy_hd95: only integer precision >= 1 (nearest up-sampling) is implemented")
+    p = int(precision)
+    fx = f32c(require_device_tensor(fixed, "fixed"))
+    mv = f32c(require_device_tensor(moving, "moving"))
+    if fx.shape != mv.shape or fx.dim() != 3:
+        raise ValueError("cupy_hd95: label maps must be (H, W, D) tensors of the same shape")
+    if float(fx.min()) < 0 or float(mv.min()) < 0 or float(fx.max()) > num_labels or float(mv.max()) > num_labels:
+        raise RuntimeError("cupy_hd95: class values must be in 0 .. num_labels (F.one_hot, :33)")
+    H, W, D = [int(v) for v in fx.shape]
+    Ho, Wo, Do = H * p, W * p, D * p
+    nbins = (Ho - 1) ** 2 + (Wo - 1) ** 2 + (Do - 1) ** 2 + 2
+    L = lib()
+    dev = fx.device
+    hd95 = np.zeros(int(num_labels), np.float64)
+
+    def distances(seg, label):
+        inside = torch.empty((Ho, Wo, Do), dtype=torch.float32, device=dev)
+        outside = torch.empty_like(inside)
+        cnt = torch.empty(1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            check(L.cvx_label_mask_f32(ptr(seg), H, W, D, int(label), p, ptr(inside), ptr(outside), ptr(cnt), stream_ptr(dev)))
+        if int(cnt.cpu()[0]) == 0:
+            return None
+        d_in = torch.empty((Ho, Wo, Do), dtype=torch.int32, device=dev)
+        d_out = torch.empty_like(d_in)
+        for obj, dst in ((inside, d_in), (outside, d_out)):
+            feat = feature_transform(obj)
+            with torch.cuda.device(dev):
+                check(L.cvx_edt_sqdist_i32(ptr(obj), ptr(feat), Ho, Wo, Do, ptr(dst), stream_ptr(dev)))
+        return d_in, d_out
+
+    for i in range(int(num_labels)):
+        df = distances(fx, i + 1)
+        dm = distances(mv, i + 1) if df is not None else None
+        if df is None or dm is None:
+            hd95[i] = 30
+            continue
+        p1 = _surface_percentile(df[0], df[1], dm[0], nbins)          # dist1[surf2]
+        p2 = _surface_percentile(dm[0], dm[1], df[0], nbins)          # dist2[surf1]
+        hd95[i] = np.maximum(p1, p2)
+    # true division on the host (like the CPU capture of the reference); torch's device kernel would multiply by the reciprocal,
+    # 1 ulp off for a precision that is not a power of two
+    return torch.as_tensor(hd95 * 1 / precision).to(dev)

@@ -79,14 +79,15 @@ def evaluate_item(disp, seg_fixed, seg_moving, key_fixed, key_moving, num_labels
     dice0 = HU.dice_coeff(seg_fixed, seg_moving, num_labels + 1)
     tre, _ = HU.tre_at_keypoints(d, key_fixed, key_moving)                                 # convex_run_paired_mind.py:165-173
     tre0 = (key_fixed - key_moving).square().sum(-1).sqrt()
+    hd95 = HU.cupy_hd95(seg_fixed, warped, num_labels)                                     # convex_run_withconfig.py:143
     return dict(dice=float(dice.mean()), dice_before=float(dice0.mean()), jstd=jstd, folding=fold, tre=float(tre.mean()),
-                tre_before=float(tre0.mean()))
+                tre_before=float(tre0.mean()), hd95=float(hd95.mean()))
 
 
 def aggregate_ranks(results, n_settings):
     """Per-setting means over pairs and the reference's rank: prod(sort_rank(metric)) ** (1/n) (convex_run_withconfig.py:160-168)."""
     from convexadam_amd.convexAdam_hyper_util import sort_rank
-    acc = {k: torch.zeros(n_settings) for k in ("dice", "jstd", "tre")}
+    acc = {k: torch.zeros(n_settings) for k in ("dice", "jstd", "tre", "hd95")}
     cnt = torch.zeros(n_settings)
     for r in results:
         if "dice" not in r:
@@ -95,9 +96,10 @@ def aggregate_ranks(results, n_settings):
             acc[k][r["setting"]] += r[k]
         cnt[r["setting"]] += 1
     cnt = cnt.clamp(min=1)
-    dice, jstd, tre = acc["dice"] / cnt, acc["jstd"] / cnt, acc["tre"] / cnt
-    rank = (sort_rank(-dice) * sort_rank(tre) * sort_rank(jstd)).pow(1 / 3)
-    return dict(dice=dice.tolist(), jstd=jstd.tolist(), tre=tre.tolist(), rank=rank.tolist(), best_setting=int(rank.argmax()))
+    dice, jstd, tre, hd95 = acc["dice"] / cnt, acc["jstd"] / cnt, acc["tre"] / cnt, acc["hd95"] / cnt
+    rank = (sort_rank(-dice) * sort_rank(tre) * sort_rank(jstd) * sort_rank(hd95)).pow(1 / 4)
+    return dict(dice=dice.tolist(), jstd=jstd.tolist(), tre=tre.tolist(), hd95=hd95.tolist(), rank=rank.tolist(),
+                best_setting=int(rank.argmax()))
 
 
 def main(argv=None):

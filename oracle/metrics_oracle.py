@@ -161,3 +161,33 @@ def apply_convex(disp, moving):
                 out += ((m64[zi, yj, xk] * wi) * wj) * wk
     out[~inside] = 0.0
     return out
+
+
+def hd95(fixed, moving, num_labels, precision=1):
+    """cupy_hd95 (self_configuring/convexAdam_hyper_util.py:32-51) with numpy/scipy in the place of cupy/cupyx (absent here; same
+    definitions: float32 Euclidean distances, linear-interpolation percentile).  fixed, moving: (H,W,D) integer label maps."""
+    from scipy.ndimage import distance_transform_edt
+    fixed, moving = np.asarray(fixed).astype(np.int64), np.asarray(moving).astype(np.int64)
+    p = int(precision)
+
+    def up(mask):                                       # upsample_nearest3d with scale_factor p: src = min(floor(dst * (1/p)), in - 1)
+        idx = []
+        for n in mask.shape:
+            dst = np.arange(n * p, dtype=np.float32)
+            idx.append(np.minimum(np.floor(dst * (np.float32(1.0) / np.float32(p))).astype(np.int64), n - 1))
+        return mask[np.ix_(*idx)]
+
+    def edt32(m):
+        return distance_transform_edt(m).astype(np.float32)
+
+    out = np.zeros(int(num_labels), np.float64)
+    for i in range(int(num_labels)):
+        f, m = up((fixed == i + 1).astype(np.uint8)), up((moving == i + 1).astype(np.uint8))
+        if f.sum() > 0 and m.sum() > 0:
+            d1 = edt32(f); s1 = d1 == 1; d1 = d1 + edt32(1 - f)
+            d2 = edt32(m); s2 = d2 == 1; d2 = d2 + edt32(1 - m)
+            out[i] = np.maximum(np.percentile(d1[s2], 95), np.percentile(d2[s1], 95))
+        else:
+            out[i] = 30
+    return out * 1 / precision
+

@@ -153,7 +153,7 @@ def main():
         torch.Tensor.cuda, torch.Tensor.half = _cuda, _half
 
 
-if __name__ == "__main__" and "--smoothers" not in sys.argv and "--metrics" not in sys.argv:
+if __name__ == "__main__" and "--smoothers" not in sys.argv and "--metrics" not in sys.argv and "--hd95" not in sys.argv:
     main()
     smoother_goldens_later = True
 
@@ -259,8 +259,41 @@ def metrics_goldens():
     save("metrics", **out)
 
 
+def hd95_goldens():
+    """cupy_hd95 (self_configuring/convexAdam_hyper_util.py:32-51) run from the reference module itself.  cupy and
+    cupyx are absent from this image (and the module's own cupyx import is commented out, :23), so the two names the function
+    needs are supplied with their numpy/scipy equivalents: cupy.asarray/zeros -> numpy, distance_transform_edt(x,
+    float64_distances=False) -> scipy's EDT cast to float32.  The goldens therefore pin the function's logic (masks, surfaces,
+    the two percentiles, the 30 default), not cupy's rounding."""
+    import types
+    from scipy.ndimage import distance_transform_edt as sedt
+    cp = types.ModuleType("cupy")
+    cp.asarray = lambda x: np.asarray(x)
+    cp.zeros = lambda n: np.zeros(n)
+    sys.modules["cupy"] = cp
+    for m in ("cupyx", "cupyx.scipy", "cupyx.scipy.ndimage"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.path.insert(0, os.path.join(os.environ.get("CONVEXADAM_REFERENCE", "/root/reference"), "self_configuring"))
+    sys.modules.pop("convexAdam_hyper_util", None)
+    import convexAdam_hyper_util as HU
+    HU.cupy = cp
+    HU.distance_transform_edt = lambda x, float64_distances=False: sedt(np.asarray(x)).astype(np.float32)
+    g = torch.Generator().manual_seed(321)
+    H, W, D = 20, 24, 28
+    lab = torch.randn(1, 6, 4, 5, 6, generator=g)
+    seg_f = F.interpolate(lab, size=(H, W, D), mode="trilinear", align_corners=False).argmax(1)[0]
+    seg_m = torch.roll(seg_f, (2, -1, 3), (0, 1, 2)).clone()
+    seg_m[seg_m == 4] = 0                                                     # label 4 absent from one map -> 30
+    out = dict(seg_fixed=seg_f.numpy(), seg_moving=seg_m.numpy())
+    out["hd95_p1"] = HU.cupy_hd95(seg_f.long(), seg_m.long(), 6).numpy()       # label 6 absent from both
+    out["hd95_p2"] = HU.cupy_hd95(seg_f.long(), seg_m.long(), 6, precision=2).numpy()
+    save("hd95", **out)
+
+
 if __name__ == "__main__":
-    if "--metrics" in sys.argv:
+    if "--hd95" in sys.argv:
+        hd95_goldens()
+    elif "--metrics" in sys.argv:
         metrics_goldens()
     else:
         smoother_goldens()

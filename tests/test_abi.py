@@ -68,6 +68,12 @@ def test_argument_validation_without_gpu(L):
     assert L.cvx_warp_labels_nearest_f32(dummy, dummy, 8, 8, 8, dummy, dummy, dummy, dummy, None) == -1   # in place
     assert L.cvx_label_overlap_i64(dummy, dummy, 10, 0, dummy, None) == -1 and b"num_labels" in L.cvx_last_error()
     assert L.cvx_map_coordinates_linear_f64(dummy, dummy, 4, 4, 0, C.c_void_p(512), None) == -1
+    # Hausdorff-95 building blocks
+    assert L.cvx_label_mask_f32(dummy, 4, 4, 4, 1, 0, dummy, dummy, dummy, None) == -1 and b"precision" in L.cvx_last_error()
+    assert L.cvx_label_mask_f32(dummy, 4, 4, 4, 1, 1, None, dummy, dummy, None) == -1
+    assert L.cvx_edt_sqdist_i32(dummy, dummy, 40000, 40000, 4, dummy, None) == -1 and b"int32" in L.cvx_last_error()
+    assert L.cvx_surface_hist_i64(dummy, dummy, dummy, 0, 8, dummy, dummy, None) == -1
+    assert L.cvx_hist_order_stats_i64(dummy, 0, 0, 0, dummy, None) == -1
 
 
 def test_workspace_queries(L):

@@ -527,6 +527,29 @@ def test_warp_labels_and_dice_vs_oracle(HU, morc, shape):
     assert np.array_equal(HU.dice_coeff(dev(seg2), w, 9).numpy(), morc.dice_coeff(seg2, host(w), 9))
 
 
+def test_hd95_vs_golden_and_oracle(HU, morc, golden):
+    """cupy_hd95 on the device (feature transforms + histogram percentile) == the reference capture and the numpy/scipy oracle."""
+    g = golden("hd95")
+    sf, sm = torch.from_numpy(g["seg_fixed"]).to(DEV), torch.from_numpy(g["seg_moving"]).to(DEV)
+    out = HU.cupy_hd95(sf.long(), sm.long(), 6)
+    assert out.dtype == torch.float64 and out.device.type == "cuda"
+    assert np.array_equal(host(out), g["hd95_p1"])
+    assert np.array_equal(host(HU.cupy_hd95(sf, sm, 6, precision=2)), g["hd95_p2"])
+    rng = np.random.default_rng(11)
+    for shape in ((9, 7, 12), (16, 16, 16), (5, 30, 11)):
+        a = rng.integers(0, 4, [max(1, s // 3) for s in shape])
+        a = np.kron(a, np.ones((3, 3, 3), np.int64))[: shape[0], : shape[1], : shape[2]]
+        a = np.pad(a, [(0, s - t) for s, t in zip(shape, a.shape)])
+        b = np.roll(a, (1, -1, 2), (0, 1, 2))
+        for prec in (1, 3):
+            got = host(HU.cupy_hd95(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), 4, precision=prec))
+            assert np.array_equal(got, morc.hd95(a, b, 4, prec)), (shape, prec)
+    with pytest.raises(RuntimeError):
+        HU.cupy_hd95(sf, sm, 3)                                                         # label 5 present: one_hot would fail
+    with pytest.raises(NotImplementedError):
+        HU.cupy_hd95(sf, sm, 6, precision=0.5)
+
+
 def test_apply_convex_vs_scipy_and_golden(morc, golden):
     from scipy.ndimage import map_coordinates
     from convexadam_amd.apply_convex import apply_convex

@@ -241,6 +241,27 @@ def test_torch_linspace_restatement():
             assert np.array_equal(mo.linspace(a, b, n), torch.linspace(a, b, n).numpy())
 
 
+def test_hd95_oracle_vs_reference_golden(golden):
+    """cupy_hd95 captured from the reference module (cupy/cupyx supplied by numpy/scipy, see make_golden.py --hd95)."""
+    from oracle import metrics_oracle as mo
+    g = golden("hd95")
+    assert np.array_equal(mo.hd95(g["seg_fixed"], g["seg_moving"], 6), g["hd95_p1"])
+    assert np.array_equal(mo.hd95(g["seg_fixed"], g["seg_moving"], 6, 2), g["hd95_p2"])
+    assert g["hd95_p1"][3] == 30 and g["hd95_p1"][5] == 30 and g["hd95_p2"][3] == 15
+
+
+def test_percentile_restatement_vs_numpy():
+    """The product reads the percentile from a histogram: two order statistics + numpy's interpolation rule (float32)."""
+    from convexadam_amd.convexAdam_hyper_util import percentile_linear_from_sorted_pair, percentile_neighbours
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 19, 20, 21, 40, 41, 1000, 99991, 1234567):
+        x = np.sort(np.sqrt(rng.integers(0, 500, n).astype(np.float64)).astype(np.float32))
+        for q in (95, 50, 0, 100, 30):
+            k0, k1, gamma = percentile_neighbours(n, q)
+            got, ref = percentile_linear_from_sorted_pair(x[k0], x[k1], gamma), np.percentile(x, q)
+            assert got == ref and got.dtype == ref.dtype, (n, q)
+
+
 def test_feature_transform_restatement_vs_scipy(orc):
     """The masked path's nearest-in-mask search: scipy.ndimage.distance_transform_edt(return_indices=True) (a third-party
     dependency of the reference) restated with its tie-breaking; compared with scipy itself on random and tie-heavy masks."""
