@@ -15,28 +15,9 @@
 // the full-resolution descriptor is materialised); the 27-tap raster-order sums (ATen avg_pool3d
 // order, one exact division) make it VALU/LDS-bound in practice -- see DESIGN.md.
 #include "cvx_common.h"
+#include "mind_common.h"
 
 namespace cvx {
-
-// shift pairs in the reference's PRE-permutation channel order (derived by executing :31-47)
-struct MindOffsets {
-    int o1[12][3] = {{0,0,-1},{0,-1,0},{0,-1,0},{0,0,1},{0,0,1},{1,0,0},
-                     {1,0,0},{1,0,0},{0,1,0},{0,1,0},{0,1,0},{0,1,0}};
-    int o2[12][3] = {{-1,0,0},{-1,0,0},{0,0,-1},{-1,0,0},{0,-1,0},{0,0,-1},
-                     {0,-1,0},{0,0,1},{-1,0,0},{0,0,-1},{0,0,1},{1,0,0}};
-};
-// final channel j holds pre-permutation channel PERM[j], PERM = {6,8,1,11,2,10,0,7,9,4,5,3}
-// (convex_adam_utils.py:66); the store below uses its inverse.
-
-// destination channel of pre-permutation channel c (inverse of PERM)
-__device__ constexpr int MIND_INV[12] = {6, 2, 4, 11, 9, 10, 0, 7, 1, 8, 5, 3};
-
-struct MindStats {
-    double m1, m2, m3;     // split grids (see oracle orc_split_make)
-    double a1, a2, a3;     // exact partial sums
-    float lo, hi, mean;    // clamp bounds
-    float imin, imax;
-};
 
 constexpr int TZ = 4, TY = 8, TX = 64, RUN = 4, NT = 512;
 
@@ -394,6 +375,12 @@ static size_t mind_lds_bytes(int R, int dil, int nbuf) {
 
 template <int R>
 static int mind_launch_r(const float* img, int H, int W, int D, int dil, MindStats* st, float* out, hipStream_t s) {
+    static const bool tiled_only = getenv("CVX_MIND_TILED") != nullptr;
+    if (!tiled_only && mind_march_supported(img, out, H, W, D, R, dil)) {
+        launch_mind_march(img, H, W, D, st, out, s);
+        hipLaunchKernelGGL(k_mind_stats_finish, dim3(1), dim3(1), 0, s, st, (double)H * W * D);
+        return check_last("mindssc");
+    }
     const dim3 grid(cdiv(D, TX), cdiv(W, TY), cdiv(H, TZ));
     const int nbuf = mind_lds_bytes(R, dil, 2) <= 160 * 1024 ? 2 : 1;
     const size_t lds = mind_lds_bytes(R, dil, nbuf);
