@@ -78,9 +78,9 @@ __device__ __forceinline__ float cvx_expf(float d) {
     u = __builtin_fmaf(u, s, 0.166666671633720397949219f);
     u = __builtin_fmaf(u, s, 0.5f);
     u = 1.0f + __builtin_fmaf(s * s, u, s);
-    const float a = __int_as_float(((q >> 1) + 127) << 23);
-    const float b = __int_as_float(((q - (q >> 1)) + 127) << 23);
-    u = u * a * b;
+    // scaling by 2^q: one v_ldexp_f32 (single rounding, denormals included) == the oracle's two exact-then-rounded
+    // multiplications u * 2^(q>>1) * 2^(q-(q>>1)) for every argument (tools/expf_ldexp_check.hip, all 2^32 floats)
+    u = __builtin_ldexpf(u, q);
     if (d < -104.0f) u = 0.0f;
     if (d > 100.0f) u = __int_as_float(0x7f800000);
     return u;
@@ -219,6 +219,8 @@ int launch_argmin(const float* ssd, const float* mesh, const float* u, float coe
 // out = interp(in * pre_mul) / post_div   (pre_mul, post_div = 1 -> plain F.interpolate)
 int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D, float pre_mul,
                   float post_div, hipStream_t s);
+int launch_resize2(const float* in, int C, int h, int w, int d, int H, int W, int D, float* scratch, float* out, int h2, int w2,
+                   int d2, float post_div, hipStream_t s);
 // Adam step constants of one iteration (torch.optim.Adam, lr = 1, eps = 1e-8) and the in-place update of one element
 struct AdamConsts { float w1, b2, omb2, bc2s, neg_step; };
 __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& v, const AdamConsts& ac) {

@@ -246,6 +246,7 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
     mark("coupled_convex", s);
 
     const float* disp_hr = F(L.soft);          // ic=False: coarse field, coarse units (:143-144)
+    const float* coarse_src = nullptr;         // ic=True + Adam: the coarse field whose up-sampling is folded into the next resize
     int hh = L.h, hw_ = L.w, hd = L.d;
     if (p->ic) {                                // (:133-141)
         if ((rc = cvx_correlate_f32(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
@@ -260,9 +261,14 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
         if ((rc = cvx_inverse_consistency_f32(F(L.in1), F(L.in2), L.h, L.w, L.d, 15, F(L.bh), F(L.bw), F(L.bd), F(L.ic1), F(L.ic2),
                                               ws + L.ic_ws, cvx_inverse_consistency_workspace_bytes(L.h, L.w, L.d), stream))) return rc;
         hipLaunchKernelGGL(k_ic_finish, gv, dim3(256), 0, s, F(L.ic1), L.h, L.w, L.d, (float)p->grid_sp, F(L.upin));
-        float* hr = (p->lambda_weight > 0) ? F(L.disp_hr) : out_field;
-        if ((rc = launch_resize(F(L.upin), 3, L.h, L.w, L.d, hr, p->H, p->W, p->D, 1.0f, 1.0f, s))) return rc;
-        disp_hr = hr; hh = p->H; hw_ = p->W; hd = p->D;
+        // with the Adam stage following, disp_hr is only ever read by the down-sampling to the Adam grid: the two resizes are
+        // folded into one there (launch_resize2) and the full-resolution field is never written
+        if (p->lambda_weight > 0) { coarse_src = F(L.upin); }
+        else {
+            if ((rc = launch_resize(F(L.upin), 3, L.h, L.w, L.d, out_field, p->H, p->W, p->D, 1.0f, 1.0f, s))) return rc;
+            disp_hr = out_field;
+        }
+        hh = p->H; hw_ = p->W; hd = p->D;
         mark("inverse_consistency", s);
     }
 
@@ -272,7 +278,9 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
             if ((rc = cvx_avgpool_f32(featM, L.C, p->H, p->W, p->D, p->grid_sp_adam, F(L.M2), stream))) return rc;
         }
         // disp_lr = interpolate(disp_hr, (H2,W2,D2)); weight = disp_lr / grid_sp_adam       (:153,156)
-        if ((rc = launch_resize(disp_hr, 3, hh, hw_, hd, F(L.P), L.h2, L.w2, L.d2, 1.0f, (float)p->grid_sp_adam, s))) return rc;
+        if (coarse_src) {
+            if ((rc = launch_resize2(coarse_src, 3, L.h, L.w, L.d, hh, hw_, hd, F(L.disp_hr), F(L.P), L.h2, L.w2, L.d2, (float)p->grid_sp_adam, s))) return rc;
+        } else if ((rc = launch_resize(disp_hr, 3, hh, hw_, hd, F(L.P), L.h2, L.w2, L.d2, 1.0f, (float)p->grid_sp_adam, s))) return rc;
         (void)hipMemsetAsync(F(L.m), 0, sizeof(float) * 3 * L.V2, s);
         (void)hipMemsetAsync(F(L.v_), 0, sizeof(float) * 3 * L.V2, s);
         mark("adam_setup", s);

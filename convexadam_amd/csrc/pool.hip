@@ -241,6 +241,77 @@ int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H
     return check_last("resize_trilinear");
 }
 
+// Two chained resizes without the (H,W,D) intermediate: out = resize(resize(in, (H,W,D)), (h2,w2,d2)) / post_div (the pipeline's
+// disp_hr -> disp_lr, convex_adam_MIND.py:141,153: 82 MB written and read back at OASIS size).  ATen's trilinear kernel is a
+// chain of three 1-D interpolations (x, then y, then z), each rounded to float, so the first resize factors exactly:
+//   k_resize_yx : T[c][zc][Y][X] = the y-level value for COARSE plane zc at fine (Y, X)            (h x W x D, 13 MB)
+//   k_resize2   : an output needs 2 x 2 x 2 intermediate values; each is fma(T[z0], lz0, T[z1] * lz1) -- the z level of the
+//                 first resize -- followed by the three levels of the second resize, all with k_resize's operations and
+//                 roundings: bit-identical to the two-pass form.
+__global__ __launch_bounds__(256) void k_resize_yx(const float* __restrict__ in, int C, int h, int w, int d, float* __restrict__ T,
+                                                   int W, int D) {
+    const size_t n = (size_t)h * W * D;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % D), y = (int)((i / D) % W), z = (int)(i / ((size_t)D * W));
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    lin_coef(y, w, W, y0, y1, ly0, ly1);
+    lin_coef(x, d, D, x0, x1, lx0, lx1);
+    for (int c = 0; c < C; ++c) {
+        const float* r0 = in + (((size_t)c * h + z) * w + y0) * d;
+        const float* r1 = in + (((size_t)c * h + z) * w + y1) * d;
+        const float a = __builtin_fmaf(r0[x0], lx0, r0[x1] * lx1);
+        const float b = __builtin_fmaf(r1[x0], lx0, r1[x1] * lx1);
+        T[(size_t)c * n + i] = __builtin_fmaf(a, ly0, b * ly1);
+    }
+}
+__global__ __launch_bounds__(256) void k_resize2(const float* __restrict__ T, int C, int h, int H, int W, int D, float* __restrict__ out,
+                                                 int h2, int w2, int d2, float post_div) {
+    const size_t n = (size_t)h2 * w2 * d2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % d2), y = (int)((i / d2) % w2), z = (int)(i / ((size_t)d2 * w2));
+    int Z[2], Y[2], X[2], cz[2][2];
+    float LZ[2], LY[2], LX[2], wz[2][2];
+    lin_coef(z, H, h2, Z[0], Z[1], LZ[0], LZ[1]);
+    lin_coef(y, W, w2, Y[0], Y[1], LY[0], LY[1]);
+    lin_coef(x, D, d2, X[0], X[1], LX[0], LX[1]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) lin_coef(Z[a], h, H, cz[a][0], cz[a][1], wz[a][0], wz[a][1]);
+    const size_t plane = (size_t)W * D;
+    for (int c = 0; c < C; ++c) {
+        const float* Tc = T + (size_t)c * h * plane;
+        float lev1[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float* p0 = Tc + (size_t)cz[a][0] * plane;
+            const float* p1 = Tc + (size_t)cz[a][1] * plane;
+            float lev2[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const size_t ro = (size_t)Y[b] * D;
+                const float m0 = __builtin_fmaf(p0[ro + X[0]], wz[a][0], p1[ro + X[0]] * wz[a][1]);   // intermediate (Z[a], Y[b], X[0])
+                const float m1 = __builtin_fmaf(p0[ro + X[1]], wz[a][0], p1[ro + X[1]] * wz[a][1]);
+                lev2[b] = __builtin_fmaf(m0, LX[0], m1 * LX[1]);
+            }
+            lev1[a] = __builtin_fmaf(lev2[0], LY[0], lev2[1] * LY[1]);
+        }
+        float r = __builtin_fmaf(lev1[0], LZ[0], lev1[1] * LZ[1]);
+        if (post_div != 1.0f) r = fdiv(r, post_div);
+        out[(size_t)c * n + i] = r;
+    }
+}
+// `scratch`: C * h * W * D floats
+int launch_resize2(const float* in, int C, int h, int w, int d, int H, int W, int D, float* scratch, float* out, int h2, int w2, int d2,
+                   float post_div, hipStream_t s) {
+    const size_t nt = (size_t)h * W * D, n = (size_t)h2 * w2 * d2;
+    hipLaunchKernelGGL(k_resize_yx, dim3((unsigned)cdiv64((int64_t)nt, 256)), dim3(256), 0, s, in, C, h, w, d, scratch, W, D);
+    hipLaunchKernelGGL(k_resize2, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, s, scratch, C, h, H, W, D, out, h2, w2, d2,
+                       post_div);
+    return check_last("resize_trilinear2");
+}
+
 // ---- generic grid_sample ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_grid_sample(const float* __restrict__ vol, int C, int h, int w, int d,
                                                      const float* __restrict__ grid, size_t vo, float* __restrict__ out) {
