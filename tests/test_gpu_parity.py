@@ -56,6 +56,18 @@ def test_mindssc_vs_oracle(U, orc, shape, r, d):
     assert np.array_equal(out, ref), "max |diff| %g" % np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 4), (2, 3, 4), (3, 9, 8), (5, 8, 64), (7, 17, 68), (21, 9, 132), (40, 24, 64), (45, 30, 128),
+                                   (9, 8, 192), (16, 1, 60)])
+def test_mindssc_marching_kernel_shapes(U, orc, shape):
+    """r = 1, d = 2 with rows of a multiple of 4 voxels take the z-marching stencil (mindmarch.hip): single planes, tiles that
+    overhang in y and x, several z chunks with a partial last one, the last < 32 voxels of the volume (interleaved channel sum)."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[2])
+    img = (rng.standard_normal(shape) * 10).astype(np.float32)
+    out = host(U.MINDSSC(dev(img)[None, None], 1, 2, device=DEV))[0]
+    ref = orc.mindssc(img, 1, 2)
+    assert np.array_equal(out, ref), "max |diff| %g" % np.abs(out - ref).max()
+
+
 def test_mindssc_flat_and_clamped_regions(U, orc):
     """Zero background (mind_var = 0 -> clamped to 0.001*mean) and a bright blob: exercises both clamp bounds."""
     img = np.zeros((24, 20, 28), np.float32)
