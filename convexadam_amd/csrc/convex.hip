@@ -151,6 +151,14 @@ __device__ __forceinline__ CandBox cand_box(const float* __restrict__ ssd, const
     return c;
 }
 
+// Two independent problems in one launch (the forward and the reverse direction of a pair): gridDim.y = 2, and the second
+// problem's buffers are the first one's displaced by these byte offsets (all workspace-carved buffers share `ws`).
+struct Prob2 { ptrdiff_t ssd, argmin, out, ws; };
+template <typename T>
+__device__ __forceinline__ T* shifted(T* p, ptrdiff_t bytes) {
+    return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes);
+}
+
 // (the kernel first evaluates u = box3(mesh[previous winners]) for its voxel -- the reference's smoothing step between two
 // passes -- and stores it for the wavefront kernel and as the running result)
 template <typename PrevT>
@@ -158,7 +166,12 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const float* __restrict__ s
                                                      float* __restrict__ u, float coef, int K, int n, int h, int w, int d,
                                                      const float* __restrict__ smin, const PrevT* __restrict__ kprev, int limit,
                                                      unsigned long long* __restrict__ list, int* __restrict__ list_count,
-                                                     int* __restrict__ next_count, unsigned long long* __restrict__ keys) {
+                                                     int* __restrict__ next_count, unsigned long long* __restrict__ keys, Prob2 o) {
+    if (blockIdx.y) {
+        ssd = shifted(ssd, o.ssd); u = shifted(u, o.out); smin = shifted(smin, o.ws); kprev = shifted(kprev, o.ws);
+        list = shifted(list, o.ws); list_count = shifted(list_count, o.ws); next_count = shifted(next_count, o.ws);
+        keys = shifted(keys, o.ws);
+    }
     const size_t v = (size_t)h * w * d;
     const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x == 0) *next_count = 0;                            // list length of the NEXT pass (the two counters alternate)
@@ -199,7 +212,11 @@ __global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ s
                                                      const float* __restrict__ u, float coef, int K, int n, size_t v,
                                                      const float* __restrict__ smin, const PrevT* __restrict__ kprev,
                                                      const unsigned long long* __restrict__ list, const int* __restrict__ list_count,
-                                                     unsigned long long* __restrict__ keys) {
+                                                     unsigned long long* __restrict__ keys, Prob2 o) {
+    if (blockIdx.y) {
+        ssd = shifted(ssd, o.ssd); u = shifted(u, o.out); smin = shifted(smin, o.ws); kprev = shifted(kprev, o.ws);
+        list = shifted(list, o.ws); list_count = shifted(list_count, o.ws); keys = shifted(keys, o.ws);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
     const int cnt = *list_count;
@@ -253,7 +270,8 @@ __global__ __launch_bounds__(256) void k_keys_to_min(const unsigned long long* _
 
 // smin[x] = ssd[argmin[x], x]: the exact minimum over the search window (argmin is the plain argmin of the same volume)
 __global__ __launch_bounds__(256) void k_gather_min(const float* __restrict__ ssd, const int* __restrict__ idx, size_t v,
-                                                    float* __restrict__ smin) {
+                                                    float* __restrict__ smin, Prob2 o) {
+    if (blockIdx.y) { ssd = shifted(ssd, o.ssd); idx = shifted(idx, o.ws); smin = shifted(smin, o.ws); }
     const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x < v) smin[x] = ssd[(size_t)idx[x] * v + x];
 }
@@ -266,7 +284,8 @@ __global__ __launch_bounds__(256) void k_keys_to_index(const unsigned long long*
     if (idx32) idx32[x] = (int)k;
     if (idx64) idx64[x] = (int64_t)k;
 }
-__global__ __launch_bounds__(256) void k_index64_to_32(const int64_t* __restrict__ in, size_t v, int* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_index64_to_32(const int64_t* __restrict__ in, size_t v, int* __restrict__ out, Prob2 o) {
+    if (blockIdx.y) { in = shifted(in, o.argmin); out = shifted(out, o.ws); }
     const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x < v) out[x] = (int)in[x];
 }
@@ -275,7 +294,12 @@ __global__ __launch_bounds__(256) void k_index64_to_32(const int64_t* __restrict
 template <typename IndexT>
 __global__ __launch_bounds__(256) void k_gather_box3(const IndexT* __restrict__ idx, const float* __restrict__ mesh, int K,
                                                      int h, int w, int d, float* __restrict__ out,
-                                                     unsigned long long* __restrict__ reset, int* __restrict__ clear_count) {
+                                                     unsigned long long* __restrict__ reset, int* __restrict__ clear_count, Prob2 o) {
+    if (blockIdx.y) {
+        idx = shifted(idx, o.ws); out = shifted(out, o.out);
+        if (reset) reset = shifted(reset, o.ws);
+        if (clear_count) clear_count = shifted(clear_count, o.ws);
+    }
     const size_t v = (size_t)h * w * d;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && clear_count) *clear_count = 0;            // list length of the pruned pass that follows
@@ -314,12 +338,12 @@ static int argmin_pass(const float* ssd, const float* mesh, const float* u, floa
 template <typename PrevT>
 static int argmin_pass_pruned(const float* ssd, const float* mesh, float* u, float coef, int K, int n, int h, int w, int d,
                               const float* smin, const PrevT* kprev, unsigned long long* list, int* list_count, int* next_count,
-                              unsigned long long* keys, hipStream_t s) {
+                              unsigned long long* keys, const Prob2& o, int nprob, hipStream_t s) {
     const size_t v = (size_t)h * w * d;
-    hipLaunchKernelGGL((k_argmin_voxel<PrevT>), dim3((unsigned)cdiv64((int64_t)v, 64)), dim3(64), 0, s, ssd, mesh, u, coef, K, n, h, w, d,
-                       smin, kprev, 8, list, list_count, next_count, keys);
-    hipLaunchKernelGGL((k_argmin_wave<PrevT>), dim3(512), dim3(256), 0, s, ssd, mesh, u, coef, K, n, v, smin, kprev, list, list_count,
-                       keys);
+    hipLaunchKernelGGL((k_argmin_voxel<PrevT>), dim3((unsigned)cdiv64((int64_t)v, 64), nprob), dim3(64), 0, s, ssd, mesh, u, coef, K, n, h,
+                       w, d, smin, kprev, 8, list, list_count, next_count, keys, o);
+    hipLaunchKernelGGL((k_argmin_wave<PrevT>), dim3(512, nprob), dim3(256), 0, s, ssd, mesh, u, coef, K, n, v, smin, kprev, list,
+                       list_count, keys, o);
     return check_last("argmin_pruned");
 }
 
@@ -375,8 +399,9 @@ extern "C" int cvx_coupled_convex_f32(const float* ssd, const int64_t* argmin, c
 
 // argmin_is_exact: `argmin` is the plain argmin of `ssd` (the whole-pair pipeline computes it itself), so ssd[argmin] is the
 // per-voxel minimum and the extra streaming pass that determines it can be skipped.
-int cvx::coupled_convex_impl(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
-                             bool argmin_is_exact, void* workspace, size_t workspace_bytes, void* stream) {
+// nprob = 2: a second, independent problem (displaced by `o`, see Prob2) is solved by the same launches.
+static int coupled_core(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
+                        bool argmin_is_exact, void* workspace, size_t workspace_bytes, const Prob2& o, int nprob, void* stream) {
     CVX_REQUIRE(ssd && argmin && mesh && out && workspace, "cvx_coupled_convex_f32: null pointer");
     CVX_REQUIRE(h > 0 && w > 0 && d > 0 && disp_hw >= 0, "cvx_coupled_convex_f32: bad arguments");
     if (workspace_bytes < cvx_coupled_convex_workspace_bytes(h, w, d, disp_hw))
@@ -393,43 +418,71 @@ int cvx::coupled_convex_impl(const float* ssd, const int64_t* argmin, const floa
     const size_t list_cap = (size_t)((K + 255) / 256) * v;
     unsigned long long* list = cv.take<unsigned long long>(list_cap + 8);
     int* list_count = reinterpret_cast<int*>(list + list_cap);
-    const dim3 gv((unsigned)cdiv64((int64_t)v, 256));
-    hipLaunchKernelGGL(k_index64_to_32, gv, dim3(256), 0, s, argmin, v, idx);
+    const dim3 gv((unsigned)cdiv64((int64_t)v, 256), nprob);
+    hipLaunchKernelGGL(k_index64_to_32, gv, dim3(256), 0, s, argmin, v, idx, o);
     // exact pruning needs smin[x] = min_k ssd[k,x].  CVX_NO_PRUNE=1 streams every pass instead.
     static const bool no_prune = getenv("CVX_NO_PRUNE") != nullptr;
     const bool prune = !no_prune;
     if (prune) {
         int* counts = list_count;                                       // two alternating list lengths
-        if (hipMemsetAsync(counts, 0, 2 * sizeof(int), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
-        if (argmin_is_exact) hipLaunchKernelGGL(k_gather_min, gv, dim3(256), 0, s, ssd, idx, v, smin);
+        for (int q = 0; q < nprob; ++q)
+            if (hipMemsetAsync(reinterpret_cast<char*>(counts) + (q ? o.ws : 0), 0, 2 * sizeof(int), s) != hipSuccess)
+                return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
+        if (argmin_is_exact) hipLaunchKernelGGL(k_gather_min, gv, dim3(256), 0, s, ssd, idx, v, smin, o);
         else {
             int rc = argmin_pass(ssd, nullptr, nullptr, 0.0f, false, K, v, keys[0], true, s);   // per-voxel minimum of the volume
             if (rc) return rc;
-            hipLaunchKernelGGL(k_keys_to_min, gv, dim3(256), 0, s, keys[0], v, smin);
+            hipLaunchKernelGGL(k_keys_to_min, dim3(gv.x), dim3(256), 0, s, keys[0], v, smin);
         }
         static const float coeffs[6] = {0.003f, 0.01f, 0.03f, 0.1f, 0.3f, 1.0f};   // torch.tensor([...]) float32 (:98)
         for (int it = 0; it < 6; ++it) {
             // smoothing of the previous winners + pruned argmin; keys[1], keys[2] alternate (keys[0] may hold the minimum pass)
             unsigned long long* kc = keys[1 + (it & 1)];
             int rc;
-            if (it == 0) rc = argmin_pass_pruned<int>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, idx, list, counts + (it & 1), counts + ((it + 1) & 1), kc, s);
-            else rc = argmin_pass_pruned<unsigned long long>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, keys[1 + ((it - 1) & 1)], list, counts + (it & 1), counts + ((it + 1) & 1), kc, s);
+            if (it == 0) rc = argmin_pass_pruned<int>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, idx, list, counts + (it & 1), counts + ((it + 1) & 1), kc, o, nprob, s);
+            else rc = argmin_pass_pruned<unsigned long long>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, keys[1 + ((it - 1) & 1)], list, counts + (it & 1), counts + ((it + 1) & 1), kc, o, nprob, s);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_gather_box3<unsigned long long>, gv, dim3(256), 0, s, keys[1 + (5 & 1)], mesh, K, h, w, d, out, (unsigned long long*)nullptr, (int*)nullptr);
+        hipLaunchKernelGGL(k_gather_box3<unsigned long long>, gv, dim3(256), 0, s, keys[1 + (5 & 1)], mesh, K, h, w, d, out, (unsigned long long*)nullptr, (int*)nullptr, o);
         return check_last("coupled_convex");
     }
+    // streaming path: one problem per call
     if (hipMemsetAsync(keys[0], 0xff, sizeof(unsigned long long) * v, s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
-    hipLaunchKernelGGL(k_gather_box3<int>, gv, dim3(256), 0, s, idx, mesh, K, h, w, d, out, keys[1], (int*)nullptr);
+    hipLaunchKernelGGL(k_gather_box3<int>, dim3(gv.x), dim3(256), 0, s, idx, mesh, K, h, w, d, out, keys[1], (int*)nullptr, o);
     static const float coeffs[6] = {0.003f, 0.01f, 0.03f, 0.1f, 0.3f, 1.0f};   // torch.tensor([...]) float32 (:98)
     for (int it = 0; it < 6; ++it) {
         int rc = argmin_pass(ssd, mesh, out, coeffs[it], true, K, v, keys[it % 3], false, s);
         if (rc) return rc;
         // the streamed passes need their key buffer re-armed two passes ahead
-        hipLaunchKernelGGL(k_gather_box3<unsigned long long>, gv, dim3(256), 0, s, keys[it % 3], mesh, K, h, w, d, out,
-                           it < 4 ? keys[(it + 2) % 3] : nullptr, (int*)nullptr);
+        hipLaunchKernelGGL(k_gather_box3<unsigned long long>, dim3(gv.x), dim3(256), 0, s, keys[it % 3], mesh, K, h, w, d, out,
+                           it < 4 ? keys[(it + 2) % 3] : nullptr, (int*)nullptr, o);
     }
     return check_last("coupled_convex");
+}
+
+int cvx::coupled_convex_impl(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
+                             bool argmin_is_exact, void* workspace, size_t workspace_bytes, void* stream) {
+    return coupled_core(ssd, argmin, mesh, h, w, d, disp_hw, out, argmin_is_exact, workspace, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);
+}
+
+// Forward and reverse direction of a pair in the same launches (the per-pass kernels are latency-bound at 30 000 voxels, so two
+// problems cost about as much as one).  Both argmins must be the plain argmins of their volumes; both workspaces have the size
+// cvx_coupled_convex_workspace_bytes.  Falls back to two sequential solves when pruning is switched off.
+int cvx::coupled_convex_dual_impl(const float* ssdA, const int64_t* argminA, float* outA, void* wsA, const float* ssdB,
+                                  const int64_t* argminB, float* outB, void* wsB, const float* mesh, int h, int w, int d, int disp_hw,
+                                  size_t workspace_bytes, void* stream) {
+    static const bool no_prune = getenv("CVX_NO_PRUNE") != nullptr;
+    if (no_prune || !ssdB || !argminB || !outB || !wsB) {
+        int rc = coupled_core(ssdA, argminA, mesh, h, w, d, disp_hw, outA, true, wsA, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);
+        if (rc || !ssdB) return rc;
+        return coupled_core(ssdB, argminB, mesh, h, w, d, disp_hw, outB, true, wsB, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);
+    }
+    auto diff = [](const void* b, const void* a) { return (ptrdiff_t)(reinterpret_cast<uintptr_t>(b) - reinterpret_cast<uintptr_t>(a)); };
+    // the carve-up of a workspace depends on its alignment modulo 256: equal residues give equal layouts
+    if (((reinterpret_cast<uintptr_t>(wsA) ^ reinterpret_cast<uintptr_t>(wsB)) & 255) != 0)
+        return fail(CVX_ERR_INVALID_ARG, "coupled_convex_dual: workspaces must share their alignment modulo 256");
+    const Prob2 o{diff(ssdB, ssdA), diff(argminB, argminA), diff(outB, outA), diff(wsB, wsA)};
+    return coupled_core(ssdA, argminA, mesh, h, w, d, disp_hw, outA, true, wsA, workspace_bytes, o, 2, stream);
 }
 
 extern "C" size_t cvx_inverse_consistency_workspace_bytes(int h, int w, int d) {

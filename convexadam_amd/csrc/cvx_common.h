@@ -241,6 +241,9 @@ int adam_run_impl(const float* F2, const float* M2, int C, int h, int w, int d, 
 // convex.hip: coupled convex regularisation behind cvx_coupled_convex_f32 (argmin_is_exact: see there)
 int coupled_convex_impl(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
                         bool argmin_is_exact, void* workspace, size_t workspace_bytes, void* stream);
+int coupled_convex_dual_impl(const float* ssdA, const int64_t* argminA, float* outA, void* wsA, const float* ssdB, const int64_t* argminB,
+                             float* outB, void* wsB, const float* mesh, int h, int w, int d, int disp_hw, size_t workspace_bytes,
+                             void* stream);
 // mind.hip: MIND-SSC delivered only through its stride poolings (pipeline path, no full-resolution descriptor)
 bool mind_pooled_supported(int H, int W, int D, int g1, int g2);
 int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int dilation, int g1, float* out1, int g2, float* out2,

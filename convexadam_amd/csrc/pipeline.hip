@@ -60,7 +60,7 @@ struct PairLayout {
     int H, W, D, h, w, d, h2, w2, d2, C, K;
     size_t V, v, V2;
     // byte offsets into the workspace (0 = not used)
-    size_t featF, featM, mind_ws, fs, ms, corr_ws, ssd, argmin, mesh, conv_ws, soft, soft2, in1, in2, ic1, ic2, ic_ws,
+    size_t featF, featM, mind_ws, fs, ms, corr_ws, ssd, argmin, mesh, conv_ws, ssd2, argmin2, conv_ws2, soft, soft2, in1, in2, ic1, ic2, ic_ws,
         upin, disp_hr, F2, M2, P, m, v_, U, adam_ws, smooth_ws, bh, bw, bd, bh2, bw2, bd2, total;
 };
 
@@ -96,6 +96,10 @@ static PairLayout pair_layout(const cvx_pair_params& p) {
     L.soft = take(u, f * 3 * L.v);
     L.bh = take(u, f * L.h); L.bw = take(u, f * L.w); L.bd = take(u, f * L.d);
     if (p.ic) {
+        // the reverse direction keeps its own cost volume: both coupled-convex solves share their launches
+        L.ssd2 = take(u, f * (size_t)L.K * L.v);
+        L.argmin2 = take(u, sizeof(int64_t) * L.v);
+        L.conv_ws2 = take(u, cvx_coupled_convex_workspace_bytes(L.h, L.w, L.d, p.disp_hw));
         L.soft2 = take(u, f * 3 * L.v);
         L.in1 = take(u, f * 3 * L.v); L.in2 = take(u, f * 3 * L.v);
         L.ic1 = take(u, f * 3 * L.v); L.ic2 = take(u, f * 3 * L.v);
@@ -242,19 +246,24 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
     mark("correlate", s);
     if ((rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s))) return rc;
     mark("argmin", s);
-    if ((rc = coupled_convex_impl(F(L.ssd), am, F(L.mesh), L.h, L.w, L.d, p->disp_hw, F(L.soft), true, ws + L.conv_ws, vws, stream))) return rc;
+    int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
+    if (p->ic) {                                // reverse direction (:136-138): same operators with the roles swapped
+        unsigned long long* keys2 = reinterpret_cast<unsigned long long*>(ws + L.conv_ws2);
+        if ((rc = cvx_correlate_f32(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd2), nullptr, ws + L.corr_ws, cws, stream))) return rc;
+        mark("correlate_rev", s);
+        if ((rc = launch_argmin(F(L.ssd2), nullptr, nullptr, 0.0f, false, L.K, L.v, keys2, am2, s))) return rc;
+        mark("argmin_rev", s);
+    }
+    // both coupled-convex solves in the same launches (ic) or the forward one alone
+    if ((rc = coupled_convex_dual_impl(F(L.ssd), am, F(L.soft), ws + L.conv_ws, p->ic ? F(L.ssd2) : nullptr, am2,
+                                       p->ic ? F(L.soft2) : nullptr, p->ic ? ws + L.conv_ws2 : nullptr, F(L.mesh), L.h, L.w, L.d,
+                                       p->disp_hw, vws, stream))) return rc;
     mark("coupled_convex", s);
 
     const float* disp_hr = F(L.soft);          // ic=False: coarse field, coarse units (:143-144)
     const float* coarse_src = nullptr;         // ic=True + Adam: the coarse field whose up-sampling is folded into the next resize
     int hh = L.h, hw_ = L.w, hd = L.d;
     if (p->ic) {                                // (:133-141)
-        if ((rc = cvx_correlate_f32(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
-        mark("correlate_rev", s);
-        if ((rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s))) return rc;
-        mark("argmin_rev", s);
-        if ((rc = coupled_convex_impl(F(L.ssd), am, F(L.mesh), L.h, L.w, L.d, p->disp_hw, F(L.soft2), true, ws + L.conv_ws, vws, stream))) return rc;
-        mark("coupled_convex_rev", s);
         const dim3 gv((unsigned)cdiv64((int64_t)L.v, 256));
         hipLaunchKernelGGL(k_ic_prepare, gv, dim3(256), 0, s, F(L.soft), L.h, L.w, L.d, F(L.in1));
         hipLaunchKernelGGL(k_ic_prepare, gv, dim3(256), 0, s, F(L.soft2), L.h, L.w, L.d, F(L.in2));
