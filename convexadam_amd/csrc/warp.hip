@@ -11,12 +11,20 @@ namespace cvx {
 // corner of a 4-channel chunk is one 16-byte load, and the 16 consecutive voxels of a tile row read 256 contiguous
 // bytes (every byte of the two cache lines is used; a [V][CP] record layout touches CP/4 times as many lines).
 // Record V of every chunk is all zero: corners outside the volume are gathered from it.
-__global__ __launch_bounds__(256) void k_to_chunked(const float* __restrict__ in, int C, int CP, size_t V, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (V + 1) * (size_t)CP) return;
-    const int c = (int)(i & 3) + 4 * (int)(i / (4 * (V + 1)));
-    const size_t p = (i >> 2) % (V + 1);
-    out[i] = (c < C && p < V) ? in[(size_t)c * V + p] : 0.0f;
+__global__ __launch_bounds__(256) void k_to_chunked(const float* __restrict__ in, int C, size_t V, float* __restrict__ out) {
+    // one thread = one record: 4 coalesced channel reads, one 16-byte store
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > V) return;
+    const int c0 = 4 * (int)blockIdx.y;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < V) {
+        const float* src = in + (size_t)c0 * V + p;
+        r.x = src[0];
+        if (c0 + 1 < C) r.y = src[V];
+        if (c0 + 2 < C) r.z = src[2 * V];
+        if (c0 + 3 < C) r.w = src[3 * V];
+    }
+    reinterpret_cast<float4*>(out)[(size_t)blockIdx.y * (V + 1) + p] = r;
 }
 
 __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2, const float* __restrict__ M2, int C, int CP,
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
 int launch_to_chunked(const float* in, int C, size_t V, float* out, hipStream_t s) {
     const int CP = (C + 3) / 4 * 4;
     if ((V + 1) * 16 >= ((size_t)1 << 32)) return fail(CVX_ERR_UNSUPPORTED, "adam_run: control grid too large (%zu voxels)", V);
-    hipLaunchKernelGGL(k_to_chunked, dim3((unsigned)cdiv64((int64_t)((V + 1) * CP), 256)), dim3(256), 0, s, in, C, CP, V, out);
+    hipLaunchKernelGGL(k_to_chunked, dim3((unsigned)cdiv64((int64_t)(V + 1), 256), CP / 4), dim3(256), 0, s, in, C, V, out);
     return check_last("to_chunked");
 }
 
