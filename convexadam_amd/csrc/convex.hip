@@ -268,6 +268,18 @@ __global__ __launch_bounds__(256) void k_keys_to_min(const unsigned long long* _
     smin[x] = __uint_as_float((b & 0x80000000u) ? (b & 0x7fffffffu) : ~b);
 }
 
+// (cost, index) keys of a plain argmin pass -> int32 winners + per-voxel minimum in one launch (whole-pair pipeline)
+__global__ __launch_bounds__(256) void k_keys_to_idx_min(const unsigned long long* __restrict__ keys, size_t v, int* __restrict__ idx,
+                                                         float* __restrict__ smin, Prob2 o) {
+    if (blockIdx.y) { keys = shifted(keys, o.ws); idx = shifted(idx, o.ws); smin = shifted(smin, o.ws); }
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= v) return;
+    const unsigned long long k = keys[x];
+    const unsigned b = (unsigned)(k >> 32);
+    idx[x] = (int)(unsigned)(k & 0xffffffffull);
+    smin[x] = __uint_as_float((b & 0x80000000u) ? (b & 0x7fffffffu) : ~b);
+}
+
 // smin[x] = ssd[argmin[x], x]: the exact minimum over the search window (argmin is the plain argmin of the same volume)
 __global__ __launch_bounds__(256) void k_gather_min(const float* __restrict__ ssd, const int* __restrict__ idx, size_t v,
                                                     float* __restrict__ smin, Prob2 o) {
@@ -347,6 +359,11 @@ static int argmin_pass_pruned(const float* ssd, const float* mesh, float* u, flo
     return check_last("argmin_pruned");
 }
 
+// plain argmin pass that leaves its (cost, index) keys in `keys` (first key buffer of a coupled-convex workspace)
+int launch_argmin_keys(const float* ssd, int K, size_t v, unsigned long long* keys, hipStream_t s) {
+    return argmin_pass(ssd, nullptr, nullptr, 0.0f, false, K, v, keys, true, s);
+}
+
 int launch_argmin(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
                   unsigned long long* keys, int64_t* argmin_out, hipStream_t s) {
     int rc = argmin_pass(ssd, mesh, u, coef, coupled, K, v, keys, true, s);
@@ -402,7 +419,9 @@ extern "C" int cvx_coupled_convex_f32(const float* ssd, const int64_t* argmin, c
 // nprob = 2: a second, independent problem (displaced by `o`, see Prob2) is solved by the same launches.
 static int coupled_core(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
                         bool argmin_is_exact, void* workspace, size_t workspace_bytes, const Prob2& o, int nprob, void* stream) {
-    CVX_REQUIRE(ssd && argmin && mesh && out && workspace, "cvx_coupled_convex_f32: null pointer");
+    // argmin == nullptr: the (cost, index) keys of the plain argmin pass sit in the first key buffer of the workspace
+    const bool from_keys = argmin == nullptr;
+    CVX_REQUIRE(ssd && mesh && out && workspace, "cvx_coupled_convex_f32: null pointer");
     CVX_REQUIRE(h > 0 && w > 0 && d > 0 && disp_hw >= 0, "cvx_coupled_convex_f32: bad arguments");
     if (workspace_bytes < cvx_coupled_convex_workspace_bytes(h, w, d, disp_hw))
         return fail(CVX_ERR_WORKSPACE, "cvx_coupled_convex_f32: workspace too small");
@@ -419,7 +438,9 @@ static int coupled_core(const float* ssd, const int64_t* argmin, const float* me
     unsigned long long* list = cv.take<unsigned long long>(list_cap + 8);
     int* list_count = reinterpret_cast<int*>(list + list_cap);
     const dim3 gv((unsigned)cdiv64((int64_t)v, 256), nprob);
-    hipLaunchKernelGGL(k_index64_to_32, gv, dim3(256), 0, s, argmin, v, idx, o);
+    static const bool no_prune_env = getenv("CVX_NO_PRUNE") != nullptr;
+    if (from_keys && (no_prune_env || !argmin_is_exact)) return fail(CVX_ERR_INVALID_ARG, "coupled_convex: key input needs the pruned path");
+    if (!from_keys) hipLaunchKernelGGL(k_index64_to_32, gv, dim3(256), 0, s, argmin, v, idx, o);
     // exact pruning needs smin[x] = min_k ssd[k,x].  CVX_NO_PRUNE=1 streams every pass instead.
     static const bool no_prune = getenv("CVX_NO_PRUNE") != nullptr;
     const bool prune = !no_prune;
@@ -428,7 +449,8 @@ static int coupled_core(const float* ssd, const int64_t* argmin, const float* me
         for (int q = 0; q < nprob; ++q)
             if (hipMemsetAsync(reinterpret_cast<char*>(counts) + (q ? o.ws : 0), 0, 2 * sizeof(int), s) != hipSuccess)
                 return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
-        if (argmin_is_exact) hipLaunchKernelGGL(k_gather_min, gv, dim3(256), 0, s, ssd, idx, v, smin, o);
+        if (from_keys) hipLaunchKernelGGL(k_keys_to_idx_min, gv, dim3(256), 0, s, keys[0], v, idx, smin, o);
+        else if (argmin_is_exact) hipLaunchKernelGGL(k_gather_min, gv, dim3(256), 0, s, ssd, idx, v, smin, o);
         else {
             int rc = argmin_pass(ssd, nullptr, nullptr, 0.0f, false, K, v, keys[0], true, s);   // per-voxel minimum of the volume
             if (rc) return rc;
@@ -467,12 +489,13 @@ int cvx::coupled_convex_impl(const float* ssd, const int64_t* argmin, const floa
 
 // Forward and reverse direction of a pair in the same launches (the per-pass kernels are latency-bound at 30 000 voxels, so two
 // problems cost about as much as one).  Both argmins must be the plain argmins of their volumes; both workspaces have the size
-// cvx_coupled_convex_workspace_bytes.  Falls back to two sequential solves when pruning is switched off.
+// cvx_coupled_convex_workspace_bytes.  Falls back to two sequential solves when pruning is switched off.  argminA == argminB ==
+// nullptr: the plain argmin passes left their (cost, index) keys at the start of the respective workspace (launch_argmin_keys).
 int cvx::coupled_convex_dual_impl(const float* ssdA, const int64_t* argminA, float* outA, void* wsA, const float* ssdB,
                                   const int64_t* argminB, float* outB, void* wsB, const float* mesh, int h, int w, int d, int disp_hw,
                                   size_t workspace_bytes, void* stream) {
     static const bool no_prune = getenv("CVX_NO_PRUNE") != nullptr;
-    if (no_prune || !ssdB || !argminB || !outB || !wsB) {
+    if (no_prune || !ssdB || !outB || !wsB) {
         int rc = coupled_core(ssdA, argminA, mesh, h, w, d, disp_hw, outA, true, wsA, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);
         if (rc || !ssdB) return rc;
         return coupled_core(ssdB, argminB, mesh, h, w, d, disp_hw, outB, true, wsB, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);

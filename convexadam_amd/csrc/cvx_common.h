@@ -214,6 +214,7 @@ __device__ __forceinline__ float tri_sample(const Tri& t, const float* __restric
 int launch_box_zero(const float* in, float* out, int C, int H, int W, int D, int k, bool backward, hipStream_t s);
 int launch_smoother(const float* in, float* out, float* tmp, int C, int H, int W, int D, const cvx_smoother& sm, bool backward,
                     hipStream_t s);
+int launch_argmin_keys(const float* ssd, int K, size_t v, unsigned long long* keys, hipStream_t s);
 int launch_argmin(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
                   unsigned long long* keys, int64_t* argmin_out, hipStream_t s);
 // out = interp(in * pre_mul) / post_div   (pre_mul, post_div = 1 -> plain F.interpolate)

@@ -76,12 +76,12 @@ __global__ __launch_bounds__(256) void k_mind_stats_init(const float* part, int 
     st->imin = mn;
     st->imax = mx;
 }
-__global__ void k_mind_stats_finish(MindStats* st, double count) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// clamp bounds of the normalisation from the exact partial sums (every consumer evaluates them itself: a handful of scalar
+// operations instead of a one-thread launch between the two passes)
+__device__ __forceinline__ void mind_bounds(const MindStats* __restrict__ st, double count, float& lo, float& hi) {
     const float gm = (float)((st->a1 + (st->a2 + st->a3)) / count);
-    st->mean = gm;
-    st->lo = (float)((double)gm * 0.001);      // python: mind_var.mean().item()*0.001   (:61)
-    st->hi = (float)((double)gm * 1000.0);
+    lo = (float)((double)gm * 0.001);      // python: mind_var.mean().item()*0.001   (:61)
+    hi = (float)((double)gm * 1000.0);
 }
 
 // ---- the tiled stencil ---------------------------------------------------------------------------
@@ -262,9 +262,10 @@ __device__ __forceinline__ void mind_normalise(float (&r)[12], float lo, float h
 // The channel mean runs over the reference's PRE-permutation channel order (the permutation is applied last, :66).
 template <int NV>
 __global__ __launch_bounds__(256) void k_mind_finish(float* __restrict__ out, size_t V, const MindStats* __restrict__ st) {
+    float lo, hi;
+    mind_bounds(st, (double)V, lo, hi);
     const size_t x = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * NV;
     if (x >= V) return;
-    const float lo = st->lo, hi = st->hi;
     const size_t tail_from = (V / 32) * 32;
     float r[NV][12];
 #pragma unroll
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restr
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * MP_TX, y0 = blockIdx.y * T, z0 = blockIdx.z * T;
     const size_t V = (size_t)H * W * D;
-    const float lo = st->lo, hi = st->hi;
+    float lo, hi;
+    mind_bounds(st, (double)V, lo, hi);
     const size_t tail_from = (V / 32) * 32;
     constexpr int NP = MP_TX / 2;
     for (int i = tid; i < T * T * NP; i += MP_NT) {
@@ -390,7 +392,6 @@ static int mind_launch_r(const float* img, int H, int W, int D, int dil, MindSta
     static const bool tiled_only = getenv("CVX_MIND_TILED") != nullptr;
     if (!tiled_only && mind_march_supported(img, out, H, W, D, R, dil)) {
         launch_mind_march(img, H, W, D, st, out, s);
-        hipLaunchKernelGGL(k_mind_stats_finish, dim3(1), dim3(1), 0, s, st, (double)H * W * D);
         return check_last("mindssc");
     }
     const dim3 grid(cdiv(D, TX), cdiv(W, TY), cdiv(H, TZ));
@@ -399,7 +400,6 @@ static int mind_launch_r(const float* img, int H, int W, int D, int dil, MindSta
     static size_t granted0 = 0;
     ensure_dynamic_lds(&k_mind<R>, lds, granted0);
     hipLaunchKernelGGL((k_mind<R>), grid, dim3(NT), lds, s, img, H, W, D, dil, nbuf, st, out);
-    hipLaunchKernelGGL(k_mind_stats_finish, dim3(1), dim3(1), 0, s, st, (double)H * W * D);
     return check_last("mindssc");
 }
 

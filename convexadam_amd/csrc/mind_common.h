@@ -18,7 +18,6 @@ __device__ constexpr int MIND_INV[12] = {6, 2, 4, 11, 9, 10, 0, 7, 1, 8, 5, 3};
 struct MindStats {
     double m1, m2, m3;     // split grids (see oracle orc_split_make)
     double a1, a2, a3;     // exact partial sums
-    float lo, hi, mean;    // clamp bounds
     float imin, imax;
 };
 

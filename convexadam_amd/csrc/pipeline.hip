@@ -241,21 +241,27 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
     const size_t cws = cvx_correlate_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);
     const size_t vws = cvx_coupled_convex_workspace_bytes(L.h, L.w, L.d, p->disp_hw);
     int64_t* am = reinterpret_cast<int64_t*>(ws + L.argmin);
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + L.conv_ws);   // same scratch the coupled pass uses first
+    // first key buffer of the coupled-convex workspace (carved exactly as coupled_core does): the plain argmin leaves its keys there
+    unsigned long long* keys = Carver(ws + L.conv_ws, vws).take<unsigned long long>(L.v);
     if ((rc = cvx_correlate_f32(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
     mark("correlate", s);
-    if ((rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s))) return rc;
+    static const bool no_prune = getenv("CVX_NO_PRUNE") != nullptr;      // streaming coupled passes need int64 winners
+    if (no_prune) rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s);
+    else rc = launch_argmin_keys(F(L.ssd), L.K, L.v, keys, s);            // keys stay in the coupled workspace's first buffer
+    if (rc) return rc;
     mark("argmin", s);
     int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
     if (p->ic) {                                // reverse direction (:136-138): same operators with the roles swapped
-        unsigned long long* keys2 = reinterpret_cast<unsigned long long*>(ws + L.conv_ws2);
+        unsigned long long* keys2 = Carver(ws + L.conv_ws2, vws).take<unsigned long long>(L.v);
         if ((rc = cvx_correlate_f32(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd2), nullptr, ws + L.corr_ws, cws, stream))) return rc;
         mark("correlate_rev", s);
-        if ((rc = launch_argmin(F(L.ssd2), nullptr, nullptr, 0.0f, false, L.K, L.v, keys2, am2, s))) return rc;
+        if (no_prune) rc = launch_argmin(F(L.ssd2), nullptr, nullptr, 0.0f, false, L.K, L.v, keys2, am2, s);
+        else rc = launch_argmin_keys(F(L.ssd2), L.K, L.v, keys2, s);
+        if (rc) return rc;
         mark("argmin_rev", s);
     }
     // both coupled-convex solves in the same launches (ic) or the forward one alone
-    if ((rc = coupled_convex_dual_impl(F(L.ssd), am, F(L.soft), ws + L.conv_ws, p->ic ? F(L.ssd2) : nullptr, am2,
+    if ((rc = coupled_convex_dual_impl(F(L.ssd), no_prune ? am : nullptr, F(L.soft), ws + L.conv_ws, p->ic ? F(L.ssd2) : nullptr, no_prune ? am2 : nullptr,
                                        p->ic ? F(L.soft2) : nullptr, p->ic ? ws + L.conv_ws2 : nullptr, F(L.mesh), L.h, L.w, L.d,
                                        p->disp_hw, vws, stream))) return rc;
     mark("coupled_convex", s);
