@@ -200,44 +200,63 @@ __device__ __forceinline__ void lin_coef(int o, int in, int out, int& i0, int& i
     l1 = l;
     l0 = 1.0f - l;
 }
+// One thread per output voxel, all channels.  CT > 0: the channel count at compile time (fields: 3) -- the channel loop is
+// unrolled and the 8 * CT taps are in flight together; with a run-time count the loop runs one memory round trip per channel
+// and the kernel is bound by that latency (59 vs 3x us for the 82 MB field of the final up-sampling).
+template <int CT>
 __global__ __launch_bounds__(256) void k_resize(const float* __restrict__ in, int C, int h, int w, int d,
                                                 float* __restrict__ out, int H, int W, int D, float pre_mul,
                                                 float post_div) {
+    // grid = (pieces of a row, W, H): no integer division by run-time extents, z and y coefficients are wave-uniform
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x), y = (int)blockIdx.y, z = (int)blockIdx.z;
+    if (x >= D) return;
     const size_t n = (size_t)H * W * D;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int x = (int)(i % D), y = (int)((i / D) % W), z = (int)(i / ((size_t)D * W));
+    const size_t i = ((size_t)z * W + y) * D + x;
     int z0, z1, y0, y1, x0, x1;
     float lz0, lz1, ly0, ly1, lx0, lx1;
     lin_coef(z, h, H, z0, z1, lz0, lz1);
     lin_coef(y, w, W, y0, y1, ly0, ly1);
     lin_coef(x, d, D, x0, x1, lx0, lx1);
-    for (int c = 0; c < C; ++c) {
-        const float* ic = in + (size_t)c * h * w * d;
-        float lev1[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int zz = a ? z1 : z0;
-            float lev2[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int yy = b ? y1 : y0;
-                const float* row = ic + ((size_t)zz * w + yy) * d;
-                const float v0 = row[x0] * pre_mul, v1 = row[x1] * pre_mul;   // pre_mul = 1: exact no-op
-                lev2[b] = __builtin_fmaf(v0, lx0, v1 * lx1);
-            }
-            lev1[a] = __builtin_fmaf(lev2[0], ly0, lev2[1] * ly1);
-        }
-        float r = __builtin_fmaf(lev1[0], lz0, lev1[1] * lz1);
+    const size_t o00 = ((size_t)z0 * w + y0) * d, o01 = ((size_t)z0 * w + y1) * d, o10 = ((size_t)z1 * w + y0) * d,
+                 o11 = ((size_t)z1 * w + y1) * d;
+    const size_t cs = (size_t)h * w * d;
+    auto one = [&](const float (&v)[8]) {
+        const float a0 = __builtin_fmaf(v[0] * pre_mul, lx0, (v[1] * pre_mul) * lx1);   // pre_mul = 1: exact no-op
+        const float a1 = __builtin_fmaf(v[2] * pre_mul, lx0, (v[3] * pre_mul) * lx1);
+        const float b0 = __builtin_fmaf(v[4] * pre_mul, lx0, (v[5] * pre_mul) * lx1);
+        const float b1 = __builtin_fmaf(v[6] * pre_mul, lx0, (v[7] * pre_mul) * lx1);
+        const float l0 = __builtin_fmaf(a0, ly0, a1 * ly1);
+        const float l1 = __builtin_fmaf(b0, ly0, b1 * ly1);
+        float r = __builtin_fmaf(l0, lz0, l1 * lz1);
         if (post_div != 1.0f) r = fdiv(r, post_div);
-        out[(size_t)c * n + i] = r;
+        return r;
+    };
+    auto fetch = [&](const float* ic, float (&v)[8]) {
+        v[0] = ic[o00 + x0]; v[1] = ic[o00 + x1]; v[2] = ic[o01 + x0]; v[3] = ic[o01 + x1];
+        v[4] = ic[o10 + x0]; v[5] = ic[o10 + x1]; v[6] = ic[o11 + x0]; v[7] = ic[o11 + x1];
+    };
+    if (CT > 0) {
+        float v[CT > 0 ? CT : 1][8];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) fetch(in + (size_t)c * cs, v[c]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) out[(size_t)c * n + i] = one(v[c]);
+    } else {
+        for (int c = 0; c < C; ++c) {
+            float v[8];
+            fetch(in + (size_t)c * cs, v);
+            out[(size_t)c * n + i] = one(v);
+        }
     }
 }
 int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D, float pre_mul,
                   float post_div, hipStream_t s) {
-    const size_t n = (size_t)H * W * D;
-    hipLaunchKernelGGL(k_resize, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, s, in, C, h, w, d, out, H, W, D,
-                       pre_mul, post_div);
+    if (H > 65535 || W > 65535) return fail(CVX_ERR_UNSUPPORTED, "resize_trilinear: output extent %dx%d exceeds the grid limits", H, W);
+    const int bx = D > 128 ? 256 : (D > 64 ? 128 : 64);              // short rows: do not pad them to 256 lanes
+    const dim3 grid((unsigned)cdiv(D, bx), (unsigned)W, (unsigned)H), block(bx);
+    if (C == 3) hipLaunchKernelGGL(k_resize<3>, grid, block, 0, s, in, C, h, w, d, out, H, W, D, pre_mul, post_div);
+    else if (C == 1) hipLaunchKernelGGL(k_resize<1>, grid, block, 0, s, in, C, h, w, d, out, H, W, D, pre_mul, post_div);
+    else hipLaunchKernelGGL(k_resize<0>, grid, block, 0, s, in, C, h, w, d, out, H, W, D, pre_mul, post_div);
     return check_last("resize_trilinear");
 }
 
@@ -248,30 +267,37 @@ int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H
 //   k_resize2   : an output needs 2 x 2 x 2 intermediate values; each is fma(T[z0], lz0, T[z1] * lz1) -- the z level of the
 //                 first resize -- followed by the three levels of the second resize, all with k_resize's operations and
 //                 roundings: bit-identical to the two-pass form.
+template <int CT>
 __global__ __launch_bounds__(256) void k_resize_yx(const float* __restrict__ in, int C, int h, int w, int d, float* __restrict__ T,
                                                    int W, int D) {
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x), y = (int)blockIdx.y, z = (int)blockIdx.z;     // z: coarse plane
+    if (x >= D) return;
     const size_t n = (size_t)h * W * D;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int x = (int)(i % D), y = (int)((i / D) % W), z = (int)(i / ((size_t)D * W));
+    const size_t i = ((size_t)z * W + y) * D + x;
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
     lin_coef(y, w, W, y0, y1, ly0, ly1);
     lin_coef(x, d, D, x0, x1, lx0, lx1);
-    for (int c = 0; c < C; ++c) {
+    auto one = [&](int c) {
         const float* r0 = in + (((size_t)c * h + z) * w + y0) * d;
         const float* r1 = in + (((size_t)c * h + z) * w + y1) * d;
         const float a = __builtin_fmaf(r0[x0], lx0, r0[x1] * lx1);
         const float b = __builtin_fmaf(r1[x0], lx0, r1[x1] * lx1);
         T[(size_t)c * n + i] = __builtin_fmaf(a, ly0, b * ly1);
-    }
+    };
+    if (CT > 0) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) one(c);
+    } else
+        for (int c = 0; c < C; ++c) one(c);
 }
+template <int CT>
 __global__ __launch_bounds__(256) void k_resize2(const float* __restrict__ T, int C, int h, int H, int W, int D, float* __restrict__ out,
                                                  int h2, int w2, int d2, float post_div) {
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x), y = (int)blockIdx.y, z = (int)blockIdx.z;
+    if (x >= d2) return;
     const size_t n = (size_t)h2 * w2 * d2;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int x = (int)(i % d2), y = (int)((i / d2) % w2), z = (int)(i / ((size_t)d2 * w2));
+    const size_t i = ((size_t)z * w2 + y) * d2 + x;
     int Z[2], Y[2], X[2], cz[2][2];
     float LZ[2], LY[2], LX[2], wz[2][2];
     lin_coef(z, H, h2, Z[0], Z[1], LZ[0], LZ[1]);
@@ -280,19 +306,25 @@ __global__ __launch_bounds__(256) void k_resize2(const float* __restrict__ T, in
 #pragma unroll
     for (int a = 0; a < 2; ++a) lin_coef(Z[a], h, H, cz[a][0], cz[a][1], wz[a][0], wz[a][1]);
     const size_t plane = (size_t)W * D;
-    for (int c = 0; c < C; ++c) {
+    auto one = [&](int c) {
         const float* Tc = T + (size_t)c * h * plane;
+        float v[2][2][2][2];                                        // [a][level-1 plane][b][e]: all 16 taps in flight
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) v[a][p][b][e] = Tc[(size_t)cz[a][p] * plane + (size_t)Y[b] * D + X[e]];
         float lev1[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const float* p0 = Tc + (size_t)cz[a][0] * plane;
-            const float* p1 = Tc + (size_t)cz[a][1] * plane;
             float lev2[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const size_t ro = (size_t)Y[b] * D;
-                const float m0 = __builtin_fmaf(p0[ro + X[0]], wz[a][0], p1[ro + X[0]] * wz[a][1]);   // intermediate (Z[a], Y[b], X[0])
-                const float m1 = __builtin_fmaf(p0[ro + X[1]], wz[a][0], p1[ro + X[1]] * wz[a][1]);
+                const float m0 = __builtin_fmaf(v[a][0][b][0], wz[a][0], v[a][1][b][0] * wz[a][1]);   // intermediate (Z[a], Y[b], X[0])
+                const float m1 = __builtin_fmaf(v[a][0][b][1], wz[a][0], v[a][1][b][1] * wz[a][1]);
                 lev2[b] = __builtin_fmaf(m0, LX[0], m1 * LX[1]);
             }
             lev1[a] = __builtin_fmaf(lev2[0], LY[0], lev2[1] * LY[1]);
@@ -300,15 +332,26 @@ __global__ __launch_bounds__(256) void k_resize2(const float* __restrict__ T, in
         float r = __builtin_fmaf(lev1[0], LZ[0], lev1[1] * LZ[1]);
         if (post_div != 1.0f) r = fdiv(r, post_div);
         out[(size_t)c * n + i] = r;
-    }
+    };
+    if (CT > 0) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) one(c);
+    } else
+        for (int c = 0; c < C; ++c) one(c);
 }
 // `scratch`: C * h * W * D floats
 int launch_resize2(const float* in, int C, int h, int w, int d, int H, int W, int D, float* scratch, float* out, int h2, int w2, int d2,
                    float post_div, hipStream_t s) {
-    const size_t nt = (size_t)h * W * D, n = (size_t)h2 * w2 * d2;
-    hipLaunchKernelGGL(k_resize_yx, dim3((unsigned)cdiv64((int64_t)nt, 256)), dim3(256), 0, s, in, C, h, w, d, scratch, W, D);
-    hipLaunchKernelGGL(k_resize2, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, s, scratch, C, h, H, W, D, out, h2, w2, d2,
-                       post_div);
+    if (W > 65535 || h > 65535 || w2 > 65535 || h2 > 65535) return fail(CVX_ERR_UNSUPPORTED, "resize_trilinear2: extent exceeds the grid limits");
+    auto bx = [](int n) { return n > 128 ? 256 : (n > 64 ? 128 : 64); };
+    const dim3 g1((unsigned)cdiv(D, bx(D)), (unsigned)W, (unsigned)h), g2((unsigned)cdiv(d2, bx(d2)), (unsigned)w2, (unsigned)h2);
+    if (C == 3) {
+        hipLaunchKernelGGL(k_resize_yx<3>, g1, dim3(bx(D)), 0, s, in, C, h, w, d, scratch, W, D);
+        hipLaunchKernelGGL(k_resize2<3>, g2, dim3(bx(d2)), 0, s, scratch, C, h, H, W, D, out, h2, w2, d2, post_div);
+    } else {
+        hipLaunchKernelGGL(k_resize_yx<0>, g1, dim3(bx(D)), 0, s, in, C, h, w, d, scratch, W, D);
+        hipLaunchKernelGGL(k_resize2<0>, g2, dim3(bx(d2)), 0, s, scratch, C, h, H, W, D, out, h2, w2, d2, post_div);
+    }
     return check_last("resize_trilinear2");
 }
 
