@@ -175,6 +175,13 @@ def test_resize_vs_oracle(U, orc, src, dst):
     assert np.array_equal(host(U.resize_trilinear(dev(x)[None], dst))[0], orc.resize_trilinear(x, dst))
 
 
+@pytest.mark.parametrize("C,src,dst", [(1, (7, 9, 40), (14, 9, 300)), (5, (6, 5, 9), (11, 13, 70)), (2, (4, 4, 4), (4, 4, 4))])
+def test_resize_channel_counts_and_long_rows(U, orc, C, src, dst):
+    """The kernels specialise C = 1 and C = 3; other counts take the generic channel loop; rows longer than a workgroup."""
+    x = np.random.default_rng(C).standard_normal((C,) + src).astype(np.float32)
+    assert np.array_equal(host(U.resize_trilinear(dev(x)[None], dst))[0], orc.resize_trilinear(x, dst))
+
+
 def test_grid_sample_vs_oracle(U, orc):
     rng = np.random.default_rng(2)
     vol = rng.standard_normal((4, 7, 8, 9)).astype(np.float32)
