@@ -4,12 +4,14 @@
 // D_c(x)   = box_{(2r+1)^3}[ (I(P + o1_c*d) - I(P + o2_c*d))^2 ](x)      replicate borders twice
 // mu       = mean over the volume of mean_c(D - min)
 //
-// Two launches (the global mean mu is a grid-wide dependency):
-//   k_mind        : tiled stencil -- the 12 patch-SSDs D_c(x) -> out (raw), per-voxel variance -> order-independent
-//                   exact sum (three power-of-two split grids, double atomics)   [reads V*4, writes 12*V*4 B]
+// Two passes (the global mean mu is a grid-wide dependency), after a min/max pre-pass that sizes the exact accumulation:
+//   stencil pass  : the 12 patch-SSDs D_c(x) -> out (raw), per-voxel variance -> order-independent exact sum (three
+//                   power-of-two split grids, double atomics)   [reads V*4, writes 12*V*4 B]
+//                   k_mind_march (mindmarch.hip) for radius 1 / dilation 2 / rows of 4k voxels, the tiled k_mind<R> below otherwise
 //   k_mind_finish : streaming, in place -- min, mean, clamp, exp per voxel        [reads + writes 12*V*4 B]
+//   k_mind_finish_pool : the pipeline's variant of the second pass -- normalisation and both stride poolings in one go
 // (recomputing the stencil in the second pass instead costs 2.2 x the time of streaming the 12 channels once)
-// Tile: 4 x 8 x 64 voxels (H x W x D) per 512-thread workgroup, image tile with halo r+d staged in
+// Tiled stencil: 4 x 8 x 64 voxels (H x W x D) per 512-thread workgroup, image tile with halo r+d staged in
 // LDS once, squared-difference tile per channel double-buffered in LDS, each thread owns 4
 // consecutive D-voxels and keeps 12 x 4 results in registers.  Roofline: HBM (385 MB per image when
 // the full-resolution descriptor is materialised); the 27-tap raster-order sums (ATen avg_pool3d
