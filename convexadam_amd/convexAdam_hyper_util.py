@@ -225,38 +225,27 @@ def percentile_linear_from_sorted_pair(a, b, gamma):
     return np.add(a32, diff * t)
 
 
-def _surface_percentile(a_in2, a_out2, b_in2, nbins, q=95):
-    """np.percentile(dist_a[surf_b], q) with dist_a = sqrt(a_in2 + a_out2) in float32 and surf_b = (b_in2 == 1)   (:48)"""
+def edt_squared(obj):
+    """Exact squared Euclidean distance of every voxel of a (H,W,D) device tensor to its nearest ZERO voxel (0 on zero voxels),
+    int32: round(scipy.ndimage.distance_transform_edt(obj)**2) (csrc/edt.hip, Meijster's passes)."""
+    o = f32c(require_device_tensor(obj, "obj"))
+    H, W, D = [int(v) for v in o.shape[-3:]]
     L = lib()
-    dev = a_in2.device
-    n = int(a_in2.numel())
-    hist = torch.empty(nbins, dtype=torch.int64, device=dev)
-    flag = torch.empty(1, dtype=torch.int32, device=dev)
-    out3 = torch.empty(3, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
-        check(L.cvx_surface_hist_i64(ptr(a_in2), ptr(a_out2), ptr(b_in2), n, nbins, ptr(hist), ptr(flag), stream_ptr(dev)))
-        check(L.cvx_hist_order_stats_i64(ptr(hist), nbins, -1, -1, ptr(out3), stream_ptr(dev)))
-        cnt = int(out3.cpu()[2])
-        if int(flag.cpu()[0]) != 0:
-            raise RuntimeError("cupy_hd95: squared distance exceeds the histogram range")
-        if cnt == 0:
-            return float("nan")                        # numpy: percentile of an empty selection
-        k0, k1, gamma = percentile_neighbours(cnt, q)
-        check(L.cvx_hist_order_stats_i64(ptr(hist), nbins, k0, k1, ptr(out3), stream_ptr(dev)))
-    o = out3.cpu().numpy()
-    # float32 distances (float64_distances=False, :40): correctly rounded square roots of exact integers
-    a = np.sqrt(np.float64(o[0])).astype(np.float32)
-    b = np.sqrt(np.float64(o[1])).astype(np.float32)
-    return float(percentile_linear_from_sorted_pair(a, b, gamma))
+    out = torch.empty((H, W, D), dtype=torch.int32, device=o.device)
+    nws = L.cvx_edt_squared_workspace_bytes(H, W, D)
+    ws = workspace(nws, o.device)
+    with torch.cuda.device(o.device):
+        check(L.cvx_edt_squared_i32(ptr(o), H, W, D, ptr(out), ptr(ws), nws, stream_ptr(o.device)))
+    return out
 
 
 def cupy_hd95(fixed, moving, num_labels, precision=1):
     """hyper_util.py:32-51: 95th-percentile symmetric surface distance for labels 1 .. num_labels (30 where a label is absent from
     either map), float64 tensor on the device of `fixed`.  Per label on the device: masks on the nearest-upsampled grid, exact
-    Euclidean feature transforms of the mask and of its complement (csrc/edt.hip), integer squared distances, histogram of
-    dist_a over the surface of b (edt == 1); the percentile is read from the histogram (two order statistics), so no sort and no
-    host copy of a volume.  `precision` must be a positive integer (the reference's call sites use the default 1)."""
-    from .convex_adam_MIND import feature_transform
+    squared Euclidean distance transforms of the mask and of its complement (csrc/edt.hip), histogram of dist_a over the
+    surface of b (edt == 1); the percentile is read from the histogram (two order statistics), so no sort and no host copy of a
+    volume.  Two host synchronisations per call (label presence, results).  `precision` must be a positive integer (the
+    reference's call sites use the default 1)."""
     if int(precision) != precision or precision < 1:
         raise NotImplementedError("cupy_hd95: only integer precision >= 1 (nearest up-sampling) is implemented")
     p = int(precision)
@@ -264,40 +253,63 @@ def cupy_hd95(fixed, moving, num_labels, precision=1):
     mv = f32c(require_device_tensor(moving, "moving"))
     if fx.shape != mv.shape or fx.dim() != 3:
         raise ValueError("cupy_hd95: label maps must be (H, W, D) tensors of the same shape")
-    if float(fx.min()) < 0 or float(mv.min()) < 0 or float(fx.max()) > num_labels or float(mv.max()) > num_labels:
-        raise RuntimeError("cupy_hd95: class values must be in 0 .. num_labels (F.one_hot, :33)")
     H, W, D = [int(v) for v in fx.shape]
     Ho, Wo, Do = H * p, W * p, D * p
     nbins = (Ho - 1) ** 2 + (Wo - 1) ** 2 + (Do - 1) ** 2 + 2
+    nl = int(num_labels)
     L = lib()
     dev = fx.device
-    hd95 = np.zeros(int(num_labels), np.float64)
-
-    def distances(seg, label):
-        inside = torch.empty((Ho, Wo, Do), dtype=torch.float32, device=dev)
-        outside = torch.empty_like(inside)
-        cnt = torch.empty(1, dtype=torch.int64, device=dev)
-        with torch.cuda.device(dev):
-            check(L.cvx_label_mask_f32(ptr(seg), H, W, D, int(label), p, ptr(inside), ptr(outside), ptr(cnt), stream_ptr(dev)))
-        if int(cnt.cpu()[0]) == 0:
-            return None
-        d_in = torch.empty((Ho, Wo, Do), dtype=torch.int32, device=dev)
-        d_out = torch.empty_like(d_in)
-        for obj, dst in ((inside, d_in), (outside, d_out)):
-            feat = feature_transform(obj)
-            with torch.cuda.device(dev):
-                check(L.cvx_edt_sqdist_i32(ptr(obj), ptr(feat), Ho, Wo, Do, ptr(dst), stream_ptr(dev)))
-        return d_in, d_out
-
-    for i in range(int(num_labels)):
-        df = distances(fx, i + 1)
-        dm = distances(mv, i + 1) if df is not None else None
-        if df is None or dm is None:
+    sp = stream_ptr(dev)
+    hd95 = np.zeros(nl, np.float64)
+    with torch.cuda.device(dev):
+        # label range (F.one_hot, :33) and presence in one pass: voxel counts of labels 0 .. num_labels in both maps
+        lohi = torch.stack([fx.min(), fx.max(), mv.min(), mv.max()]).cpu()
+        if float(lohi[0]) < 0 or float(lohi[2]) < 0 or float(lohi[1]) > nl or float(lohi[3]) > nl:
+            raise RuntimeError("cupy_hd95: class values must be in 0 .. num_labels (F.one_hot, :33)")
+        counts = torch.empty((3, nl + 1), dtype=torch.int64, device=dev)
+        check(L.cvx_label_overlap_i64(ptr(fx), ptr(mv), int(fx.numel()), nl + 1, ptr(counts), sp))
+        cnt = counts.cpu().numpy()
+        present = [i for i in range(1, nl + 1) if cnt[0, i] > 0 and cnt[1, i] > 0]
+        if present:
+            shape = (Ho, Wo, Do)
+            inside = torch.empty(shape, dtype=torch.float32, device=dev)
+            outside = torch.empty_like(inside)
+            dist = [[torch.empty(shape, dtype=torch.int32, device=dev) for _ in range(2)] for _ in range(2)]   # [map][in, out]
+            nws = L.cvx_edt_squared_workspace_bytes(Ho, Wo, Do)
+            ws = workspace(nws, dev)
+            hist = torch.empty(nbins, dtype=torch.int64, device=dev)
+            flag = torch.zeros(2 * len(present), dtype=torch.int32, device=dev)
+            out3 = torch.empty((len(present), 2, 3), dtype=torch.int64, device=dev)
+            quant = float(np.true_divide(95, np.float32(100)))               # numpy: q / float32(100) for float32 data
+            n = Ho * Wo * Do
+            for j, lab in enumerate(present):
+                for k, seg in enumerate((fx, mv)):
+                    check(L.cvx_label_mask_f32(ptr(seg), H, W, D, lab, p, ptr(inside), ptr(outside), None, sp))
+                    check(L.cvx_edt_squared_i32(ptr(inside), Ho, Wo, Do, ptr(dist[k][0]), ptr(ws), nws, sp))
+                    check(L.cvx_edt_squared_i32(ptr(outside), Ho, Wo, Do, ptr(dist[k][1]), ptr(ws), nws, sp))
+                # dist1[surf2] and dist2[surf1]                                                       (:48)
+                for k in range(2):
+                    a, b = dist[k], dist[1 - k]
+                    check(L.cvx_surface_hist_i64(ptr(a[0]), ptr(a[1]), ptr(b[0]), n, nbins, ptr(hist), ptr(flag[2 * j + k:]), sp))
+                    check(L.cvx_hist_percentile_neighbours_i64(ptr(hist), nbins, quant, ptr(out3[j, k]), sp))
+            res = out3.cpu().numpy()
+            if int(flag.cpu().max()) != 0:
+                raise RuntimeError("cupy_hd95: squared distance exceeds the histogram range")
+        for i in range(nl):
             hd95[i] = 30
-            continue
-        p1 = _surface_percentile(df[0], df[1], dm[0], nbins)          # dist1[surf2]
-        p2 = _surface_percentile(dm[0], dm[1], df[0], nbins)          # dist2[surf1]
-        hd95[i] = np.maximum(p1, p2)
+        for j, lab in enumerate(present):
+            pk = []
+            for k in range(2):
+                b0, b1, m = [int(v) for v in res[j, k]]
+                if m == 0:
+                    pk.append(float("nan"))                                  # numpy: percentile of an empty selection
+                    continue
+                _, _, gamma = percentile_neighbours(m, 95)
+                # float32 distances (float64_distances=False, :40): correctly rounded square roots of exact integers
+                lo = np.sqrt(np.float64(b0)).astype(np.float32)
+                hi = np.sqrt(np.float64(b1)).astype(np.float32)
+                pk.append(float(percentile_linear_from_sorted_pair(lo, hi, gamma)))
+            hd95[lab - 1] = np.maximum(pk[0], pk[1])
     # true division on the host (like the CPU capture of the reference); torch's device kernel would multiply by the reciprocal,
     # 1 ulp off for a precision that is not a power of two
     return torch.as_tensor(hd95 * 1 / precision).to(dev)

@@ -100,6 +100,84 @@ __global__ __launch_bounds__(256) void k_ft_flat_index(const int* __restrict__ f
 }
 
 
+// ---- squared Euclidean distance transform, distances only (HD95 needs no indices) -----------------------------------------------
+// Meijster, Roerdink & Hesselink (2000): a 1-D pass along x (distance to the nearest zero voxel of the row) and two lower-envelope
+// passes along y and z.  Integer arithmetic throughout: the result is the exact squared distance whatever the order of ties, so it
+// equals round(scipy.ndimage.distance_transform_edt(obj)**2) bit for bit.  Rows without a zero voxel carry EDT_INF.
+// The y / z passes run one thread per line with the threads of a wavefront on adjacent x (coalesced); their stacks live in a
+// thread-interleaved scratch.  A volume without any zero voxel yields values >= EDT_INF^2 (clamped to INT_MAX).
+constexpr long long EDT_INF = 1 << 20;
+
+// one wavefront per row: nearest zero to the left / right by scans over the lanes' segments
+__global__ __launch_bounds__(256) void k_edt_rows(const float* __restrict__ obj, int nrows, int D, int* __restrict__ g) {
+    const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (row >= nrows) return;
+    const float* src = obj + (size_t)row * D;
+    int* dst = g + (size_t)row * D;
+    const int per = (D + 63) >> 6;                       // contiguous elements per lane
+    const int lo = min(lane * per, D), hi = min(lo + per, D);
+    // last zero at or before each position: per-lane last zero, then an inclusive max-scan across lanes
+    int last = -1;
+    for (int i = lo; i < hi; ++i) if (src[i] == 0.0f) last = i;
+    int incl = last;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl = max(incl, v); }
+    int carry = __shfl_up(incl, 1);
+    if (lane == 0) carry = -1;
+    // first zero at or after each position: per-lane first zero, then an inclusive min-scan from the right
+    int first = INT_MAX;
+    for (int i = hi - 1; i >= lo; --i) if (src[i] == 0.0f) first = i;
+    int incr = first;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_down(incr, o); if (lane + o < 64) incr = min(incr, v); }
+    int carry_r = __shfl_down(incr, 1);
+    if (lane == 63) carry_r = INT_MAX;
+    // left distances in a forward walk, right distances in a backward walk
+    int l = carry;
+    for (int i = lo; i < hi; ++i) {
+        if (src[i] == 0.0f) l = i;
+        dst[i] = l < 0 ? (int)EDT_INF : i - l;
+    }
+    int r = carry_r;
+    for (int i = hi - 1; i >= lo; --i) {
+        if (src[i] == 0.0f) r = i;
+        const int dr = r == INT_MAX ? (int)EDT_INF : r - i;
+        dst[i] = min(dst[i], dr);
+    }
+}
+
+// lower envelope along one axis; SQUARE_IN: the input holds plain distances (after the row pass) and is squared on the fly
+template <bool SQUARE_IN>
+__global__ __launch_bounds__(128) void k_edt_envelope(int* __restrict__ vol, int len, int nlines, int inner, size_t line_stride,
+                                                      size_t outer_stride, int* __restrict__ scr) {
+    // line t: base = (t / inner) * outer_stride + (t % inner); consecutive elements are line_stride apart
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlines) return;
+    int* p = vol + (size_t)(t / inner) * outer_stride + (size_t)(t % inner);
+    auto F = [&](int i) -> long long { const long long v = p[(size_t)i * line_stride]; return SQUARE_IN ? v * v : v; };
+    auto S = [&](int q) -> int& { return scr[(size_t)(2 * q) * nlines + t]; };
+    auto T = [&](int q) -> int& { return scr[(size_t)(2 * q + 1) * nlines + t]; };
+    auto f = [&](long long x, int i) { const long long dx = x - i; return dx * dx + F(i); };
+    int q = 0;
+    S(0) = 0; T(0) = 0;
+    for (int u = 1; u < len; ++u) {
+        while (q >= 0 && f(T(q), S(q)) > f(T(q), u)) --q;
+        if (q < 0) { q = 0; S(0) = u; }
+        else {
+            const long long i = S(q);
+            const long long num = (long long)u * u - i * i + F(u) - F((int)i), den = 2 * ((long long)u - i);
+            const long long sep = num >= 0 ? num / den : -((-num + den - 1) / den);      // floor division
+            const long long w = 1 + sep;
+            if (w < len) { ++q; S(q) = u; T(q) = (int)w; }
+        }
+    }
+    // results go to a second scratch plane first: the inputs of this line are still needed while the envelope is evaluated
+    for (int u = len - 1; u >= 0; --u) {
+        const long long v = f(u, S(q));
+        scr[(size_t)(2 * len + u) * nlines + t] = v > INT_MAX ? INT_MAX : (int)v;
+        if (u == T(q)) --q;
+    }
+    for (int u = 0; u < len; ++u) p[(size_t)u * line_stride] = scr[(size_t)(2 * len + u) * nlines + t];
+}
+
 // ---- Hausdorff-95 building blocks (reference: cupy_hd95, self_configuring/convexAdam_hyper_util.py:32-51) ----------
 // inside = (nearest-upsampled label map == label), outside = 1 - inside; nearest index as in ATen's upsample_nearest3d with a
 // given scale factor: src = min(floor(dst * (1.0f / p)), in - 1) in float32 (:33-34)
@@ -119,8 +197,16 @@ __global__ __launch_bounds__(256) void k_label_mask(const float* __restrict__ se
         inside[i] = in ? 1.0f : 0.0f;
         outside[i] = in ? 0.0f : 1.0f;
     }
-    const unsigned long long b = __ballot(in);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
+    if (count) {                                      // one atomic per workgroup (a single hot address serialises them)
+        __shared__ unsigned int wsum[4];
+        const unsigned long long b = __ballot(in);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)__popcll(b);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (t) atomicAdd(count, (unsigned long long)t);
+        }
+    }
 }
 
 // squared Euclidean distance to the nearest zero voxel of obj (0 on the zero voxels themselves), from the feature transform
@@ -142,17 +228,31 @@ __global__ __launch_bounds__(256) void k_edt_sqdist(const float* __restrict__ ob
 __global__ __launch_bounds__(256) void k_surface_hist(const int* __restrict__ a_in2, const int* __restrict__ a_out2,
                                                       const int* __restrict__ b_in2, size_t n, int nbins,
                                                       unsigned long long* __restrict__ hist, int* __restrict__ overflow) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || b_in2[i] != 1) return;
-    const int bin = a_in2[i] + a_out2[i];
-    if (bin < 0 || bin >= nbins) { *overflow = 1; return; }
-    atomicAdd(&hist[bin], 1ull);
+    // surface voxels are close to the other surface: almost every count lands in a few low bins, which are accumulated per
+    // workgroup in LDS and flushed once (global atomics on those few addresses would serialise)
+    constexpr int LB = 2048;
+    __shared__ unsigned int low[LB];
+    for (int i = threadIdx.x; i < LB; i += blockDim.x) low[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (b_in2[i] != 1) continue;
+        const int bin = a_in2[i] + a_out2[i];
+        if (bin < 0 || bin >= nbins) { *overflow = 1; continue; }
+        if (bin < LB) atomicAdd(&low[bin], 1u);
+        else atomicAdd(&hist[bin], 1ull);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LB && i < nbins; i += blockDim.x)
+        if (low[i]) atomicAdd(&hist[i], (unsigned long long)low[i]);
 }
 
-// out[0], out[1] = value (bin index) of the k0-th and k1-th smallest entry (0-based), out[2] = number of entries; -1 if out of range
+// out[0], out[1] = value (bin index) of the k0-th and k1-th smallest entry (0-based), out[2] = number of entries; -1 if out of range.
+// k0 == -2: the two neighbours numpy.percentile interpolates for the quantile `quant` of float32 data are determined here, in
+// numpy's float32 arithmetic: virt = float32(n-1) * quant; beyond the last index both are n-1, else floor(virt) and floor(virt)+1.
 __global__ __launch_bounds__(1024) void k_hist_order_stats(const unsigned long long* __restrict__ hist, int nbins, long long k0,
-                                                           long long k1, long long* __restrict__ out) {
+                                                           long long k1, float quant, long long* __restrict__ out) {
     __shared__ unsigned long long part[1024];
+    __shared__ long long kk[2];
     const int t = threadIdx.x;
     const int per = (nbins + 1023) / 1024;
     const int lo = min(t * per, nbins), hi = min(lo + per, nbins);
@@ -164,8 +264,19 @@ __global__ __launch_bounds__(1024) void k_hist_order_stats(const unsigned long l
         unsigned long long run = 0;
         for (int i = 0; i < 1024; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
         out[0] = -1; out[1] = -1; out[2] = (long long)run;
+        if (k0 == -2) {
+            const long long n = (long long)run;
+            if (n > 0) {
+                const float last = (float)(n - 1);
+                const float virt = last * quant;
+                if (virt >= last) { k0 = k1 = n - 1; }
+                else { k0 = (long long)floorf(virt); k1 = k0 + 1; }
+            } else k0 = k1 = -1;
+        }
+        kk[0] = k0; kk[1] = k1;
     }
     __syncthreads();
+    k0 = kk[0]; k1 = kk[1];
     unsigned long long before = part[t];
     for (int i = lo; i < hi; ++i) {
         const unsigned long long c = hist[i];
@@ -213,12 +324,12 @@ extern "C" int cvx_feature_flat_index_i64(const int* feat, int H, int W, int D, 
 
 extern "C" int cvx_label_mask_f32(const float* seg, int H, int W, int D, int label, int precision, float* inside, float* outside,
                                   int64_t* count, void* stream) {
-    CVX_REQUIRE(seg && inside && outside && count, "cvx_label_mask_f32: null pointer");
+    CVX_REQUIRE(seg && inside && outside, "cvx_label_mask_f32: null pointer");     // count may be NULL
     CVX_REQUIRE(H > 0 && W > 0 && D > 0, "cvx_label_mask_f32: bad extent %dx%dx%d", H, W, D);
     CVX_REQUIRE(precision >= 1 && precision <= 8, "cvx_label_mask_f32: precision %d not in 1..8", precision);
     hipStream_t s = as_stream(stream);
     const size_t Vo = (size_t)H * W * D * precision * precision * precision;
-    if (hipMemsetAsync(count, 0, sizeof(int64_t), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "cvx_label_mask_f32: memset failed");
+    if (count && hipMemsetAsync(count, 0, sizeof(int64_t), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "cvx_label_mask_f32: memset failed");
     hipLaunchKernelGGL(k_label_mask, dim3((unsigned)cdiv64((int64_t)Vo, 256)), dim3(256), 0, s, seg, H, W, D, (float)label, precision,
                        inside, outside, reinterpret_cast<unsigned long long*>(count));
     return check_last("label_mask");
@@ -240,7 +351,8 @@ extern "C" int cvx_surface_hist_i64(const int* a_in2, const int* a_out2, const i
     hipStream_t s = as_stream(stream);
     if (hipMemsetAsync(hist, 0, sizeof(int64_t) * (size_t)nbins, s) != hipSuccess || hipMemsetAsync(overflow, 0, sizeof(int), s) != hipSuccess)
         return fail(CVX_ERR_LAUNCH, "cvx_surface_hist_i64: memset failed");
-    hipLaunchKernelGGL(k_surface_hist, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a_in2, a_out2, b_in2, (size_t)n, nbins,
+    const unsigned nb = (unsigned)(cdiv64(n, 256) < 2048 ? cdiv64(n, 256) : 2048);
+    hipLaunchKernelGGL(k_surface_hist, dim3(nb), dim3(256), 0, s, a_in2, a_out2, b_in2, (size_t)n, nbins,
                        reinterpret_cast<unsigned long long*>(hist), overflow);
     return check_last("surface_hist");
 }
@@ -249,6 +361,35 @@ extern "C" int cvx_hist_order_stats_i64(const int64_t* hist, int nbins, int64_t 
     CVX_REQUIRE(hist && out3, "cvx_hist_order_stats_i64: null pointer");
     CVX_REQUIRE(nbins > 0, "cvx_hist_order_stats_i64: bad size");
     hipLaunchKernelGGL(k_hist_order_stats, dim3(1), dim3(1024), 0, as_stream(stream), reinterpret_cast<const unsigned long long*>(hist),
-                       nbins, (long long)k0, (long long)k1, reinterpret_cast<long long*>(out3));
+                       nbins, (long long)k0, (long long)k1, 0.0f, reinterpret_cast<long long*>(out3));
     return check_last("hist_order_stats");
+}
+
+extern "C" int cvx_hist_percentile_neighbours_i64(const int64_t* hist, int nbins, float quantile, int64_t* out3, void* stream) {
+    CVX_REQUIRE(hist && out3, "cvx_hist_percentile_neighbours_i64: null pointer");
+    CVX_REQUIRE(nbins > 0 && quantile >= 0.0f && quantile <= 1.0f, "cvx_hist_percentile_neighbours_i64: bad arguments");
+    hipLaunchKernelGGL(k_hist_order_stats, dim3(1), dim3(1024), 0, as_stream(stream), reinterpret_cast<const unsigned long long*>(hist),
+                       nbins, -2ll, -2ll, quantile, reinterpret_cast<long long*>(out3));
+    return check_last("hist_percentile_neighbours");
+}
+
+extern "C" size_t cvx_edt_squared_workspace_bytes(int H, int W, int D) {
+    // per line: 2 stack entries + 1 result per element, for the pass with the largest (lines x length) = 3 * V ints
+    return 256 + sizeof(int) * 3 * (size_t)H * W * D;
+}
+
+extern "C" int cvx_edt_squared_i32(const float* obj, int H, int W, int D, int* d2, void* workspace, size_t workspace_bytes, void* stream) {
+    CVX_REQUIRE(obj && d2 && workspace, "cvx_edt_squared_i32: null pointer");
+    CVX_REQUIRE(H > 0 && W > 0 && D > 0, "cvx_edt_squared_i32: bad extent %dx%dx%d", H, W, D);
+    CVX_REQUIRE((double)H * H + (double)W * W + (double)D * D < 2147483647.0, "cvx_edt_squared_i32: extent too large for int32 squared distances");
+    if (workspace_bytes < cvx_edt_squared_workspace_bytes(H, W, D)) return fail(CVX_ERR_WORKSPACE, "cvx_edt_squared_i32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    Carver cv(workspace, workspace_bytes);
+    int* scr = cv.take<int>(3 * (size_t)H * W * D);
+    const int nrows = H * W;
+    hipLaunchKernelGGL(k_edt_rows, dim3((unsigned)cdiv(nrows, 4)), dim3(256), 0, s, obj, nrows, D, d2);
+    // along y: lines (z, x), consecutive elements D apart; along z: lines (y, x), consecutive elements W*D apart
+    hipLaunchKernelGGL(k_edt_envelope<true>, dim3((unsigned)cdiv(H * D, 128)), dim3(128), 0, s, d2, W, H * D, D, (size_t)D, (size_t)W * D, scr);
+    hipLaunchKernelGGL(k_edt_envelope<false>, dim3((unsigned)cdiv(W * D, 128)), dim3(128), 0, s, d2, H, W * D, W * D, (size_t)W * D, (size_t)0, scr);
+    return check_last("edt_squared");
 }

@@ -234,18 +234,25 @@ int cvx_feature_flat_index_i64(const int* feat, int H, int W, int D, int W_full,
 
 /* ---- Hausdorff-95 building blocks: cupy_hd95, self_configuring/convexAdam_hyper_util.py:32-51 -------------
  *   per label: dist = edt(mask) + edt(1 - mask), surf = (edt(mask) == 1), hd95 = max(P95(dist_fix[surf_mov]), P95(dist_mov[surf_fix]))
- *   cvx_label_mask_f32       : (:33-34) inside/outside masks of one label on the nearest-upsampled grid [H*p][W*p][D*p], voxel count
+ *   cvx_label_mask_f32       : (:33-34) inside/outside masks of one label on the nearest-upsampled grid [H*p][W*p][D*p], voxel count (count may be NULL)
  *   cvx_edt_sqdist_i32       : (:40,42) squared distance to the nearest zero voxel of obj from its feature transform (exact integers;
  *                              the reference's float32 distance is the correctly rounded square root)
  *   cvx_surface_hist_i64     : (:48) histogram over the squared distance a_in2 + a_out2 of the voxels with b_in2 == 1; *overflow is
  *                              set when a value does not fit nbins
- *   cvx_hist_order_stats_i64 : the k0-th / k1-th smallest value and the entry count -> out3 (np.percentile's two neighbours) */
+ *   cvx_hist_order_stats_i64 : the k0-th / k1-th smallest value and the entry count -> out3
+ *   cvx_hist_percentile_neighbours_i64 : the same for the two order statistics numpy.percentile(x, 100*quantile) interpolates for float32
+ *                              data (virtual index float32(n-1)*quantile evaluated on the device), no host round trip for n
+ *   cvx_edt_squared_i32      : (:40,42) exact squared Euclidean distance to the nearest zero voxel, distances only (Meijster's
+ *                              lower-envelope passes); 0 on zero voxels */
 int cvx_label_mask_f32(const float* seg, int H, int W, int D, int label, int precision, float* inside, float* outside,
                        int64_t* count, void* stream);
 int cvx_edt_sqdist_i32(const float* obj, const int* feat, int H, int W, int D, int* d2, void* stream);
 int cvx_surface_hist_i64(const int* a_in2, const int* a_out2, const int* b_in2, int64_t n, int nbins, int64_t* hist, int* overflow,
                          void* stream);
 int cvx_hist_order_stats_i64(const int64_t* hist, int nbins, int64_t k0, int64_t k1, int64_t* out3, void* stream);
+int cvx_hist_percentile_neighbours_i64(const int64_t* hist, int nbins, float quantile, int64_t* out3, void* stream);
+size_t cvx_edt_squared_workspace_bytes(int H, int W, int D);
+int cvx_edt_squared_i32(const float* obj, int H, int W, int D, int* d2, void* workspace, size_t workspace_bytes, void* stream);
 
 #pragma GCC visibility pop
 

@@ -546,6 +546,24 @@ def test_warp_labels_and_dice_vs_oracle(HU, morc, shape):
     assert np.array_equal(HU.dice_coeff(dev(seg2), w, 9).numpy(), morc.dice_coeff(seg2, host(w), 9))
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 4, 5), (9, 7, 70), (12, 33, 64), (20, 24, 130), (40, 5, 257)])
+def test_edt_squared_vs_scipy(HU, shape):
+    """Distance-only EDT (Meijster passes, integer arithmetic) == scipy's distances squared: random masks of several densities,
+    rows / planes without a zero voxel, a single zero voxel, a lattice (ties everywhere)."""
+    from scipy.ndimage import distance_transform_edt as edt
+    rng = np.random.default_rng(sum(shape))
+    masks = [(rng.random(shape) < pz).astype(np.float32) for pz in (0.5, 0.9, 0.995)]
+    one = np.ones(shape, np.float32); one[tuple(s // 2 for s in shape)] = 0; masks.append(one)
+    lat = np.ones(shape, np.float32); lat[::3, ::2, ::4] = 0; masks.append(lat)
+    masks.append(np.zeros(shape, np.float32))
+    for m in masks:
+        if not (m == 0).any():
+            continue
+        got = host(HU.edt_squared(dev(m)))
+        ref = np.rint(edt(m) ** 2).astype(np.int64)
+        assert np.array_equal(got.astype(np.int64), ref)
+
+
 def test_hd95_vs_golden_and_oracle(HU, morc, golden):
     """cupy_hd95 on the device (feature transforms + histogram percentile) == the reference capture and the numpy/scipy oracle."""
     g = golden("hd95")
