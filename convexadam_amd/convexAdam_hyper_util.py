@@ -226,16 +226,19 @@ def percentile_linear_from_sorted_pair(a, b, gamma):
 
 
 def edt_squared(obj):
-    """Exact squared Euclidean distance of every voxel of a (H,W,D) device tensor to its nearest ZERO voxel (0 on zero voxels),
-    int32: round(scipy.ndimage.distance_transform_edt(obj)**2) (csrc/edt.hip, Meijster's passes)."""
+    """Exact squared Euclidean distance of every voxel of a (H,W,D) -- or a batch (B,H,W,D) -- device tensor to the nearest ZERO
+    voxel of its volume (0 on zero voxels), int32: round(scipy.ndimage.distance_transform_edt(obj)**2) (csrc/edt.hip)."""
     o = f32c(require_device_tensor(obj, "obj"))
+    if o.dim() not in (3, 4):
+        raise ValueError("edt_squared: (H,W,D) or (B,H,W,D) tensor expected")
+    B = int(o.shape[0]) if o.dim() == 4 else 1
     H, W, D = [int(v) for v in o.shape[-3:]]
     L = lib()
-    out = torch.empty((H, W, D), dtype=torch.int32, device=o.device)
-    nws = L.cvx_edt_squared_workspace_bytes(H, W, D)
+    out = torch.empty(tuple(o.shape), dtype=torch.int32, device=o.device)
+    nws = L.cvx_edt_squared_workspace_bytes(B, H, W, D)
     ws = workspace(nws, o.device)
     with torch.cuda.device(o.device):
-        check(L.cvx_edt_squared_i32(ptr(o), H, W, D, ptr(out), ptr(ws), nws, stream_ptr(o.device)))
+        check(L.cvx_edt_squared_i32(ptr(o), B, H, W, D, ptr(out), ptr(ws), nws, stream_ptr(o.device)))
     return out
 
 
@@ -271,27 +274,31 @@ def cupy_hd95(fixed, moving, num_labels, precision=1):
         cnt = counts.cpu().numpy()
         present = [i for i in range(1, nl + 1) if cnt[0, i] > 0 and cnt[1, i] > 0]
         if present:
-            shape = (Ho, Wo, Do)
-            inside = torch.empty(shape, dtype=torch.float32, device=dev)
-            outside = torch.empty_like(inside)
-            dist = [[torch.empty(shape, dtype=torch.int32, device=dev) for _ in range(2)] for _ in range(2)]   # [map][in, out]
-            nws = L.cvx_edt_squared_workspace_bytes(Ho, Wo, Do)
+            n = Ho * Wo * Do
+            # labels are processed in groups: 4 volumes per label (mask / complement of both maps) go through ONE batched distance
+            # transform; the group size bounds the scratch (20 bytes per voxel and volume) to about 4 GB
+            group = max(1, min(len(present), int((4 << 30) // (80 * n))))
+            obj = torch.empty((group, 4, Ho, Wo, Do), dtype=torch.float32, device=dev)       # [label][in_f, out_f, in_m, out_m]
+            dist = torch.empty((group, 4, Ho, Wo, Do), dtype=torch.int32, device=dev)
+            nws = L.cvx_edt_squared_workspace_bytes(4 * group, Ho, Wo, Do)
             ws = workspace(nws, dev)
             hist = torch.empty(nbins, dtype=torch.int64, device=dev)
             flag = torch.zeros(2 * len(present), dtype=torch.int32, device=dev)
             out3 = torch.empty((len(present), 2, 3), dtype=torch.int64, device=dev)
             quant = float(np.true_divide(95, np.float32(100)))               # numpy: q / float32(100) for float32 data
-            n = Ho * Wo * Do
-            for j, lab in enumerate(present):
-                for k, seg in enumerate((fx, mv)):
-                    check(L.cvx_label_mask_f32(ptr(seg), H, W, D, lab, p, ptr(inside), ptr(outside), None, sp))
-                    check(L.cvx_edt_squared_i32(ptr(inside), Ho, Wo, Do, ptr(dist[k][0]), ptr(ws), nws, sp))
-                    check(L.cvx_edt_squared_i32(ptr(outside), Ho, Wo, Do, ptr(dist[k][1]), ptr(ws), nws, sp))
-                # dist1[surf2] and dist2[surf1]                                                       (:48)
-                for k in range(2):
-                    a, b = dist[k], dist[1 - k]
-                    check(L.cvx_surface_hist_i64(ptr(a[0]), ptr(a[1]), ptr(b[0]), n, nbins, ptr(hist), ptr(flag[2 * j + k:]), sp))
-                    check(L.cvx_hist_percentile_neighbours_i64(ptr(hist), nbins, quant, ptr(out3[j, k]), sp))
+            for g0 in range(0, len(present), group):
+                labs = present[g0:g0 + group]
+                for i, lab in enumerate(labs):
+                    for k, seg in enumerate((fx, mv)):
+                        check(L.cvx_label_mask_f32(ptr(seg), H, W, D, lab, p, ptr(obj[i, 2 * k]), ptr(obj[i, 2 * k + 1]), None, sp))
+                check(L.cvx_edt_squared_i32(ptr(obj), 4 * len(labs), Ho, Wo, Do, ptr(dist), ptr(ws), nws, sp))
+                for i, lab in enumerate(labs):
+                    j = g0 + i
+                    # dist1[surf2] and dist2[surf1]                                                   (:48)
+                    for k in range(2):
+                        a_in, a_out, b_in = dist[i, 2 * k], dist[i, 2 * k + 1], dist[i, 2 * (1 - k)]
+                        check(L.cvx_surface_hist_i64(ptr(a_in), ptr(a_out), ptr(b_in), n, nbins, ptr(hist), ptr(flag[2 * j + k:]), sp))
+                        check(L.cvx_hist_percentile_neighbours_i64(ptr(hist), nbins, quant, ptr(out3[j, k]), sp))
             res = out3.cpu().numpy()
             if int(flag.cpu().max()) != 0:
                 raise RuntimeError("cupy_hd95: squared distance exceeds the histogram range")

@@ -373,23 +373,29 @@ extern "C" int cvx_hist_percentile_neighbours_i64(const int64_t* hist, int nbins
     return check_last("hist_percentile_neighbours");
 }
 
-extern "C" size_t cvx_edt_squared_workspace_bytes(int H, int W, int D) {
-    // per line: 2 stack entries + 1 result per element, for the pass with the largest (lines x length) = 3 * V ints
-    return 256 + sizeof(int) * 3 * (size_t)H * W * D;
+extern "C" size_t cvx_edt_squared_workspace_bytes(int batch, int H, int W, int D) {
+    // per line: 2 stack entries + 1 result per element, for the pass with the largest (lines x length) = 3 * V ints per volume
+    return 256 + sizeof(int) * 3 * (size_t)(batch > 0 ? batch : 1) * H * W * D;
 }
 
-extern "C" int cvx_edt_squared_i32(const float* obj, int H, int W, int D, int* d2, void* workspace, size_t workspace_bytes, void* stream) {
+// `batch` independent volumes [batch][H][W][D] in one set of launches (one thread per line: a single 160 x 192 x 224 volume leaves
+// most of the GPU idle in the envelope passes)
+extern "C" int cvx_edt_squared_i32(const float* obj, int batch, int H, int W, int D, int* d2, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
     CVX_REQUIRE(obj && d2 && workspace, "cvx_edt_squared_i32: null pointer");
-    CVX_REQUIRE(H > 0 && W > 0 && D > 0, "cvx_edt_squared_i32: bad extent %dx%dx%d", H, W, D);
+    CVX_REQUIRE(batch > 0 && H > 0 && W > 0 && D > 0, "cvx_edt_squared_i32: bad extent %d x %dx%dx%d", batch, H, W, D);
     CVX_REQUIRE((double)H * H + (double)W * W + (double)D * D < 2147483647.0, "cvx_edt_squared_i32: extent too large for int32 squared distances");
-    if (workspace_bytes < cvx_edt_squared_workspace_bytes(H, W, D)) return fail(CVX_ERR_WORKSPACE, "cvx_edt_squared_i32: workspace too small");
+    CVX_REQUIRE((double)batch * H * W * D < 2147483647.0 * 0.3, "cvx_edt_squared_i32: batch too large");
+    if (workspace_bytes < cvx_edt_squared_workspace_bytes(batch, H, W, D)) return fail(CVX_ERR_WORKSPACE, "cvx_edt_squared_i32: workspace too small");
     hipStream_t s = as_stream(stream);
     Carver cv(workspace, workspace_bytes);
-    int* scr = cv.take<int>(3 * (size_t)H * W * D);
-    const int nrows = H * W;
+    int* scr = cv.take<int>(3 * (size_t)batch * H * W * D);
+    const int nrows = batch * H * W;
     hipLaunchKernelGGL(k_edt_rows, dim3((unsigned)cdiv(nrows, 4)), dim3(256), 0, s, obj, nrows, D, d2);
-    // along y: lines (z, x), consecutive elements D apart; along z: lines (y, x), consecutive elements W*D apart
-    hipLaunchKernelGGL(k_edt_envelope<true>, dim3((unsigned)cdiv(H * D, 128)), dim3(128), 0, s, d2, W, H * D, D, (size_t)D, (size_t)W * D, scr);
-    hipLaunchKernelGGL(k_edt_envelope<false>, dim3((unsigned)cdiv(W * D, 128)), dim3(128), 0, s, d2, H, W * D, W * D, (size_t)W * D, (size_t)0, scr);
+    // along y: lines (volume, z, x), consecutive elements D apart; along z: lines (volume, y, x), consecutive elements W*D apart
+    hipLaunchKernelGGL(k_edt_envelope<true>, dim3((unsigned)cdiv(batch * H * D, 128)), dim3(128), 0, s, d2, W, batch * H * D, D, (size_t)D,
+                       (size_t)W * D, scr);
+    hipLaunchKernelGGL(k_edt_envelope<false>, dim3((unsigned)cdiv(batch * W * D, 128)), dim3(128), 0, s, d2, H, batch * W * D, W * D,
+                       (size_t)W * D, (size_t)H * W * D, scr);
     return check_last("edt_squared");
 }

@@ -243,7 +243,7 @@ int cvx_feature_flat_index_i64(const int* feat, int H, int W, int D, int W_full,
  *   cvx_hist_percentile_neighbours_i64 : the same for the two order statistics numpy.percentile(x, 100*quantile) interpolates for float32
  *                              data (virtual index float32(n-1)*quantile evaluated on the device), no host round trip for n
  *   cvx_edt_squared_i32      : (:40,42) exact squared Euclidean distance to the nearest zero voxel, distances only (Meijster's
- *                              lower-envelope passes); 0 on zero voxels */
+ *                              lower-envelope passes) for `batch` independent volumes [batch][H][W][D]; 0 on zero voxels */
 int cvx_label_mask_f32(const float* seg, int H, int W, int D, int label, int precision, float* inside, float* outside,
                        int64_t* count, void* stream);
 int cvx_edt_sqdist_i32(const float* obj, const int* feat, int H, int W, int D, int* d2, void* stream);
@@ -251,8 +251,9 @@ int cvx_surface_hist_i64(const int* a_in2, const int* a_out2, const int* b_in2, 
                          void* stream);
 int cvx_hist_order_stats_i64(const int64_t* hist, int nbins, int64_t k0, int64_t k1, int64_t* out3, void* stream);
 int cvx_hist_percentile_neighbours_i64(const int64_t* hist, int nbins, float quantile, int64_t* out3, void* stream);
-size_t cvx_edt_squared_workspace_bytes(int H, int W, int D);
-int cvx_edt_squared_i32(const float* obj, int H, int W, int D, int* d2, void* workspace, size_t workspace_bytes, void* stream);
+size_t cvx_edt_squared_workspace_bytes(int batch, int H, int W, int D);
+int cvx_edt_squared_i32(const float* obj, int batch, int H, int W, int D, int* d2, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 #pragma GCC visibility pop
 

@@ -75,8 +75,9 @@ def test_argument_validation_without_gpu(L):
     assert L.cvx_surface_hist_i64(dummy, dummy, dummy, 0, 8, dummy, dummy, None) == -1
     assert L.cvx_hist_order_stats_i64(dummy, 0, 0, 0, dummy, None) == -1
     assert L.cvx_hist_percentile_neighbours_i64(dummy, 8, C.c_float(1.5), dummy, None) == -1
-    assert L.cvx_edt_squared_i32(dummy, 40000, 40000, 4, dummy, dummy, 1 << 40, None) == -1 and b"int32" in L.cvx_last_error()
-    assert L.cvx_edt_squared_i32(dummy, 4, 4, 4, dummy, dummy, 16, None) == -2
+    assert L.cvx_edt_squared_i32(dummy, 1, 40000, 40000, 4, dummy, dummy, 1 << 40, None) == -1 and b"int32" in L.cvx_last_error()
+    assert L.cvx_edt_squared_i32(dummy, 2, 4, 4, 4, dummy, dummy, 16, None) == -2
+    assert L.cvx_edt_squared_i32(dummy, 0, 4, 4, 4, dummy, dummy, 1 << 20, None) == -1
 
 
 def test_workspace_queries(L):

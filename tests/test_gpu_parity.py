@@ -562,6 +562,11 @@ def test_edt_squared_vs_scipy(HU, shape):
         got = host(HU.edt_squared(dev(m)))
         ref = np.rint(edt(m) ** 2).astype(np.int64)
         assert np.array_equal(got.astype(np.int64), ref)
+    # batched: independent volumes in one set of launches
+    keep = [m for m in masks if (m == 0).any()]
+    got = host(HU.edt_squared(dev(np.stack(keep))))
+    for i, m in enumerate(keep):
+        assert np.array_equal(got[i].astype(np.int64), np.rint(edt(m) ** 2).astype(np.int64)), i
 
 
 def test_hd95_vs_golden_and_oracle(HU, morc, golden):
