@@ -17,11 +17,19 @@
 
 namespace cvx {
 
-constexpr int MM_TY = 8, MM_TX = 64, MM_NT = 512, MM_NS = 4, MM_CPS = 3;     // 4 wave groups x 3 channels
-constexpr int MM_RP = 74;                         // ring row pitch (floats): 2 (mod 4) -> the 8-byte reads of two adjacent rows hit disjoint banks
-constexpr int MM_ROWS = MM_TY + 6;                // ring row r = volume row clamp(y0 - 3 + r); ring column k = volume column clamp(x0 - 5 + k)
-constexpr int MM_PLANE = MM_ROWS * MM_RP;
-constexpr int MM_LQ = 18;                         // loader quads per row: columns x0-4 .. x0+67
+constexpr int MM_NT = 512, MM_NS = 4, MM_CPS = 3;     // 4 wave groups x 3 channels
+// Tile shapes: 8 rows x 64 columns, or 16 x 32 when the last 64-column tile of a row would be at most half full (D = 224: 7 tiles
+// of 32 instead of 3.5 of 64).  A wave group (128 threads) covers the TY x TX/4 quads of the tile either way.
+template <int TY_, int TX_>
+struct MMGeo {
+    static constexpr int TY = TY_, TX = TX_, TXQ = TX_ / 4;
+    static constexpr int RP = TX_ + 10;           // ring row pitch (floats): 2 (mod 4) -> for TX = 64 the 8-byte reads of two adjacent rows hit disjoint
+                                                  // banks (TX = 32: four rows per 32-lane group, 2-way conflicts; the LDS is not the bound)
+    static constexpr int ROWS = TY_ + 6;          // ring row r = volume row clamp(y0 - 3 + r); ring column k = volume column clamp(x0 - 5 + k)
+    static constexpr int PLANE = ROWS * RP;
+    static constexpr int LQ = TXQ + 2;            // loader quads per row: columns x0-4 .. x0+TX+3
+    static_assert(TY_ * TXQ == 128 && ROWS * LQ <= MM_NT, "tile shape");
+};
 __device__ constexpr int MM_SETS[MM_NS][MM_CPS] = {{0, 1, 2}, {3, 4, 5}, {6, 7, 8}, {9, 10, 11}};   // pre-permutation channels of the wave groups
 
 struct MMLoader {
@@ -43,9 +51,10 @@ __device__ __forceinline__ void mm_fetch(const float* __restrict__ img, int H, i
         v.w = row[clampi(L.gx + 3, 0, D - 1)];
     }
 }
+template <int PLANE>
 __device__ __forceinline__ void mm_publish(const MMLoader& L, float* ring, int l, const float4& v) {
     if (!L.on) return;
-    float* p = L.dst + ((l + 12) % 6) * MM_PLANE;           // odd index: b32 + b64 + b32
+    float* p = L.dst + ((l + 12) % 6) * PLANE;           // odd index: b32 + b64 + b32
     p[0] = v.x;
     const f32x2 mid = {v.y, v.z};
     lds_store2(p + 1, mid);
@@ -53,22 +62,22 @@ __device__ __forceinline__ void mm_publish(const MMLoader& L, float* ring, int l
 }
 
 // one plane of one wave group: taps of squared-difference plane zc -> running sums; EMIT: output plane gz is due
-template <int SET, bool EMIT>
+template <typename G, int SET, bool EMIT>
 __device__ __forceinline__ void mm_box_step(const float* __restrict__ ring, float* __restrict__ X, float* __restrict__ out, size_t V,
                                             size_t lin, bool store_ok, int zc, const int (&rowoff)[3], int colbase, bool left,
                                             bool right, int row, int q, float (&A)[MM_CPS][4], float (&P)[MM_CPS][4]) {
     constexpr MindOffsets MO{};
     const float* sb[3];
 #pragma unroll
-    for (int o = 0; o < 3; ++o) sb[o] = ring + ((zc + 2 * (o - 1) + 12) % 6) * MM_PLANE + colbase;
+    for (int o = 0; o < 3; ++o) sb[o] = ring + ((zc + 2 * (o - 1) + 12) % 6) * G::PLANE + colbase;
 #pragma unroll
     for (int k = 0; k < MM_CPS; ++k) {
         const int c = MM_SETS[SET][k];
         float t[3][6];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float* p1 = sb[MO.o1[c][0] + 1] + rowoff[i] + 2 * MO.o1[c][1] * MM_RP + 2 * MO.o1[c][2];
-            const float* p2 = sb[MO.o2[c][0] + 1] + rowoff[i] + 2 * MO.o2[c][1] * MM_RP + 2 * MO.o2[c][2];
+            const float* p1 = sb[MO.o1[c][0] + 1] + rowoff[i] + 2 * MO.o1[c][1] * G::RP + 2 * MO.o1[c][2];
+            const float* p2 = sb[MO.o2[c][0] + 1] + rowoff[i] + 2 * MO.o2[c][1] * G::RP + 2 * MO.o2[c][2];
             const f32x2 a0 = lds_load2(p1), a1 = lds_load2(p1 + 2), a2 = lds_load2(p1 + 4);
             const f32x2 b0 = lds_load2(p2), b1 = lds_load2(p2 + 2), b2 = lds_load2(p2 + 4);
             float d0 = a0.x - b0.x, d1 = a0.y - b0.y, d2 = a1.x - b1.x, d3 = a1.y - b1.y, d4 = a2.x - b2.x, d5 = a2.y - b2.y;
@@ -98,26 +107,26 @@ __device__ __forceinline__ void mm_box_step(const float* __restrict__ ring, floa
         }
         if (EMIT) {
             const f32x4 r = {dv[0], dv[1], dv[2], dv[3]};
-            lds_store4(X + c * (MM_TY * MM_TX) + row * MM_TX + 4 * q, r);
+            lds_store4(X + c * (G::TY * G::TX) + row * G::TX + 4 * q, r);
             if (store_ok) *reinterpret_cast<float4*>(out + (size_t)MIND_INV[c] * V + lin) = make_float4(r.x, r.y, r.z, r.w);
         }
     }
 }
 
-template <int SET>
+template <typename G, int SET>
 __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __restrict__ out, MindStats* __restrict__ st, float* ring,
                                        float* X, double (*red)[MM_NT / 64], int H, int W, int D, int z0, int z1, int y0, int x0,
                                        MMLoader& L) {
     const int tid = threadIdx.x, t128 = tid & 127;
-    const int row = t128 >> 4, q = t128 & 15;
+    const int row = t128 / G::TXQ, q = t128 % G::TXQ;
     const int gy = y0 + row, gx0 = x0 + 4 * q;
     const size_t V = (size_t)H * W * D;
     int rowoff[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) rowoff[i] = (clampi(gy + i - 1, 0, W - 1) - y0 + 3) * MM_RP;
+    for (int i = 0; i < 3; ++i) rowoff[i] = (clampi(gy + i - 1, 0, W - 1) - y0 + 3) * G::RP;
     // rows beyond the volume (overhanging tile): clamp keeps the reads inside the ring
 #pragma unroll
-    for (int i = 0; i < 3; ++i) rowoff[i] = min(rowoff[i], (MM_ROWS - 3) * MM_RP);
+    for (int i = 0; i < 3; ++i) rowoff[i] = min(rowoff[i], (G::ROWS - 3) * G::RP);
     const int colbase = 4 * q + 4;
     const bool left = gx0 == 0, right = gx0 + 4 == D;
     const bool store_ok = gy < W && gx0 < D;
@@ -128,7 +137,7 @@ __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __r
         for (int j = 0; j < 4; ++j) { A[k][j] = 0.0f; P[k][j] = 0.0f; }
 
     // statistics: every thread owns one voxel of the plane
-    const int srow = tid >> 6, scol = tid & 63;
+    const int srow = tid / G::TX, scol = tid % G::TX;
     const double m1 = st->m1, m2 = st->m2, m3 = st->m3;
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const size_t tail_from = (V / 32) * 32;
@@ -137,7 +146,7 @@ __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __r
     auto stats = [&](const float* Xb, int gz) {
         float r[12];
 #pragma unroll
-        for (int c = 0; c < 12; ++c) r[c] = Xb[c * (MM_TY * MM_TX) + srow * MM_TX + scol];
+        for (int c = 0; c < 12; ++c) r[c] = Xb[c * (G::TY * G::TX) + srow * G::TX + scol];
         const int sy = y0 + srow, sx = x0 + scol;
         float mn = r[0];
 #pragma unroll
@@ -159,20 +168,20 @@ __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __r
     };
     // One barrier per plane: step s publishes ring plane zc+2 into the slot that no reader of step s-1 touches (6 slots), the
     // box pass writes exchange buffer s & 1 and the statistics read the buffer of the previous step.
-    constexpr int XSZ = 12 * MM_TY * MM_TX;
+    constexpr int XSZ = 12 * G::TY * G::TX;
     const int nsteps = (z1 - z0) + 2;
     int zc_prev = clampi(z0 - 1, 0, H - 1);
     for (int s = 0; s < nsteps; ++s) {
         const int zc = clampi(z0 - 1 + s, 0, H - 1);
-        if (zc != zc_prev) mm_publish(L, ring, zc + 2, L.pre);
+        if (zc != zc_prev) mm_publish<G::PLANE>(L, ring, zc + 2, L.pre);
         mm_fetch(img, H, W, D, L, zc + 3, L.pre);
         zc_prev = zc;
         __syncthreads();
         const int gz = z0 + s - 2;
         const size_t lin = ((size_t)(gz < 0 ? 0 : gz) * W + (gy < W ? gy : 0)) * D + (gx0 < D ? gx0 : 0);
         float* Xs = X + (s & 1) * XSZ;
-        if (s >= 2) mm_box_step<SET, true>(ring, Xs, out, V, lin, store_ok, zc, rowoff, colbase, left, right, row, q, A, P);
-        else mm_box_step<SET, false>(ring, Xs, out, V, lin, store_ok, zc, rowoff, colbase, left, right, row, q, A, P);
+        if (s >= 2) mm_box_step<G, SET, true>(ring, Xs, out, V, lin, store_ok, zc, rowoff, colbase, left, right, row, q, A, P);
+        else mm_box_step<G, SET, false>(ring, Xs, out, V, lin, store_ok, zc, rowoff, colbase, left, right, row, q, A, P);
         if (s >= 3) stats(X + ((s - 1) & 1) * XSZ, gz - 1);
     }
     __syncthreads();
@@ -187,26 +196,27 @@ __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __r
     }
 }
 
+template <typename G>
 __global__ __launch_bounds__(MM_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mind_march(const float* __restrict__ img, int H, int W, int D, int zc_len, int nzc, int nyt,
                                                       int nxt, MindStats* __restrict__ st, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float ring[6 * MM_PLANE];      // 5 live planes + the one being replaced
-    __shared__ __attribute__((aligned(16))) float X[2 * 12 * MM_TY * MM_TX];   // double buffered
+    __shared__ __attribute__((aligned(16))) float ring[6 * G::PLANE];      // 5 live planes + the one being replaced
+    __shared__ __attribute__((aligned(16))) float X[2 * 12 * G::TY * G::TX];   // double buffered
     __shared__ double red[3][MM_NT / 64];
     // XCD-aware order: XCD k (workgroups k, k+8, ..) takes the k-th contiguous run of (z chunk, y tile, x tile) triples
     const int nblk = nzc * nyt * nxt;
     const int b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     if (b >= nblk) return;
     const int xi = b % nxt, yi = (b / nxt) % nyt, zi = b / (nxt * nyt);
-    const int x0 = xi * MM_TX, y0 = yi * MM_TY, z0 = zi * zc_len, z1 = min(H, z0 + zc_len);
+    const int x0 = xi * G::TX, y0 = yi * G::TY, z0 = zi * zc_len, z1 = min(H, z0 + zc_len);
     const int tid = threadIdx.x;
 
     MMLoader L;
-    L.on = tid < MM_ROWS * MM_LQ;
-    const int lr = tid / MM_LQ, lq = tid - lr * MM_LQ;
+    L.on = tid < G::ROWS * G::LQ;
+    const int lr = tid / G::LQ, lq = tid - lr * G::LQ;
     L.gy = clampi(y0 - 3 + lr, 0, W - 1);
     L.gx = x0 - 4 + 4 * lq;
     L.fast = L.gx >= 0 && L.gx + 3 <= D - 1;
-    L.dst = ring + lr * MM_RP + 4 * lq + 1;
+    L.dst = ring + lr * G::RP + 4 * lq + 1;
     L.pre = make_float4(0.f, 0.f, 0.f, 0.f);
     // ring around the first centre plane
     const int zc0 = clampi(z0 - 1, 0, H - 1);
@@ -215,14 +225,14 @@ __global__ __launch_bounds__(MM_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
         for (int o = 0; o < 5; ++o) { v[o] = make_float4(0.f, 0.f, 0.f, 0.f); mm_fetch(img, H, W, D, L, zc0 - 2 + o, v[o]); }
 #pragma unroll
-        for (int o = 0; o < 5; ++o) mm_publish(L, ring, zc0 - 2 + o, v[o]);
+        for (int o = 0; o < 5; ++o) mm_publish<G::PLANE>(L, ring, zc0 - 2 + o, v[o]);
     }
     // (the first barrier of the march makes the ring visible)
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 7);
-    if (grp == 0) mm_run<0>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
-    else if (grp == 1) mm_run<1>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
-    else if (grp == 2) mm_run<2>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
-    else mm_run<3>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
+    if (grp == 0) mm_run<G, 0>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
+    else if (grp == 1) mm_run<G, 1>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
+    else if (grp == 2) mm_run<G, 2>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
+    else mm_run<G, 3>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
 }
 
 bool mind_march_supported(const float* img, const float* out, int H, int W, int D, int radius, int dilation) {
@@ -231,8 +241,9 @@ bool mind_march_supported(const float* img, const float* out, int H, int W, int 
     return radius == 1 && dilation == 2 && (D & 3) == 0 && al(img) && al(out);
 }
 
-void launch_mind_march(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s) {
-    const int nyt = cdiv(W, MM_TY), nxt = cdiv(D, MM_TX);
+template <typename G>
+static void launch_mind_march_g(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s) {
+    const int nyt = cdiv(W, G::TY), nxt = cdiv(D, G::TX);
     // two workgroups per CU (register bound): at most 512 workgroups so that all of them are resident at once -- a second,
     // partly filled round costs more than the longer chunks; chunks of at least 8 planes keep the 2-plane fill below 25 %
     static const int slots = getenv("CVX_MM_SLOTS") ? atoi(getenv("CVX_MM_SLOTS")) : 512;
@@ -242,7 +253,15 @@ void launch_mind_march(const float* img, int H, int W, int D, MindStats* st, flo
     if (zc_len < 8) zc_len = 8;
     nzc = cdiv(H, zc_len);
     const unsigned grid = (unsigned)((nzc * nyt * nxt + 7) / 8 * 8);
-    hipLaunchKernelGGL(k_mind_march, dim3(grid), dim3(MM_NT), 0, s, img, H, W, D, zc_len, nzc, nyt, nxt, st, out);
+    hipLaunchKernelGGL(k_mind_march<G>, dim3(grid), dim3(MM_NT), 0, s, img, H, W, D, zc_len, nzc, nyt, nxt, st, out);
+}
+
+void launch_mind_march(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s) {
+    static const int force = getenv("CVX_MM_TX") ? atoi(getenv("CVX_MM_TX")) : 0;
+    const int rem = D % 64;
+    const bool narrow = force ? force == 32 : (rem != 0 && rem <= 32);
+    if (narrow) launch_mind_march_g<MMGeo<16, 32>>(img, H, W, D, st, out, s);
+    else launch_mind_march_g<MMGeo<8, 64>>(img, H, W, D, st, out, s);
 }
 
 }  // namespace cvx
