@@ -537,7 +537,7 @@ extern "C" int cvx_inverse_consistency_f32(const float* f1, const float* f2, int
         const bool to_out = ((iters - 1 - it) & 1) == 0;
         float* d1 = to_out ? o1 : t1;
         float* d2 = to_out ? o2 : t2;
-        hipLaunchKernelGGL(k_ic_step, gv, dim3(256), 0, s, s1, s2, h, w, d, base_h, base_w, base_d, d1, d2);
+        hipLaunchKernelGGL(k_ic_step, dim3((unsigned)cdiv64((int64_t)v, 64)), dim3(64), 0, s, s1, s2, h, w, d, base_h, base_w, base_d, d1, d2);   // one wave per workgroup: the 30 000 voxels spread over all CUs
         s1 = d1; s2 = d2;
     }
     return check_last("inverse_consistency");
