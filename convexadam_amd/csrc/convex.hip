@@ -107,15 +107,37 @@ template <typename IndexT>
 __device__ __forceinline__ void smooth_winner(const IndexT* __restrict__ idx, const float* __restrict__ mesh, int K, int h, int w,
                                               int d, size_t i, float& o0, float& o1, float& o2) {
     const int x = (int)(i % d), y = (int)((i / d) % w), z = (int)(i / ((size_t)d * w));
+    // Fully unrolled with clamped (always valid) addresses: the 9 winners of a plane are fetched together, then their 27 mesh
+    // entries; taps outside the volume contribute an exact +0.0 (a partial sum that starts at +0.0 is never -0.0, so adding
+    // +0.0 changes nothing) -- two memory round trips per plane instead of two per tap.
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int a = max(z - 1, 0); a <= min(z + 1, h - 1); ++a)
-        for (int b = max(y - 1, 0); b <= min(y + 1, w - 1); ++b)
-            for (int c = max(x - 1, 0); c <= min(x + 1, d - 1); ++c) {
-                const int k = (int)(unsigned)idx[((size_t)a * w + b) * d + c];
-                s0 += mesh[k];
-                s1 += mesh[K + k];
-                s2 += mesh[2 * K + k];
+#pragma unroll
+    for (int a = -1; a <= 1; ++a) {
+        const int za = z + a;
+        const bool zok = za >= 0 && za < h;
+        const int zc = zok ? za : z;
+        int kk[9];
+        bool ok[9];
+#pragma unroll
+        for (int b = -1; b <= 1; ++b)
+#pragma unroll
+            for (int c = -1; c <= 1; ++c) {
+                const int yb = y + b, xc = x + c;
+                const bool in = zok && yb >= 0 && yb < w && xc >= 0 && xc < d;
+                const int t = (b + 1) * 3 + (c + 1);
+                ok[t] = in;
+                kk[t] = (int)(unsigned)idx[((size_t)zc * w + (in ? yb : y)) * d + (in ? xc : x)];
             }
+        float m0[9], m1[9], m2[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { m0[t] = mesh[kk[t]]; m1[t] = mesh[K + kk[t]]; m2[t] = mesh[2 * K + kk[t]]; }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            s0 += ok[t] ? m0[t] : 0.0f;
+            s1 += ok[t] ? m1[t] : 0.0f;
+            s2 += ok[t] ? m2[t] : 0.0f;
+        }
+    }
     o0 = fdiv(s0, 27.0f);
     o1 = fdiv(s1, 27.0f);
     o2 = fdiv(s2, 27.0f);
@@ -127,18 +149,18 @@ struct CandBox {
     long long vol;
     bool degenerate;
 };
-template <typename PrevT>
-__device__ __forceinline__ CandBox cand_box(const float* __restrict__ ssd, const float* __restrict__ mesh, float uc, float ub, float ua,
-                                            float coef, int K, int n, size_t v, const float* __restrict__ smin,
-                                            const PrevT* __restrict__ kprev, size_t x) {
+// kp = previous winner of the voxel (low 32 bits of its key), ssd_kp = ssd[kp, x], sm_x = smin[x]: fetched by the caller, who can
+// issue these loads before the smoothing step instead of after it (one memory round trip less on the critical path)
+__device__ __forceinline__ CandBox cand_box(const float* __restrict__ mesh, float uc, float ub, float ua, float coef, int K, int n,
+                                            int kp, float ssd_kp, float sm_x) {
     CandBox c;
-    c.uc = uc; c.ub = ub; c.ua = ua; c.sm = smin[x];
-    c.kp = (int)(unsigned)kprev[x];                                     // low 32 bits of a key = displacement index
+    c.uc = uc; c.ub = ub; c.ua = ua; c.sm = sm_x;
+    c.kp = kp;
     const float e0 = mesh[c.kp] - c.uc, e1 = mesh[K + c.kp] - c.ub, e2 = mesh[2 * K + c.kp] - c.ua;
     float q = e0 * e0;
     q += e1 * e1;
     q += e2 * e2;
-    c.bound = ssd[(size_t)c.kp * v + x] + coef * q;                     // the reference cost of the previous winner
+    c.bound = ssd_kp + coef * q;                                        // the reference cost of the previous winner
     const float hwf = (float)((n - 1) / 2);
     const float qmax = fdiv((c.bound - c.sm) + fabsf(c.bound) * 2.384185791015625e-07f, coef) * 1.00001f;
     const float R = fsqrt(fmaxf(qmax, 0.0f)) * 1.00001f + 1.0e-4f;
@@ -176,10 +198,14 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const float* __restrict__ s
     const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x == 0) *next_count = 0;                            // list length of the NEXT pass (the two counters alternate)
     if (x >= v) return;
+    // the voxel's own previous winner, its cost and the per-voxel minimum do not depend on the smoothing: loads issued first
+    const int kp = (int)(unsigned)kprev[x];                 // low 32 bits of a key = displacement index
+    const float ssd_kp = ssd[(size_t)kp * v + x];
+    const float sm_x = smin[x];
     float uc, ub, ua;
     smooth_winner(kprev, mesh, K, h, w, d, x, uc, ub, ua);
     u[x] = uc; u[v + x] = ub; u[2 * v + x] = ua;
-    const CandBox c = cand_box(ssd, mesh, uc, ub, ua, coef, K, n, v, smin, kprev, x);
+    const CandBox c = cand_box(mesh, uc, ub, ua, coef, K, n, kp, ssd_kp, sm_x);
     if (c.vol > limit) {                // hand the box over in chunks of 256 displacements: (voxel << 8 | chunk) work items
         const int nchunks = (int)((c.vol + 255) >> 8);
         const int at = atomicAdd(list_count, nchunks);
@@ -224,7 +250,8 @@ __global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ s
         const unsigned long long item = list[e];
         const size_t x = (size_t)(item >> 8);
         const long long first = (long long)(item & 255) << 8;              // 256 displacements of the box: 4 per lane
-        const CandBox c = cand_box(ssd, mesh, u[x], u[v + x], u[2 * v + x], coef, K, n, v, smin, kprev, x);
+        const int kp = (int)(unsigned)kprev[x];
+        const CandBox c = cand_box(mesh, u[x], u[v + x], u[2 * v + x], coef, K, n, kp, ssd[(size_t)kp * v + x], smin[x]);
         const int nc = c.c_hi - c.c_lo + 1, nb = c.b_hi - c.b_lo + 1;
         int kk[4];
         float pen[4];
