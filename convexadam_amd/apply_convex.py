@@ -5,14 +5,14 @@
 `disp` is the (H,W,D,3) field convex_adam_pt returns (channel a = displacement along axis a, voxels); `moving` any
 (H,W,D) array or tensor.  Like scipy, the interpolation runs in float64; numpy inputs are converted with
 `astype(float)` exactly as validate_image does (convex_adam_utils.py:268-279), tensors keep their dtype for the result.
-apply_convex_original_moving (:27-78) resamples with SimpleITK and rotates by the direction cosines: host-side geometry,
-out of scope.
+apply_convex_original_moving (:27-78): the field is first carried onto the grid, axes and voxel size of the original moving image
+(host-side SimpleITK geometry, convex_adam_utils.rescale_displacement_field), then the warp above runs on the device.
 """
 import numpy as np
 import torch
 
 from ._lib import check, lib, ptr, stream_ptr
-from .convex_adam_utils import validate_image
+from .convex_adam_utils import rescale_displacement_field, validate_image
 
 
 def apply_convex(disp, moving, device=None) -> np.ndarray:
@@ -30,3 +30,16 @@ def apply_convex(disp, moving, device=None) -> np.ndarray:
     with torch.cuda.device(dev):
         check(lib().cvx_map_coordinates_linear_f64(ptr(m), ptr(d), H, W, D, ptr(out), stream_ptr(dev)))
     return out.to(out_dtype).cpu().numpy()
+
+
+
+def apply_convex_original_moving(disp, moving_image_original, fixed_image_original, fixed_image_resampled):
+    """Warp the ORIGINAL moving image (its own grid, orientation and spacing) with a field estimated on the resampled fixed grid
+    (apply_convex.py:27-78): SimpleITK images in, SimpleITK float32 image with the moving image's geometry out."""
+    import SimpleITK as sitk  # noqa: N813  (same dependency as the reference; rescale_displacement_field reports its absence)
+    field = validate_image(disp).cpu().numpy()
+    field = rescale_displacement_field(field, moving_image_original, fixed_image_original, fixed_image_resampled)
+    warped = apply_convex(disp=field, moving=moving_image_original)
+    out = sitk.GetImageFromArray(warped.astype(np.float32))
+    out.CopyInformation(moving_image_original)
+    return out

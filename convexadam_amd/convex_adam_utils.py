@@ -236,6 +236,66 @@ def validate_image(img):
     return img
 
 
+# ---- geometry helpers around the registration (host side, SimpleITK images; convex_adam_utils.py:282-351) ------------------------
+# Kept importable under the reference's names (tests/test_convex_adam_mind_aniso.py:10-12, convex_adam_translation.py:9).  They
+# are glue around SimpleITK's resampler -- no device work -- and need the same optional dependency as the reference.
+def _sitk():
+    try:
+        import SimpleITK as sitk  # noqa: N813
+    except ImportError as e:
+        raise ImportError("this helper wraps SimpleITK's resampler (as in the reference, convex_adam_utils.py:282-351); "
+                          "SimpleITK is not installed") from e
+    return sitk
+
+
+def _linear_resampler(sitk, spacing, size, direction, origin):
+    r = sitk.ResampleImageFilter()
+    r.SetInterpolator(sitk.sitkLinear)
+    r.SetTransform(sitk.Transform())          # identity
+    r.SetDefaultPixelValue(0)                 # outside the source: zero
+    r.SetOutputSpacing(spacing)
+    r.SetSize(size)
+    r.SetOutputDirection(direction)
+    r.SetOutputOrigin(origin)
+    return r
+
+
+def resample_img(img, spacing):
+    """Linear resampling of a SimpleITK image to `spacing` on its own origin / orientation; size = floor(n * old / new + 0.5)."""
+    sitk = _sitk()
+    size = [int(n * old / new + 0.5) for n, old, new in zip(img.GetSize(), img.GetSpacing(), spacing)]
+    return _linear_resampler(sitk, spacing, size, img.GetDirection(), img.GetOrigin()).Execute(img)
+
+
+def resample_moving_to_fixed(fixed, moving):
+    """Linear resampling of `moving` onto the voxel grid of `fixed` (zero outside)."""
+    sitk = _sitk()
+    return _linear_resampler(sitk, fixed.GetSpacing(), fixed.GetSize(), fixed.GetDirection(), fixed.GetOrigin()).Execute(moving)
+
+
+def rescale_displacement_field(displacement_field, moving_image, fixed_image, fixed_image_resampled):
+    """Displacement field (H,W,D,3; components z,y,x in voxels of `fixed_image_resampled`) -> the grid, axes and voxel size of the
+    original `moving_image`: every component is resampled onto the moving grid, the vectors are rotated by the rotation between
+    the two direction-cosine frames and scaled by the spacing ratio."""
+    sitk = _sitk()
+    field = np.asarray(displacement_field)
+    onto_moving = sitk.ResampleImageFilter()
+    onto_moving.SetReferenceImage(moving_image)
+    onto_moving.SetInterpolator(sitk.sitkLinear)
+    comps = []
+    for axis in range(3):
+        comp = sitk.GetImageFromArray(field[..., axis])
+        comp.CopyInformation(fixed_image_resampled)
+        comps.append(sitk.GetArrayFromImage(onto_moving.Execute(comp)))
+    moved = np.stack(comps, axis=-1)                                   # (..., 3) in z, y, x order
+    frame_fixed = np.array(fixed_image.GetDirection()).reshape(3, 3)
+    frame_moving = np.array(moving_image.GetDirection()).reshape(3, 3)
+    rot = np.linalg.inv(frame_fixed) @ frame_moving
+    rotated = (moved[..., ::-1] @ rot)[..., ::-1]                      # rotate in x, y, z order, back to z, y, x
+    ratio = np.array(fixed_image_resampled.GetSpacing()) / np.array(moving_image.GetSpacing())     # x, y, z
+    return rotated * ratio[::-1]
+
+
 def gpu_usage():
     print('gpu usage (current/max): {:.2f} / {:.2f} GB'.format(torch.cuda.memory_allocated() * 1e-9,
                                                                  torch.cuda.max_memory_allocated() * 1e-9))

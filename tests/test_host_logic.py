@@ -104,3 +104,29 @@ def test_sharded_driver_gloo_world_size_2(tmp_path):
     assert res["world_size"] == 2 and res["n_items"] == 15
     assert sorted(res["items_done"]) == list(range(15))
     assert sorted(len(v) for v in res["per_rank"].values()) == [7, 8]
+
+
+def test_geometry_helpers_importable_under_reference_names():
+    """tests/test_convex_adam_mind_aniso.py:10-12, convex_adam_translation.py:9 and apply_convex.py:13,27 of the reference: these
+    names are imported from convexAdam.*; the geometry helpers wrap SimpleITK and say so when it is missing.  (Own process: the
+    import shim must not shadow the live reference import of tests/test_oracle_vs_reference_live.py.)"""
+    code = """
+import numpy as np
+from convexAdam.convex_adam_utils import resample_img, resample_moving_to_fixed, rescale_displacement_field
+from convexAdam.apply_convex import apply_convex, apply_convex_original_moving
+try:
+    import SimpleITK
+except ImportError:
+    for fn, args in ((resample_img, (None, (1.0, 1.0, 1.0))), (resample_moving_to_fixed, (None, None)),
+                     (rescale_displacement_field, (np.zeros((2, 2, 2, 3)), None, None, None))):
+        try:
+            fn(*args)
+        except ImportError as e:
+            assert "SimpleITK" in str(e)
+        else:
+            raise SystemExit("no ImportError from " + fn.__name__)
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
