@@ -130,3 +130,21 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_translation_wrapper_arithmetic():
+    """convex_adam_translation.py:12-29, 88-103 of the reference: direction-cosine product and the field -> whole-voxel translation
+    reduction (checked against the reference's expressions written out with numpy)."""
+    from convexadam_amd.convex_adam_translation import field_to_translation, index_translation_to_world_translation
+    rng = np.random.default_rng(4)
+    direction = (0.0, -1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0)
+    assert np.array_equal(index_translation_to_world_translation((1.0, 2.0, 3.0), direction), np.array([-2.0, 1.0, 3.0]))
+    field = rng.standard_normal((5, 6, 7, 3)) * 4
+    spacing_xyz = (0.7, 1.5, 3.0)
+    mask = rng.random((5, 6, 7)) > 0.5
+    for m in (None, mask):
+        t_zyx = np.mean(field[m], axis=0) if m is not None else np.mean(field, axis=(0, 1, 2))
+        sp_zyx = np.array(list(spacing_xyz)[::-1])
+        ref = tuple(list((np.round(t_zyx / sp_zyx, decimals=0) * sp_zyx)[::-1]))
+        assert field_to_translation(field, spacing_xyz, m) == ref
+
