@@ -34,8 +34,8 @@ def _require_hip(device):
 
 
 def _load_mask(path):
-    import nibabel as nib   # same dependency as the reference (:94-95)
-    return torch.from_numpy(nib.load(path).get_fdata()).float()
+    from .nifti_io import load_fdata   # nib.load(path).get_fdata() (:94-95); built-in NIfTI-1 reader when nibabel is absent
+    return torch.from_numpy(load_fdata(path)).float()
 
 
 def feature_transform(obj):
@@ -270,17 +270,16 @@ def convex_adam(
     verbose: bool = False,
 ) -> None:
     """File wrapper: reads two NIfTI images, writes `disp.nii.gz` with the fixed image's affine.
-    (convex_adam_MIND.py:205-248; needs nibabel like the reference)"""
-    import nibabel as nib
-    img_fixed = torch.from_numpy(nib.load(path_img_fixed).get_fdata()).float()
-    img_moving = torch.from_numpy(nib.load(path_img_moving).get_fdata()).float()
+    (convex_adam_MIND.py:205-248; through nibabel when it is installed, else the built-in NIfTI-1 reader / writer of nifti_io.py)"""
+    from .nifti_io import load_affine, load_fdata, save_image
+    img_fixed = torch.from_numpy(load_fdata(path_img_fixed)).float()
+    img_moving = torch.from_numpy(load_fdata(path_img_moving)).float()
     displacements = convex_adam_pt(img_fixed=img_fixed, img_moving=img_moving, mind_r=mind_r, mind_d=mind_d,
                                    lambda_weight=lambda_weight, grid_sp=grid_sp, disp_hw=disp_hw,
                                    selected_niter=selected_niter, selected_smooth=selected_smooth,
                                    grid_sp_adam=grid_sp_adam, ic=ic, use_mask=use_mask, path_fixed_mask=path_fixed_mask,
                                    path_moving_mask=path_moving_mask, verbose=verbose)
-    affine = nib.load(path_img_fixed).affine
-    nib.save(nib.Nifti1Image(displacements, affine), os.path.join(result_path, 'disp.nii.gz'))
+    save_image(displacements, load_affine(path_img_fixed), os.path.join(result_path, 'disp.nii.gz'))
 
 
 if __name__ == "__main__":

@@ -61,14 +61,13 @@ def convex_adam_pt(pred_fixed, pred_moving, lambda_weight, grid_sp, disp_hw, sel
 def convex_adam(path_pred_fixed, path_pred_moving, lambda_weight, grid_sp, disp_hw, selected_niter, selected_smooth,
                 grid_sp_adam=2, ic=True, result_path='./'):
     """File wrapper (convex_adam_nnUNet.py:41-159): NIfTI label maps in, `disp.nii.gz` out."""
-    import nibabel as nib
-    pred_fixed = torch.from_numpy(nib.load(path_pred_fixed).get_fdata()).float()
-    pred_moving = torch.from_numpy(nib.load(path_pred_moving).get_fdata()).float()
+    from .nifti_io import load_affine, load_fdata, save_image      # nibabel when installed, else the built-in NIfTI-1 reader / writer
+    pred_fixed = torch.from_numpy(load_fdata(path_pred_fixed)).float()
+    pred_moving = torch.from_numpy(load_fdata(path_pred_moving)).float()
     torch.cuda.synchronize()
     t0 = time.time()
     displacements = convex_adam_pt(pred_fixed, pred_moving, lambda_weight, grid_sp, disp_hw, selected_niter, selected_smooth,
                                    grid_sp_adam, ic)
     torch.cuda.synchronize()
     print('case time: ', time.time() - t0)
-    affine = nib.load(path_pred_fixed).affine
-    nib.save(nib.Nifti1Image(displacements, affine), os.path.join(result_path, 'disp.nii.gz'))
+    save_image(displacements, load_affine(path_pred_fixed), os.path.join(result_path, 'disp.nii.gz'))

@@ -592,6 +592,26 @@ def test_hd95_vs_golden_and_oracle(HU, morc, golden):
         HU.cupy_hd95(sf, sm, 6, precision=0.5)
 
 
+def test_file_wrapper_writes_the_field_as_nifti(M, tmp_path):
+    """convex_adam (convex_adam_MIND.py:205-248): NIfTI in, disp.nii.gz out with the fixed image's affine -- through nibabel when it
+    is installed, else through the built-in NIfTI-1 reader / writer; the stored field equals convex_adam_pt's return value."""
+    from convexadam_amd import nifti_io as N
+    from convexadam_amd.phantom import phantom
+    shape = (32, 28, 36)
+    fix = phantom(shape, 7, 70).numpy()
+    mov = np.roll(fix, (1, -1, 2), (0, 1, 2))
+    aff = np.diag([1.5, 1.5, 2.0, 1.0]); aff[:3, 3] = (-20.0, 11.0, 3.0)
+    pf, pm = str(tmp_path / "fixed.nii.gz"), str(tmp_path / "moving.nii.gz")
+    N.save_image(fix, aff, pf)
+    N.save_image(mov, aff, pm)
+    kw = dict(grid_sp=4, disp_hw=2, selected_niter=3, grid_sp_adam=2)
+    M.convex_adam(pf, pm, result_path=str(tmp_path), **kw)
+    got = N.load_fdata(str(tmp_path / "disp.nii.gz"))
+    ref = M.convex_adam_pt(torch.from_numpy(N.load_fdata(pf)).float(), torch.from_numpy(N.load_fdata(pm)).float(), **kw)
+    assert got.shape == shape + (3,) and np.array_equal(got, ref)
+    assert np.allclose(N.load_affine(str(tmp_path / "disp.nii.gz")), aff)
+
+
 def test_apply_convex_vs_scipy_and_golden(morc, golden):
     from scipy.ndimage import map_coordinates
     from convexadam_amd.apply_convex import apply_convex

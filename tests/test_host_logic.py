@@ -148,3 +148,39 @@ def test_translation_wrapper_arithmetic():
         ref = tuple(list((np.round(t_zyx / sp_zyx, decimals=0) * sp_zyx)[::-1]))
         assert field_to_translation(field, spacing_xyz, m) == ref
 
+
+def test_nifti_io_round_trip(tmp_path):
+    """Built-in NIfTI-1 reader / writer (used by the file wrappers when nibabel is absent): data types, gzip, 4-D fields, affines
+    with rotation / flips, the quaternion (qform) path, scl_slope / scl_inter."""
+    import struct
+    from convexadam_amd import nifti_io as N
+    rng = np.random.default_rng(0)
+    th = 0.3
+    rot = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    aff = np.eye(4); aff[:3, :3] = rot * np.array([0.8, 1.2, 2.5]); aff[:3, 3] = (10, -20, 5.5)
+    flip = np.diag([-1.0, 1.0, 1.0, 1.0]); flip[:3, 3] = (90, -126, -72)
+    for dt in (np.float32, np.float64, np.int16, np.uint8):
+        a = (rng.standard_normal((5, 6, 7)) * 50).astype(dt)
+        for ext in (".nii", ".nii.gz"):
+            for A in (aff, flip):
+                p = str(tmp_path / ("t" + ext))
+                N.save(a, A, p)
+                b, A2 = N.load(p)
+                assert b.dtype == np.float64 and np.array_equal(b, a.astype(np.float64)) and np.allclose(A2, A, atol=1e-6)
+    field = rng.standard_normal((4, 5, 6, 3))
+    p = str(tmp_path / "disp.nii.gz")
+    N.save_image(field, np.eye(4), p)
+    assert np.array_equal(N.load_fdata(p), field) and np.array_equal(N.load_affine(p), np.eye(4))
+    # qform only (sform_code = 0) and intensity scaling
+    p = str(tmp_path / "q.nii")
+    N.save((rng.standard_normal((3, 4, 5)) * 10).astype(np.int16), aff, p)
+    raw = bytearray(open(p, "rb").read())
+    struct.pack_into("<h", raw, 254, 0)                       # sform_code
+    struct.pack_into("<2f", raw, 112, 0.5, 3.0)               # scl_slope, scl_inter
+    open(p, "wb").write(bytes(raw))
+    b, A2 = N.load(p)
+    ref = np.frombuffer(bytes(raw), "<i2", 60, 352).reshape((3, 4, 5), order="F").astype(np.float64) * 0.5 + 3.0
+    assert np.array_equal(b, ref) and np.allclose(A2, aff, atol=1e-5)
+    with pytest.raises(ValueError):
+        open(p, "wb").write(b"x" * 400); N.load(p)
+
