@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from ._lib import Smoother, check, f32c, lib, ptr, require_device_tensor, stream_ptr, workspace
-from .convex_adam_utils import coupled_convex, correlate, inverse_consistency  # noqa: F401  (same operators)
+from .convex_adam_utils import coupled_convex, correlate, gpu_usage, inverse_consistency  # noqa: F401  (same operators)
 from .convex_adam_utils import MINDSSC as _MINDSSC
 from .convex_adam_MIND import extract_features as _extract_features
 from .convex_adam_nnUNet import extract_features as _extract_features_nnunet
