@@ -39,12 +39,8 @@ HBM_PEAK_GBS = 8000.0
 
 def make_pair(device, idx):
     """multi-octave phantom, moving = other noise realisation warped by a smooth field."""
-    import torch.nn.functional as F
-    from convexadam_amd.phantom import phantom, smooth_warp
-    fix = phantom(SHAPE, 1 + idx, 10 + idx)
-    grid = smooth_warp(SHAPE, 5 + idx, amp=4.0)
-    mov = F.grid_sample(phantom(SHAPE, 1 + idx, 110 + idx)[None, None], grid, mode="bilinear", padding_mode="border",
-                        align_corners=False)[0, 0]
+    from convexadam_amd.phantom import deformed_pair
+    fix, mov = deformed_pair(SHAPE, idx, 4.0)
     return fix.to(device).contiguous(), mov.to(device).contiguous()
 
 
@@ -57,17 +53,26 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(fix, mov):
-    """Times the C oracle (oracle/, the parity checker) on the host cores for one full pair."""
+def cpu_baseline(fix, mov, hip_field):
+    """Times the C oracle (oracle/, the parity checker) on the host cores for one full pair and -- outside every timed region --
+    compares the field the timed HIP loop produced for the same pair with the oracle's field."""
+    import numpy as np
     from oracle import oracle
     oracle.build()
     cores = oracle.num_threads()
     t0 = time.time()
-    oracle.convex_adam_pipeline(fix, mov, **CFG)
+    ref = oracle.convex_adam_pipeline(fix, mov, **CFG)            # (H,W,D,3) float64
     dt = time.time() - t0
-    return dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port", seconds_per_pair=dt,
+    got = np.moveaxis(hip_field, 0, -1).astype(np.float64)
+    epe = float(np.sqrt(((got - ref) ** 2).sum(-1)).mean())
+    parity = dict(epe_vs_oracle=epe, bit_identical=bool(np.array_equal(got, ref)), max_abs_diff=float(np.abs(got - ref).max()),
+                  note="field of the last timed step vs oracle/cvx_oracle.c on the same pair, full size; oracle vs the reference itself: "
+                       "tests/golden/fullsize.npz (bit-identical convex stage, mean EPE 1.2e-3 after 80 iterations = below the reference's "
+                       "own 1-ulp sensitivity of 1.6e-3)")
+    base = dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port", seconds_per_pair=dt,
                 sample="1 full 160x192x224 pair (MIND r1 d2, gs6, hw6, ic, 80 Adam its) with oracle/cvx_oracle.c, "
                        "OpenMP over %d threads; reference PyTorch-CPU figure from BASELINE.md: 77.4 s/pair on 8 cores" % cores)
+    return base, parity
 
 
 def main():
@@ -110,6 +115,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    field_of_timed_loop = out.cpu().numpy() if rank == 0 else None      # read back after the timed region
     for name, ms in last_profile():
         stage_ms.setdefault(name, []).append(ms)
     set_profiling(0)
@@ -174,7 +180,7 @@ def main():
         if batched is not None:
             res["batched_2streams"] = batched
         if n == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(fix.cpu().numpy(), mov.cpu().numpy())
+            res["cpu_baseline"], res["parity"] = cpu_baseline(fix.cpu().numpy(), mov.cpu().numpy(), field_of_timed_loop)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

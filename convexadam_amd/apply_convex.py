@@ -3,8 +3,9 @@
     apply_convex(disp, moving) -> np.ndarray     warped = scipy.ndimage.map_coordinates(moving, disp + identity, order=1)
 
 `disp` is the (H,W,D,3) field convex_adam_pt returns (channel a = displacement along axis a, voxels); `moving` any
-(H,W,D) array or tensor.  Like scipy, the interpolation runs in float64; numpy inputs are converted with
-`astype(float)` exactly as validate_image does (convex_adam_utils.py:268-279), tensors keep their dtype for the result.
+(H,W,D) array, image or tensor.  Like scipy, the interpolation runs in float64; non-tensor inputs of any dtype are converted with
+`astype(float)` exactly as validate_image does (convex_adam_utils.py:268-279) and give a float64 result; tensors keep their dtype
+for the result (integer tensors are rounded to nearest like scipy's integer output arrays).
 apply_convex_original_moving (:27-78): the field is first carried onto the grid, axes and voxel size of the original moving image
 (host-side SimpleITK geometry, convex_adam_utils.rescale_displacement_field), then the warp above runs on the device.
 """
@@ -16,9 +17,10 @@ from .convex_adam_utils import rescale_displacement_field, validate_image
 
 
 def apply_convex(disp, moving, device=None) -> np.ndarray:
-    # validate_image(img, dtype=float): numpy input becomes float64 (convex_adam_utils.py:276), tensors pass through
-    mov_t = validate_image(moving.astype(float) if isinstance(moving, np.ndarray) else moving)
-    disp_t = validate_image(disp.astype(float) if isinstance(disp, np.ndarray) else disp)
+    # validate_image(img, dtype=float): every non-tensor input (numpy, SimpleITK, nibabel; any integer type) becomes float64
+    # (convex_adam_utils.py:268-279), tensors pass through with their dtype
+    mov_t = validate_image(moving)
+    disp_t = validate_image(disp)
     if disp_t.dim() != 4 or disp_t.shape[-1] != 3 or tuple(disp_t.shape[:3]) != tuple(mov_t.shape):
         raise ValueError("apply_convex: disp must be (H,W,D,3) matching moving (H,W,D)")
     dev = torch.device(device) if device is not None else (mov_t.device if mov_t.is_cuda else torch.device("cuda", torch.cuda.current_device()))
@@ -29,8 +31,9 @@ def apply_convex(disp, moving, device=None) -> np.ndarray:
     out = torch.empty_like(m)
     with torch.cuda.device(dev):
         check(lib().cvx_map_coordinates_linear_f64(ptr(m), ptr(d), H, W, D, ptr(out), stream_ptr(dev)))
+    if not out_dtype.is_floating_point:
+        out = torch.trunc(out + torch.where(out > 0, 0.5, -0.5))   # scipy's integer outputs: (type)(t > 0 ? t + 0.5 : t - 0.5), ni_interpolation.c
     return out.to(out_dtype).cpu().numpy()
-
 
 
 def apply_convex_original_moving(disp, moving_image_original, fixed_image_original, fixed_image_resampled):

@@ -214,9 +214,11 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
     return U
 
 
-def validate_image(img):
+def validate_image(img, dtype=float):
     """np.ndarray / torch.Tensor (and SimpleITK / nibabel images when those packages are installed) -> torch.Tensor.
-    (convex_adam_utils.py:268-279; raises ValueError for unsupported types like the reference)"""
+    Like the reference (convex_adam_utils.py:268-279) tensors pass through unchanged and everything else is converted with
+    `astype(dtype)` -- float64 by default, so an int16 SimpleITK image is interpolated in floating point downstream;
+    raises ValueError for unsupported types."""
     try:
         import SimpleITK as sitk  # noqa: N813
         if isinstance(img, sitk.Image):
@@ -230,7 +232,7 @@ def validate_image(img):
     except ImportError:
         pass
     if isinstance(img, np.ndarray):
-        img = torch.from_numpy(np.ascontiguousarray(img))
+        img = torch.from_numpy(np.ascontiguousarray(img.astype(dtype)))
     if not isinstance(img, torch.Tensor):
         raise ValueError("Input image must be a SimpleITK image, a nibabel image, a numpy array or a torch tensor")
     return img

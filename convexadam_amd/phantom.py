@@ -37,3 +37,21 @@ def label_phantom(shape, n_labels, seed):
     g = torch.Generator().manual_seed(seed)
     z = F.interpolate(torch.randn(1, n_labels, 8, 8, 8, generator=g), size=tuple(shape), mode="trilinear", align_corners=False)
     return torch.argmax(z, 1)[0].float().contiguous()
+
+
+def deformed_pair(shape, idx=0, amp=4.0):
+    """Synthetic pair of SURVEY 8(d) config 2 (and bench.py): fixed = multi-octave phantom, moving = another noise
+    realisation of the same phantom pulled back through a smooth random warp of about `amp` voxels.  CPU tensors."""
+    fix = phantom(shape, 1 + idx, 10 + idx)
+    grid = smooth_warp(shape, 5 + idx, amp=amp)
+    mov = F.grid_sample(phantom(shape, 1 + idx, 110 + idx)[None, None], grid, mode="bilinear", padding_mode="border",
+                        align_corners=False)[0, 0]
+    return fix.contiguous(), mov.contiguous()
+
+
+def ellipsoid_mask(shape, semi=0.35, shift=(0, 0, 0)):
+    """(H,W,D) float32 0/1 mask: ellipsoid with semi-axes `semi` x extent around the (shifted) volume centre
+    (the lung-mask stand-in)."""
+    ax = [(torch.arange(s, dtype=torch.float32) - (s - 1) / 2.0 - sh) / (semi * s) for s, sh in zip(shape, shift)]
+    r2 = ax[0].view(-1, 1, 1) ** 2 + ax[1].view(1, -1, 1) ** 2 + ax[2].view(1, 1, -1) ** 2
+    return (r2 <= 1.0).float().contiguous()

@@ -280,3 +280,25 @@ def test_feature_transform_restatement_vs_scipy(orc):
         m = np.ones(shape, bool)
         m[0, 0, 0] = m[-1, -1, -1] = m[0, -1, 0] = False
         assert np.array_equal(orc.feature_transform(m), edt(m, return_indices=True)[1])
+
+
+@pytest.mark.timeout(600)
+def test_full_size_benchmark_pair_vs_reference_golden(orc, golden):
+    """BASELINE configs[1] at FULL size (160x192x224, hw 6, gs 6, ic, 80 Adam iterations), reference captured by
+    tests/golden/make_golden_fullsize.py: the whole convex stage (MIND, both correlations, coupled convex, inverse consistency)
+    is bit-identical to the reference; after 80 Adam iterations the oracle is closer to the reference than the reference is to
+    a copy of itself whose warped features were perturbed by one ulp (the loop amplifies MKL's 1-ulp exp / sqrt sites)."""
+    from convexadam_amd.phantom import deformed_pair
+    g = golden("fullsize")
+    shape = (160, 192, 224)
+    fix, mov = deformed_pair(shape, 0, 4.0)
+    kw = dict(mind_r=1, mind_d=2, grid_sp=6, disp_hw=6, grid_sp_adam=2, ic=True)
+    conv = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), lambda_weight=0, **kw)
+    assert np.array_equal(np.moveaxis(conv, -1, 0).astype(np.float32), orc.resize_trilinear(g["c1_coarse_ic"], shape))
+    out = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), lambda_weight=1.25, selected_niter=80, **kw)
+    s = int(g["sub"])
+    e = epe(out[::s, ::s, ::s], np.moveaxis(g["c1_adam_80_sub"], 0, -1))
+    self_e = float(g["c1_self_perturbation_epe_sub"][list(g["c1_snaps"]).index(80)])
+    print("80 iterations, full size: oracle vs reference mean EPE %.3e; reference vs its 1-ulp-perturbed self %.3e" % (e, self_e))
+    assert e <= self_e
+    assert e < 2e-3

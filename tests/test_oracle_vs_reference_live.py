@@ -9,7 +9,10 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-from _ref_import import import_reference, reference_available  # noqa: E402
+try:                                                     # the import harness itself stays in the build container (.gpurunignore)
+    from _ref_import import import_reference, reference_available  # noqa: E402
+except ImportError:
+    import_reference, reference_available = None, (lambda: False)
 
 pytestmark = pytest.mark.skipif(not reference_available(), reason="upstream reference not mounted")
 
