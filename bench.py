@@ -12,7 +12,7 @@ registers its own pairs (no collective on the data path); the timed
 barrier + synchronize and the slowest rank's time is used: value = N*K / T (weak scaling).
 
 Extra objects on the JSON line:
-  roofline     the SSD correlation stage (k_corr_prep/raw/tail/box2 of one direction): algorithmic bytes
+  roofline     the SSD correlation stage (k_corr_prep + k_corr_fused of one direction): algorithmic bytes
                (n^3*v*4 written + 2*C*v*4 read = 273.5 MB) / its mean duration measured with HIP events on the
                launch stream inside the timed region, against 8 TB/s HBM3E peak; `traffic` = HBM bytes per launch
                from the committed rocprofv3 PMC passes (profiles/pmc_hbm_traffic.json: 2*FETCH_SIZE + WRITE_SIZE).
@@ -171,7 +171,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 160x192x224 pair, MIND-SSC r1 d2, grid_sp 6, disp_hw 6, ic, "
                                    "lambda 1.25, grid_sp_adam 2, 80 Adam iterations, float32",
                        "pairs_per_gpu_per_step": 1, "parallelism": "one pair per GPU, no collectives"},
-            "roofline": {"kernel": "correlate stage = k_corr_prep + k_corr_raw + k_corr_tail + k_corr_box2 (one direction)",
+            "roofline": {"kernel": "correlate stage = k_corr_prep + k_corr_fused (raw SSD + both boxes in one kernel, one direction)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(), "algorithmic_bytes": alg_bytes,
                          "avg_launch_ms": corr_ms},

@@ -11,8 +11,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["api.hip", "mind.hip", "mindmarch.hip", "pool.hip", "correlate.hip", "corrbox.hip", "convex.hip", "adam.hip", "warp.hip", "boxmarch.hip", "metrics.hip", "edt.hip", "pipeline.hip"]
-PER_FILE_FLAGS = {"warp.hip": ["-fno-slp-vectorize"], "boxmarch.hip": ["-fno-slp-vectorize"], "corrbox.hip": ["-fno-slp-vectorize"], "mindmarch.hip": ["-fno-slp-vectorize"]}     # see the header of warp.hip
+SOURCES = ["api.hip", "mind.hip", "mindmarch.hip", "pool.hip", "correlate.hip", "corrbox.hip", "corrfused.hip", "convex.hip", "adam.hip", "warp.hip", "boxmarch.hip", "metrics.hip", "edt.hip", "pipeline.hip"]
+PER_FILE_FLAGS = {"warp.hip": ["-fno-slp-vectorize"], "boxmarch.hip": ["-fno-slp-vectorize"], "corrbox.hip": ["-fno-slp-vectorize"], "corrfused.hip": ["-fno-slp-vectorize"], "mindmarch.hip": ["-fno-slp-vectorize"]}     # see the header of warp.hip
 LIB = os.path.join(HERE, "libconvexadam_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-fvisibility=hidden",
@@ -35,7 +35,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(HERE, "cvx_common.h"), os.path.join(ROOT, "include", "convexadam_hip.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith(".h")] + [os.path.join(ROOT, "include", "convexadam_hip.h"), os.path.abspath(__file__)]
     jobs = []
     for src in SOURCES:
         s = os.path.join(HERE, src)

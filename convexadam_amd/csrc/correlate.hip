@@ -16,6 +16,8 @@
 // Roofline: HBM by bytes (K*v*4 written + 2*C*v*4 read); the reference's summation order costs
 // 2 x (26 adds + 1 division) + 36 flops per output, which makes the stage VALU-bound.
 
+#include <algorithm>
+
 #include "cvx_common.h"
 
 namespace cvx {
@@ -183,6 +185,49 @@ __global__ void k_corr_tail(const float* __restrict__ fix, const float* __restri
     raw[kk * ((size_t)g.h * g.w * g.px) + ((size_t)z * g.w + y) * g.px + x + 1] = p[0];
 }
 
+// the same tail values into a compact side buffer tail[iH][32] for the fused kernel (corrfused.hip)
+__global__ void k_corr_tail_compact(const float* __restrict__ fix, const float* __restrict__ mov, CorrGeom g, int64_t tail_from,
+                                    int ntail, float* __restrict__ tail) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntail * g.n) return;
+    const int iH = t / ntail;
+    const int64_t flat = tail_from + (t % ntail);
+    const int x = (int)(flat % g.d), y = (int)((flat / g.d) % g.w);
+    const int jj = (int)((flat / ((int64_t)g.d * g.w)) % (g.n * g.n)), z = (int)(flat / ((int64_t)g.d * g.w * g.n * g.n));
+    const int iW = jj / g.n, iD = jj % g.n;
+    const int mz = z + iH - g.hw, my = y + iW - g.hw, mx = x + iD - g.hw;
+    const bool inb = mz >= 0 && mz < g.h && my >= 0 && my < g.w && mx >= 0 && mx < g.d;
+    const size_t v = (size_t)g.h * g.w * g.d;
+    float sq[16];
+    for (int c = 0; c < g.C; ++c) {
+        const float f = fix[(size_t)c * v + ((size_t)z * g.w + y) * g.d + x];
+        const float m = inb ? mov[(size_t)c * v + ((size_t)mz * g.w + my) * g.d + mx] : 0.0f;
+        const float df = f - m;
+        sq[c] = df * df;
+    }
+    const int n4 = g.C / 4;
+    float p[4];
+    for (int k = 0; k < 4; ++k) { p[k] = 0.f; for (int i = 0; i < n4; ++i) p[k] += sq[4 * i + k]; }   // C < 16: one cascade level
+    for (int i = n4 * 4; i < g.C; ++i) p[0] += sq[i];
+    p[0] += p[1]; p[0] += p[2]; p[0] += p[3];
+    tail[iH * 32 + (t % ntail)] = p[0];
+}
+
+void launch_corr_prep_generic(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int px, int PL, int dq, float* Fp,
+                              float* Mp, hipStream_t s) {
+    CorrGeom g = corr_geom(C, h, w, d, hw);
+    g.px = px; g.PL = PL; g.dq = dq;
+    const size_t nprep = std::max((size_t)C * g.hq * g.wq * g.dq, (size_t)C * h * w * g.px);
+    hipLaunchKernelGGL(k_corr_prep, dim3((unsigned)cdiv64((int64_t)nprep, 256)), dim3(256), 0, s, fix, mov, g, Fp, Mp);
+}
+
+void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* tail, hipStream_t s) {
+    const CorrGeom g = corr_geom(C, h, w, d, hw);
+    const int64_t ncols = (int64_t)h * g.n * g.n * w * d, tail_from = (ncols / 32) * 32;
+    const int ntail = (int)(ncols - tail_from);
+    if (ntail > 0) hipLaunchKernelGGL(k_corr_tail_compact, dim3(cdiv(ntail * g.n, 64)), dim3(64), 0, s, fix, mov, g, tail_from, ntail, tail);
+}
+
 template <int HW>
 static void corr_raw_dispatch(const float* Fp, const float* Mp, const CorrGeom& g, float* raw, hipStream_t s) {
     const int nruns = g.h * g.w * (g.px / 4);
@@ -196,6 +241,8 @@ static void corr_raw_dispatch(const float* Fp, const float* Mp, const CorrGeom& 
 using namespace cvx;
 
 extern "C" size_t cvx_correlate_workspace_bytes(int C, int h, int w, int d, int disp_hw) {
+    if (corr_fused_supported(C, h, w, d, disp_hw))       // fused kernel: no raw intermediate
+        return carve_size(corr_fused_workspace_bytes(C, h, w, d, disp_hw), sizeof(unsigned long long) * (size_t)h * w * d) + 256;
     const CorrGeom g = corr_geom(C, h, w, d, disp_hw);
     const size_t K = (size_t)g.n * g.n * g.n;
     size_t used = 0;
@@ -217,6 +264,16 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
     hipStream_t s = as_stream(stream);
     const CorrGeom g = corr_geom(C, h, w, d, disp_hw);
     const size_t K = (size_t)g.n * g.n * g.n;
+    if (corr_fused_supported(C, h, w, d, disp_hw)) {
+        const size_t fws = corr_fused_workspace_bytes(C, h, w, d, disp_hw);
+        int rc = launch_corr_fused(fix, mov, C, h, w, d, disp_hw, ssd, workspace, fws, s);
+        if (rc) return rc;
+        if (argmin) {
+            unsigned long long* keys = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + align_up(fws, 256));
+            return launch_argmin(ssd, nullptr, nullptr, 0.0f, false, (int)K, (size_t)h * w * d, keys, argmin, s);
+        }
+        return CVX_OK;
+    }
     if (!corr_box2_supported(h, w, d, g.px))
         return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
     Carver cv(workspace, workspace_bytes);

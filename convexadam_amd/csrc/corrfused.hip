@@ -1,0 +1,404 @@
+// corrfused.hip -- the SSD correlation volume in ONE kernel: raw SSD -> box filter -> box filter -> ssd, nothing but the
+// cost volume itself goes to HBM (reference: correlate, convex_adam_utils.py:72-89).
+//
+//   raw[k,x] = sum_c (F_c(x) - M0_c(x + delta_k))^2   (channel order of `.sum(0)`, M0 = zero-padded moving features)
+//   ssd      = avg_pool3d(avg_pool3d(raw, 3, 1, 1), 3, 1, 1): two zero-padded 27-tap means in ATen's raster order
+//
+// Work item = one workgroup = a group of G <= 5 displacements that share (dH, dW) and are adjacent in dD; it marches along z
+// over whole (w x d) planes.  The 2*hw+1 D-shifts are split into groups of 4 with a last group of 3..5 (13 -> 4+4+5), so a
+// thread of the raw stage loads one 16-byte piece of the fixed row and two of the moving row per channel for 4 voxels x G
+// shifts (20 outputs, 60 flops per 48 bytes from L1/L2; F and M together are 3 MB and never leave the caches), and the
+// BASELINE workload gives 3 x 169 = 507 items: one round on the 2 x 256 workgroup slots of the chip.
+//
+// Three groups of specialised wavefronts run concurrently, one plane per step (step s: raw plane s, box-1 plane s-2, output
+// plane s-4):
+//   raw    thread = (row y, 4 columns): accumulates the G x 4 squared differences over the channels in registers
+//   box 1  thread = (row y, 4 columns): newest raw plane -> box-1 plane
+//   box 2  thread = (row y, 4 columns): newest box-1 plane -> 16-byte store of the cost volume
+// A box thread reads ONLY the newest plane of its input (3 rows x 6 columns from LDS) and carries, per displacement and column,
+// two running sums in registers: when plane m arrives it finishes output plane m-1 as (prefix(m-2) + taps(m-1)) + taps(m) --
+// ATen's raster order: z slowest -- and starts the next two sums; 26 adds + 1 exact division per output, every tap read once.
+// LDS holds rings of G+2 planes per stage; a step is cut into sub-intervals of two displacements (one barrier each): the box-1
+// plane of displacement g overwrites the plane box 2 consumed two displacements -- one sub-interval -- earlier, so no stage
+// needs a second copy of its planes and no thread parks finished results in registers (64 VGPRs, two workgroups = 30 waves
+// per CU).  Rows are stored back to back (pitch 4*lpr, the zero column x = -1 of a row is the zero tail of the previous row):
+// lane -> 16-byte slot is the identity, so every ds_read_b128 / ds_write_b128 is conflict-free.
+// The <= 31 trailing elements whose channel sum ATen evaluates in its interleaved order come from k_corr_tail (correlate.hip)
+// through a small side buffer.  C >= 16 (cascade sum) and planes of more than 320 quads keep the unfused path.
+#include "cvx_common.h"
+
+namespace cvx {
+
+constexpr int CF_GMAX = 5;
+#ifndef CF_RAW_PRIO
+#define CF_RAW_PRIO 2
+#endif
+
+struct CFGeom {
+    int C, h, w, d, hw, n;
+    int lpr, RS;            // quads per row; row pitch of LDS planes and of Fp (floats) = 4 * lpr
+    int dq, hq, wq;         // Mp row pitch, plane extents (h + 2hw, w + 2hw); element x at index x + 1 + hw
+    int ng;                 // D-shift groups per (dH, dW)
+    int wpr;                // wavefronts per role
+    int PF;                 // floats per LDS plane: 4 + (w + 2) * RS + 4
+    int64_t tail_from;      // first flat index (h, n^2, w, d order) of ATen's interleaved-order tail; ntail = ncols - tail_from
+    int ntail;
+    unsigned long long* dbg;   // optional residency census (CVX_CF_CENSUS): per workgroup {start, end, HW_ID, XCC_ID}
+};
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte global access at 4-byte alignment
+
+__device__ __forceinline__ int cf_group_size(int n, int ng, int grp) { return grp < ng - 1 ? 4 : n - 4 * (ng - 1); }
+
+// box stage of one displacement: `src` = window origin of the thread in the newest input plane, `rs` = its row pitch (a zero
+// block with pitch 0 stands in for an all-zero plane); mid / pre = the two running sums per column.  Returns the four finished sums
+// (not yet divided).  Rows 1 and 2 run as a rolled loop: one row of the window (6 values) is live at a time, which is what keeps
+// 5 displacements x 8 running sums + a window inside 64 VGPRs; the LDS latency per row is covered by the other wavefronts.
+__device__ __forceinline__ void cf_box_item(const float* src, int rs, float (&mid)[4], float (&pre)[4], float (&fin)[4]) {
+    float f[4], m[4], p[4];
+    {
+        const f32x4 a = lds_load4(src);
+        const f32x2 b = lds_load2(src + 4);
+        src += rs;
+        const float w[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[j] = mid[j] + w[j]; m[j] = pre[j] + w[j]; p[j] = w[j];             // 0 + first tap = first tap
+            f[j] += w[j + 1]; m[j] += w[j + 1]; p[j] += w[j + 1];
+            f[j] += w[j + 2]; m[j] += w[j + 2]; p[j] += w[j + 2];
+        }
+    }
+#pragma unroll 1
+    for (int i = 1; i < 3; ++i) {
+        const f32x4 a = lds_load4(src);
+        const f32x2 b = lds_load2(src + 4);
+        src += rs;
+        const float w[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[j] += w[j]; m[j] += w[j]; p[j] += w[j];
+            f[j] += w[j + 1]; m[j] += w[j + 1]; p[j] += w[j + 1];
+            f[j] += w[j + 2]; m[j] += w[j + 2]; p[j] += w[j + 2];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { fin[j] = f[j]; mid[j] = m[j]; pre[j] = p[j]; }
+}
+
+// what every role needs to know about its work item
+struct CFItem {
+    int iH, iW, grp, y, q;
+    bool active;
+};
+
+// 16-byte load through a buffer descriptor: address = descriptor base + per-lane byte offset (VGPR) + uniform byte offset (SGPR);
+// no vector address arithmetic at all (the flat form costs a 64-bit vector add per load in a loop)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 cf_ld16(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, unsigned uni_off) {
+    const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)uni_off, 0));
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+
+// ---- raw stage: G x 4 channel sums per thread and step ---------------------------------------------------------------------
+// CT = compile-time channel count (12: fully unrolled software pipeline, every register static) or 0 (run-time count, rolled loop)
+template <int G, int CT>
+__device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float* __restrict__ Mp, const float* __restrict__ tail,
+                                       const CFGeom& g, const CFItem& it, float* S0) {
+    constexpr int R = G + 2, NSUB = (G + 1) / 2;
+    const int n = g.n, nn = n * n, y = it.y, q = it.q, RS = g.RS, PF = g.PF;
+    const int C = CT ? CT : g.C;
+    // the raw stage is the longest instruction stream of every sub-interval: its wavefronts win the issue arbitration
+    static_assert(true, "");
+    if (CF_RAW_PRIO) __builtin_amdgcn_s_setprio(CF_RAW_PRIO);
+    // per-thread byte offsets; everything else of an address is wave-uniform and travels in the scalar offset
+    const unsigned foff = 4u * (unsigned)(y * RS + 4 * q);
+    const unsigned moff = 4u * (unsigned)((y + it.iW) * g.dq + 4 * q + 4 * it.grp);
+    const unsigned doff = (unsigned)((y + 1) * RS + 4 * q);
+    const unsigned fstride = 4u * (unsigned)(g.h * g.w * RS), mstride = 4u * (unsigned)(g.hq * g.wq * g.dq);     // bytes per channel
+    const unsigned fplane = 4u * (unsigned)(g.w * RS), mplane = 4u * (unsigned)(g.wq * g.dq);                    // bytes per plane
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Fp), 0, (int)(fstride * (unsigned)g.C), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Mp), 0, (int)(mstride * (unsigned)g.C + 32u), 0x00020000);
+    // does this item hold elements of ATen's interleaved-order tail (the last < 32 elements of the (h, n^2, w, d) tensor)?
+    const int64_t item_last = (((int64_t)(g.h - 1) * nn + it.iW * n + 4 * it.grp + G - 1) * g.w + (g.w - 1)) * g.d + g.d - 1;
+    const bool tail_item = g.ntail > 0 && item_last >= g.tail_from;
+    const int nsteps = g.h + 4;
+    int base = 0;                                          // (s * G) mod R
+    for (int s = 0; s < nsteps; ++s) {
+        const bool live = s < g.h;
+        float acc[G][4];
+#pragma unroll
+        for (int k = 0; k < G; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[k][j] = 0.0f;
+        const unsigned fz = (unsigned)s * fplane, mz = (unsigned)(s + it.iH) * mplane;     // uniform
+        auto consume = [&](const float4& f4, const float4& m0, const float4& m1) {
+            const float f[4] = {f4.x, f4.y, f4.z, f4.w};
+            const float m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+            for (int k = 0; k < G; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float df = f[j] - m[j + k];
+                    acc[k][j] += df * df;
+                }
+        };
+        // channels per sub-interval follow the box stages' load (two displacements, two, one)
+        auto part_end = [&](int part) { return part == NSUB - 1 ? C : (C * (2 * (part + 1) < G ? 2 * (part + 1) : G) + (G >> 1)) / G; };
+        if (CT) {
+            float4 fa, ma0, ma1, fb, mb0, mb1;             // two register sets, channel c in set (c & 1)
+            if (live) { fa = cf_ld16(fr, foff, fz); ma0 = cf_ld16(mr, moff, mz); ma1 = cf_ld16(mr, moff + 16, mz); }
+#pragma unroll
+            for (int part = 0; part < NSUB; ++part) {
+                if (live) {
+#pragma unroll
+                    for (int c = part == 0 ? 0 : (CT * (2 * part < G ? 2 * part : G) + (G >> 1)) / G;
+                         c < (part == NSUB - 1 ? CT : (CT * (2 * (part + 1) < G ? 2 * (part + 1) : G) + (G >> 1)) / G); ++c) {
+                        if (c + 1 < CT) {
+                            const unsigned fo = fz + (unsigned)(c + 1) * fstride, mo = mz + (unsigned)(c + 1) * mstride;
+                            if (c & 1) { fa = cf_ld16(fr, foff, fo); ma0 = cf_ld16(mr, moff, mo); ma1 = cf_ld16(mr, moff + 16, mo); }
+                            else { fb = cf_ld16(fr, foff, fo); mb0 = cf_ld16(mr, moff, mo); mb1 = cf_ld16(mr, moff + 16, mo); }
+                        }
+                        if (c & 1) consume(fb, mb0, mb1); else consume(fa, ma0, ma1);
+                    }
+                }
+                if (part < NSUB - 1) __syncthreads();
+            }
+        } else {
+            int c = 0;
+#pragma unroll
+            for (int part = 0; part < NSUB; ++part) {
+                const int cend = part_end(part);
+                if (live) {
+#pragma unroll 1
+                    for (; c < cend; ++c) {
+                        const unsigned fo = fz + (unsigned)c * fstride, mo = mz + (unsigned)c * mstride;
+                        consume(cf_ld16(fr, foff, fo), cf_ld16(mr, moff, mo), cf_ld16(mr, moff + 16, mo));
+                    }
+                }
+                if (part < NSUB - 1) __syncthreads();
+            }
+        }
+        if (live && it.active) {
+            // all planes of the step go to the ring in the last sub-interval (their slots were consumed earlier in the step)
+            if (tail_item && s == g.h - 1) {           // rare: replace the channel sums of the tail elements
+#pragma unroll 1
+                for (int k = 0; k < G; ++k)
+#pragma unroll 1
+                    for (int j = 0; j < 4; ++j) {
+                        const int x = 4 * q + j - 1;
+                        const int64_t flat = (((int64_t)s * nn + it.iW * n + 4 * it.grp + k) * g.w + y) * g.d + x;
+                        if (x >= 0 && x < g.d && flat >= g.tail_from) {
+                            const float t = tail[it.iH * 32 + (int)(flat - g.tail_from)];
+#pragma unroll
+                            for (int kk = 0; kk < G; ++kk)
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj)
+                                    if (kk == k && jj == j) acc[kk][jj] = t;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                int slot = base + k; slot = slot >= R ? slot - R : slot;
+                float* o = S0 + doff + slot * PF;
+                lds_store4(o, f32x4{acc[k][0], acc[k][1], acc[k][2], acc[k][3]});
+                if (q == 0) o[0] = 0.0f;                         // x = -1
+                if (4 * q + 3 > g.d)                             // x >= d: the boxes zero-pad
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * q + j > g.d) o[j] = 0.0f;
+            }
+        }
+        __syncthreads();
+        base += G; base = base >= R ? base - R : base; base = base >= R ? base - R : base;
+    }
+}
+
+// ---- box stages: FIRST = raw -> box 1 (LDS to LDS), else box 1 -> cost volume (LDS to HBM) --------------------------------------
+template <int G, bool FIRST>
+__device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const float* Sin, float* S1, const float* zero, float* __restrict__ ssd) {
+    constexpr int R = G + 2, NSUB = (G + 1) / 2;
+    const int n = g.n, nn = n * n, y = it.y, q = it.q, RS = g.RS, PF = g.PF;
+    float mid[G][4], pre[G][4];
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mid[k][j] = 0.0f; pre[k][j] = 0.0f; }
+    // window origin in a ring plane: rows y-1 .. y+1 = ring rows y .. y+2; box 1 reads raw columns 4q-1 .. 4q+4 (index x + 1),
+    // box 2 reads box-1 columns 4q-4 .. 4q+1 (index x)
+    const float* srcbase = Sin + y * RS + 4 * q - (FIRST ? 0 : 4);
+    const unsigned doff1 = (unsigned)((y + 1) * RS + 4 * q);                           // box 1 writes columns 4q .. 4q+3
+    const int c0 = 4 * q - 3;                                                          // box 2 writes columns 4q-3 .. 4q
+    const unsigned vol = (unsigned)(g.h * g.w * g.d), plane = (unsigned)(g.w * g.d);
+    const unsigned ooff = 4u * (unsigned)(y * g.d + 4 * q);                            // bytes, relative to (plane base - 3 floats)
+    float* ssd_item = ssd + ((size_t)((4 * it.grp) * n + it.iW) * n + it.iH) * vol - 3;   // uniform
+    const size_t kstride = (size_t)nn * vol;                                           // next D-shift
+    const bool full = c0 >= 0 && c0 + 3 < g.d;
+    const int jlo = c0 < 0 ? -c0 : 0, jhi = min(4, g.d - c0);                          // valid columns of a partial quad
+    const int nsteps = g.h + 4;
+    int base_prev = 0, base = 0;                               // ((s-1) * G) mod R, (s * G) mod R
+    for (int s = 0; s < nsteps; ++s) {
+        // box 1: newest raw plane m = s-1 (zero for m >= h), emits plane s-2; box 2: newest box-1 plane m = s-3, emits plane s-4
+        const int m = FIRST ? s - 1 : s - 3;
+        const bool have = m >= 0 && m <= g.h;                 // m == h: the zero plane that closes the last output
+        const bool readable = m >= 0 && m < g.h;
+        const bool emit = m >= 1 && m <= g.h;
+        if (!have) {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) __syncthreads();
+        } else {
+            const float* sb = readable ? srcbase : zero;
+            const int rs = readable ? RS : 0, pf = readable ? PF : 0;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    constexpr int KMAX = G - 1;
+                    const int k = 2 * sub + kk < KMAX ? 2 * sub + kk : KMAX;   // compile-time after unrolling
+                    if (2 * sub + kk < G) {
+                        int sp = base_prev + k; sp = sp >= R ? sp - R : sp;
+                        float fin[4];
+                        cf_box_item(sb + sp * pf, rs, mid[k], pre[k], fin);
+                        if (emit && it.active) {
+                            if (FIRST) {
+                                int sn = base + k; sn = sn >= R ? sn - R : sn;
+                                float* o = S1 + doff1 + sn * PF;
+                                lds_store4(o, f32x4{div_exact<27>(fin[0]), div_exact<27>(fin[1]), div_exact<27>(fin[2]), div_exact<27>(fin[3])});
+                                if (4 * q + 3 >= g.d)
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        if (4 * q + j >= g.d) o[j] = 0.0f;
+                            } else {
+                                char* ob = reinterpret_cast<char*>(ssd_item + (size_t)k * kstride + (size_t)(m - 1) * plane);   // uniform
+                                const f32x4u o = {div_exact<27>(fin[0]), div_exact<27>(fin[1]), div_exact<27>(fin[2]), div_exact<27>(fin[3])};
+                                if (full) *reinterpret_cast<f32x4u*>(ob + ooff) = o;
+                                else {
+                                    float* oe = reinterpret_cast<float*>(ob + ooff);
+                                    if (jlo <= 0 && jhi > 0) oe[0] = o.x;
+                                    if (jlo <= 1 && jhi > 1) oe[1] = o.y;
+                                    if (jlo <= 2 && jhi > 2) oe[2] = o.z;
+                                    if (jlo <= 3 && jhi > 3) oe[3] = o.w;
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        base_prev = base;
+        base += G; base = base >= R ? base - R : base; base = base >= R ? base - R : base;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void cf_roles(int role, const float* Fp, const float* Mp, const float* tail, const CFGeom& g, const CFItem& it,
+                                         float* lds, float* S0, float* S1, float* ssd) {
+    if (role == 0) { if (g.C == 12) cf_raw<G, 12>(Fp, Mp, tail, g, it, S0); else cf_raw<G, 0>(Fp, Mp, tail, g, it, S0); }
+    else if (role == 1) cf_box<G, true>(g, it, S0, S1, lds, ssd);
+    else cf_box<G, false>(g, it, S1, S1, lds, ssd);
+}
+
+template <int GMAX>
+__global__ __launch_bounds__(1024, 8) void k_corr_fused(const float* __restrict__ Fp, const float* __restrict__ Mp,
+                                                        const float* __restrict__ tail, CFGeom g, float* __restrict__ ssd) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int n = g.n, nn = n * n;
+    CFItem it;
+    // items: the large last groups first (they take longest), then the groups of four
+    int pair;
+    if ((int)blockIdx.x < nn) { it.grp = g.ng - 1; pair = blockIdx.x; }
+    else { const int b = blockIdx.x - nn; it.grp = b / nn; pair = b - it.grp * nn; }
+    it.iH = pair % n; it.iW = pair / n;
+    const int G = cf_group_size(n, g.ng, it.grp);
+    if (g.dbg && tid == 0) {
+        g.dbg[4 * blockIdx.x] = __builtin_amdgcn_s_memtime();
+        g.dbg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+        g.dbg[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // HW_REG_XCC_ID
+    }
+    float* S0 = lds + 16 + 4;                                 // (16 zeros first) plane p of stage 0: S0 + p * PF, row r = y + 1, index i = x + 1
+    float* S1 = S0 + (size_t)(GMAX + 2) * g.PF;               // stage 1: index = x
+    for (int i = tid * 4; i < 16 + 2 * (GMAX + 2) * g.PF; i += blockDim.x * 4) *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const int role = __builtin_amdgcn_readfirstlane(tid / (64 * g.wpr));
+    const int tr = tid - role * 64 * g.wpr;
+    it.active = tr < g.w * g.lpr;
+    const int trc = it.active ? tr : g.w * g.lpr - 1;
+    it.y = trc / g.lpr; it.q = trc - it.y * g.lpr;
+    // the group size is a compile-time constant inside the roles (ring arithmetic, register arrays, no idle accumulators)
+    switch (G) {
+        case 5: cf_roles<5>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 4: cf_roles<4>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 3: cf_roles<3>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 2: cf_roles<2>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        default: cf_roles<1>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+    }
+    if (g.dbg && tid == 0) g.dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+static CFGeom cf_geom(int C, int h, int w, int d, int hw) {
+    CFGeom g{};
+    g.C = C; g.h = h; g.w = w; g.d = d; g.hw = hw; g.n = 2 * hw + 1;
+    g.lpr = (d + 3 + 3) / 4;
+    g.RS = 4 * g.lpr;
+    const int n = g.n;
+    g.ng = (n >= 4 && n % 4 <= 1) ? n / 4 : (n + 3) / 4;
+    g.dq = g.RS + 4 * g.ng + 4;
+    g.hq = h + 2 * hw; g.wq = w + 2 * hw;
+    g.wpr = cdiv(w * g.lpr, 64);
+    g.PF = (w + 2) * g.RS + 8;
+    const int64_t ncols = (int64_t)h * n * n * w * d;
+    g.tail_from = (ncols / 32) * 32;
+    g.ntail = (int)(ncols - g.tail_from);
+    return g;
+}
+static size_t cf_lds_bytes(const CFGeom& g) { return sizeof(float) * (16 + 2 * (size_t)(CF_GMAX + 2) * g.PF); }
+
+bool corr_fused_supported(int C, int h, int w, int d, int hw) {
+    static const bool off = getenv("CVX_CORR_UNFUSED") != nullptr;
+    if (off || C >= 16 || hw < 0 || hw > 8) return false;
+    const CFGeom g = cf_geom(C, h, w, d, hw);
+    return 3 * g.wpr <= 16 && cf_lds_bytes(g) <= 160 * 1024;
+}
+
+size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw) {
+    const CFGeom g = cf_geom(C, h, w, d, hw);
+    size_t used = 0;
+    used = carve_size(used, sizeof(float) * (size_t)C * h * w * g.RS);            // Fp
+    used = carve_size(used, sizeof(float) * ((size_t)C * g.hq * g.wq * g.dq + 8));  // Mp
+    used = carve_size(used, sizeof(float) * 32 * g.n);                             // tail values
+    used = carve_size(used, 32 * (size_t)g.n * g.n * g.ng);                         // residency census (CVX_CF_CENSUS)
+    return used + 256;
+}
+
+// prep / tail kernels of correlate.hip
+void launch_corr_prep_generic(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int px, int PL, int dq, float* Fp,
+                              float* Mp, hipStream_t s);
+void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* tail, hipStream_t s);
+
+int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* ssd, void* workspace,
+                      size_t workspace_bytes, hipStream_t s) {
+    const CFGeom g = cf_geom(C, h, w, d, hw);
+    if (workspace_bytes < corr_fused_workspace_bytes(C, h, w, d, hw)) return fail(CVX_ERR_WORKSPACE, "correlate (fused): workspace too small");
+    Carver cv(workspace, workspace_bytes);
+    float* Fp = cv.take<float>((size_t)C * h * w * g.RS);
+    float* Mp = cv.take<float>((size_t)C * g.hq * g.wq * g.dq + 8);
+    float* tail = cv.take<float>((size_t)32 * g.n);
+    unsigned long long* census_buf = cv.take<unsigned long long>((size_t)4 * g.n * g.n * g.ng);
+    launch_corr_prep_generic(fix, mov, C, h, w, d, hw, g.RS, hw, g.dq, Fp, Mp, s);
+    if (g.ntail > 0) launch_corr_tail_compact(fix, mov, C, h, w, d, hw, tail, s);
+    const size_t lds = cf_lds_bytes(g);
+    static size_t granted = 0;
+    ensure_dynamic_lds(&k_corr_fused<CF_GMAX>, lds, granted);
+    const int items = g.n * g.n * g.ng;
+    CFGeom gl = g;
+    static const char* census = getenv("CVX_CF_CENSUS");      // debugging aid: per-workgroup start / end / placement in the workspace
+    gl.dbg = census ? census_buf : nullptr;
+    hipLaunchKernelGGL((k_corr_fused<CF_GMAX>), dim3(items), dim3(3 * 64 * g.wpr), lds, s, Fp, Mp, tail, gl, ssd);
+    return check_last("corr_fused");
+}
+
+}  // namespace cvx

@@ -86,11 +86,13 @@ def test_workspace_queries(L):
     p = PairParams(160, 192, 224, 1, 2, 1.25, 6, 6, 80, 0, 2, 1, 0, 12.0)
     n = L.cvx_register_pair_workspace_bytes(C.byref(p))
     K, v = 13 ** 3, 26 * 32 * 37
-    assert n > 4 * K * v * 2 + 2 * 12 * 160 * 192 * 224 * 4
+    assert n > 4 * K * v * 2 + 2 * 12 * 160 * 192 * 224 * 4          # two cost volumes + two descriptors
     assert n < 3 * 1024 ** 3
     bad = PairParams(160, 192, 224, 1, 2, 1.25, 6, 6, 0, 0, 2, 1, 0, 12.0)       # niter 0 with lambda > 0
     assert L.cvx_register_pair_workspace_bytes(C.byref(bad)) == 0
-    assert L.cvx_correlate_workspace_bytes(12, 26, 32, 37, 6) >= 4 * K * 26 * 32 * 40
+    # fused correlation kernel (C < 16): padded feature copies only, no raw SSD intermediate; C >= 16 keeps the unfused path
+    assert L.cvx_correlate_workspace_bytes(12, 26, 32, 37, 6) < 16 * 1024 ** 2
+    assert L.cvx_correlate_workspace_bytes(20, 26, 32, 37, 6) >= 4 * K * 26 * 32 * 40
 
 
 def test_no_cpu_fallback():
