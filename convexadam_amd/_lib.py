@@ -27,12 +27,18 @@ class Smoother(C.Structure):
     _fields_ = [("kind", C.c_int), ("n_boxes", C.c_int), ("box_k", C.c_int * 4), ("gauss_w", C.c_float * 5)]
 
 
+class CorrOpts(C.Structure):
+    """struct cvx_corr_opts (include/convexadam_hip.h)."""
+    _fields_ = [("cost", C.c_int), ("n_box", C.c_int), ("fast", C.c_int), ("f16", C.c_int)]
+
+
 class PairParams(C.Structure):
     """struct cvx_pair_params (include/convexadam_hip.h)."""
     _fields_ = [("H", C.c_int), ("W", C.c_int), ("D", C.c_int), ("mind_r", C.c_int), ("mind_d", C.c_int),
                 ("lambda_weight", C.c_float), ("grid_sp", C.c_int), ("disp_hw", C.c_int), ("selected_niter", C.c_int),
                 ("selected_smooth", C.c_int), ("grid_sp_adam", C.c_int), ("ic", C.c_int), ("n_feat", C.c_int),
-                ("cost_scale", C.c_float)]
+                ("cost_scale", C.c_float), ("cost", C.c_int), ("n_box", C.c_int), ("n_spline_pools", C.c_int), ("corr_fast", C.c_int),
+                ("fp16_storage", C.c_int)]
 
 
 _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -47,6 +53,7 @@ SIGNATURES = {
     "cvx_mindssc_workspace_bytes": (_sz, [_i] * 5),
     "cvx_mindssc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "cvx_avgpool_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cvx_round_f16_f32": (_i, [_vp, _i64, _vp]),
     "cvx_box_smooth_workspace_bytes": (_sz, [_i] * 5),
     "cvx_box_smooth_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "cvx_mask_erode_f32": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
@@ -56,6 +63,7 @@ SIGNATURES = {
     "cvx_label_weights_host": (_i, [_vp, _vp, _i, _vp, _vp]),
     "cvx_label_features_f32": (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp]),
     "cvx_correlate_workspace_bytes": (_sz, [_i] * 5),
+    "cvx_correlate_ex_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cvx_correlate_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "cvx_coupled_convex_workspace_bytes": (_sz, [_i] * 4),
     "cvx_coupled_convex_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

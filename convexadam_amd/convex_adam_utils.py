@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, f32c, lib, ptr, require_device_tensor, stream_ptr, workspace
+from ._lib import CorrOpts, check, f32c, lib, ptr, require_device_tensor, stream_ptr, workspace
 
 
 # ---- table helpers (host, exact restatements of torch.linspace / affine_grid) ----------------------
@@ -72,9 +72,12 @@ def avg_pool(features, g):
     return out if features.dtype == torch.float32 else out.to(features.dtype)
 
 
-def correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch=12):
+def correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch=12, cost="ssd", n_box=2, mode="exact"):
     """SSD cost volume + argmin.  (convex_adam_utils.py:72-89)
-    mind_fix/mind_mov (1,C,H',W',D') -> ssd (n^3,H',W',D') in the feature dtype, argmin (H',W',D') int64."""
+    mind_fix/mind_mov (1,C,H',W',D') -> ssd (n^3,H',W',D') in the feature dtype, argmin (H',W',D') int64.
+    Beyond the packaged operator: cost="sad" and n_box=1 are the variants of the challenge scripts
+    (l2r_2021_convexAdam_task3_docker.py:54,56; task2:60); mode="fast" evaluates the same sums with fused multiply-adds and
+    separable box filters (last-bit differences, not bit-compatible with the reference; SSD with two boxes only)."""
     mind_fix = require_device_tensor(mind_fix, "mind_fix")
     mind_mov = require_device_tensor(mind_mov, "mind_mov")
     H, W, D = int(shape[0]), int(shape[1]), int(shape[2])
@@ -88,8 +91,12 @@ def correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch=12):
     am = torch.empty((h, w, d), dtype=torch.int64, device=f.device)
     nws = lib().cvx_correlate_workspace_bytes(ch, h, w, d, int(disp_hw))
     ws = workspace(nws, f.device)
+    if cost not in ("ssd", "sad") or n_box not in (1, 2) or mode not in ("exact", "fast"):
+        raise ValueError("correlate: cost must be 'ssd' or 'sad', n_box 1 or 2, mode 'exact' or 'fast'")
+    opts = CorrOpts(1 if cost == "sad" else 0, int(n_box), 1 if mode == "fast" else 0, 0)
     with torch.cuda.device(f.device):
-        check(lib().cvx_correlate_f32(ptr(f), ptr(m), ch, h, w, d, int(disp_hw), ptr(ssd), ptr(am), ptr(ws), nws, stream_ptr(f.device)))
+        check(lib().cvx_correlate_ex_f32(ptr(f), ptr(m), ch, h, w, d, int(disp_hw), C.byref(opts), ptr(ssd), ptr(am), ptr(ws), nws,
+                                         stream_ptr(f.device)))
     if mind_fix.dtype != torch.float32:
         ssd = ssd.to(mind_fix.dtype)
     return ssd, am

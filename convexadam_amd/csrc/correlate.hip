@@ -187,7 +187,7 @@ __global__ void k_corr_tail(const float* __restrict__ fix, const float* __restri
 
 // the same tail values into a compact side buffer tail[iH][32] for the fused kernel (corrfused.hip)
 __global__ void k_corr_tail_compact(const float* __restrict__ fix, const float* __restrict__ mov, CorrGeom g, int64_t tail_from,
-                                    int ntail, float* __restrict__ tail) {
+                                    int ntail, int sad, float* __restrict__ tail) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntail * g.n) return;
     const int iH = t / ntail;
@@ -203,7 +203,7 @@ __global__ void k_corr_tail_compact(const float* __restrict__ fix, const float* 
         const float f = fix[(size_t)c * v + ((size_t)z * g.w + y) * g.d + x];
         const float m = inb ? mov[(size_t)c * v + ((size_t)mz * g.w + my) * g.d + mx] : 0.0f;
         const float df = f - m;
-        sq[c] = df * df;
+        sq[c] = sad ? fabsf(df) : df * df;
     }
     const int n4 = g.C / 4;
     float p[4];
@@ -221,11 +221,11 @@ void launch_corr_prep_generic(const float* fix, const float* mov, int C, int h, 
     hipLaunchKernelGGL(k_corr_prep, dim3((unsigned)cdiv64((int64_t)nprep, 256)), dim3(256), 0, s, fix, mov, g, Fp, Mp);
 }
 
-void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* tail, hipStream_t s) {
+void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int sad, float* tail, hipStream_t s) {
     const CorrGeom g = corr_geom(C, h, w, d, hw);
     const int64_t ncols = (int64_t)h * g.n * g.n * w * d, tail_from = (ncols / 32) * 32;
     const int ntail = (int)(ncols - tail_from);
-    if (ntail > 0) hipLaunchKernelGGL(k_corr_tail_compact, dim3(cdiv(ntail * g.n, 64)), dim3(64), 0, s, fix, mov, g, tail_from, ntail, tail);
+    if (ntail > 0) hipLaunchKernelGGL(k_corr_tail_compact, dim3(cdiv(ntail * g.n, 64)), dim3(64), 0, s, fix, mov, g, tail_from, ntail, sad, tail);
 }
 
 template <int HW>
@@ -255,6 +255,13 @@ extern "C" size_t cvx_correlate_workspace_bytes(int C, int h, int w, int d, int 
 
 extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int h, int w, int d, int disp_hw, float* ssd,
                                  int64_t* argmin, void* workspace, size_t workspace_bytes, void* stream) {
+    return cvx_correlate_ex_f32(fix, mov, C, h, w, d, disp_hw, nullptr, ssd, argmin, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, int h, int w, int d, int disp_hw, const cvx_corr_opts* opts,
+                                    float* ssd, int64_t* argmin, void* workspace, size_t workspace_bytes, void* stream) {
+    const int cost = opts ? opts->cost : 0, n_box = opts ? opts->n_box : 2, fast = opts ? opts->fast : 0, f16 = opts ? opts->f16 : 0;
+    CVX_REQUIRE((cost == 0 || cost == 1) && (n_box == 1 || n_box == 2) && (fast == 0 || fast == 1), "cvx_correlate_ex_f32: bad options");
     CVX_REQUIRE(fix && mov && ssd && workspace, "cvx_correlate_f32: null pointer");
     CVX_REQUIRE(C > 0 && C < 256 && h > 0 && w > 0 && d > 0, "cvx_correlate_f32: bad extent C=%d %dx%dx%d", C, h, w, d);
     CVX_REQUIRE(disp_hw >= 0, "cvx_correlate_f32: negative disp_hw");
@@ -266,7 +273,7 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
     const size_t K = (size_t)g.n * g.n * g.n;
     if (corr_fused_supported(C, h, w, d, disp_hw)) {
         const size_t fws = corr_fused_workspace_bytes(C, h, w, d, disp_hw);
-        int rc = launch_corr_fused(fix, mov, C, h, w, d, disp_hw, ssd, workspace, fws, s);
+        int rc = launch_corr_fused(fix, mov, C, h, w, d, disp_hw, cost, n_box, fast, f16, ssd, workspace, fws, s);
         if (rc) return rc;
         if (argmin) {
             unsigned long long* keys = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + align_up(fws, 256));
@@ -274,6 +281,8 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
         }
         return CVX_OK;
     }
+    if (cost != 0 || n_box != 2 || fast || f16)
+        return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_ex_f32: cost / n_box / fast variants need the fused kernel (C < 16, planes of at most 320 quads)");
     if (!corr_box2_supported(h, w, d, g.px))
         return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
     Carver cv(workspace, workspace_bytes);

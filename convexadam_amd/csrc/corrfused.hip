@@ -25,6 +25,8 @@
 // lane -> 16-byte slot is the identity, so every ds_read_b128 / ds_write_b128 is conflict-free.
 // The <= 31 trailing elements whose channel sum ATen evaluates in its interleaved order come from k_corr_tail (correlate.hip)
 // through a small side buffer.  C >= 16 (cascade sum) and planes of more than 320 quads keep the unfused path.
+#include <hip/hip_fp16.h>
+
 #include "cvx_common.h"
 
 namespace cvx {
@@ -85,6 +87,33 @@ __device__ __forceinline__ void cf_box_item(const float* src, int rs, float (&mi
     for (int j = 0; j < 4; ++j) { fin[j] = f[j]; mid[j] = m[j]; pre[j] = p[j]; }
 }
 
+// FAST variant of the box stage (opt-in, not bit-compatible): the 3 x 3 plane sum is evaluated separably (column sums over the three
+// rows, then three neighbours) and the three planes are combined with two running values per column: A = p(m-1), B = p(m-2) + p(m-1).
+// 28 adds per 4 outputs instead of 104; the divisions by 27 are folded into one multiplication at the end of the chain.
+__device__ __forceinline__ void cf_box_item_fast(const float* src, int rs, float (&B)[4], float (&A)[4], float (&out)[4]) {
+    float c[6];
+    {
+        const f32x4 a = lds_load4(src);
+        const f32x2 b = lds_load2(src + 4);
+        src += rs;
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y;
+    }
+#pragma unroll 1
+    for (int i = 1; i < 3; ++i) {
+        const f32x4 a = lds_load4(src);
+        const f32x2 b = lds_load2(src + 4);
+        src += rs;
+        c[0] += a.x; c[1] += a.y; c[2] += a.z; c[3] += a.w; c[4] += b.x; c[5] += b.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float p = (c[j] + c[j + 1]) + c[j + 2];
+        out[j] = B[j] + p;
+        B[j] = A[j] + p;
+        A[j] = p;
+    }
+}
+
 // what every role needs to know about its work item
 struct CFItem {
     int iH, iW, grp, y, q;
@@ -101,9 +130,9 @@ __device__ __forceinline__ float4 cf_ld16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 
 // ---- raw stage: G x 4 channel sums per thread and step ---------------------------------------------------------------------
 // CT = compile-time channel count (12: fully unrolled software pipeline, every register static) or 0 (run-time count, rolled loop)
-template <int G, int CT>
+template <int G, int CT, bool FAST, bool SAD>
 __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float* __restrict__ Mp, const float* __restrict__ tail,
-                                       const CFGeom& g, const CFItem& it, float* S0) {
+                                       const CFGeom& g, const CFItem& it, float* S0, int nsteps) {
     constexpr int R = G + 2, NSUB = (G + 1) / 2;
     const int n = g.n, nn = n * n, y = it.y, q = it.q, RS = g.RS, PF = g.PF;
     const int C = CT ? CT : g.C;
@@ -120,8 +149,7 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
     const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Mp), 0, (int)(mstride * (unsigned)g.C + 32u), 0x00020000);
     // does this item hold elements of ATen's interleaved-order tail (the last < 32 elements of the (h, n^2, w, d) tensor)?
     const int64_t item_last = (((int64_t)(g.h - 1) * nn + it.iW * n + 4 * it.grp + G - 1) * g.w + (g.w - 1)) * g.d + g.d - 1;
-    const bool tail_item = g.ntail > 0 && item_last >= g.tail_from;
-    const int nsteps = g.h + 4;
+    const bool tail_item = !FAST && g.ntail > 0 && item_last >= g.tail_from;
     int base = 0;                                          // (s * G) mod R
     for (int s = 0; s < nsteps; ++s) {
         const bool live = s < g.h;
@@ -139,7 +167,9 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float df = f[j] - m[j + k];
-                    acc[k][j] += df * df;
+                    if (SAD) acc[k][j] += __builtin_fabsf(df);                       // .abs().sum(0)   l2r_2021 task 3 :54
+                    else if (FAST) acc[k][j] = __builtin_fmaf(df, df, acc[k][j]);
+                    else acc[k][j] += df * df;                                       // .pow(2).sum(0)
                 }
         };
         // channels per sub-interval follow the box stages' load (two displacements, two, one)
@@ -214,8 +244,9 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
     }
 }
 
-// ---- box stages: FIRST = raw -> box 1 (LDS to LDS), else box 1 -> cost volume (LDS to HBM) --------------------------------------
-template <int G, bool FIRST>
+// ---- box stages: FIRST = reads the raw planes (else the box-1 planes), LAST = writes the cost volume (else the box-1 planes);
+// FIRST && LAST is the single-box variant of the challenge scripts (l2r_2021_convexAdam_task2_docker.py:60) ------------------------
+template <int G, bool FIRST, bool LAST, bool FAST, bool ONEBOX, bool F16>
 __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const float* Sin, float* S1, const float* zero, float* __restrict__ ssd) {
     constexpr int R = G + 2, NSUB = (G + 1) / 2;
     const int n = g.n, nn = n * n, y = it.y, q = it.q, RS = g.RS, PF = g.PF;
@@ -224,22 +255,23 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
     for (int k = 0; k < G; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { mid[k][j] = 0.0f; pre[k][j] = 0.0f; }
-    // window origin in a ring plane: rows y-1 .. y+1 = ring rows y .. y+2; box 1 reads raw columns 4q-1 .. 4q+4 (index x + 1),
-    // box 2 reads box-1 columns 4q-4 .. 4q+1 (index x)
+    // window origin in a ring plane: rows y-1 .. y+1 = ring rows y .. y+2; a FIRST stage reads raw columns 4q-1 .. 4q+4 (index x + 1)
+    // and produces columns 4q .. 4q+3, the second stage reads box-1 columns 4q-4 .. 4q+1 (index x) and produces 4q-3 .. 4q
     const float* srcbase = Sin + y * RS + 4 * q - (FIRST ? 0 : 4);
-    const unsigned doff1 = (unsigned)((y + 1) * RS + 4 * q);                           // box 1 writes columns 4q .. 4q+3
-    const int c0 = 4 * q - 3;                                                          // box 2 writes columns 4q-3 .. 4q
+    const unsigned doff1 = (unsigned)((y + 1) * RS + 4 * q);
+    const int c0 = FIRST ? 4 * q : 4 * q - 3;                                          // first column of the four outputs
     const unsigned vol = (unsigned)(g.h * g.w * g.d), plane = (unsigned)(g.w * g.d);
-    const unsigned ooff = 4u * (unsigned)(y * g.d + 4 * q);                            // bytes, relative to (plane base - 3 floats)
-    float* ssd_item = ssd + ((size_t)((4 * it.grp) * n + it.iW) * n + it.iH) * vol - 3;   // uniform
+    const unsigned ooff = 4u * (unsigned)(y * g.d + 4 * q);                            // bytes, relative to (plane base + c0 - 4q)
+    float* ssd_item = ssd + ((size_t)((4 * it.grp) * n + it.iW) * n + it.iH) * vol - (FIRST ? 0 : 3);   // uniform
     const size_t kstride = (size_t)nn * vol;                                           // next D-shift
     const bool full = c0 >= 0 && c0 + 3 < g.d;
     const int jlo = c0 < 0 ? -c0 : 0, jhi = min(4, g.d - c0);                          // valid columns of a partial quad
-    const int nsteps = g.h + 4;
+    const int lag = FIRST ? 1 : 3;                                                     // newest input plane of step s = s - lag
+    const int nsteps = g.h + (ONEBOX ? 2 : 4);
+    constexpr float SCALE = ONEBOX ? 1.0f / 27.0f : 1.0f / 729.0f;                     // fast mode: one multiplication for all divisions
     int base_prev = 0, base = 0;                               // ((s-1) * G) mod R, (s * G) mod R
     for (int s = 0; s < nsteps; ++s) {
-        // box 1: newest raw plane m = s-1 (zero for m >= h), emits plane s-2; box 2: newest box-1 plane m = s-3, emits plane s-4
-        const int m = FIRST ? s - 1 : s - 3;
+        const int m = s - lag;
         const bool have = m >= 0 && m <= g.h;                 // m == h: the zero plane that closes the last output
         const bool readable = m >= 0 && m < g.h;
         const bool emit = m >= 1 && m <= g.h;
@@ -257,27 +289,38 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
                     const int k = 2 * sub + kk < KMAX ? 2 * sub + kk : KMAX;   // compile-time after unrolling
                     if (2 * sub + kk < G) {
                         int sp = base_prev + k; sp = sp >= R ? sp - R : sp;
-                        float fin[4];
-                        cf_box_item(sb + sp * pf, rs, mid[k], pre[k], fin);
+                        float fin[4], o[4];
+                        if (FAST) {
+                            cf_box_item_fast(sb + sp * pf, rs, mid[k], pre[k], fin);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = LAST ? fin[j] * SCALE : fin[j];
+                        } else {
+                            cf_box_item(sb + sp * pf, rs, mid[k], pre[k], fin);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = div_exact<27>(fin[j]);
+                        }
+                        if (F16 && LAST) {                   // cost volume kept at half precision (values)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = __half2float(__float2half_rn(o[j]));
+                        }
                         if (emit && it.active) {
-                            if (FIRST) {
+                            if (!LAST) {
                                 int sn = base + k; sn = sn >= R ? sn - R : sn;
-                                float* o = S1 + doff1 + sn * PF;
-                                lds_store4(o, f32x4{div_exact<27>(fin[0]), div_exact<27>(fin[1]), div_exact<27>(fin[2]), div_exact<27>(fin[3])});
+                                float* ol = S1 + doff1 + sn * PF;
+                                lds_store4(ol, f32x4{o[0], o[1], o[2], o[3]});
                                 if (4 * q + 3 >= g.d)
 #pragma unroll
                                     for (int j = 0; j < 4; ++j)
-                                        if (4 * q + j >= g.d) o[j] = 0.0f;
+                                        if (4 * q + j >= g.d) ol[j] = 0.0f;
                             } else {
                                 char* ob = reinterpret_cast<char*>(ssd_item + (size_t)k * kstride + (size_t)(m - 1) * plane);   // uniform
-                                const f32x4u o = {div_exact<27>(fin[0]), div_exact<27>(fin[1]), div_exact<27>(fin[2]), div_exact<27>(fin[3])};
-                                if (full) *reinterpret_cast<f32x4u*>(ob + ooff) = o;
+                                if (full) *reinterpret_cast<f32x4u*>(ob + ooff) = f32x4u{o[0], o[1], o[2], o[3]};
                                 else {
                                     float* oe = reinterpret_cast<float*>(ob + ooff);
-                                    if (jlo <= 0 && jhi > 0) oe[0] = o.x;
-                                    if (jlo <= 1 && jhi > 1) oe[1] = o.y;
-                                    if (jlo <= 2 && jhi > 2) oe[2] = o.z;
-                                    if (jlo <= 3 && jhi > 3) oe[3] = o.w;
+                                    if (jlo <= 0 && jhi > 0) oe[0] = o[0];
+                                    if (jlo <= 1 && jhi > 1) oe[1] = o[1];
+                                    if (jlo <= 2 && jhi > 2) oe[2] = o[2];
+                                    if (jlo <= 3 && jhi > 3) oe[3] = o[3];
                                 }
                             }
                         }
@@ -291,15 +334,20 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
     }
 }
 
-template <int G>
+// MODE bits: 1 = FAST (FMA + separable sums, not bit-compatible), 2 = SAD cost, 4 = single box, 8 = cost volume rounded to fp16
+template <int G, int MODE>
 __device__ __forceinline__ void cf_roles(int role, const float* Fp, const float* Mp, const float* tail, const CFGeom& g, const CFItem& it,
                                          float* lds, float* S0, float* S1, float* ssd) {
-    if (role == 0) { if (g.C == 12) cf_raw<G, 12>(Fp, Mp, tail, g, it, S0); else cf_raw<G, 0>(Fp, Mp, tail, g, it, S0); }
-    else if (role == 1) cf_box<G, true>(g, it, S0, S1, lds, ssd);
-    else cf_box<G, false>(g, it, S1, S1, lds, ssd);
+    constexpr bool FAST = (MODE & 1) != 0, SAD = (MODE & 2) != 0, ONEBOX = (MODE & 4) != 0, F16 = (MODE & 8) != 0;
+    if (role == 0) {
+        if (g.C == 12) cf_raw<G, 12, FAST, SAD>(Fp, Mp, tail, g, it, S0, ONEBOX ? g.h + 2 : g.h + 4);
+        else cf_raw<G, 0, FAST, SAD>(Fp, Mp, tail, g, it, S0, ONEBOX ? g.h + 2 : g.h + 4);
+    } else if (ONEBOX) cf_box<G, true, true, FAST, true, F16>(g, it, S0, S1, lds, ssd);
+    else if (role == 1) cf_box<G, true, false, FAST, false, F16>(g, it, S0, S1, lds, ssd);
+    else cf_box<G, false, true, FAST, false, F16>(g, it, S1, S1, lds, ssd);
 }
 
-template <int GMAX>
+template <int GMAX, int MODE>
 __global__ __launch_bounds__(1024, 8) void k_corr_fused(const float* __restrict__ Fp, const float* __restrict__ Mp,
                                                         const float* __restrict__ tail, CFGeom g, float* __restrict__ ssd) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -319,7 +367,8 @@ __global__ __launch_bounds__(1024, 8) void k_corr_fused(const float* __restrict_
     }
     float* S0 = lds + 16 + 4;                                 // (16 zeros first) plane p of stage 0: S0 + p * PF, row r = y + 1, index i = x + 1
     float* S1 = S0 + (size_t)(GMAX + 2) * g.PF;               // stage 1: index = x
-    for (int i = tid * 4; i < 16 + 2 * (GMAX + 2) * g.PF; i += blockDim.x * 4) *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nlds = 16 + ((MODE & 4) ? 1 : 2) * (GMAX + 2) * g.PF;
+    for (int i = tid * 4; i < nlds; i += blockDim.x * 4) *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
     const int role = __builtin_amdgcn_readfirstlane(tid / (64 * g.wpr));
@@ -329,11 +378,11 @@ __global__ __launch_bounds__(1024, 8) void k_corr_fused(const float* __restrict_
     it.y = trc / g.lpr; it.q = trc - it.y * g.lpr;
     // the group size is a compile-time constant inside the roles (ring arithmetic, register arrays, no idle accumulators)
     switch (G) {
-        case 5: cf_roles<5>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
-        case 4: cf_roles<4>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
-        case 3: cf_roles<3>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
-        case 2: cf_roles<2>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
-        default: cf_roles<1>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 5: cf_roles<5, MODE>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 4: cf_roles<4, MODE>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 3: cf_roles<3, MODE>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 2: cf_roles<2, MODE>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        default: cf_roles<1, MODE>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
     }
     if (g.dbg && tid == 0) g.dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
 }
@@ -361,7 +410,7 @@ bool corr_fused_supported(int C, int h, int w, int d, int hw) {
     static const bool off = getenv("CVX_CORR_UNFUSED") != nullptr;
     if (off || C >= 16 || hw < 0 || hw > 8) return false;
     const CFGeom g = cf_geom(C, h, w, d, hw);
-    return 3 * g.wpr <= 16 && cf_lds_bytes(g) <= 160 * 1024;
+    return 3 * g.wpr <= 16 && cf_lds_bytes(g) <= 160 * 1024 && (size_t)g.n * g.n * g.n * h * w * d * 4 < ((size_t)1 << 32);
 }
 
 size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw) {
@@ -377,27 +426,42 @@ size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw) {
 // prep / tail kernels of correlate.hip
 void launch_corr_prep_generic(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int px, int PL, int dq, float* Fp,
                               float* Mp, hipStream_t s);
-void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* tail, hipStream_t s);
+void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int sad, float* tail, hipStream_t s);
 
-int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* ssd, void* workspace,
-                      size_t workspace_bytes, hipStream_t s) {
+template <int MODE>
+static void cf_launch(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, float* ssd, hipStream_t s) {
+    constexpr bool ONEBOX = (MODE & 4) != 0;
+    const size_t lds = sizeof(float) * (16 + (ONEBOX ? 1 : 2) * (size_t)(CF_GMAX + 2) * gl.PF);
+    static size_t granted = 0;
+    ensure_dynamic_lds(&k_corr_fused<CF_GMAX, MODE>, lds, granted);
+    const int items = gl.n * gl.n * gl.ng;
+    hipLaunchKernelGGL((k_corr_fused<CF_GMAX, MODE>), dim3(items), dim3((ONEBOX ? 2 : 3) * 64 * gl.wpr), lds, s, Fp, Mp, tail, gl, ssd);
+}
+
+// opts: cost 0 = SSD / 1 = SAD, n_box 2 / 1, fast 0 / 1 (fast: SSD with two boxes only)
+int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
+                      float* ssd, void* workspace, size_t workspace_bytes, hipStream_t s) {
     const CFGeom g = cf_geom(C, h, w, d, hw);
     if (workspace_bytes < corr_fused_workspace_bytes(C, h, w, d, hw)) return fail(CVX_ERR_WORKSPACE, "correlate (fused): workspace too small");
+    if (fast && (cost != 0 || n_box != 2)) return fail(CVX_ERR_UNSUPPORTED, "correlate: the fast mode exists for the SSD cost with two boxes only");
     Carver cv(workspace, workspace_bytes);
     float* Fp = cv.take<float>((size_t)C * h * w * g.RS);
     float* Mp = cv.take<float>((size_t)C * g.hq * g.wq * g.dq + 8);
     float* tail = cv.take<float>((size_t)32 * g.n);
     unsigned long long* census_buf = cv.take<unsigned long long>((size_t)4 * g.n * g.n * g.ng);
     launch_corr_prep_generic(fix, mov, C, h, w, d, hw, g.RS, hw, g.dq, Fp, Mp, s);
-    if (g.ntail > 0) launch_corr_tail_compact(fix, mov, C, h, w, d, hw, tail, s);
-    const size_t lds = cf_lds_bytes(g);
-    static size_t granted = 0;
-    ensure_dynamic_lds(&k_corr_fused<CF_GMAX>, lds, granted);
-    const int items = g.n * g.n * g.ng;
+    if (g.ntail > 0 && !fast) launch_corr_tail_compact(fix, mov, C, h, w, d, hw, cost, tail, s);
     CFGeom gl = g;
     static const char* census = getenv("CVX_CF_CENSUS");      // debugging aid: per-workgroup start / end / placement in the workspace
     gl.dbg = census ? census_buf : nullptr;
-    hipLaunchKernelGGL((k_corr_fused<CF_GMAX>), dim3(items), dim3(3 * 64 * g.wpr), lds, s, Fp, Mp, tail, gl, ssd);
+    if (f16 && (cost != 0 || n_box != 2)) return fail(CVX_ERR_UNSUPPORTED, "correlate: fp16 storage exists for the SSD cost with two boxes only");
+    if (fast && f16) cf_launch<9>(gl, Fp, Mp, tail, ssd, s);
+    else if (fast) cf_launch<1>(gl, Fp, Mp, tail, ssd, s);
+    else if (f16) cf_launch<8>(gl, Fp, Mp, tail, ssd, s);
+    else if (cost == 0 && n_box == 2) cf_launch<0>(gl, Fp, Mp, tail, ssd, s);
+    else if (cost == 0) cf_launch<4>(gl, Fp, Mp, tail, ssd, s);
+    else if (n_box == 2) cf_launch<2>(gl, Fp, Mp, tail, ssd, s);
+    else cf_launch<6>(gl, Fp, Mp, tail, ssd, s);
     return check_last("corr_fused");
 }
 

@@ -255,8 +255,8 @@ int launch_corr_box2(const float* raw, int K, int h, int w, int d, int px, float
 // corrfused.hip: raw SSD + both boxes in one kernel (C < 16, planes of at most 320 quads); else the unfused path above
 bool corr_fused_supported(int C, int h, int w, int d, int hw);
 size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw);
-int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* ssd, void* workspace,
-                      size_t workspace_bytes, hipStream_t s);
+int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
+                      float* ssd, void* workspace, size_t workspace_bytes, hipStream_t s);
 // boxmarch.hip: three chained 3^3 boxes (forward / adjoint / adjoint + Adam) for rows of at most 126 voxels
 bool box3_march_supported(int d);
 int launch_box3_march(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,

@@ -148,6 +148,9 @@ static int validate(const cvx_pair_params* p) {
     CVX_REQUIRE(p->n_feat >= 0 && p->n_feat < 256, "cvx_register_pair: n_feat out of range");
     CVX_REQUIRE(p->selected_smooth == 0 || (p->selected_smooth & 1), "cvx_register_pair: selected_smooth must be odd "
                 "(an even kernel changes the volume size in the reference, convex_adam_MIND.py:185-191)");
+    CVX_REQUIRE((p->cost == 0 || p->cost == 1) && (p->n_box == 0 || p->n_box == 1 || p->n_box == 2) &&
+                (p->n_spline_pools == 0 || p->n_spline_pools == 2 || p->n_spline_pools == 3) && (p->corr_fast == 0 || p->corr_fast == 1) &&
+                (p->fp16_storage == 0 || p->fp16_storage == 1), "cvx_register_pair: bad variant fields (cost, n_box, n_spline_pools, corr_fast, fp16_storage)");
     if (p->lambda_weight > 0) {
         CVX_REQUIRE(p->selected_niter >= 1, "cvx_register_pair: selected_niter must be >= 1 when lambda_weight > 0 "
                     "(the reference raises UnboundLocalError, convex_adam_MIND.py:181)");
@@ -243,7 +246,12 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
     int64_t* am = reinterpret_cast<int64_t*>(ws + L.argmin);
     // first key buffer of the coupled-convex workspace (carved exactly as coupled_core does): the plain argmin leaves its keys there
     unsigned long long* keys = Carver(ws + L.conv_ws, vws).take<unsigned long long>(L.v);
-    if ((rc = cvx_correlate_f32(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
+    const cvx_corr_opts copt = {p->cost, p->n_box == 1 ? 1 : 2, p->corr_fast, p->fp16_storage};
+    const bool variant = copt.cost || copt.n_box == 1 || copt.fast || copt.f16;
+    if (p->fp16_storage) {                      // features are stored in half precision by the reference's GPU default (MIND:79)
+        if ((rc = cvx_round_f16_f32(F(L.fs), (int64_t)L.C * L.v, stream)) || (rc = cvx_round_f16_f32(F(L.ms), (int64_t)L.C * L.v, stream))) return rc;
+    }
+    if ((rc = cvx_correlate_ex_f32(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, variant ? &copt : nullptr, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
     mark("correlate", s);
     static const bool no_prune = getenv("CVX_NO_PRUNE") != nullptr;      // streaming coupled passes need int64 winners
     if (no_prune) rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s);
@@ -253,7 +261,7 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
     int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
     if (p->ic) {                                // reverse direction (:136-138): same operators with the roles swapped
         unsigned long long* keys2 = Carver(ws + L.conv_ws2, vws).take<unsigned long long>(L.v);
-        if ((rc = cvx_correlate_f32(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd2), nullptr, ws + L.corr_ws, cws, stream))) return rc;
+        if ((rc = cvx_correlate_ex_f32(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, variant ? &copt : nullptr, F(L.ssd2), nullptr, ws + L.corr_ws, cws, stream))) return rc;
         mark("correlate_rev", s);
         if (no_prune) rc = launch_argmin(F(L.ssd2), nullptr, nullptr, 0.0f, false, L.K, L.v, keys2, am2, s);
         else rc = launch_argmin_keys(F(L.ssd2), L.K, L.v, keys2, s);
@@ -298,10 +306,14 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
         } else if ((rc = launch_resize(disp_hr, 3, hh, hw_, hd, F(L.P), L.h2, L.w2, L.d2, 1.0f, (float)p->grid_sp_adam, s))) return rc;
         (void)hipMemsetAsync(F(L.m), 0, sizeof(float) * 3 * L.V2, s);
         (void)hipMemsetAsync(F(L.v_), 0, sizeof(float) * 3 * L.V2, s);
+        if (p->fp16_storage) {
+            if ((rc = cvx_round_f16_f32(F(L.F2), (int64_t)L.C * L.V2, stream)) || (rc = cvx_round_f16_f32(F(L.M2), (int64_t)L.C * L.V2, stream))) return rc;
+        }
         mark("adam_setup", s);
+        const cvx_smoother two_pools = {0, 2, {3, 3, 0, 0}, {0.f, 0.f, 0.f, 0.f, 0.f}};            // task3_docker.py:191
         if ((rc = adam_run_impl(F(L.F2), F(L.M2), L.C, L.h2, L.w2, L.d2, F(L.P), F(L.m), F(L.v_), p->lambda_weight,
                                 p->selected_niter, 0, p->cost_scale, F(L.bh2), F(L.bw2), F(L.bd2), F(L.U), nullptr, nullptr, 0,
-                                nullptr, nullptr, /*keep_state=*/false, ws + L.adam_ws,
+                                nullptr, p->n_spline_pools == 2 ? &two_pools : nullptr, /*keep_state=*/false, ws + L.adam_ws,
                                 cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2), stream))) return rc;
         mark("adam", s);
         // disp_hr = interpolate(fitted_grid * grid_sp_adam, (H,W,D))                            (:182)

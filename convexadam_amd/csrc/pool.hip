@@ -6,6 +6,8 @@
 // label one-hot features convex_adam_nnUNet.py:19-38.
 // All of them are HBM/L2-bound gathers; arithmetic follows the ATen CPU kernels (raster-order sums,
 // one division; FMA exactly where the ATen build fuses).
+#include <hip/hip_fp16.h>
+
 #include "cvx_common.h"
 
 namespace cvx {
@@ -530,4 +532,18 @@ extern "C" int cvx_label_features_f32(const float* lab, int64_t V, int C, const 
     hipLaunchKernelGGL(k_label_features, dim3((unsigned)cdiv64(V, 256)), dim3(256), 0, as_stream(stream), lab, V, C, present,
                        weights, mult, feat);
     return check_last("label_features");
+}
+
+
+// fp16 storage of a float32 buffer: x = float(half(x)), round to nearest even
+namespace cvx {
+__global__ __launch_bounds__(256) void k_round_f16(float* __restrict__ x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = __half2float(__float2half_rn(x[i]));
+}
+}  // namespace cvx
+extern "C" int cvx_round_f16_f32(float* x, int64_t n, void* stream) {
+    CVX_REQUIRE(x && n >= 0, "cvx_round_f16_f32: bad arguments");
+    if (n > 0) hipLaunchKernelGGL(cvx::k_round_f16, dim3((unsigned)cvx::cdiv64(n, 256)), dim3(256), 0, cvx::as_stream(stream), x, n);
+    return cvx::check_last("round_f16");
 }

@@ -362,8 +362,16 @@ ORC_API float orc_outer_sum_rows(const float* vals, int64_t size, int ilp) { ret
  *   argmin over k, first minimum wins.
  * fix, mov: [C][h][w][d] ; ssd: [n^3][h][w][d] ; argmin: int64 [h][w][d]
  * ---------------------------------------------------------------------------------------------- */
+ORC_API void orc_correlate_ex(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box,
+                              float* ssd, int64_t* argmin);
 ORC_API void orc_correlate(const float* fix, const float* mov, int C, int h, int w, int d, int hw,
                            float* ssd, int64_t* argmin) {
+    orc_correlate_ex(fix, mov, C, h, w, d, hw, 0, 2, ssd, argmin);
+}
+/* variants of the challenge scripts: cost 1 = `.abs().sum(0)` (l2r_2021_convexAdam_task3_docker.py:54), n_box 1 = a single
+ * avg_pool3d (l2r_2021_convexAdam_task2_docker.py:60, task3:56) */
+ORC_API void orc_correlate_ex(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box,
+                              float* ssd, int64_t* argmin) {
     const int n = 2 * hw + 1;
     const size_t v = (size_t)h * w * d;
     const int64_t K = (int64_t)n * n * n;
@@ -386,16 +394,16 @@ ORC_API void orc_correlate(const float* fix, const float* mov, int C, int h, int
                             const float f = fix[(size_t)c * v + ((size_t)z * w + y) * d + x];
                             const float m = inb ? mov[(size_t)c * v + ((size_t)mz * w + my) * d + mx] : 0.0f;
                             const float df = f - m;
-                            cv[c] = df * df;
+                            cv[c] = cost ? fabsf(df) : df * df;
                         }
                         /* position of this element inside the reference's (C,h,n^2,w,d) difference tensor */
                         const int64_t flat = (((int64_t)z * n * n + jj) * w + y) * d + x;
                         raw[((size_t)z * w + y) * d + x] = outer_sum_rows(cv, C, flat >= tail_from);
                     }
             /* two zero-padded 3^3 box filters, raster order, /27 (inlined single-thread version) */
-            for (int pass = 0; pass < 2; ++pass) {
+            for (int pass = 0; pass < n_box; ++pass) {
                 const float* src = pass == 0 ? raw : b1;
-                float* dst = pass == 0 ? b1 : ssd + (size_t)k * v;
+                float* dst = pass == n_box - 1 ? ssd + (size_t)k * v : b1;
                 for (int z = 0; z < h; ++z)
                     for (int y = 0; y < w; ++y)
                         for (int x = 0; x < d; ++x) {

@@ -62,6 +62,7 @@ def lib():
         L.orc_box3_replicate.argtypes = [_f32p, _f32p] + [C.c_int] * 3
         L.orc_mindssc.argtypes = [_f32p] + [C.c_int] * 5 + [_f32p, C.POINTER(C.c_float)]
         L.orc_correlate.argtypes = [_f32p, _f32p] + [C.c_int] * 5 + [_f32p, _i64p]
+        L.orc_correlate_ex.argtypes = [_f32p, _f32p] + [C.c_int] * 7 + [_f32p, _i64p]
         L.orc_coupled_convex.argtypes = [_f32p, _i64p, _f32p] + [C.c_int] * 4 + [_f32p]
         L.orc_grid_sample.argtypes = [_f32p] + [C.c_int] * 4 + [_f32p] + [C.c_int] * 3 + [_f32p]
         L.orc_inverse_consistency.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [_f32p, _f32p]
@@ -161,11 +162,13 @@ def mindssc(img, radius=2, dilation=2, return_mean=False):
     return (out, gm.value) if return_mean else out
 
 
-def correlate(fix, mov, disp_hw):
-    """fix/mov (C,h,w,d) -> ssd (n^3,h,w,d), argmin (h,w,d) int64; convex_adam_utils.py:72-89."""
+def correlate(fix, mov, disp_hw, cost="ssd", n_box=2):
+    """fix/mov (C,h,w,d) -> ssd (n^3,h,w,d), argmin (h,w,d) int64; convex_adam_utils.py:72-89.
+    cost "sad" / n_box 1: the variants of the challenge scripts (l2r_2021_convexAdam_task3_docker.py:54,56; task2:60)."""
     fix = _f(fix); mov = _f(mov); c, h, w, d = fix.shape; n = 2 * disp_hw + 1
     ssd = np.empty((n ** 3, h, w, d), np.float32); am = np.empty((h, w, d), np.int64)
-    lib().orc_correlate(fix.reshape(-1), mov.reshape(-1), c, h, w, d, disp_hw, ssd.reshape(-1), am.reshape(-1))
+    lib().orc_correlate_ex(fix.reshape(-1), mov.reshape(-1), c, h, w, d, disp_hw, 1 if cost == "sad" else 0, int(n_box),
+                           ssd.reshape(-1), am.reshape(-1))
     return ssd, am
 
 
@@ -228,10 +231,18 @@ def label_features(lab_fix, lab_mov, mult=10.0):
 
 
 # ---- whole pipeline (convex_adam_MIND.py:64-202), composed from the operators above -------------
+def _h(x):
+    """fp16 storage of a float32 array (round to nearest even), values back in float32."""
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
 def convex_adam_pipeline(img_fixed, img_moving, mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6, disp_hw=4,
                          selected_niter=80, selected_smooth=0, grid_sp_adam=2, ic=True, features=None,
-                         return_stages=False):
-    """float32 restatement of convex_adam_pt(); returns (H,W,D,3) float64 like the reference."""
+                         return_stages=False, cost="ssd", n_box=2, n_spline_pools=3, storage="fp32"):
+    """float32 restatement of convex_adam_pt(); returns (H,W,D,3) float64 like the reference.
+    cost / n_box / n_spline_pools: the operator variants of the challenge scripts (l2r_2021_convexAdam_task3_docker.py:54,56,191;
+    task2:60); storage="fp16": pooled features and cost volume rounded to half precision (float32 accumulation)."""
+    q = _h if storage == "fp16" else (lambda a: a)
     st = {}
     if features is None:
         img_fixed = _f(img_fixed); img_moving = _f(img_moving)
@@ -239,15 +250,23 @@ def convex_adam_pipeline(img_fixed, img_moving, mind_r=1, mind_d=2, lambda_weigh
     else:
         ffix, fmov = _f(features[0]), _f(features[1])
     H, W, D = ffix.shape[1:]
-    fs = avgpool_stride(ffix, grid_sp); ms = avgpool_stride(fmov, grid_sp)
+    fs = q(avgpool_stride(ffix, grid_sp)); ms = q(avgpool_stride(fmov, grid_sp))
     h, w, d = fs.shape[1:]
     mesh = disp_mesh(disp_hw)
-    ssd, am = correlate(fs, ms, disp_hw)
+
+    def corr(a, b):
+        ssd, am = correlate(a, b, disp_hw, cost=cost, n_box=n_box)
+        if storage == "fp16":
+            ssd = _h(ssd)
+            am = ssd.reshape(ssd.shape[0], -1).argmin(0).reshape(am.shape).astype(np.int64)     # first minimum of the stored values
+        return ssd, am
+
+    ssd, am = corr(fs, ms)
     soft = coupled_convex(ssd, am, mesh, disp_hw)
     st.update(fs=fs, ms=ms, argmin=am, soft=soft)
     if ic:
         scale = (np.array([h - 1, w - 1, d - 1], np.float32) / np.float32(2)).reshape(3, 1, 1, 1)
-        ssd_, am_ = correlate(ms, fs, disp_hw)
+        ssd_, am_ = corr(ms, fs)
         soft_ = coupled_convex(ssd_, am_, mesh, disp_hw)
         i1, _ = inverse_consistency((soft / scale)[::-1], (soft_ / scale)[::-1], 15)
         disp_hr = resize_trilinear((i1[::-1] * scale) * np.float32(grid_sp), (H, W, D))
@@ -257,10 +276,10 @@ def convex_adam_pipeline(img_fixed, img_moving, mind_r=1, mind_d=2, lambda_weigh
     st.update(disp_hr0=disp_hr)
     if lambda_weight > 0:
         g = grid_sp_adam
-        F2 = avgpool_stride(ffix, g); M2 = avgpool_stride(fmov, g)
+        F2 = q(avgpool_stride(ffix, g)); M2 = q(avgpool_stride(fmov, g))
         disp_lr = resize_trilinear(disp_hr, (H // g, W // g, D // g))
         P0 = disp_lr / np.float32(g)
-        r = adam_run(F2, M2, P0, lambda_weight, selected_niter)
+        r = adam_run(F2, M2, P0, lambda_weight, selected_niter, smoother=make_smoother([3, 3]) if n_spline_pools == 2 else None)
         st.update(P0=P0, U=r["U"])
         disp_hr = resize_trilinear(r["U"] * np.float32(g), (H, W, D))
         if selected_smooth > 0:

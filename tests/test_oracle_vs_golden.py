@@ -302,3 +302,14 @@ def test_full_size_benchmark_pair_vs_reference_golden(orc, golden):
     print("80 iterations, full size: oracle vs reference mean EPE %.3e; reference vs its 1-ulp-perturbed self %.3e" % (e, self_e))
     assert e <= self_e
     assert e < 2e-3
+
+
+def test_correlate_variants_vs_reference_scripts(orc, golden):
+    """cost="sad" / n_box=1: bit-identical to the `correlate` functions of the challenge scripts, which
+    tests/golden/make_golden_variants.py lifts out of l2r_2021_convexAdam_task2/3_docker.py and executes."""
+    g = golden("variants")
+    for tag, cost in (("sad1", "sad"), ("ssd1", "ssd"), ("sad1_w", "sad")):
+        ssd, am = orc.correlate(g[tag + "_fix"], g[tag + "_mov"], int(g[tag + "_hw"]), cost=cost, n_box=1)
+        step = 7 if tag.endswith("_w") else 1
+        assert np.array_equal(ssd[::step], g[tag + "_ssd"]) and np.array_equal(am, g[tag + "_argmin"]), tag
+        assert float(ssd.astype(np.float64).sum()) == float(g[tag + "_ssd_sum"])
