@@ -80,6 +80,8 @@ SIGNATURES = {
                                        _vp, C.POINTER(Smoother), _vp, _sz, _vp]),
     "cvx_register_pair_workspace_bytes": (_sz, [C.POINTER(PairParams)]),
     "cvx_register_pair_f32": (_i, [_vp, _vp, _vp, _vp, C.POINTER(PairParams), _vp, _vp, _vp, _sz, _vp]),
+    "cvx_register_pair_snapshots_workspace_bytes": (_sz, [_vp, _i, _vp, _i]),
+    "cvx_register_pair_snapshots_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "cvx_register_pairs_f32": (_i, [_i, _vp, _vp, _vp, _vp, C.POINTER(PairParams), _vp, _vp, _vp, _sz, _i, _vp]),
     "cvx_last_pair_profile": (_i, [_vp, _vp, _i]),
     "cvx_set_profiling": (None, [_i]),

@@ -157,6 +157,38 @@ def register_pair_device(img_fixed=None, img_moving=None, feat_fixed=None, feat_
     return out
 
 
+def register_pair_snapshots_device(img_fixed=None, img_moving=None, feat_fixed=None, feat_moving=None, snapshot_iters=(40, 60, 80),
+                                   smooths=(0, 3, 5), mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6, disp_hw=4, grid_sp_adam=2, ic=True,
+                                   cost_scale=12.0, n_spline_pools=3):
+    """One Adam run, several results: the up-sampled `disp_sample` after each iteration of `snapshot_iters`
+    (1-based), once per entry of `smooths` (0 = as is, k = three k^3 mean filters) -> (n_snap, n_smooth, 3, H, W, D) device tensor.
+    The default is the 9-field variant of self_configuring/convex_adam_MIND.py:115-139; the sweep's stage 2 evaluates iterations
+    60 / 80 / 100 / 120 of one 120-iteration run the same way (adam_run_withconfig_shiftSpline.py:234-246)."""
+    if feat_fixed is not None:
+        ff, fm = f32c(feat_fixed), f32c(feat_moving)
+        n_feat = int(ff.shape[0]); H, W, D = [int(v) for v in ff.shape[1:]]; dev = ff.device; a = b = None
+    else:
+        a, b = f32c(img_fixed), f32c(img_moving)
+        H, W, D = [int(v) for v in a.shape]; dev = a.device; ff = fm = None; n_feat = 0
+    _require_hip(dev)
+    its = [int(v) for v in snapshot_iters]
+    sms = [int(v) for v in smooths]
+    p = PairParams(H, W, D, int(mind_r), int(mind_d), float(lambda_weight), int(grid_sp), int(disp_hw), its[-1], 0, int(grid_sp_adam),
+                   1 if ic else 0, n_feat, float(cost_scale), 0, 0, int(n_spline_pools), 0, 0)
+    L = lib()
+    it_arr = (C.c_int * len(its))(*its)
+    sm_arr = (C.c_int * len(sms))(*sms)
+    nws = L.cvx_register_pair_snapshots_workspace_bytes(C.byref(p), len(its), C.cast(sm_arr, C.c_void_p), len(sms))
+    if nws == 0:
+        raise _lib.CvxError(_lib.CVX_ERR_INVALID_ARG, L.cvx_last_error().decode() or "bad snapshot arguments")
+    out = torch.empty((len(its), len(sms), 3, H, W, D), dtype=torch.float32, device=dev)
+    ws = workspace(nws, dev)
+    with torch.cuda.device(dev):
+        check(L.cvx_register_pair_snapshots_f32(ptr(a), ptr(b), ptr(ff), ptr(fm), C.byref(p), C.cast(it_arr, C.c_void_p), len(its),
+                                                C.cast(sm_arr, C.c_void_p), len(sms), ptr(out), ptr(ws), nws, stream_ptr(dev)))
+    return out
+
+
 def register_pairs_device(imgs_fixed, imgs_moving, outs=None, n_streams=2, mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6,
                           disp_hw=4, selected_niter=80, selected_smooth=0, grid_sp_adam=2, ic=True, cost_scale=12.0):
     """Several independent pairs (lists of (H,W,D) device tensors, equal shapes) in one call: the library deals them

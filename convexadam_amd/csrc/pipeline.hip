@@ -61,7 +61,7 @@ struct PairLayout {
     size_t V, v, V2;
     // byte offsets into the workspace (0 = not used)
     size_t featF, featM, mind_ws, fs, ms, corr_ws, ssd, argmin, mesh, conv_ws, ssd2, argmin2, conv_ws2, soft, soft2, in1, in2, ic1, ic2, ic_ws,
-        upin, disp_hr, F2, M2, P, m, v_, U, adam_ws, smooth_ws, bh, bw, bd, bh2, bw2, bd2, total;
+        upin, disp_hr, F2, M2, P, m, v_, U, adam_ws, smooth_ws, snaps, bh, bw, bd, bh2, bw2, bd2, total;
 };
 
 static size_t take(size_t& used, size_t bytes) {
@@ -70,7 +70,7 @@ static size_t take(size_t& used, size_t bytes) {
     return off;
 }
 
-static PairLayout pair_layout(const cvx_pair_params& p) {
+static PairLayout pair_layout(const cvx_pair_params& p, int n_snap = 0, int max_smooth = 0) {
     PairLayout L{};
     L.H = p.H; L.W = p.W; L.D = p.D;
     L.h = p.H / p.grid_sp; L.w = p.W / p.grid_sp; L.d = p.D / p.grid_sp;
@@ -113,7 +113,8 @@ static PairLayout pair_layout(const cvx_pair_params& p) {
         L.P = take(u, f * 3 * L.V2); L.m = take(u, f * 3 * L.V2); L.v_ = take(u, f * 3 * L.V2); L.U = take(u, f * 3 * L.V2);
         L.adam_ws = take(u, cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2));
         L.bh2 = take(u, f * L.h2); L.bw2 = take(u, f * L.w2); L.bd2 = take(u, f * L.d2);
-        if (p.selected_smooth > 0) L.smooth_ws = take(u, 2 * (256 + f * 3 * L.V));
+        if (p.selected_smooth > 0 || max_smooth > 0) L.smooth_ws = take(u, 2 * (256 + f * 3 * L.V));
+        if (n_snap > 0) L.snaps = take(u, f * 3 * L.V2 * (size_t)n_snap);
     }
     L.total = u + 256;
     return L;
@@ -190,15 +191,57 @@ extern "C" size_t cvx_register_pair_workspace_bytes(const cvx_pair_params* p) {
     return pair_layout(*p).total;
 }
 
+namespace cvx {
+static int smooth_max(const int* smooth_host, int n_smooth) {
+    int m = 0;
+    for (int i = 0; i < n_smooth; ++i) m = smooth_host[i] > m ? smooth_host[i] : m;
+    return m;
+}
+// out_field: the field of the packaged pipeline ([3][H][W][D]) when n_snap == 0; otherwise [n_snap][n_smooth][3][H][W][D]: for every
+// listed Adam iteration the up-sampled disp_sample of that iteration, once per listed final smoothing (0 = none, k = three k^3 boxes)
+static int register_pair_core(const float* img_fixed, const float* img_moving, const float* feat_fixed, const float* feat_moving,
+                              const cvx_pair_params* p, float* out_field, int* out_dims_host, const int* snap_iters_host, int n_snap,
+                              const int* smooth_host, int n_smooth, void* workspace, size_t workspace_bytes, void* stream);
+}  // namespace cvx
+
 extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_moving, const float* feat_fixed,
                                      const float* feat_moving, const cvx_pair_params* p, float* out_field,
                                      int* out_dims_host, void* workspace, size_t workspace_bytes, void* stream) {
+    return register_pair_core(img_fixed, img_moving, feat_fixed, feat_moving, p, out_field, out_dims_host, nullptr, 0, nullptr, 0, workspace,
+                              workspace_bytes, stream);
+}
+
+extern "C" size_t cvx_register_pair_snapshots_workspace_bytes(const cvx_pair_params* p, int n_snap, const int* smooth_host, int n_smooth) {
+    if (validate(p) != CVX_OK || n_snap < 1 || n_smooth < 1 || !smooth_host) return 0;
+    return pair_layout(*p, n_snap, smooth_max(smooth_host, n_smooth)).total;
+}
+
+extern "C" int cvx_register_pair_snapshots_f32(const float* img_fixed, const float* img_moving, const float* feat_fixed,
+                                               const float* feat_moving, const cvx_pair_params* p, const int* snapshot_iters_host, int n_snap,
+                                               const int* smooth_host, int n_smooth, float* out_fields, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+    int rc = validate(p);
+    if (rc) return rc;
+    CVX_REQUIRE(snapshot_iters_host && n_snap >= 1 && smooth_host && n_smooth >= 1, "cvx_register_pair_snapshots_f32: snapshot / smoothing lists missing");
+    CVX_REQUIRE(p->lambda_weight > 0, "cvx_register_pair_snapshots_f32: snapshots exist only with the Adam stage (lambda_weight > 0)");
+    for (int i = 0; i < n_snap; ++i)
+        CVX_REQUIRE(snapshot_iters_host[i] >= 1 && snapshot_iters_host[i] <= p->selected_niter && (i == 0 || snapshot_iters_host[i] > snapshot_iters_host[i - 1]),
+                    "cvx_register_pair_snapshots_f32: snapshot iterations must be ascending and within 1..selected_niter");
+    for (int i = 0; i < n_smooth; ++i)
+        CVX_REQUIRE(smooth_host[i] == 0 || (smooth_host[i] & 1), "cvx_register_pair_snapshots_f32: smoothing sizes must be 0 or odd");
+    return register_pair_core(img_fixed, img_moving, feat_fixed, feat_moving, p, out_fields, nullptr, snapshot_iters_host, n_snap, smooth_host,
+                              n_smooth, workspace, workspace_bytes, stream);
+}
+
+static int cvx::register_pair_core(const float* img_fixed, const float* img_moving, const float* feat_fixed, const float* feat_moving,
+                                   const cvx_pair_params* p, float* out_field, int* out_dims_host, const int* snap_iters_host, int n_snap,
+                                   const int* smooth_host, int n_smooth, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = validate(p);
     if (rc) return rc;
     CVX_REQUIRE(out_field && workspace, "cvx_register_pair_f32: null pointer");
     if (p->n_feat == 0) CVX_REQUIRE(img_fixed && img_moving, "cvx_register_pair_f32: images missing");
     else CVX_REQUIRE(feat_fixed && feat_moving, "cvx_register_pair_f32: feature volumes missing");
-    const PairLayout L = pair_layout(*p);
+    const PairLayout L = pair_layout(*p, n_snap, n_snap ? smooth_max(smooth_host, n_smooth) : 0);
     if (workspace_bytes < L.total) return fail(CVX_ERR_WORKSPACE, "cvx_register_pair_f32: workspace %zu < %zu", workspace_bytes, L.total);
     hipStream_t s = as_stream(stream);
     char* ws = static_cast<char*>(workspace);
@@ -312,12 +355,27 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
         mark("adam_setup", s);
         const cvx_smoother two_pools = {0, 2, {3, 3, 0, 0}, {0.f, 0.f, 0.f, 0.f, 0.f}};            // task3_docker.py:191
         if ((rc = adam_run_impl(F(L.F2), F(L.M2), L.C, L.h2, L.w2, L.d2, F(L.P), F(L.m), F(L.v_), p->lambda_weight,
-                                p->selected_niter, 0, p->cost_scale, F(L.bh2), F(L.bw2), F(L.bd2), F(L.U), nullptr, nullptr, 0,
-                                nullptr, p->n_spline_pools == 2 ? &two_pools : nullptr, /*keep_state=*/false, ws + L.adam_ws,
+                                p->selected_niter, 0, p->cost_scale, F(L.bh2), F(L.bw2), F(L.bd2), F(L.U), nullptr, snap_iters_host, n_snap,
+                                n_snap ? F(L.snaps) : nullptr, p->n_spline_pools == 2 ? &two_pools : nullptr, /*keep_state=*/false, ws + L.adam_ws,
                                 cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2), stream))) return rc;
         mark("adam", s);
         // disp_hr = interpolate(fitted_grid * grid_sp_adam, (H,W,D))                            (:182)
-        if (p->selected_smooth > 0) {
+        if (n_snap > 0) {                       // self_configuring/convex_adam_MIND.py:115-139: every snapshot x every final smoothing
+            float* tmp = F(L.smooth_ws);
+            float* tmp2 = L.smooth_ws ? reinterpret_cast<float*>(ws + align_up(L.smooth_ws + sizeof(float) * 3 * L.V, 256)) : nullptr;
+            for (int i = 0; i < n_snap; ++i)
+                for (int j = 0; j < n_smooth; ++j) {
+                    float* dst = out_field + ((size_t)i * n_smooth + j) * 3 * L.V;
+                    const float* snap = F(L.snaps) + (size_t)i * 3 * L.V2;
+                    const int k = smooth_host[j];
+                    if (k > 0) {
+                        if ((rc = launch_resize(snap, 3, L.h2, L.w2, L.d2, tmp, p->H, p->W, p->D, (float)p->grid_sp_adam, 1.0f, s))) return rc;
+                        if ((rc = launch_box_zero(tmp, tmp2, 3, p->H, p->W, p->D, k, false, s))) return rc;
+                        if ((rc = launch_box_zero(tmp2, tmp, 3, p->H, p->W, p->D, k, false, s))) return rc;
+                        if ((rc = launch_box_zero(tmp, dst, 3, p->H, p->W, p->D, k, false, s))) return rc;
+                    } else if ((rc = launch_resize(snap, 3, L.h2, L.w2, L.d2, dst, p->H, p->W, p->D, (float)p->grid_sp_adam, 1.0f, s))) return rc;
+                }
+        } else if (p->selected_smooth > 0) {
             float* tmp = F(L.smooth_ws);
             float* tmp2 = reinterpret_cast<float*>(ws + align_up(L.smooth_ws + sizeof(float) * 3 * L.V, 256));
             if ((rc = launch_resize(F(L.U), 3, L.h2, L.w2, L.d2, tmp, p->H, p->W, p->D, (float)p->grid_sp_adam, 1.0f, s))) return rc;

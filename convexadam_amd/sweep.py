@@ -1,21 +1,29 @@
-"""Sharded sweep driver: (hyper-parameter setting x image pair) items over the GPUs of one node.
+"""Self-configuring sweep, sharded over the GPUs of one node (BASELINE configs[4]).
 
-Counterpart of the reference's manual scheme -- one OS process per GPU started by hand with a GPU id
-(self_configuring/convex_run_withconfig.py:42-43,178-180) -- done properly: one process per GPU under
-`torch.distributed.run`, items assigned round-robin by rank, NO collective on the data path (a pair is
-~20 GB of HBM traffic and never worth splitting over xGMI); torch.distributed is used only
-for the start barrier and the final gather of per-item results on rank 0 (RCCL on GPUs, gloo on CPU).
+The reference tunes convexAdam in two stages (self_configuring/convex_run_withconfig.py, adam_run_withconfig_shiftSpline.py and their
+`*_paired_mind*` twins), each started by hand once per GPU id (:42-43,178-180):
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        convexadam_amd/sweep.py --pairs 4 --settings 256 --shape 160 192 224 --evaluate --out sweep.json
+  stage 1  convex only: N1 random settings (MIND radius / dilation, grid_sp, disp_hw) x all validation pairs; every field is scored
+           (Dice, Dice of the 30 % hardest labels, HD95, std of the log-Jacobian) and the settings are ranked by the geometric mean of
+           their per-metric ranks (convex_run_withconfig.py:63-172)
+  stage 2  Adam: with the best stage-1 setting, N2 random settings (grid_sp_adam, smoother of the control grid, lambda); ONE
+           120-iteration Adam run per (setting, pair) is scored 16 times -- disp_sample after iterations 60 / 80 / 100 / 120, each
+           after 0..3 extra 3^3 mean filters at full resolution -- and (setting, snapshot, smoothing) triples are ranked the same way
+           (adam_run_withconfig_shiftSpline.py:143-266)
 
-With --evaluate every item is scored on the device the way the reference's sweep scripts do it
-(convex_run_withconfig.py:136-150, convex_run_paired_mind.py:165-177): Jacobian log-std and folding fraction,
-nearest-neighbour warp of the moving label map and Dice against the fixed one, key-point TRE; only those scalars
-return to the host, and rank 0 aggregates the per-setting means into the reference's geometric-mean rank
-(convex_run_withconfig.py:160-168, sort_rank of hyper_util:28-31).
+Here: one process per GPU under `torch.distributed.run`; items = (setting, pair), handed out by a SHARED WORK QUEUE (an atomic counter in
+a TCPStore on rank 0; items are queued most-expensive-first, so the slowest rank never ends up with the big cost volumes), no collective
+on the data path; every finished item is appended to `<out>.rank<r>.jsonl` at once, so a killed sweep restarts with
+`--resume` and skips what is on disk (the reference saves after every setting, convex_run_withconfig.py:156,172); all scoring runs on the
+device (csrc/metrics.hip, edt.hip).  torch.distributed is used for the phase barriers and the hand-over of the stage-1 winner only.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        convexadam_amd/sweep.py --pairs 4 --shape 160 192 224 --stage1 100 --stage2 75 --out sweep.json
+
+`--settings N --evaluate` keeps the round-1 behaviour (the build's own 256-point grid, whole pipeline per item).
 """
 import argparse
+import glob
 import itertools
 import json
 import os
@@ -29,16 +37,14 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
+SNAP_ITERS = (60, 80, 100, 120)          # disp_sample after these iterations (adam_run_withconfig_shiftSpline.py:234: iter 59, 79, ...)
+N_EXTRA_SMOOTH = 4                       # 0..3 extra 3^3 mean filters (:244-246)
+ADAM_ITERS = 120
 
-def shard_items(items, rank, world_size):
-    """Static round-robin assignment (item i -> rank i mod world_size)."""
-    return list(items)[rank::world_size]
 
-
+# ---- settings ------------------------------------------------------------------------------------------------------------------
 def sweep_settings():
-    """The build's own 256-point grid for BASELINE config 5 (the reference draws 100 + 75 random settings
-    from torch.manual_seed(1004)/(2004), convex_run_withconfig.py:65-69; a fixed grid is reproducible
-    without torch's RNG stream): 4 MIND shapes x 4 grid spacings x 4 search half-widths x 4 lambdas."""
+    """The build's own 256-point grid (round-1 mode): 4 MIND shapes x 4 grid spacings x 4 search half-widths x 4 lambdas."""
     out = []
     for (r, d), gs, hw, lam in itertools.product(((1, 1), (1, 2), (2, 1), (2, 2)), (4, 5, 6, 8), (3, 4, 5, 6),
                                                  (0.75, 1.0, 1.25, 1.5)):
@@ -47,6 +53,49 @@ def sweep_settings():
     return out
 
 
+def stage1_settings(n, seed=1004):
+    """n random convex-stage settings, drawn like the reference's (torch.manual_seed(1004), convex_run_paired_mind.py): MIND radius
+    1..3, dilation 1..3, grid_sp 2..5, disp_hw 2..7, the search capped at 5 for grid_sp 2 (its cost volume would not fit)."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n, 4, generator=g)
+    out = []
+    for a, b, c, e in u.tolist():
+        gs = 2 + int(c * 4)
+        hw = 2 + int(e * 6)
+        if gs == 2:
+            hw = min(hw, 5)
+        out.append(dict(mind_r=1 + int(a * 3), mind_d=1 + int(b * 3), grid_sp=gs, disp_hw=hw))
+    return out
+
+
+def stage2_settings(n, seed=2004):
+    """n random Adam-stage settings (torch.manual_seed(2004), adam_run_withconfig_shiftSpline.py:143-171): grid_sp_adam 1..4, smoother
+    index 1..5 shifted by +2 / +1 for grid_sp_adam 1 / 2 (the finer the control grid, the wider the spline), lambda 0.4 .. 1.6."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n, 3, generator=g)
+    out = []
+    for a, b, c in u.tolist():
+        gsa = 1 + int(a * 4)
+        avg = 1 + int(b * 5) + (2 if gsa == 1 else (1 if gsa == 2 else 0))
+        out.append(dict(grid_sp_adam=gsa, avg_n=min(avg, 7), lambda_weight=round(0.2 * (2 + int(c * 7)), 1)))
+    return out
+
+
+def smoother_table():
+    """avgs of adam_run_withconfig_shiftSpline.py:140-141."""
+    from convexadam_amd import convexAdam_hyper_util as HU
+    return [HU.GaussianSmoothing(0.7), HU.GaussianSmoothing(1.0)] + [HU.kovesi_spline(s, 4) for s in (1.3, 1.6, 1.9, 2.2, 2.5, 2.8)]
+
+
+def item_cost(cfg, shape):
+    """Rough relative cost of one item (cost-volume bytes + Adam work): orders the queue, nothing else."""
+    gs, hw = cfg.get("grid_sp", 6), cfg.get("disp_hw", 4)
+    v = (shape[0] // gs) * (shape[1] // gs) * (shape[2] // gs)
+    gsa = cfg.get("grid_sp_adam", 2)
+    return (2 * hw + 1) ** 3 * v * 8 + ADAM_ITERS * 12 * (shape[0] // gsa) * (shape[1] // gsa) * (shape[2] // gsa) * 40 * (1 if "avg_n" in cfg or cfg.get("lambda_weight", 0) > 0 else 0)
+
+
+# ---- synthetic validation data -------------------------------------------------------------------------------------------------
 SHIFT = (2, -1, 3)          # moving = fixed content rolled by SHIFT voxels: the field to recover is +SHIFT
 
 
@@ -68,7 +117,8 @@ def _make_labels(shape, idx, device, num_labels=13):
     return lab.to(device), torch.roll(lab, SHIFT, (0, 1, 2)).to(device), key_f, key_m, num_labels
 
 
-def evaluate_item(disp, seg_fixed, seg_moving, key_fixed, key_moving, num_labels):
+# ---- scoring ----------------------------------------------------------------------------------------------------------------------
+def evaluate_item(disp, seg_fixed, seg_moving, key_fixed, key_moving, num_labels, robust=None):
     """disp (3,H,W,D) device field in voxels -> dict of the reference's evaluation scalars (computed on the device)."""
     from convexadam_amd import convexAdam_hyper_util as HU
     d = disp[None]
@@ -80,12 +130,30 @@ def evaluate_item(disp, seg_fixed, seg_moving, key_fixed, key_moving, num_labels
     tre, _ = HU.tre_at_keypoints(d, key_fixed, key_moving)                                 # convex_run_paired_mind.py:165-173
     tre0 = (key_fixed - key_moving).square().sum(-1).sqrt()
     hd95 = HU.cupy_hd95(seg_fixed, warped, num_labels)                                     # convex_run_withconfig.py:143
-    return dict(dice=float(dice.mean()), dice_before=float(dice0.mean()), jstd=jstd, folding=fold, tre=float(tre.mean()),
-                tre_before=float(tre0.mean()), hd95=float(hd95.mean()))
+    if robust is None:                                                                      # the 30 % labels with the lowest initial overlap (:60-61)
+        robust = dice0.topk(max(1, int(num_labels * 0.3)), largest=False).indices
+    return dict(dice=float(dice.mean()), dice30=float(dice[robust].mean()), dice_before=float(dice0.mean()), jstd=jstd, folding=fold,
+                tre=float(tre.mean()), tre_before=float(tre0.mean()), hd95=float(hd95.mean()))
+
+
+def rank_records(records, keys):
+    """Geometric mean of the per-metric ranks over the groups identified by `keys` (means over pairs first)
+    (convex_run_withconfig.py:160-168, adam_run_withconfig_shiftSpline.py:259-264; sort_rank of hyper_util:28-31)."""
+    from convexadam_amd.convexAdam_hyper_util import sort_rank
+    groups = {}
+    for r in records:
+        groups.setdefault(tuple(r[k] for k in keys), []).append(r)
+    ids = sorted(groups)
+    mean = lambda k: torch.tensor([sum(x[k] for x in groups[i]) / len(groups[i]) for i in ids])   # noqa: E731
+    dice, dice30, jstd, hd95, tre = mean("dice"), mean("dice30"), mean("jstd"), mean("hd95"), mean("tre")
+    rank = (sort_rank(-dice) * sort_rank(-dice30) * sort_rank(jstd) * sort_rank(hd95)).pow(1 / 4)
+    best = int(rank.argmax())
+    return dict(ids=[list(i) for i in ids], dice=dice.tolist(), dice30=dice30.tolist(), jstd=jstd.tolist(), hd95=hd95.tolist(),
+                tre=tre.tolist(), rank=rank.tolist(), best=list(ids[best]))
 
 
 def aggregate_ranks(results, n_settings):
-    """Per-setting means over pairs and the reference's rank: prod(sort_rank(metric)) ** (1/n) (convex_run_withconfig.py:160-168)."""
+    """Round-1 mode: per-setting means and rank (Dice, TRE, log-Jacobian std, HD95)."""
     from convexadam_amd.convexAdam_hyper_util import sort_rank
     acc = {k: torch.zeros(n_settings) for k in ("dice", "jstd", "tre", "hd95")}
     cnt = torch.zeros(n_settings)
@@ -102,15 +170,148 @@ def aggregate_ranks(results, n_settings):
                 best_setting=int(rank.argmax()))
 
 
+# ---- sharding ----------------------------------------------------------------------------------------------------------------------
+def shard_items(items, rank, world_size):
+    """Static round-robin assignment (item i -> rank i mod world_size); kept for the dry-run and as the queue's fallback."""
+    return list(items)[rank::world_size]
+
+
+class WorkQueue:
+    """Shared queue over the processes of a sweep: an atomic counter per phase in a TCPStore hosted by rank 0.  `order` lists the
+    item ids most-expensive-first; every `next()` hands out one id until the phase is exhausted."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.store = rank, world, None
+        if world > 1:
+            port = int(os.environ.get("MASTER_PORT", "29500")) + 17
+            self.store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, is_master=(rank == 0), wait_for_workers=True)
+        self.local = {}
+
+    def next(self, phase, order):
+        if self.store is not None:
+            i = self.store.add("q_" + phase, 1) - 1
+        else:
+            i = self.local.get(phase, 0)
+            self.local[phase] = i + 1
+        return order[i] if i < len(order) else None
+
+
+class ResultLog:
+    """Append-only results of one rank (`<out>.rank<r>.jsonl`), keyed by (stage, setting, pair); `--resume` reads every rank's file."""
+
+    def __init__(self, out, rank, resume):
+        self.path = "%s.rank%d.jsonl" % (out, rank) if out else None
+        self.done = {}
+        if out and resume:
+            for f in glob.glob(out + ".rank*.jsonl"):
+                for line in open(f):
+                    line = line.strip()
+                    if line:
+                        try:
+                            r = json.loads(line)
+                        except ValueError:
+                            continue                                        # a line cut off by the kill
+                        self.done[(r["stage"], r["setting"], r["pair"])] = r
+        elif self.path and os.path.exists(self.path):
+            os.remove(self.path)
+
+    def add(self, rec):
+        self.done[(rec["stage"], rec["setting"], rec["pair"])] = rec
+        if self.path:
+            with open(self.path, "a") as f:
+                f.write(json.dumps(rec) + "\n")
+                f.flush()
+                os.fsync(f.fileno())
+
+
+def gather_records(local, world):
+    if world == 1:
+        return list(local)
+    got = [None] * world
+    dist.all_gather_object(got, list(local))
+    return [r for part in got for r in part]
+
+
+# ---- the two stages ------------------------------------------------------------------------------------------------------------------
+class PairData:
+    """Validation pairs and their labels, made on demand and kept on the device (a few pairs per GPU fit easily in 288 GB)."""
+
+    def __init__(self, shape, device):
+        self.shape, self.device, self.pairs, self.labels, self.coarse = tuple(shape), device, {}, {}, {}
+
+    def pair(self, p):
+        if p not in self.pairs:
+            self.pairs[p] = _make_pair(self.shape, p, self.device)
+        return self.pairs[p]
+
+    def label(self, p):
+        if p not in self.labels:
+            self.labels[p] = _make_labels(self.shape, p, self.device)
+        return self.labels[p]
+
+
+def run_stage1_item(cfg, p, data):
+    from convexadam_amd.convex_adam_MIND import register_pair_device
+    fix, mov = data.pair(p)
+    torch.cuda.synchronize(data.device)
+    t = time.time()
+    disp = register_pair_device(fix, mov, lambda_weight=0, ic=True, **cfg)                  # convex stage + inverse consistency (:100-128)
+    torch.cuda.synchronize(data.device)
+    rec = dict(ms=(time.time() - t) * 1e3)
+    rec.update(evaluate_item(disp, *data.label(p)))
+    return rec
+
+
+def run_stage2_item(best1, cfg2, p, data, smoothers):
+    """One 120-iteration Adam run from the stage-1 field, scored at 4 iterations x 4 smoothings (adam_run_withconfig_shiftSpline.py:159-246)."""
+    from convexadam_amd import convex_adam_utils as U
+    from convexadam_amd.convex_adam_MIND import register_pair_device
+    fix, mov = data.pair(p)
+    H, W, D = data.shape
+    key = (p, tuple(sorted(best1.items())))
+    if key not in data.coarse:                                                              # the convex stage runs once per pair (:100-126)
+        data.coarse[key] = register_pair_device(fix, mov, lambda_weight=0, ic=True, **best1)
+    disp_hr = data.coarse[key]
+    gsa, lam = cfg2["grid_sp_adam"], cfg2["lambda_weight"]
+    torch.cuda.synchronize(data.device)
+    t = time.time()
+    ff = U.MINDSSC(fix[None, None], best1["mind_r"], best1["mind_d"], device=data.device)
+    fm = U.MINDSSC(mov[None, None], best1["mind_r"], best1["mind_d"], device=data.device)
+    F2, M2 = U.avg_pool(ff, gsa), U.avg_pool(fm, gsa)
+    del ff, fm
+    h2, w2, d2 = H // gsa, W // gsa, D // gsa
+    P0 = U.resize_trilinear(disp_hr[None], (h2, w2, d2)) / float(gsa)
+    n_ch = int(F2.shape[1])
+    _, st = U.adam_run(F2, M2, P0, lam, ADAM_ITERS, smoother=smoothers[cfg2["avg_n"]], cost_scale=float(n_ch), snapshot_iters=SNAP_ITERS,
+                       return_state=True)
+    torch.cuda.synchronize(data.device)
+    ms = (time.time() - t) * 1e3
+    recs = []
+    lab = data.label(p)
+    for ii in range(len(SNAP_ITERS)):
+        field = U.resize_trilinear(st["snapshots"][ii][None] * float(gsa), (H, W, D))
+        for kk in range(N_EXTRA_SMOOTH):
+            if kk > 0:
+                field = U.box_smooth(field, 3, 1)
+            r = dict(snap=ii, smooth=kk, ms=ms)
+            r.update(evaluate_item(field[0], *lab))
+            recs.append(r)
+    return recs
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=2)
-    ap.add_argument("--settings", type=int, default=4, help="use the first N settings of the 256-point grid")
     ap.add_argument("--shape", type=int, nargs=3, default=[64, 64, 64])
-    ap.add_argument("--niter", type=int, default=None, help="override selected_niter")
+    ap.add_argument("--stage1", type=int, default=0, help="number of random convex-stage settings (two-stage mode)")
+    ap.add_argument("--stage2", type=int, default=0, help="number of random Adam-stage settings (two-stage mode)")
+    ap.add_argument("--settings", type=int, default=4, help="round-1 mode: first N settings of the 256-point grid, whole pipeline per item")
+    ap.add_argument("--niter", type=int, default=None, help="round-1 mode: override selected_niter")
     ap.add_argument("--out", type=str, default=None)
-    ap.add_argument("--dry-run", action="store_true", help="no kernels: exercises sharding + gather only (CPU/gloo)")
-    ap.add_argument("--evaluate", action="store_true", help="score every item on the device (Dice, Jacobian, TRE) and rank the settings")
+    ap.add_argument("--resume", action="store_true", help="skip the items already present in <out>.rank*.jsonl")
+    ap.add_argument("--static", action="store_true", help="round-robin assignment instead of the shared queue")
+    ap.add_argument("--dry-run", action="store_true", help="no kernels: exercises queue, logs, resume and gather only (CPU/gloo)")
+    ap.add_argument("--evaluate", action="store_true", help="round-1 mode: score every item on the device and rank the settings")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", 0))
@@ -122,59 +323,118 @@ def main(argv=None):
     if use_gpu:
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    two_stage = a.stage1 > 0
+    queue = WorkQueue(rank, world)
+    log = ResultLog(a.out, rank, a.resume)
+    data = PairData(a.shape, device)
+    shape = tuple(a.shape)
 
-    settings = sweep_settings()[: a.settings]
-    items = [(s, p) for s in range(len(settings)) for p in range(a.pairs)]
-    mine = shard_items(list(enumerate(items)), rank, world)
+    def run_phase(phase, settings, worker):
+        """Hands out (setting, pair) items of one phase; returns this rank's records (resumed ones included)."""
+        items = [(s, p) for s in range(len(settings)) for p in range(a.pairs)]
+        order = sorted(range(len(items)), key=lambda i: -item_cost(settings[items[i][0]], shape))
+        mine, fresh = [], 0
+        static = shard_items(order, rank, world) if a.static else None
+        k = 0
+        while True:
+            if static is not None:
+                i = static[k] if k < len(static) else None
+                k += 1
+            else:
+                i = queue.next(phase, order)
+            if i is None:
+                break
+            s, p = items[i]
+            if (phase, s, p) in log.done:                                   # --resume: already on disk; reported by whoever draws it
+                mine.append(dict(log.done[(phase, s, p)], item=i))
+                continue
+            rec = dict(stage=phase, setting=s, pair=p, rank=rank, item=i)
+            rec.update(worker(settings[s], p))
+            log.add(rec)
+            mine.append(rec)
+            fresh += 1
+        return mine, fresh
 
-    results = []
-    pair_cache = {}
-    label_cache = {}
     if world > 1:
         dist.barrier()
     t0 = time.time()
-    for item_id, (s, p) in mine:
-        cfg = dict(settings[s])
-        if a.niter is not None:
-            cfg["selected_niter"] = a.niter
+    summary = dict(world_size=world, shape=list(shape), pairs=a.pairs)
+    if two_stage:
+        s1 = stage1_settings(a.stage1)
         if a.dry_run:
-            results.append(dict(item=item_id, setting=s, pair=p, rank=rank, ms=0.0, mean_abs_disp=0.0))
-            continue
-        from convexadam_amd.convex_adam_MIND import register_pair_device
-        if p not in pair_cache:
-            pair_cache[p] = _make_pair(tuple(a.shape), p, device)
-        fix, mov = pair_cache[p]
-        torch.cuda.synchronize(device)
-        t1 = time.time()
-        disp = register_pair_device(fix, mov, **cfg)
-        torch.cuda.synchronize(device)
-        res = dict(item=item_id, setting=s, pair=p, rank=rank, ms=(time.time() - t1) * 1e3, mean_abs_disp=float(disp.abs().mean()))
-        if a.evaluate:
-            if p not in label_cache:
-                label_cache[p] = _make_labels(tuple(a.shape), p, device)
-            res.update(evaluate_item(disp, *label_cache[p]))
-        results.append(res)
-    if use_gpu:
-        torch.cuda.synchronize(device)
-    elapsed = time.time() - t0
-
-    gathered = [None] * world
-    if world > 1:
-        dist.all_gather_object(gathered, dict(rank=rank, results=results, elapsed=elapsed))
+            w1 = lambda cfg, p: dict(ms=0.0, dice=0.5 + 0.001 * cfg["grid_sp"], dice30=0.4, jstd=0.1, hd95=3.0, tre=1.0, folding=0.0)   # noqa: E731
+        else:
+            w1 = lambda cfg, p: run_stage1_item(cfg, p, data)                                                                          # noqa: E731
+        mine1, fresh1 = run_phase("convex", s1, w1)
+        all1 = gather_records(mine1, world)
+        seen = {}
+        for r in all1:
+            seen[(r["setting"], r["pair"])] = r
+        rank1 = rank_records(list(seen.values()), ("setting",))
+        best1 = s1[rank1["best"][0]]
+        summary.update(stage1=dict(n_settings=len(s1), n_items=len(seen), fresh_items=sum(gather_records([fresh1], world)), ranking=rank1,
+                                   best_setting=best1, per_rank={str(r): sorted(x["item"] for x in all1 if x["rank"] == r) for r in range(world)}))
+        if a.stage2 > 0:
+            s2 = stage2_settings(a.stage2)
+            smoothers = None if a.dry_run else smoother_table()
+            if a.dry_run:
+                w2 = lambda cfg, p: dict(evals=[dict(snap=i, smooth=k, dice=0.6 + 0.01 * i - 0.001 * k, dice30=0.5, jstd=0.1 + 0.01 * k, hd95=2.5, tre=0.8, folding=0.0, ms=0.0)   # noqa: E731
+                                                for i in range(len(SNAP_ITERS)) for k in range(N_EXTRA_SMOOTH)])
+            else:
+                w2 = lambda cfg, p: dict(evals=run_stage2_item(best1, cfg, p, data, smoothers))                                     # noqa: E731
+            mine2, fresh2 = run_phase("adam", s2, w2)
+            all2 = gather_records(mine2, world)
+            flat, seen2 = [], set()
+            for r in all2:
+                if (r["setting"], r["pair"]) in seen2:
+                    continue
+                seen2.add((r["setting"], r["pair"]))
+                for e in r["evals"]:
+                    flat.append(dict(e, setting=r["setting"], pair=r["pair"]))
+            rank2 = rank_records(flat, ("setting", "snap", "smooth"))
+            b = rank2["best"]
+            summary.update(stage2=dict(n_settings=len(s2), n_items=len(seen2), fresh_items=sum(gather_records([fresh2], world)), evaluations=len(flat), ranking=dict(best=b, best_rank=max(rank2["rank"])),
+                                       best_setting=dict(s2[b[0]], selected_niter=SNAP_ITERS[b[1]], extra_smooth=b[2])))
     else:
-        gathered = [dict(rank=rank, results=results, elapsed=elapsed)]
-    if rank == 0:
-        allres = sorted((r for g in gathered for r in g["results"]), key=lambda r: r["item"])
-        wall = max(g["elapsed"] for g in gathered)
-        summary = dict(world_size=world, n_items=len(items), items_done=[r["item"] for r in allres],
-                       per_rank={str(g["rank"]): [r["item"] for r in g["results"]] for g in gathered},
-                       wall_s=wall, items_per_s=(len(items) / wall if wall > 0 else None), results=allres)
+        settings = sweep_settings()[: a.settings]
+
+        def w0(cfg, p):
+            cfg = dict(cfg)
+            if a.niter is not None:
+                cfg["selected_niter"] = a.niter
+            if a.dry_run:
+                return dict(ms=0.0, mean_abs_disp=0.0)
+            from convexadam_amd.convex_adam_MIND import register_pair_device
+            fix, mov = data.pair(p)
+            torch.cuda.synchronize(device)
+            t1 = time.time()
+            disp = register_pair_device(fix, mov, **cfg)
+            torch.cuda.synchronize(device)
+            res = dict(ms=(time.time() - t1) * 1e3, mean_abs_disp=float(disp.abs().mean()))
+            if a.evaluate:
+                res.update(evaluate_item(disp, *data.label(p)))
+            return res
+
+        mine, _ = run_phase("pipeline", settings, w0)
+        allres = sorted(gather_records(mine, world), key=lambda r: r["item"])
+        summary.update(n_items=len(settings) * a.pairs, items_done=sorted(r["item"] for r in allres),
+                       per_rank={str(r): sorted(x["item"] for x in allres if x["rank"] == r) for r in range(world)}, results=allres)
         if a.evaluate and not a.dry_run:
             summary["ranking"] = aggregate_ranks(allres, len(settings))
-        txt = json.dumps(summary)
+    if use_gpu:
+        torch.cuda.synchronize(device)
+    elapsed = torch.tensor([time.time() - t0], dtype=torch.float64)
+    if world > 1:
+        el = [None] * world
+        dist.all_gather_object(el, float(elapsed))
+        elapsed = torch.tensor([max(el)])
+    if rank == 0:
+        summary["wall_s"] = float(elapsed)
+        n_items = summary.get("n_items") or (summary.get("stage1", {}).get("n_items", 0) + summary.get("stage2", {}).get("n_items", 0))
+        summary["items_per_s"] = n_items / summary["wall_s"] if summary["wall_s"] > 0 else None
         if a.out:
             with open(a.out, "w") as f:
-                f.write(txt)
+                f.write(json.dumps(summary))
         print(json.dumps({k: v for k, v in summary.items() if k not in ("results",)}))
     if world > 1:
         dist.barrier()

@@ -208,6 +208,17 @@ int cvx_register_pair_f32(const float* img_fixed, const float* img_moving, const
                           const float* feat_moving, const cvx_pair_params* p, float* out_field,
                           int* out_dims_host, void* workspace, size_t workspace_bytes, void* stream);
 
+/* the same pipeline with iteration snapshots:
+ * replaces the 9-field variant self_configuring/convex_adam_MIND.py:115-139 (disp_sample after iterations 40 / 60 / 80, each without
+ * and with three 3^3 / 5^3 boxes) and feeds the sweep's evaluation at iterations 59/79/99/119 (adam_run_withconfig_shiftSpline.py:234).
+ *   snapshot_iters_host [n_snap] ascending, 1-based, <= selected_niter; smooth_host [n_smooth] entries 0 (none) or an odd box size
+ *   out_fields [n_snap][n_smooth][3][H][W][D]: interpolate(disp_sample_i * grid_sp_adam, (H,W,D)) followed by three k^3 boxes */
+size_t cvx_register_pair_snapshots_workspace_bytes(const cvx_pair_params* p, int n_snap, const int* smooth_host, int n_smooth);
+int cvx_register_pair_snapshots_f32(const float* img_fixed, const float* img_moving, const float* feat_fixed,
+                                    const float* feat_moving, const cvx_pair_params* p, const int* snapshot_iters_host, int n_snap,
+                                    const int* smooth_host, int n_smooth, float* out_fields, void* workspace, size_t workspace_bytes,
+                                    void* stream);
+
 /* n_pairs independent pairs with the same parameters, dealt round-robin onto n_streams (1..8) internal HIP
  * streams that fork from / join into `stream` (the sweep scripts' loop over pairs, e.g.
  * self_configuring/convex_run_withconfig.py:85).  Pointer arrays live on the HOST and hold device pointers;

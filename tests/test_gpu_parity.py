@@ -872,3 +872,66 @@ def test_full_size_fp16_storage_and_fast_mode_accuracy(M):
     print("full size: fast correlation mode: fraction of convex-stage voxels changed %.2e, final mean EPE vs exact %.3e; fp16 storage EPE %.3e" % (flips, e_fast, e_h16))
     assert flips == 0.0 and e_fast < 1e-3
     assert e_h16 < 0.1
+
+
+def test_pipeline_snapshots_match_separate_runs(M, golden):
+    """Row Q at pipeline level: one Adam run with snapshots after iterations 2 / 4 / 5 and final smoothings {none, 3, 5} returns the
+    fields that separate runs with selected_niter = 2 / 4 / 5 and selected_smooth = 0 / 3 / 5 return (the 9-field variant of
+    self_configuring/convex_adam_MIND.py:115-139)."""
+    g = golden("pipeline")
+    fix, mov = dev(g["fix"]), dev(g["mov"])
+    kw = dict(mind_r=1, mind_d=2, grid_sp=4, disp_hw=3, grid_sp_adam=2, lambda_weight=1.25, ic=True)
+    snaps = M.register_pair_snapshots_device(fix, mov, snapshot_iters=(2, 4, 5), smooths=(0, 3, 5), **kw)
+    assert snaps.shape == (3, 3) + (3,) + tuple(fix.shape)
+    for i, n in enumerate((2, 4, 5)):
+        for j, k in enumerate((0, 3, 5)):
+            assert torch.equal(snaps[i, j], M.register_pair_device(fix, mov, selected_niter=n, selected_smooth=k, **kw)), (n, k)
+    with pytest.raises(Exception):
+        M.register_pair_snapshots_device(fix, mov, snapshot_iters=(4, 2), **kw)
+
+
+@pytest.mark.timeout(1800)
+def test_two_stage_sweep_on_the_device(tmp_path):
+    """The reference's self-configuring procedure end to end on one GPU (single process): stage 1 ranks convex-only settings, stage 2 runs
+    ONE 120-iteration Adam optimisation per (setting, pair) from the stage-1 field -- smoother and grid_sp_adam per setting, n_ch cost
+    scale -- and scores its four snapshots x four smoothings; results are appended per item and the known roll is recovered."""
+    import json
+    from convexadam_amd import sweep
+    out = tmp_path / "sweep.json"
+    assert sweep.main(["--pairs", "1", "--shape", "48", "48", "48", "--stage1", "3", "--stage2", "2", "--out", str(out)]) == 0
+    s = json.loads(out.read_text())
+    assert s["stage1"]["n_items"] == 3 and s["stage2"]["n_items"] == 2 and s["stage2"]["evaluations"] == 32
+    lines = [json.loads(l) for l in open(str(out) + ".rank0.jsonl")]
+    assert len(lines) == 5 and all("ms" in l or "evals" in l for l in lines)
+    conv = [l for l in lines if l["stage"] == "convex"]
+    assert max(l["dice"] for l in conv) > conv[0]["dice_before"] + 0.1
+    best = max(e["dice"] for l in lines if l["stage"] == "adam" for e in l["evals"])
+    assert best >= max(l["dice"] for l in conv) - 0.02 and best > 0.8
+
+
+@pytest.mark.timeout(1800)
+def test_full_size_sweep_extreme_settings(M):
+    """BASELINE configs[4] at 160x192x224 with the two extremes of the setting grid: grid_sp 4 / disp_hw 6 (2197 x 40x48x56 = 945 MB
+    cost volume per direction) and grid_sp 8 / disp_hw 3.  Both run through the same entry point, recover the known shift and stay
+    bit-reproducible; their cost ratio is what the sweep's work queue orders items by."""
+    import time
+    from convexadam_amd import sweep
+    from convexadam_amd.phantom import phantom
+    shape = (160, 192, 224)
+    fix = phantom(shape, 100, 200).to(DEV)
+    mov = torch.roll(phantom(shape, 100, 300), sweep.SHIFT, (0, 1, 2)).to(DEV)
+    ms = {}
+    for name, cfg in (("gs4_hw6", dict(grid_sp=4, disp_hw=6)), ("gs8_hw3", dict(grid_sp=8, disp_hw=3))):
+        kw = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp_adam=2, selected_niter=20, ic=True, **cfg)
+        a = M.register_pair_device(fix, mov, **kw)
+        torch.cuda.synchronize()
+        t = time.time()
+        b = M.register_pair_device(fix, mov, **kw)
+        torch.cuda.synchronize()
+        ms[name] = (time.time() - t) * 1e3
+        assert torch.equal(a, b)
+        c = a[:, 32:128, 38:154, 45:179]
+        for ax in range(3):
+            assert abs(float(c[ax].mean()) - sweep.SHIFT[ax]) < 0.5, (name, ax, float(c[ax].mean()))
+    print("full-size extreme sweep settings: %s ms" % ms)
+    assert sweep.item_cost(dict(grid_sp=4, disp_hw=6), shape) > sweep.item_cost(dict(grid_sp=8, disp_hw=3), shape)

@@ -88,22 +88,65 @@ def test_sweep_grid_enumeration():
     assert all(d["disp_hw"] <= 8 and d["grid_sp"] >= 2 for d in s)
 
 
-@pytest.mark.timeout(300)
-def test_sharded_driver_gloo_world_size_2(tmp_path):
-    """The N>1 path: one process per rank, items sharded with no data-path collective, results gathered on
-    rank 0.  Runs on CPU with the gloo backend and the driver's --dry-run mode (no kernels)."""
+def _run_sweep(tmp_path, port, extra, nproc=2):
     out = tmp_path / "res.json"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29613", os.path.join(ROOT, "convexadam_amd", "sweep.py"), "--dry-run", "--pairs", "5", "--settings", "3",
-           "--out", str(out)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "convexadam_amd", "sweep.py"), "--dry-run", "--out", str(out)] + extra
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-3000:]
     import json
-    res = json.loads(out.read_text())
+    return json.loads(out.read_text()), out
+
+
+@pytest.mark.timeout(300)
+def test_sharded_driver_gloo_world_size_2(tmp_path):
+    """The N>1 path: one process per rank, items drawn from the shared queue (or dealt round-robin with --static), no data-path
+    collective, results gathered on rank 0.  Runs on CPU with the gloo backend and the driver's --dry-run mode (no kernels)."""
+    res, _ = _run_sweep(tmp_path, 29613, ["--pairs", "5", "--settings", "3"])
     assert res["world_size"] == 2 and res["n_items"] == 15
     assert sorted(res["items_done"]) == list(range(15))
+    parts = list(res["per_rank"].values())
+    assert sorted(sum(parts, [])) == list(range(15))                       # every item exactly once, whoever drew it
+    res, _ = _run_sweep(tmp_path, 29615, ["--pairs", "5", "--settings", "3", "--static"])
     assert sorted(len(v) for v in res["per_rank"].values()) == [7, 8]
+
+
+@pytest.mark.timeout(300)
+def test_two_stage_sweep_queue_and_resume_gloo(tmp_path):
+    """Two-stage mode of the reference's self-configuring scripts (convex ranking, then one Adam run per item scored at 4 snapshots x
+    4 smoothings), world size 2 on gloo: every item runs once, the per-rank logs are append-only, and a second start with --resume
+    after deleting part of the log re-runs only what is missing."""
+    import json
+    res, out = _run_sweep(tmp_path, 29617, ["--pairs", "3", "--stage1", "6", "--stage2", "4"])
+    assert res["stage1"]["n_items"] == 18 and res["stage1"]["fresh_items"] == 18
+    assert res["stage2"]["n_items"] == 12 and res["stage2"]["evaluations"] == 12 * 16
+    assert sorted(sum(res["stage1"]["per_rank"].values(), [])) == list(range(18))
+    b = res["stage2"]["best_setting"]
+    assert b["selected_niter"] in (60, 80, 100, 120) and 0 <= b["extra_smooth"] <= 3 and {"grid_sp_adam", "avg_n", "lambda_weight"} <= set(b)
+    logs = sorted(str(p) for p in tmp_path.glob("res.json.rank*.jsonl"))
+    assert len(logs) == 2
+    recs = [json.loads(l) for f in logs for l in open(f)]
+    assert len(recs) == 30
+    # kill simulation: drop the last 5 lines of rank 0's log (one of them cut in the middle), then resume
+    lines = open(logs[0]).read().splitlines()
+    kept = lines[:-5]
+    open(logs[0], "w").write("\n".join(kept) + "\n" + lines[-5][: len(lines[-5]) // 2])
+    res2, _ = _run_sweep(tmp_path, 29619, ["--pairs", "3", "--stage1", "6", "--stage2", "4", "--resume"])
+    assert res2["stage1"]["n_items"] == 18 and res2["stage2"]["n_items"] == 12
+    assert res2["stage1"]["fresh_items"] + res2["stage2"]["fresh_items"] == 5
+    assert res2["stage1"]["best_setting"] == res["stage1"]["best_setting"] and res2["stage2"]["best_setting"] == res["stage2"]["best_setting"]
+
+
+def test_sweep_settings_tables():
+    from convexadam_amd.sweep import item_cost, stage1_settings, stage2_settings
+    s1, s2 = stage1_settings(100), stage2_settings(75)
+    assert len(s1) == 100 and len(s2) == 75 and s1 == stage1_settings(100)
+    assert all(1 <= c["mind_r"] <= 3 and 1 <= c["mind_d"] <= 3 and 2 <= c["grid_sp"] <= 5 and 2 <= c["disp_hw"] <= 7 for c in s1)
+    assert all(c["disp_hw"] <= 5 for c in s1 if c["grid_sp"] == 2)
+    assert all(1 <= c["grid_sp_adam"] <= 4 and 1 <= c["avg_n"] <= 7 and 0.4 <= c["lambda_weight"] <= 1.6 for c in s2)
+    shape = (160, 192, 224)
+    assert item_cost(dict(grid_sp=4, disp_hw=6), shape) > 10 * item_cost(dict(grid_sp=8, disp_hw=3), shape)   # what the queue orders by
 
 
 def test_geometry_helpers_importable_under_reference_names():
