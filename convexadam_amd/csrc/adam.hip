@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_adam_update(const float* __restrict__ G
 static int launch_box3x3(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
                          AdamConsts ac, float* gsave, hipStream_t s) {
     // rows of up to 126 voxels: z-marching pipeline (boxmarch.hip); longer rows: the tiled kernel below
-    static const bool force_tiled = getenv("CVX_BOX_TILED") != nullptr;
+    const bool force_tiled = options().box_tiled != 0;
     if (!force_tiled && box3_march_supported(d)) return launch_box3_march(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
     const int nb = cdiv(d, BT_X) * cdiv(w, BT_Y) * cdiv(h, BT_Z) * 3;
     if (!backward) hipLaunchKernelGGL((k_box3x3<false, false>), dim3(nb), dim3(BT_NT), 0, s, in, out, h, w, d, P, m, v, ac, gsave);

@@ -1,5 +1,6 @@
 // api.hip -- error plumbing, version/device queries and the host-side table helpers of the C ABI.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "cvx_common.h"
@@ -27,7 +28,33 @@ int check_last(const char* what) {
     return CVX_OK;
 }
 
+static long long env_ll(const char* name, long long dflt) {
+    const char* e = getenv(name);
+    return e ? atoll(e) : dflt;
+}
+Options& options() {
+    static Options o = {env_ll("CVX_MIND_TILED", 0),   env_ll("CVX_MM_TX", 0),        env_ll("CVX_MM_SLOTS", 512),          env_ll("CVX_BOX_TILED", 0),
+                        env_ll("CVX_NO_PRUNE", 0),     env_ll("CVX_CORR_UNFUSED", 0), env_ll("CVX_PRUNE_STREAM_ABOVE", -1), env_ll("CVX_CF_CENSUS", 0)};
+    return o;
+}
+struct OptName { const char* name; long long Options::*field; };
+static const OptName kOptNames[] = {{"mind_tiled", &Options::mind_tiled},     {"mm_tx", &Options::mm_tx},
+                                    {"mm_slots", &Options::mm_slots},         {"box_tiled", &Options::box_tiled},
+                                    {"no_prune", &Options::no_prune},         {"corr_unfused", &Options::corr_unfused},
+                                    {"prune_stream_above", &Options::prune_stream_above}, {"cf_census", &Options::cf_census}};
+
 }  // namespace cvx
+
+extern "C" int cvx_set_option(const char* name, long long value) {
+    for (const auto& o : cvx::kOptNames)
+        if (name && strcmp(name, o.name) == 0) { cvx::options().*(o.field) = value; return CVX_OK; }
+    return cvx::fail(CVX_ERR_INVALID_ARG, "cvx_set_option: unknown option '%s'", name ? name : "(null)");
+}
+extern "C" long long cvx_get_option(const char* name) {
+    for (const auto& o : cvx::kOptNames)
+        if (name && strcmp(name, o.name) == 0) return cvx::options().*(o.field);
+    return -1;
+}
 
 extern "C" int cvx_version(void) { return 1000 * 0 + 1; }
 extern "C" const char* cvx_last_error(void) { return cvx::g_err; }

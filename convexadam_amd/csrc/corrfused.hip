@@ -407,7 +407,7 @@ static CFGeom cf_geom(int C, int h, int w, int d, int hw) {
 static size_t cf_lds_bytes(const CFGeom& g) { return sizeof(float) * (16 + 2 * (size_t)(CF_GMAX + 2) * g.PF); }
 
 bool corr_fused_supported(int C, int h, int w, int d, int hw) {
-    static const bool off = getenv("CVX_CORR_UNFUSED") != nullptr;
+    const bool off = options().corr_unfused != 0;
     if (off || C >= 16 || hw < 0 || hw > 8) return false;
     const CFGeom g = cf_geom(C, h, w, d, hw);
     return 3 * g.wpr <= 16 && cf_lds_bytes(g) <= 160 * 1024 && (size_t)g.n * g.n * g.n * h * w * d * 4 < ((size_t)1 << 32);
@@ -452,8 +452,7 @@ int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, i
     launch_corr_prep_generic(fix, mov, C, h, w, d, hw, g.RS, hw, g.dq, Fp, Mp, s);
     if (g.ntail > 0 && !fast) launch_corr_tail_compact(fix, mov, C, h, w, d, hw, cost, tail, s);
     CFGeom gl = g;
-    static const char* census = getenv("CVX_CF_CENSUS");      // debugging aid: per-workgroup start / end / placement in the workspace
-    gl.dbg = census ? census_buf : nullptr;
+    gl.dbg = options().cf_census ? census_buf : nullptr;      // debugging aid: per-workgroup start / end / placement in the workspace
     if (f16 && (cost != 0 || n_box != 2)) return fail(CVX_ERR_UNSUPPORTED, "correlate: fp16 storage exists for the SSD cost with two boxes only");
     if (fast && f16) cf_launch<9>(gl, Fp, Mp, tail, ssd, s);
     else if (fast) cf_launch<1>(gl, Fp, Mp, tail, ssd, s);

@@ -53,6 +53,22 @@ struct Carver {
 };
 static inline size_t carve_size(size_t used, size_t bytes) { return align_up(used, 256) + bytes; }
 
+// ---- run-time switches between kernel variants ---------------------------------------------------------------------------------
+// One process-wide table, initialised once from the environment (CVX_<NAME IN CAPITALS>, e.g. CVX_MIND_TILED=1) and changeable through
+// cvx_set_option(); every selectable path is bit-identical, the switches exist for A/B timing and so that the test-suite can run
+// every variant (tests/test_gpu_parity.py::test_kernel_variants_agree).
+struct Options {
+    long long mind_tiled;          // 1: tiled MIND stencil instead of the z-marching one
+    long long mm_tx;               // 32 / 64: tile width of the marching MIND stencil (0 = automatic)
+    long long mm_slots;            // workgroup budget of the marching MIND stencil (512)
+    long long box_tiled;           // 1: tiled three-box kernels of the Adam loop instead of the z-marching ones
+    long long no_prune;            // 1: streaming coupled-convex passes instead of branch and bound
+    long long corr_unfused;        // 1: k_corr_raw + k_corr_box2 instead of the fused correlation kernel
+    long long prune_stream_above;  // pruned pass falls back to a coalesced scan above this many 256-displacement chunks (-1 = K*v/2048)
+    long long cf_census;           // 1: the fused correlation kernel records per-workgroup residency in its workspace
+};
+Options& options();
+
 // ---- exact device math ---------------------------------------------------------------------------
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 

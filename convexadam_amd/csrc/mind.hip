@@ -391,7 +391,7 @@ static size_t mind_lds_bytes(int R, int dil, int nbuf) {
 
 template <int R>
 static int mind_launch_r(const float* img, int H, int W, int D, int dil, MindStats* st, float* out, hipStream_t s) {
-    static const bool tiled_only = getenv("CVX_MIND_TILED") != nullptr;
+    const bool tiled_only = options().mind_tiled != 0;
     if (!tiled_only && mind_march_supported(img, out, H, W, D, R, dil)) {
         launch_mind_march(img, H, W, D, st, out, s);
         return check_last("mindssc");

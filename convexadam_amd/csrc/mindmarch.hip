@@ -246,7 +246,7 @@ static void launch_mind_march_g(const float* img, int H, int W, int D, MindStats
     const int nyt = cdiv(W, G::TY), nxt = cdiv(D, G::TX);
     // two workgroups per CU (register bound): at most 512 workgroups so that all of them are resident at once -- a second,
     // partly filled round costs more than the longer chunks; chunks of at least 8 planes keep the 2-plane fill below 25 %
-    static const int slots = getenv("CVX_MM_SLOTS") ? atoi(getenv("CVX_MM_SLOTS")) : 512;
+    const int slots = (int)options().mm_slots;
     int nzc = slots / (nyt * nxt);
     if (nzc < 1) nzc = 1;
     int zc_len = cdiv(H, nzc);
@@ -257,7 +257,7 @@ static void launch_mind_march_g(const float* img, int H, int W, int D, MindStats
 }
 
 void launch_mind_march(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s) {
-    static const int force = getenv("CVX_MM_TX") ? atoi(getenv("CVX_MM_TX")) : 0;
+    const int force = (int)options().mm_tx;
     const int rem = D % 64;
     const bool narrow = force ? force == 32 : (rem != 0 && rem <= 32);
     if (narrow) launch_mind_march_g<MMGeo<16, 32>>(img, H, W, D, st, out, s);

@@ -296,7 +296,7 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     }
     if ((rc = cvx_correlate_ex_f32(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, variant ? &copt : nullptr, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
     mark("correlate", s);
-    static const bool no_prune = getenv("CVX_NO_PRUNE") != nullptr;      // streaming coupled passes need int64 winners
+    const bool no_prune = options().no_prune != 0;        // streaming coupled passes need int64 winners
     if (no_prune) rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s);
     else rc = launch_argmin_keys(F(L.ssd), L.K, L.v, keys, s);            // keys stay in the coupled workspace's first buffer
     if (rc) return rc;

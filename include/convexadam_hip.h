@@ -19,7 +19,9 @@
  *     scratch workspace whose size comes from the matching *_workspace_bytes() query;
  *   - return value 0 = ok, negative = CVX_ERR_*; cvx_last_error() gives a thread-local message;
  *   - floating-point evaluation order follows the ATen CPU kernels the reference calls, so results
- *     are reproducible bit-for-bit against the CPU oracle (oracle/cvx_oracle.c).
+ *     are reproducible bit-for-bit against the CPU oracle (oracle/cvx_oracle.c);
+ *   - state kept by the library: the thread-local error message, the optional per-thread stage timing (cvx_set_profiling), the
+ *     internal stream pool of cvx_register_pairs_f32 and the process-wide variant switches of cvx_set_option -- nothing else.
  */
 #ifndef CONVEXADAM_HIP_H
 #define CONVEXADAM_HIP_H
@@ -44,6 +46,12 @@ extern "C" {
 int cvx_version(void);                 /* 1000*major + minor */
 const char* cvx_last_error(void);      /* message of the last failing call on this thread */
 int cvx_device_count(void);            /* number of visible HIP devices (0 on a CPU-only host) */
+
+/* run-time switches between bit-identical kernel variants (A/B timing, variant coverage in the tests): "mind_tiled", "mm_tx", "mm_slots",
+ * "box_tiled", "no_prune", "corr_unfused", "prune_stream_above", "cf_census"; initial values come from CVX_<NAME> environment variables.
+ * Process-wide: set them while no call is in flight.  cvx_get_option returns -1 for an unknown name. */
+int cvx_set_option(const char* name, long long value);
+long long cvx_get_option(const char* name);
 
 /* host helpers (exact restatements of torch.linspace / affine_grid tables) ----------------------- */
 /* F.affine_grid(eye, size S, align_corners=False) identity coordinate along an axis of extent S.
@@ -76,8 +84,8 @@ int cvx_box_smooth_f32(const float* in, int C, int H, int W, int D, int k, int p
 
 /* masked feature extraction helpers                             convex_adam_MIND.py:36-54
  *   cvx_mask_erode_f32 : out = (AvgPool3d(3)(ReplicationPad3d(1)(mask)) > threshold) ? 1 : 0      (:40,43,48)
- *   cvx_gather_f32     : out[i] = src[index[i]]  (half-resolution nearest-in-mask gather, :45,50; the Euclidean
- *                        feature transform itself stays scipy on the host, like the reference)
+ *   cvx_gather_f32     : out[i] = src[index[i]]  (half-resolution nearest-in-mask gather, :45,50; the indices come from
+ *                        cvx_feature_transform_i32 + cvx_feature_flat_index_i64 below -- the reference calls scipy on the host)
  *   cvx_select_f32     : out[i] = mask[i] != 0 ? a[i] : b[i]                                       (:46,51) */
 int cvx_mask_erode_f32(const float* mask, int H, int W, int D, float threshold, float* out, void* stream);
 int cvx_gather_f32(const float* src, const int64_t* index, int64_t n, float* out, void* stream);

@@ -113,3 +113,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libcvx_oracle" not in txt, f
+
+
+def test_option_table(L):
+    """Run-time variant switches: known names round-trip, unknown names are rejected (no GPU needed)."""
+    for name in (b"mind_tiled", b"mm_tx", b"box_tiled", b"no_prune", b"corr_unfused", b"prune_stream_above"):
+        old = L.cvx_get_option(name)
+        assert L.cvx_set_option(name, 7) == 0 and L.cvx_get_option(name) == 7
+        assert L.cvx_set_option(name, old) == 0
+    assert L.cvx_set_option(b"bogus", 1) != 0 and L.cvx_get_option(b"bogus") == -1

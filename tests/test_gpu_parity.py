@@ -202,6 +202,20 @@ def test_coupled_convex_pruning_edge_cases(U, orc, kind):
     assert np.array_equal(host(out)[0], orc.coupled_convex(ssd, am, mesh, hw))
 
 
+def test_coupled_convex_bounded_worst_case(U, orc):
+    """Flat cost regions keep whole search windows; once the listed boxes exceed the cost of a coalesced scan the pass streams the
+    volume instead (k_argmin4_stream) -- same result, bounded time.  A zero-background volume drives every pass down that path."""
+    rng = np.random.default_rng(3)
+    shape, hw = (10, 12, 16), 4
+    K = (2 * hw + 1) ** 3
+    ssd = rng.random((K,) + shape, dtype=np.float32)
+    ssd[:, :, :7, :] = 0.25                                                 # more than half of the voxels: every displacement ties
+    am = ssd.reshape(K, -1).argmin(0).reshape(shape).astype(np.int64)
+    mesh = orc.disp_mesh(hw)
+    out = U.coupled_convex(dev(ssd), dev(am), dev(mesh)[:, :, None], 1, shape)
+    assert np.array_equal(host(out)[0], orc.coupled_convex(ssd, am, mesh, hw))
+
+
 def test_inverse_consistency_vs_oracle(U, orc):
     rng = np.random.default_rng(5)
     a = (0.2 * rng.standard_normal((3, 9, 11, 13))).astype(np.float32)
@@ -935,3 +949,43 @@ def test_full_size_sweep_extreme_settings(M):
             assert abs(float(c[ax].mean()) - sweep.SHIFT[ax]) < 0.5, (name, ax, float(c[ax].mean()))
     print("full-size extreme sweep settings: %s ms" % ms)
     assert sweep.item_cost(dict(grid_sp=4, disp_hw=6), shape) > sweep.item_cost(dict(grid_sp=8, disp_hw=3), shape)
+
+
+# ---- (9) every selectable kernel variant -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opt,val", [("mind_tiled", 1), ("mm_tx", 32), ("mm_tx", 64), ("mm_slots", 64), ("box_tiled", 1), ("no_prune", 1),
+                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1)])
+def test_kernel_variants_agree(M, U, orc, golden, opt, val):
+    """The library's run-time switches (cvx_set_option / CVX_* environment variables) select alternative kernels for the same
+    operators; every one of them is bit-identical to the oracle: marching vs tiled MIND stencil and its tile shapes, marching vs tiled
+    three-box kernels, branch-and-bound vs streaming coupled-convex passes (and the pruned pass forced onto its streaming fallback),
+    fused vs unfused correlation."""
+    from convexadam_amd import _lib
+    from convexadam_amd.phantom import phantom
+    L = _lib.lib()
+    old = L.cvx_get_option(opt.encode())
+    assert L.cvx_set_option(opt.encode(), val) == 0 and L.cvx_get_option(opt.encode()) == val
+    try:
+        g = golden("pipeline")
+        kw = dict(mind_r=1, mind_d=2, grid_sp=4, disp_hw=3, grid_sp_adam=2, lambda_weight=1.25, selected_niter=3, ic=True)
+        out = M.convex_adam_pt(g["fix"], g["mov"], dtype=torch.float32, device=torch.device(DEV), **kw)
+        assert np.array_equal(out, orc.convex_adam_pipeline(g["fix"], g["mov"], **kw))
+        # a pair whose rows are multiples of 4 voxels (marching MIND stencil, fused pooling) and a wider search
+        shape = (38, 27, 52)
+        fix = phantom(shape, 11, 21)
+        mov = torch.roll(phantom(shape, 11, 22), (1, -1, 2), (0, 1, 2))
+        kw2 = dict(mind_r=1, mind_d=2, grid_sp=6, disp_hw=5, grid_sp_adam=2, lambda_weight=1.25, selected_niter=2, ic=True)
+        out2 = M.convex_adam_pt(fix, mov, dtype=torch.float32, device=torch.device(DEV), **kw2)
+        assert np.array_equal(out2, orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), **kw2))
+        # flat cost regions through the stand-alone operator
+        rng = np.random.default_rng(3)
+        cshape, hw = (6, 8, 12), 3
+        K = (2 * hw + 1) ** 3
+        ssd = rng.random((K,) + cshape, dtype=np.float32)
+        ssd[:, :, :5, :] = 0.25
+        am = ssd.reshape(K, -1).argmin(0).reshape(cshape).astype(np.int64)
+        mesh = orc.disp_mesh(hw)
+        soft = U.coupled_convex(dev(ssd), dev(am), dev(mesh)[:, :, None], 1, cshape)
+        assert np.array_equal(host(soft)[0], orc.coupled_convex(ssd, am, mesh, hw))
+    finally:
+        L.cvx_set_option(opt.encode(), old)
+    assert L.cvx_set_option(b"no_such_switch", 1) != 0
