@@ -11,7 +11,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libconvexadam_hip.so")
+LIB_PATH = os.environ.get("CONVEXADAM_HIP_LIB") or os.path.join(_HERE, "csrc", "libconvexadam_hip.so")     # (override: race-stress build)
 
 CVX_OK, CVX_ERR_INVALID_ARG, CVX_ERR_WORKSPACE, CVX_ERR_LAUNCH, CVX_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 

@@ -38,11 +38,37 @@ def apply_convex(disp, moving, device=None) -> np.ndarray:
 
 def apply_convex_original_moving(disp, moving_image_original, fixed_image_original, fixed_image_resampled):
     """Warp the ORIGINAL moving image (its own grid, orientation and spacing) with a field estimated on the resampled fixed grid
-    (apply_convex.py:27-78): SimpleITK images in, SimpleITK float32 image with the moving image's geometry out."""
-    import SimpleITK as sitk  # noqa: N813  (same dependency as the reference; rescale_displacement_field reports its absence)
+    (apply_convex.py:27-78): images in (SimpleITK, or convexadam_amd.imageio.Image), float32 image with the moving image's geometry out."""
+    from .imageio import Image
     field = validate_image(disp).cpu().numpy()
     field = rescale_displacement_field(field, moving_image_original, fixed_image_original, fixed_image_resampled)
     warped = apply_convex(disp=field, moving=moving_image_original)
-    out = sitk.GetImageFromArray(warped.astype(np.float32))
+    if isinstance(moving_image_original, Image):
+        out = Image(warped.astype(np.float32))
+    else:
+        import SimpleITK as sitk  # noqa: N813
+        out = sitk.GetImageFromArray(warped.astype(np.float32))
     out.CopyInformation(moving_image_original)
     return out
+
+
+def main(argv=None):
+    """python -m convexAdam.apply_convex --input_field disp.nii.gz --input_moving moving.nii.gz --output_warped warped.nii.gz
+    (apply_convex.py:81-97): NIfTI through nibabel when installed, else through the built-in reader / writer."""
+    import argparse
+    from . import nifti_io
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--input_field", required=True, help="input convex displacement field (.nii.gz) full resolution")
+    ap.add_argument("--input_moving", required=True, help="input moving scan (.nii.gz)")
+    ap.add_argument("--output_warped", required=True, help="output warped scan (.nii.gz)")
+    a = ap.parse_args(argv)
+    moving = nifti_io.load_fdata(a.input_moving).astype("float32")
+    disp = nifti_io.load_fdata(a.input_field).astype("float32")
+    warped = apply_convex(disp=disp, moving=moving)
+    nifti_io.save_image(warped, nifti_io.load_affine(a.input_moving), a.output_warped)
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())

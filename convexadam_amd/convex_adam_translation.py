@@ -11,7 +11,7 @@ Host-side geometry on SimpleITK images; the registration itself runs through con
 import numpy as np
 
 from .convex_adam_MIND import convex_adam_pt
-from .convex_adam_utils import _sitk, resample_img, resample_moving_to_fixed
+from .convex_adam_utils import _is_builtin, _sitk, resample_img, resample_moving_to_fixed
 
 
 def index_translation_to_world_translation(index_translation, direction):
@@ -22,8 +22,7 @@ def index_translation_to_world_translation(index_translation, direction):
 
 def apply_translation(moving_image, translation_ijk=(0, 0, 0)):
     """Copy of `moving_image` whose origin is shifted by the world-space equivalent of `translation_ijk` (mm along the image axes)."""
-    sitk = _sitk()
-    moved = sitk.Image(moving_image)
+    moved = moving_image.copy() if _is_builtin(moving_image) else _sitk().Image(moving_image)
     shift = index_translation_to_world_translation(translation_ijk, moved.GetDirection()[0:9])
     origin = np.array(moved.GetOrigin(), dtype=float)
     origin[0:3] -= shift
@@ -45,14 +44,14 @@ def convex_adam_translation(fixed_image, moving_image, segmentation=None, co_mov
     """Register `moving_image` to `fixed_image` with convex_adam_pt on a 1 mm grid, reduce the field to one whole-voxel translation
     (mean over the segmentation if given) and apply it to the moving image and to the co-moving images.
     Returns (translation_xyz in mm, moved image, moved co-moving images)."""
-    sitk = _sitk()
     fixed_1mm = resample_img(fixed_image, spacing=(1.0, 1.0, 1.0))
     moving_1mm = resample_moving_to_fixed(fixed_1mm, moving_image)
     field = convex_adam_pt(img_fixed=fixed_1mm, img_moving=moving_1mm)
     mask = None
     if segmentation is not None:
         # linear resampling blurs the labels: everything above zero counts
-        mask = sitk.GetArrayFromImage(resample_moving_to_fixed(moving=segmentation, fixed=fixed_1mm)) > 0
+        from .imageio import get_array
+        mask = get_array(resample_moving_to_fixed(moving=segmentation, fixed=fixed_1mm)) > 0
     translation_xyz = field_to_translation(field, moving_image.GetSpacing(), mask)
     moved = apply_translation(moving_image=moving_image, translation_ijk=translation_xyz)
     if co_moving_images is not None:
@@ -64,13 +63,41 @@ def convex_adam_translation(fixed_image, moving_image, segmentation=None, co_mov
 def convex_adam_translation_from_file(fixed_path="/input/fixed.mha", moving_path="/input/moving.mha",
                                       segmentation_path="/input/segmentation.nii.gz", moving_output_path="/output/moving_warped.mha",
                                       co_moving_paths=None, co_moving_output_paths=None):
-    sitk = _sitk()
-    co = [sitk.ReadImage(str(p)) for p in co_moving_paths] if co_moving_paths is not None else None
+    """File front end (:117-146).  SimpleITK reads and writes when it is installed; otherwise the built-in MetaImage / NIfTI readers
+    and the MetaImage writer of convexadam_amd.imageio do."""
+    try:
+        import SimpleITK as sitk  # noqa: N813
+        read, write = (lambda p: sitk.ReadImage(str(p))), (lambda img, p: sitk.WriteImage(img, str(p)))
+    except ImportError:
+        from .imageio import read_image, write_mha
+        read, write = (lambda p: read_image(str(p))), (lambda img, p: write_mha(img, str(p)))
+    co = [read(p) for p in co_moving_paths] if co_moving_paths is not None else None
     translation_xyz, moved, co = convex_adam_translation(
-        fixed_image=sitk.ReadImage(str(fixed_path)), moving_image=sitk.ReadImage(str(moving_path)),
-        segmentation=sitk.ReadImage(str(segmentation_path)) if segmentation_path is not None else None, co_moving_images=co)
-    sitk.WriteImage(moved, str(moving_output_path))
+        fixed_image=read(fixed_path), moving_image=read(moving_path),
+        segmentation=read(segmentation_path) if segmentation_path is not None else None, co_moving_images=co)
+    write(moved, moving_output_path)
     if co is not None:
         for image, path in zip(co, co_moving_output_paths):
-            sitk.WriteImage(image, str(path))
+            write(image, path)
     return translation_xyz
+
+
+def main(argv=None):
+    """python -m convexAdam.convex_adam_translation (convex_adam_translation.py:149-166)."""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fixed_path", default="/input/fixed.mha")
+    ap.add_argument("--moving_path", default="/input/moving.mha")
+    ap.add_argument("--segmentation_path", default=None)
+    ap.add_argument("--moving_output_path", default="/output/moving_warped.mha")
+    ap.add_argument("--co_moving_paths", nargs="+", default=None)
+    ap.add_argument("--co_moving_output_paths", nargs="+", default=None)
+    a = ap.parse_args(argv)
+    print(convex_adam_translation_from_file(a.fixed_path, a.moving_path, a.segmentation_path, a.moving_output_path, a.co_moving_paths,
+                                            a.co_moving_output_paths))
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())

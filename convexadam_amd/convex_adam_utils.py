@@ -226,6 +226,9 @@ def validate_image(img, dtype=float):
     Like the reference (convex_adam_utils.py:268-279) tensors pass through unchanged and everything else is converted with
     `astype(dtype)` -- float64 by default, so an int16 SimpleITK image is interpolated in floating point downstream;
     raises ValueError for unsupported types."""
+    from .imageio import Image
+    if isinstance(img, Image):
+        img = img.array
     try:
         import SimpleITK as sitk  # noqa: N813
         if isinstance(img, sitk.Image):
@@ -245,16 +248,23 @@ def validate_image(img, dtype=float):
     return img
 
 
-# ---- geometry helpers around the registration (host side, SimpleITK images; convex_adam_utils.py:282-351) ------------------------
-# Kept importable under the reference's names (tests/test_convex_adam_mind_aniso.py:10-12, convex_adam_translation.py:9).  They
-# are glue around SimpleITK's resampler -- no device work -- and need the same optional dependency as the reference.
+# ---- geometry helpers around the registration (host side; convex_adam_utils.py:282-351) -----------------------------------------
+# Kept importable under the reference's names (tests/test_convex_adam_mind_aniso.py:10-12, convex_adam_translation.py:9).  Geometry
+# glue, no device work.  SimpleITK images go through SimpleITK's resampler exactly as in the reference; `imageio.Image` objects (the
+# built-in image class, used when SimpleITK is not installed or simply not wanted) go through imageio.resample, which follows ITK's
+# index -> physical-point convention and linear interpolation.
 def _sitk():
     try:
         import SimpleITK as sitk  # noqa: N813
     except ImportError as e:
-        raise ImportError("this helper wraps SimpleITK's resampler (as in the reference, convex_adam_utils.py:282-351); "
-                          "SimpleITK is not installed") from e
+        raise ImportError("this call received an object that is not a convexadam_amd.imageio.Image and needs SimpleITK's resampler "
+                          "(as in the reference, convex_adam_utils.py:282-351); SimpleITK is not installed") from e
     return sitk
+
+
+def _is_builtin(img):
+    from .imageio import Image
+    return isinstance(img, Image)
 
 
 def _linear_resampler(sitk, spacing, size, direction, origin):
@@ -269,33 +279,46 @@ def _linear_resampler(sitk, spacing, size, direction, origin):
     return r
 
 
+def _resample(img, spacing, size, direction, origin):
+    if _is_builtin(img):
+        from .imageio import resample
+        return resample(img, spacing, size, direction, origin)
+    return _linear_resampler(_sitk(), spacing, size, direction, origin).Execute(img)
+
+
 def resample_img(img, spacing):
-    """Linear resampling of a SimpleITK image to `spacing` on its own origin / orientation; size = floor(n * old / new + 0.5)."""
-    sitk = _sitk()
+    """Linear resampling of an image to `spacing` on its own origin / orientation; size = floor(n * old / new + 0.5)."""
     size = [int(n * old / new + 0.5) for n, old, new in zip(img.GetSize(), img.GetSpacing(), spacing)]
-    return _linear_resampler(sitk, spacing, size, img.GetDirection(), img.GetOrigin()).Execute(img)
+    return _resample(img, spacing, size, img.GetDirection(), img.GetOrigin())
 
 
 def resample_moving_to_fixed(fixed, moving):
     """Linear resampling of `moving` onto the voxel grid of `fixed` (zero outside)."""
-    sitk = _sitk()
-    return _linear_resampler(sitk, fixed.GetSpacing(), fixed.GetSize(), fixed.GetDirection(), fixed.GetOrigin()).Execute(moving)
+    return _resample(moving, fixed.GetSpacing(), fixed.GetSize(), fixed.GetDirection(), fixed.GetOrigin())
 
 
 def rescale_displacement_field(displacement_field, moving_image, fixed_image, fixed_image_resampled):
     """Displacement field (H,W,D,3; components z,y,x in voxels of `fixed_image_resampled`) -> the grid, axes and voxel size of the
     original `moving_image`: every component is resampled onto the moving grid, the vectors are rotated by the rotation between
     the two direction-cosine frames and scaled by the spacing ratio."""
-    sitk = _sitk()
     field = np.asarray(displacement_field)
-    onto_moving = sitk.ResampleImageFilter()
-    onto_moving.SetReferenceImage(moving_image)
-    onto_moving.SetInterpolator(sitk.sitkLinear)
     comps = []
-    for axis in range(3):
-        comp = sitk.GetImageFromArray(field[..., axis])
-        comp.CopyInformation(fixed_image_resampled)
-        comps.append(sitk.GetArrayFromImage(onto_moving.Execute(comp)))
+    if _is_builtin(moving_image):
+        from .imageio import Image, resample
+        for axis in range(3):
+            comp = Image(np.ascontiguousarray(field[..., axis]))
+            comp.CopyInformation(fixed_image_resampled)
+            comps.append(resample(comp, moving_image.GetSpacing(), moving_image.GetSize(), moving_image.GetDirection(),
+                                  moving_image.GetOrigin()).array)
+    else:
+        sitk = _sitk()
+        onto_moving = sitk.ResampleImageFilter()
+        onto_moving.SetReferenceImage(moving_image)
+        onto_moving.SetInterpolator(sitk.sitkLinear)
+        for axis in range(3):
+            comp = sitk.GetImageFromArray(field[..., axis])
+            comp.CopyInformation(fixed_image_resampled)
+            comps.append(sitk.GetArrayFromImage(onto_moving.Execute(comp)))
     moved = np.stack(comps, axis=-1)                                   # (..., 3) in z, y, x order
     frame_fixed = np.array(fixed_image.GetDirection()).reshape(3, 3)
     frame_moving = np.array(moving_image.GetDirection()).reshape(3, 3)

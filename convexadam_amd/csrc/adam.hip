@@ -129,7 +129,7 @@ __global__ __launch_bounds__(BT_NT) void k_box3x3(const float* __restrict__ in, 
         }
         *reinterpret_cast<float4*>(A + (z * AY + y) * BT_PX + 4 + 4 * ch) = q;
     }
-    __syncthreads();
+    cvx_barrier();
     float* oc = out ? out + (size_t)c * V : nullptr;
     float* Pc = P ? P + (size_t)c * V : nullptr;
     float* mc = m ? m + (size_t)c * V : nullptr;
@@ -137,9 +137,9 @@ __global__ __launch_bounds__(BT_NT) void k_box3x3(const float* __restrict__ in, 
     float* gs = gsave ? gsave + (size_t)c * V : nullptr;
     // pass 1: A (14x14 rows) -> B (12x12 rows); pass 2: B -> A (10x10 rows); pass 3: A -> tile
     box_pass<1, BACKWARD, ADAM>(A, AY, B, BT_Z + 4, BT_Y + 4, z0 - 2, y0 - 2, x0, h, w, d, nullptr, nullptr, nullptr, nullptr, ac, nullptr);
-    __syncthreads();
+    cvx_barrier();
     box_pass<2, BACKWARD, ADAM>(B, BT_Y + 4, A, BT_Z + 2, BT_Y + 2, z0 - 1, y0 - 1, x0, h, w, d, nullptr, nullptr, nullptr, nullptr, ac, nullptr);
-    __syncthreads();
+    cvx_barrier();
     box_pass<3, BACKWARD, ADAM>(A, BT_Y + 2, nullptr, BT_Z, BT_Y, z0, y0, x0, h, w, d, oc, Pc, mc, vc, ac, gs);
 }
 

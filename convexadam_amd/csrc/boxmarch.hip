@@ -212,14 +212,14 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
             }
         }
         if (ADAM) bm_adam_step<QPR, YT>(c, apre, t);
-        __syncthreads();
+        cvx_barrier();
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
     int t = 0;
-    for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD>(c, L, t); __syncthreads(); }                    // (Adam starts at t = 10)
+    for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD>(c, L, t); cvx_barrier(); }                    // (Adam starts at t = 10)
     step(P0{}, No{}, t); ++t;                                 // t = 3K-2: input plane 0
     step(P1{}, No{}, t); ++t;                                 // t = 3K-1: input plane 1
     for (; t + 1 <= tlast; t += 2) { step(P0{}, Yes{}, t); step(P1{}, Yes{}, t + 1); }       // t = 3K ..: output planes
@@ -227,7 +227,7 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     for (; t < c.nsteps; ++t) {
         bm_load_step<SLOT0, BACKWARD>(c, L, t);
         if (ADAM) bm_adam_step<QPR, YT>(c, apre, t);
-        __syncthreads();
+        cvx_barrier();
     }
 }
 
@@ -287,7 +287,7 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const flo
     L.loff = (unsigned)((lgy < 0 ? 0 : lgy) * d + 4 * L.lq);
     L.lds0 = S0 + lr * G::RS + 4 * L.lq + 7;
     bm_issue<BACKWARD>(c, L, c.z0 - 3);
-    __syncthreads();
+    cvx_barrier();
 
     // role of this wavefront (wave-uniform, kept in a scalar register)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;

@@ -33,7 +33,12 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jitter=False):
+    """jitter=True: the race-stress variant (random per-wavefront delays around every barrier, cvx_common.h) as
+    libconvexadam_hip_jitter.so; select it at run time with CONVEXADAM_HIP_LIB=<path>."""
+    global OBJDIR, LIB
+    if jitter:
+        OBJDIR, LIB = os.path.join(HERE, "build_jitter"), os.path.join(HERE, "libconvexadam_hip_jitter.so")
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith(".h")] + [os.path.join(ROOT, "include", "convexadam_hip.h"), os.path.abspath(__file__)]
     jobs = []
@@ -41,7 +46,7 @@ def build(force=False, verbose=False):
         s = os.path.join(HERE, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc()] + FLAGS + PER_FILE_FLAGS.get(src, []) + ["-DCVX_BUILDING=1", "-c", s, "-o", o])
+            jobs.append([hipcc()] + FLAGS + PER_FILE_FLAGS.get(src, []) + ["-DCVX_BUILDING=1"] + (["-DCVX_RACE_JITTER=1"] if jitter else []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -64,4 +69,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, jitter="--jitter" in sys.argv))

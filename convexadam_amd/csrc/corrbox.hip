@@ -140,7 +140,7 @@ __device__ __forceinline__ void cb2_run(const CB2Ctx& c, CB2Loader& L, int id) {
                 }
             }
         }
-        __syncthreads();
+        cvx_barrier();
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -149,14 +149,14 @@ __device__ __forceinline__ void cb2_run(const CB2Ctx& c, CB2Loader& L, int id) {
     int t = 0;
     for (; t < T0; ++t) {                                     // T0 is odd: t = 0 [, 1, 2]
         cb2_load_step(c, L, t);
-        __syncthreads();
+        cvx_barrier();
     }
     step(P0{}, Yes{}, t); ++t;                                // plane 0 arrives (t = T0, T0 - 1 is even for both roles)
     for (; t + 1 <= tlast; t += 2) { step(P1{}, No{}, t); step(P0{}, No{}, t + 1); }
     if (t <= tlast) { step(P1{}, No{}, t); ++t; }
     for (; t < c.nsteps; ++t) {
         cb2_load_step(c, L, t);
-        __syncthreads();
+        cvx_barrier();
     }
 }
 
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(1024) void k_corr_box2(const float* __restrict__ ra
     L.lds0 = c.S0 + (lrow - (c.y0 - 2)) * b.RS + 4 * lj + 4;
     L.reg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (L.ldr && b.h > 0) L.reg = *reinterpret_cast<const float4*>(c.rk + L.goff);
-    __syncthreads();
+    cvx_barrier();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (wave < b.nw1) cb2_run<1>(c, L, tid);

@@ -191,7 +191,7 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
                         if (c & 1) consume(fb, mb0, mb1); else consume(fa, ma0, ma1);
                     }
                 }
-                if (part < NSUB - 1) __syncthreads();
+                if (part < NSUB - 1) cvx_barrier();
             }
         } else {
             int c = 0;
@@ -205,7 +205,7 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
                         consume(cf_ld16(fr, foff, fo), cf_ld16(mr, moff, mo), cf_ld16(mr, moff + 16, mo));
                     }
                 }
-                if (part < NSUB - 1) __syncthreads();
+                if (part < NSUB - 1) cvx_barrier();
             }
         }
         if (live && it.active) {
@@ -239,7 +239,7 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
                         if (4 * q + j > g.d) o[j] = 0.0f;
             }
         }
-        __syncthreads();
+        cvx_barrier();
         base += G; base = base >= R ? base - R : base; base = base >= R ? base - R : base;
     }
 }
@@ -277,7 +277,7 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
         const bool emit = m >= 1 && m <= g.h;
         if (!have) {
 #pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) __syncthreads();
+            for (int sub = 0; sub < NSUB; ++sub) cvx_barrier();
         } else {
             const float* sb = readable ? srcbase : zero;
             const int rs = readable ? RS : 0, pf = readable ? PF : 0;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
                         }
                     }
                 }
-                __syncthreads();
+                cvx_barrier();
             }
         }
         base_prev = base;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(1024, 8) void k_corr_fused(const float* __restrict_
     float* S1 = S0 + (size_t)(GMAX + 2) * g.PF;               // stage 1: index = x
     const int nlds = 16 + ((MODE & 4) ? 1 : 2) * (GMAX + 2) * g.PF;
     for (int i = tid * 4; i < nlds; i += blockDim.x * 4) *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    cvx_barrier();
 
     const int role = __builtin_amdgcn_readfirstlane(tid / (64 * g.wpr));
     const int tr = tid - role * 64 * g.wpr;

@@ -69,6 +69,25 @@ struct Options {
 };
 Options& options();
 
+// ---- workgroup barrier ---------------------------------------------------------------------------------------------------------
+// Every barrier of the library goes through cvx_barrier().  The race-stress build (python -m convexadam_amd.csrc.build --jitter ->
+// libconvexadam_hip_jitter.so, tools/race_stress.sh) defines CVX_RACE_JITTER: each wavefront then sleeps a pseudo-random time (0..15
+// x 64 clocks, from the shader clock and its hardware wave id) on both sides of every barrier, which shuffles the arrival order of the
+// specialised wavefronts of the marching pipelines; a missing barrier or a ring slot reused too early shows up as a result that is no
+// longer bit-identical to the oracle.
+#ifdef CVX_RACE_JITTER
+__device__ __forceinline__ void cvx_jitter() {
+    unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+    t ^= (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) * 2654435761u;       // HW_REG_HW_ID
+    t ^= t >> 13; t *= 0x9E3779B1u; t ^= t >> 15;
+    const int n = (int)(t & 15);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);                                          // 64 clocks each
+}
+__device__ __forceinline__ void cvx_barrier() { cvx_jitter(); __syncthreads(); cvx_jitter(); }
+#else
+__device__ __forceinline__ void cvx_barrier() { __syncthreads(); }
+#endif
+
 // ---- exact device math ---------------------------------------------------------------------------
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_label_mask(const float* __restrict__ se
         __shared__ unsigned int wsum[4];
         const unsigned long long b = __ballot(in);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)__popcll(b);
-        __syncthreads();
+        cvx_barrier();
         if (threadIdx.x == 0) {
             const unsigned t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
             if (t) atomicAdd(count, (unsigned long long)t);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_surface_hist(const int* __restrict__ a_
     constexpr int LB = 2048;
     __shared__ unsigned int low[LB];
     for (int i = threadIdx.x; i < LB; i += blockDim.x) low[i] = 0;
-    __syncthreads();
+    cvx_barrier();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         if (b_in2[i] != 1) continue;
         const int bin = a_in2[i] + a_out2[i];
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_surface_hist(const int* __restrict__ a_
         if (bin < LB) atomicAdd(&low[bin], 1u);
         else atomicAdd(&hist[bin], 1ull);
     }
-    __syncthreads();
+    cvx_barrier();
     for (int i = threadIdx.x; i < LB && i < nbins; i += blockDim.x)
         if (low[i]) atomicAdd(&hist[i], (unsigned long long)low[i]);
 }
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(1024) void k_hist_order_stats(const unsigned long l
     unsigned long long s = 0;
     for (int i = lo; i < hi; ++i) s += hist[i];
     part[t] = s;
-    __syncthreads();
+    cvx_barrier();
     if (t == 0) {
         unsigned long long run = 0;
         for (int i = 0; i < 1024; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(1024) void k_hist_order_stats(const unsigned long l
         }
         kk[0] = k0; kk[1] = k1;
     }
-    __syncthreads();
+    cvx_barrier();
     k0 = kk[0]; k1 = kk[1];
     unsigned long long before = part[t];
     for (int i = lo; i < hi; ++i) {

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_label_overlap(const float* __restrict__
                                                        unsigned long long* __restrict__ counts) {
     extern __shared__ unsigned int hist[];           // [3][nlab]
     for (int i = threadIdx.x; i < 3 * nlab; i += blockDim.x) hist[i] = 0u;
-    __syncthreads();
+    cvx_barrier();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float fa = a[i], fb = b[i];
         const int la = (fa >= 0.0f && fa < (float)nlab && fa == floorf(fa)) ? (int)fa : -1;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_label_overlap(const float* __restrict__
         if (lb >= 0) atomicAdd(&hist[nlab + lb], 1u);
         if (la >= 0 && la == lb) atomicAdd(&hist[2 * nlab + la], 1u);
     }
-    __syncthreads();
+    cvx_barrier();
     for (int i = threadIdx.x; i < 3 * nlab; i += blockDim.x)
         if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
 }

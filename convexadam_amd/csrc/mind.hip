@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_minmax_partial(const float* __restrict_
     }
     __shared__ float smn[4], smx[4];
     if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
-    __syncthreads();
+    cvx_barrier();
     if (threadIdx.x == 0) {
         for (int i = 1; i < 4; ++i) { mn = fminf(mn, smn[i]); mx = fmaxf(mx, smx[i]); }
         part[2 * blockIdx.x] = mn;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_mind_stats_init(const float* part, int 
     for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_down(mn, o)); mx = fmaxf(mx, __shfl_down(mx, o)); }
     __shared__ float smn[4], smx[4];
     if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
-    __syncthreads();
+    cvx_barrier();
     if (threadIdx.x != 0) return;
     for (int i = 1; i < 4; ++i) { mn = fminf(mn, smn[i]); mx = fmaxf(mx, smx[i]); }
     const double range = (double)mx - (double)mn;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
         for (int u = 0; u < LB; ++u)
             if (i0 + u * NT < IZ * IY * IX) simg[i0 + u * NT] = v[u];
     }
-    __syncthreads();
+    cvx_barrier();
 
     const int trun = tid % (TX / RUN), ty = (tid / (TX / RUN)) % TY, tz = tid / ((TX / RUN) * TY);
     const int tx0 = trun * RUN;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
             const float df = simg[sq_src[e] + off1] - simg[sq_src[e] + off2];
             if (sq_dst[e] >= 0) sq[sq_dst[e]] = df * df;
         }
-        __syncthreads();
+        cvx_barrier();
         // raster-order box sums (z slowest, x fastest) for 4 adjacent outputs from aligned 8-byte LDS reads,
         // one exact division by K^3
         float s[RUN];
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
         for (int j = 0; j < RUN; ++j) res[c][j] = div_exact<K * K * K>(s[j]);
         // double-buffered sq (nbuf = 2): the next channel writes the other buffer, one barrier per channel;
         // large radius/dilation tiles only fit one buffer and need a second barrier
-        if (nbuf == 1) __syncthreads();
+        if (nbuf == 1) cvx_barrier();
     }
 
     const int gz = z0 + tz, gy = y0 + ty;     // threads of an overhanging tile still join the reduction
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
     }
     __shared__ double red[3][NT / 64];
     if ((tid & 63) == 0) { red[0][tid >> 6] = a1; red[1][tid >> 6] = a2; red[2][tid >> 6] = a3; }
-    __syncthreads();
+    cvx_barrier();
     if (tid == 0) {
         for (int i = 1; i < NT / 64; ++i) { a1 += red[0][i]; a2 += red[1][i]; a3 += red[2][i]; }
         atomicAdd(&st->a1, a1); atomicAdd(&st->a2, a2); atomicAdd(&st->a3, a3);
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restr
             lds_store2(E + ((MIND_INV[c] * T + z) * T + y) * MP_TX + 2 * xp, v);
         }
     }
-    __syncthreads();
+    cvx_barrier();
     constexpr int NA = 12 * (MP_TX / GA);                                          // large windows of the tile (T / GA = 1)
     constexpr int WA = (NA + 63) / 64 * 64;                                        // threads reserved for them (whole wavefronts)
     if (tid < WA) {

@@ -176,7 +176,7 @@ __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __r
         if (zc != zc_prev) mm_publish<G::PLANE>(L, ring, zc + 2, L.pre);
         mm_fetch(img, H, W, D, L, zc + 3, L.pre);
         zc_prev = zc;
-        __syncthreads();
+        cvx_barrier();
         const int gz = z0 + s - 2;
         const size_t lin = ((size_t)(gz < 0 ? 0 : gz) * W + (gy < W ? gy : 0)) * D + (gx0 < D ? gx0 : 0);
         float* Xs = X + (s & 1) * XSZ;
@@ -184,12 +184,12 @@ __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __r
         else mm_box_step<G, SET, false>(ring, Xs, out, V, lin, store_ok, zc, rowoff, colbase, left, right, row, q, A, P);
         if (s >= 3) stats(X + ((s - 1) & 1) * XSZ, gz - 1);
     }
-    __syncthreads();
+    cvx_barrier();
     stats(X + ((nsteps - 1) & 1) * XSZ, z1 - 1);
     // every partial sum is exactly representable -> any reduction order gives the same bits
     for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_down(a1, o); a2 += __shfl_down(a2, o); a3 += __shfl_down(a3, o); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = a1; red[1][tid >> 6] = a2; red[2][tid >> 6] = a3; }
-    __syncthreads();
+    cvx_barrier();
     if (tid == 0) {
         for (int i = 1; i < MM_NT / 64; ++i) { a1 += red[0][i]; a2 += red[1][i]; a3 += red[2][i]; }
         atomicAdd(&st->a1, a1); atomicAdd(&st->a2, a2); atomicAdd(&st->a3, a3);

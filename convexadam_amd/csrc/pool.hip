@@ -373,12 +373,12 @@ __global__ __launch_bounds__(256) void k_label_hist(const float* __restrict__ la
                                                     unsigned long long* __restrict__ hist) {
     extern __shared__ unsigned int sh[];
     for (int i = threadIdx.x; i <= max_label; i += blockDim.x) sh[i] = 0;
-    __syncthreads();
+    cvx_barrier();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
         const int l = (int)lab[i];
         if (l >= 0 && l <= max_label) atomicAdd(&sh[l], 1u);
     }
-    __syncthreads();
+    cvx_barrier();
     for (int i = threadIdx.x; i <= max_label; i += blockDim.x)
         if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
 }

@@ -989,3 +989,34 @@ def test_kernel_variants_agree(M, U, orc, golden, opt, val):
     finally:
         L.cvx_set_option(opt.encode(), old)
     assert L.cvx_set_option(b"no_such_switch", 1) != 0
+
+
+def test_translation_wrapper_and_original_moving_warp_on_metaimage_files(tmp_path):
+    """SURVEY 8(f).3 end to end without SimpleITK: MetaImage files in, convex_adam_translation_from_file registers on a 1 mm grid (HIP),
+    reduces the field to a whole-voxel translation and writes the moved image; apply_convex_original_moving carries a field to an
+    anisotropic moving image and warps it on the device."""
+    from convexadam_amd.apply_convex import apply_convex_original_moving
+    from convexadam_amd.convex_adam_translation import convex_adam_translation_from_file
+    from convexadam_amd.convex_adam_utils import resample_img
+    from convexadam_amd.imageio import Image, read_mha, write_mha
+    from convexadam_amd.phantom import phantom
+    vol = phantom((48, 40, 44), 5, 50).numpy()
+    shift_zyx = (3, 0, -2)
+    fixed = Image(vol, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
+    moving = Image(np.roll(vol, shift_zyx, (0, 1, 2)), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
+    pf, pm, po = str(tmp_path / "fixed.mha"), str(tmp_path / "moving.mha"), str(tmp_path / "moved.mha")
+    write_mha(fixed, pf); write_mha(moving, pm, compress=True)
+    t_xyz = convex_adam_translation_from_file(pf, pm, None, po)
+    assert tuple(t_xyz) == (float(shift_zyx[2]), float(shift_zyx[1]), float(shift_zyx[0]))      # fixed(x) ~ moving(x + u): u = +shift
+    moved = read_mha(po)
+    assert np.array_equal(moved.array, moving.array) and np.allclose(moved.GetOrigin(), (-np.array(t_xyz)).tolist())
+    # field on the 1 mm grid of an anisotropic fixed image -> warp of the original (anisotropic) moving image
+    fixed_a = Image(vol[::2].copy(), (1.0, 1.0, 2.0), (0.0, 0.0, 0.0))
+    moving_a = Image(np.roll(vol, shift_zyx, (0, 1, 2))[::2].copy(), (1.0, 1.0, 2.0), (0.0, 0.0, 0.0))
+    fixed_1mm = resample_img(fixed_a, (1.0, 1.0, 1.0))
+    field = np.zeros(fixed_1mm.array.shape + (3,))
+    field[..., 0], field[..., 2] = 4.0, -2.0                                                    # z, y, x in 1 mm voxels
+    warped = apply_convex_original_moving(field, moving_a, fixed_a, fixed_1mm)
+    assert isinstance(warped, Image) and warped.array.dtype == np.float32 and warped.GetSpacing() == moving_a.GetSpacing()
+    inner = (slice(4, -4),) * 3
+    assert np.allclose(warped.array[inner], np.roll(moving_a.array, (-2, 0, 2), (0, 1, 2))[inner], atol=1e-4)   # 4 mm = 2 voxels along z

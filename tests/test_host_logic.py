@@ -151,17 +151,25 @@ def test_sweep_settings_tables():
 
 def test_geometry_helpers_importable_under_reference_names():
     """tests/test_convex_adam_mind_aniso.py:10-12, convex_adam_translation.py:9 and apply_convex.py:13,27 of the reference: these
-    names are imported from convexAdam.*; the geometry helpers wrap SimpleITK and say so when it is missing.  (Own process: the
+    names are imported from convexAdam.*; the geometry helpers take SimpleITK images (through SimpleITK) or the built-in
+    convexadam_amd.imageio.Image, and say that SimpleITK is missing when they are handed anything else.  (Own process: the
     import shim must not shadow the live reference import of tests/test_oracle_vs_reference_live.py.)"""
     code = """
 import numpy as np
 from convexAdam.convex_adam_utils import resample_img, resample_moving_to_fixed, rescale_displacement_field
 from convexAdam.apply_convex import apply_convex, apply_convex_original_moving
+from convexAdam.convex_adam_translation import convex_adam_translation, apply_translation
+class Foreign:                       # an image object of another library: only SimpleITK's resampler could take it
+    def GetSize(self): return (4, 4, 4)
+    def GetSpacing(self): return (1.0, 1.0, 1.0)
+    def GetOrigin(self): return (0.0, 0.0, 0.0)
+    def GetDirection(self): return (1, 0, 0, 0, 1, 0, 0, 0, 1)
 try:
     import SimpleITK
 except ImportError:
-    for fn, args in ((resample_img, (None, (1.0, 1.0, 1.0))), (resample_moving_to_fixed, (None, None)),
-                     (rescale_displacement_field, (np.zeros((2, 2, 2, 3)), None, None, None))):
+    f = Foreign()
+    for fn, args in ((resample_img, (f, (1.0, 1.0, 1.0))), (resample_moving_to_fixed, (f, f)),
+                     (rescale_displacement_field, (np.zeros((4, 4, 4, 3)), f, f, f))):
         try:
             fn(*args)
         except ImportError as e:
@@ -227,3 +235,91 @@ def test_nifti_io_round_trip(tmp_path):
     with pytest.raises(ValueError):
         open(p, "wb").write(b"x" * 400); N.load(p)
 
+
+
+# ---- built-in images with geometry, MetaImage files, geometry helpers without SimpleITK ------------------------------
+def _blob_image(shape_zyx, spacing, origin, direction, seed=0):
+    from convexadam_amd.imageio import Image
+    rng = np.random.default_rng(seed)
+    return Image(rng.normal(100, 20, shape_zyx).astype(np.float32), spacing, origin, direction)
+
+
+def test_metaimage_round_trip(tmp_path):
+    from convexadam_amd.imageio import read_mha, write_mha
+    rot = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    for dtype, compress in ((np.float32, False), (np.int16, True), (np.uint8, False), (np.float64, True)):
+        img = _blob_image((5, 6, 7), (0.5, 0.75, 2.0), (-10.0, 3.5, 8.0), rot.reshape(-1))
+        img.array = img.array.astype(dtype)
+        path = str(tmp_path / "x.mha")
+        write_mha(img, path, compress=compress)
+        back = read_mha(path)
+        assert back.array.dtype == dtype and np.array_equal(back.array, img.array)
+        assert back.GetSize() == (7, 6, 5) and np.allclose(back.GetSpacing(), img.GetSpacing()) and np.allclose(back.GetOrigin(), img.GetOrigin())
+        assert np.allclose(np.array(back.GetDirection()), rot.reshape(-1))
+    # a header written by other tools: big-endian data, keys in another order, mhd-style external file
+    raw = np.arange(24, dtype=">i2").reshape(2, 3, 4)
+    (tmp_path / "d.raw").write_bytes(raw.tobytes())
+    (tmp_path / "d.mhd").write_text("ObjectType = Image\nNDims = 3\nDimSize = 4 3 2\nElementSpacing = 1 2 3\nElementType = MET_SHORT\n"
+                                    "BinaryDataByteOrderMSB = True\nOffset = 1 2 3\nElementDataFile = d.raw\n")
+    img = read_mha(str(tmp_path / "d.mhd"))
+    assert np.array_equal(img.array, raw.astype(np.int16)) and img.GetSpacing() == (1.0, 2.0, 3.0) and img.GetOrigin() == (1.0, 2.0, 3.0)
+
+
+def test_resampling_follows_itk_geometry():
+    """A linear ramp in physical space is reproduced exactly by linear resampling onto any grid that stays inside the source buffer;
+    outside the buffer the value is 0; resample_img's size rule is floor(n * old / new + 0.5)."""
+    from convexadam_amd.convex_adam_utils import resample_img, resample_moving_to_fixed
+    from convexadam_amd.imageio import Image
+    th = np.deg2rad(20.0)
+    D = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    spacing, origin = np.array([0.8, 1.25, 2.0]), np.array([-5.0, 7.0, 1.0])
+    nz, ny, nx = 12, 14, 16
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    phys = origin[:, None] + D @ (spacing[:, None] * np.stack([i, j, k], 0).reshape(3, -1))
+    coef = np.array([0.3, -0.7, 1.1])
+    src = Image((coef @ phys + 2.0).reshape(nz, ny, nx), spacing, origin, D.reshape(-1))
+    iso = resample_img(src, (1.0, 1.0, 1.0))
+    assert iso.GetSize() == tuple(int(n * s / 1.0 + 0.5) for n, s in zip((nx, ny, nz), spacing))
+    A, o = iso.index_to_physical_matrix()
+    kk, jj, ii = np.meshgrid(*[np.arange(n) for n in iso.array.shape], indexing="ij")
+    p = o[:, None] + A @ np.stack([ii, jj, kk], 0).reshape(3, -1)
+    As, os_ = src.index_to_physical_matrix()
+    ci = np.linalg.solve(As, p - os_[:, None])
+    inside = np.all((ci >= 0) & (ci <= np.array([nx - 1, ny - 1, nz - 1])[:, None]), 0)
+    assert inside.sum() > 1000
+    assert np.allclose(iso.array.reshape(-1)[inside], (coef @ p + 2.0)[inside], atol=1e-9)
+    outside = np.any((ci < -0.5) | (ci > np.array([nx, ny, nz])[:, None] - 0.5), 0)
+    # a grid that sticks out of the source on every side
+    big = Image(np.zeros((20, 20, 20)), (1.5, 1.5, 1.5), (-15.0, -2.0, -6.0), np.eye(3).reshape(-1))
+    onto = resample_moving_to_fixed(big, src)
+    assert onto.GetSize() == big.GetSize() and onto.GetSpacing() == big.GetSpacing()
+    assert (onto.array == 0).sum() > 100 and (onto.array != 0).sum() > 100
+    del outside
+
+
+def test_rescale_displacement_field_and_translation_without_simpleitk():
+    """convex_adam_utils.py:309-351 / convex_adam_translation.py:12-54 on built-in images: a field estimated on an isotropic resampled
+    grid is carried to an anisotropic, rotated moving image: components are resampled, rotated by inv(D_fixed) D_moving and scaled by
+    the spacing ratio; apply_translation shifts the origin by the world-space translation."""
+    from convexadam_amd.convex_adam_translation import apply_translation, field_to_translation, index_translation_to_world_translation
+    from convexadam_amd.convex_adam_utils import rescale_displacement_field, resample_img
+    from convexadam_amd.imageio import Image
+    Rz = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    fixed = Image(np.zeros((10, 12, 14), np.float32), (1.0, 1.0, 2.0), (0.0, 0.0, 0.0), np.eye(3).reshape(-1))
+    fixed_1mm = resample_img(fixed, (1.0, 1.0, 1.0))
+    moving = Image(np.zeros((8, 20, 18), np.float32), (0.5, 0.5, 2.5), (6.0, 0.0, 0.0), Rz.reshape(-1))
+    field = np.zeros(fixed_1mm.array.shape + (3,))
+    field[..., 0], field[..., 1], field[..., 2] = 2.0, -1.0, 0.5                      # z, y, x voxels of the 1 mm grid, constant
+    out = rescale_displacement_field(field, moving, fixed, fixed_1mm)
+    assert out.shape == moving.array.shape + (3,)
+    A, o = moving.index_to_physical_matrix()
+    centre = tuple(s // 2 for s in moving.array.shape)
+    # constant field: rotation x, y, z -> (x, y, z) @ inv(I) @ Rz, then scaled by spacing ratio (1, 1, 1) / (0.5, 0.5, 2.5) in x, y, z
+    v_xyz = np.array([0.5, -1.0, 2.0]) @ Rz
+    expect_zyx = (v_xyz * (np.array([1.0, 1.0, 1.0]) / np.array([0.5, 0.5, 2.5])))[::-1]
+    assert np.allclose(out[centre], expect_zyx)
+    # translation helpers
+    assert np.allclose(index_translation_to_world_translation((1.0, 2.0, 3.0), Rz.reshape(-1)), Rz @ np.array([1.0, 2.0, 3.0]))
+    moved = apply_translation(moving, (1.0, 2.0, 3.0))
+    assert np.allclose(np.array(moving.GetOrigin()) - np.array(moved.GetOrigin()), Rz @ np.array([1.0, 2.0, 3.0])) and moving.GetOrigin() == (6.0, 0.0, 0.0)
+    assert field_to_translation(field, (0.5, 0.5, 2.5)) == (0.5, -1.0, 2.5)            # whole voxels of the moving image, in mm (x, y, z)
