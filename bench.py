@@ -206,7 +206,7 @@ def main():
             res["coupled_convex_ms"] = {"phantom": res["stages_ms"].get("coupled_convex"), "zero_background": cc_worst.get("coupled_convex"),
                                         "zero_background_ms_per_pair": cc_worst.get("ms_per_pair"),
                                         "note": "both directions; zero_background = same pair multiplied by an ellipsoid mask (exact zeros outside): flat cost, "
-                                                "whole search windows survive the pruning and the passes stream the volume (6 coalesced scans per direction)"}
+                                                "flat cost regions; a pruned pass whose large candidate boxes exceed the cost of a coalesced scan streams the volume instead (bounded worst case)"}
         if n == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"], res["parity"] = cpu_baseline(fix.cpu().numpy(), mov.cpu().numpy(), field_of_timed_loop)
         print(json.dumps(res))

@@ -142,49 +142,39 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     const int tlast = c.zn + 5 + K;
 
     BMAdamPre apre = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    // Register state: the windows of the two newest input planes (win[n % 2]) and, instead of the window of the oldest one,
-    // its finished raster-order prefix: the 27-tap sum of plane z starts with the 9 taps of plane z-1 added to +0.0, which
-    // depends on plane z-1 alone and is evaluated when that plane arrives (pre[n % 2], consumed two steps later).
-    float win[2][3][6], pre[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pre[a][j] = 0.0f;
-    // one step; n = t - (3K-2) counts the input planes of this role, PAR = n % 2; EMIT: n >= 2, an output plane is due
-    auto step = [&](auto par, auto emit, int t) {
-        constexpr int PAR = decltype(par)::value;
+    // Register state: two running sums per output column.  The 27-tap raster-order sum of output plane z is
+    // ((0 + taps(z-1)) + taps(z)) + taps(z+1); when input plane n arrives the thread finishes plane n-1 from `mid` (= prefix of
+    // planes n-2, n-1), advances `mid` from `pre` (= taps of plane n-1 added to +0.0) and restarts `pre`: every tap is read once
+    // and only the newest plane's 3 x 6 window is live (the rows are a rolled loop: 6 window registers).
+    float mid[4] = {0.f, 0.f, 0.f, 0.f}, pre[4] = {0.f, 0.f, 0.f, 0.f};
+    // one step; n = t - (3K-2) counts the input planes of this role; EMIT: n >= 2, an output plane is due
+    auto step = [&](auto emit, int t) {
         constexpr bool EMIT = decltype(emit)::value;
         bm_load_step<SLOT0, BACKWARD>(c, L, t);
         const float* sp = src + ((t - 1) & 1) * SRC_SLOT;
+        float f[4], m[4], p[4];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 4; ++j) { f[j] = mid[j]; m[j] = pre[j]; p[j] = 0.0f; }       // (+0.0 + tap: a -0.0 tap must not survive, like ATen's sum)
+        float win[3][6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                 // all three rows in flight: one LDS round trip per step
             const f32x4 a = lds_load4(sp + i * G::RS);
             const f32x2 b = lds_load2(sp + i * G::RS + 4);
-            win[PAR][i][0] = a.x; win[PAR][i][1] = a.y; win[PAR][i][2] = a.z; win[PAR][i][3] = a.w;
-            win[PAR][i][4] = b.x; win[PAR][i][5] = b.y;
-        }
-        float s[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] = pre[PAR][j];                  // prefix of plane n-2
-        if (EMIT) {
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)                               // planes n-1, n
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        s[j] += win[(PAR + 1 + pl) % 2][i][j];
-                        s[j] += win[(PAR + 1 + pl) % 2][i][j + 1];
-                        s[j] += win[(PAR + 1 + pl) % 2][i][j + 2];
-                    }
+            win[i][0] = a.x; win[i][1] = a.y; win[i][2] = a.z; win[i][3] = a.w; win[i][4] = b.x; win[i][5] = b.y;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                                    // prefix of plane n
-            float pj = 0.0f;
+        for (int i = 0; i < 3; ++i) {
+            const float (&w)[6] = win[i];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { pj += win[PAR][i][j]; pj += win[PAR][i][j + 1]; pj += win[PAR][i][j + 2]; }
-            pre[PAR][j] = pj;
+            for (int j = 0; j < 4; ++j) {
+                f[j] += w[j]; m[j] += w[j]; p[j] += w[j];
+                f[j] += w[j + 1]; m[j] += w[j + 1]; p[j] += w[j + 1];
+                f[j] += w[j + 2]; m[j] += w[j + 2]; p[j] += w[j + 2];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mid[j] = m[j]; pre[j] = p[j]; }
+        const float (&s)[4] = f;
         if (EMIT) {
             const int gz = c.z0 - (2 * K + 3) + t;
             const bool planeok = gz >= 0 && gz < c.h;
@@ -214,16 +204,14 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
         if (ADAM) bm_adam_step<QPR, YT>(c, apre, t);
         cvx_barrier();
     };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
     int t = 0;
     for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD>(c, L, t); cvx_barrier(); }                    // (Adam starts at t = 10)
-    step(P0{}, No{}, t); ++t;                                 // t = 3K-2: input plane 0
-    step(P1{}, No{}, t); ++t;                                 // t = 3K-1: input plane 1
-    for (; t + 1 <= tlast; t += 2) { step(P0{}, Yes{}, t); step(P1{}, Yes{}, t + 1); }       // t = 3K ..: output planes
-    if (t <= tlast) { step(P0{}, Yes{}, t); ++t; }
+    step(No{}, t); ++t;                                 // t = 3K-2: input plane 0
+    step(No{}, t); ++t;                                 // t = 3K-1: input plane 1
+#pragma unroll 1
+    for (; t <= tlast; ++t) step(Yes{}, t);             // t = 3K ..: output planes
     for (; t < c.nsteps; ++t) {
         bm_load_step<SLOT0, BACKWARD>(c, L, t);
         if (ADAM) bm_adam_step<QPR, YT>(c, apre, t);
@@ -303,8 +291,8 @@ static int launch_qpr(const float* in, float* out, int h, int w, int d, bool bac
                       AdamConsts ac, float* gsave, hipStream_t s) {
     using G = BMGeomT<QPR, YT>;
     const int nyt = cdiv(w, YT);
-    const int nz_target = 256 / (3 * nyt) > 0 ? 256 / (3 * nyt) : 1;         // about one workgroup per CU (4-row tiles with two
-                                                                             // workgroups per CU were measured slower: 22 vs 20 us)
+    const int wg_target = (int)options().box_wg_target;                       // workgroups to aim for (z chunks follow from it)
+    const int nz_target = wg_target / (3 * nyt) > 0 ? wg_target / (3 * nyt) : 1;
     int zc = cdiv(h, nz_target);
     if (zc < 4) zc = 4;
     const int nzc = cdiv(h, zc);

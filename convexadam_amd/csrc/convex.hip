@@ -233,12 +233,15 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const float* __restrict__ s
     keys[x] = pack_min_key(best, (unsigned)bi);
 }
 
+__device__ void argmin4_stream(const float* __restrict__ ssd, const float* __restrict__ mesh, const float* __restrict__ u, float coef, int K,
+                               size_t v, unsigned long long* __restrict__ keys, bool vec);
+
 template <typename PrevT>
 __global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ ssd, const float* __restrict__ mesh,
                                                      const float* __restrict__ u, float coef, int K, int n, size_t v,
                                                      const float* __restrict__ smin, const PrevT* __restrict__ kprev,
                                                      const unsigned long long* __restrict__ list, const int* __restrict__ list_count,
-                                                     unsigned long long* __restrict__ keys, int stream_above, Prob2 o) {
+                                                     unsigned long long* __restrict__ keys, int stream_above, int vec, Prob2 o) {
     if (blockIdx.y) {
         ssd = shifted(ssd, o.ssd); u = shifted(u, o.out); smin = shifted(smin, o.ws); kprev = shifted(kprev, o.ws);
         list = shifted(list, o.ws); list_count = shifted(list_count, o.ws); keys = shifted(keys, o.ws);
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ s
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
     const int cnt = *list_count;
-    if (cnt > stream_above) return;                          // too many large boxes: k_argmin4_stream scans the volume instead
+    if (cnt > stream_above) { argmin4_stream(ssd, mesh, u, coef, K, v, keys, vec != 0); return; }   // too many large boxes: one coalesced scan
     for (int e = wave; e < cnt; e += nwaves) {
         const unsigned long long item = list[e];
         const size_t x = (size_t)(item >> 8);
@@ -290,42 +293,45 @@ __global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ s
 
 // Bounded worst case of a pruned pass: when the large boxes add up to more than `stream_above` chunks (flat cost regions -- zero
 // background, masked-out tissue -- keep their whole window), gathering them displacement by displacement would read far more
-// sectors than one coalesced scan of the volume, so this kernel streams the whole pass like k_argmin4<true> and the wavefront kernel
-// stands down.  Both see the same counter; exactly one of them does the work.  Voxels already settled by k_argmin_voxel receive the
+// sectors than one coalesced scan of the volume, so the wavefront kernel then streams the whole pass like k_argmin4<true> (argmin4_stream below) instead of working through its list.  Voxels already settled by k_argmin_voxel receive the
 // same winner again through atomicMin.
-__global__ __launch_bounds__(256) void k_argmin4_stream(const float* __restrict__ ssd, const float* __restrict__ mesh,
-                                                        const float* __restrict__ u, float coef, int K, size_t v, int kslice,
-                                                        const int* __restrict__ list_count, unsigned long long* __restrict__ keys,
-                                                        int stream_above, int vec, Prob2 o) {
-    if (blockIdx.z) { ssd = shifted(ssd, o.ssd); u = shifted(u, o.out); list_count = shifted(list_count, o.ws); keys = shifted(keys, o.ws); }
-    if (*list_count <= stream_above) return;
-    const size_t x0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int k0 = blockIdx.y * kslice, k1 = min(k0 + kslice, K);
-    if (x0 >= v) return;
-    const int nv = (int)min((size_t)4, v - x0);
-    float u0[4], u1[4], u2[4], best[4] = {0.f, 0.f, 0.f, 0.f};
-    int bi[4] = {-1, -1, -1, -1};
-    for (int j = 0; j < 4; ++j) { const size_t x = x0 + (j < nv ? j : 0); u0[j] = u[x]; u1[j] = u[v + x]; u2[j] = u[2 * v + x]; }
-    for (int k = k0; k < k1; ++k) {
-        const float m0 = mesh[k], m1 = mesh[K + k], m2 = mesh[2 * K + k];
-        const float* p = ssd + (size_t)k * v + x0;
-        float c4[4];
-        if (vec) { const float4 q4 = *reinterpret_cast<const float4*>(p); c4[0] = q4.x; c4[1] = q4.y; c4[2] = q4.z; c4[3] = q4.w; }
-        else for (int j = 0; j < 4; ++j) c4[j] = j < nv ? p[j] : 0.0f;
+__device__ void argmin4_stream(const float* __restrict__ ssd, const float* __restrict__ mesh, const float* __restrict__ u, float coef, int K,
+                               size_t v, unsigned long long* __restrict__ keys, bool vec) {
+    const int xb = (int)((((v + 3) >> 2) + 255) >> 8);                   // blocks of 256 threads x 4 voxels
+    int nslices = (int)gridDim.x * 2 / xb;                                // about two tiles per workgroup
+    nslices = nslices < 1 ? 1 : (nslices > K ? K : nslices);
+    const int kslice = (K + nslices - 1) / nslices;
+    nslices = (K + kslice - 1) / kslice;
+    for (int tile = blockIdx.x; tile < xb * nslices; tile += gridDim.x) {
+        const int bx = tile % xb, sl = tile / xb;
+        const size_t x0 = ((size_t)bx * 256 + threadIdx.x) * 4;
+        const int k0 = sl * kslice, k1 = min(k0 + kslice, K);
+        if (x0 >= v) continue;
+        const int nv = (int)min((size_t)4, v - x0);
+        float u0[4], u1[4], u2[4], best[4] = {0.f, 0.f, 0.f, 0.f};
+        int bi[4] = {-1, -1, -1, -1};
+        for (int j = 0; j < 4; ++j) { const size_t x = x0 + (j < nv ? j : 0); u0[j] = u[x]; u1[j] = u[v + x]; u2[j] = u[2 * v + x]; }
+        for (int k = k0; k < k1; ++k) {
+            const float m0 = mesh[k], m1 = mesh[K + k], m2 = mesh[2 * K + k];
+            const float* p = ssd + (size_t)k * v + x0;
+            float c4[4];
+            if (vec) { const float4 q4 = *reinterpret_cast<const float4*>(p); c4[0] = q4.x; c4[1] = q4.y; c4[2] = q4.z; c4[3] = q4.w; }
+            else for (int j = 0; j < 4; ++j) c4[j] = j < nv ? p[j] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j >= nv) continue;
-            const float e0 = m0 - u0[j], e1 = m1 - u1[j], e2 = m2 - u2[j];
-            float q = e0 * e0;          // (..).pow(2).sum(0): sequential over the 3 components
-            q += e1 * e1;
-            q += e2 * e2;
-            const float cost = c4[j] + coef * q;    // ssd + coeffs[j]*(...)                       (:104)
-            if (bi[j] < 0 || cost < best[j]) { best[j] = cost; bi[j] = k; }
+            for (int j = 0; j < 4; ++j) {
+                if (j >= nv) continue;
+                const float e0 = m0 - u0[j], e1 = m1 - u1[j], e2 = m2 - u2[j];
+                float q = e0 * e0;          // (..).pow(2).sum(0): sequential over the 3 components
+                q += e1 * e1;
+                q += e2 * e2;
+                const float cost = c4[j] + coef * q;    // ssd + coeffs[j]*(...)                       (:104)
+                if (bi[j] < 0 || cost < best[j]) { best[j] = cost; bi[j] = k; }
+            }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (j < nv && bi[j] >= 0) atomicMin(&keys[x0 + j], pack_min_key(best[j], (unsigned)bi[j]));
+        for (int j = 0; j < 4; ++j)
+            if (j < nv && bi[j] >= 0) atomicMin(&keys[x0 + j], pack_min_key(best[j], (unsigned)bi[j]));
+    }
 }
 
 // smin[x] from the (cost, index) keys of a plain argmin pass (inverse of pack_min_key's order-preserving map)
@@ -427,19 +433,10 @@ static int argmin_pass_pruned(const float* ssd, const float* mesh, float* u, flo
     // worst case bounded by one coalesced scan per pass: a chunk of 256 scattered reads moves about 8 KB, the scan K * v * 4 bytes
     const long long above = options().prune_stream_above >= 0 ? options().prune_stream_above : (long long)((double)K * (double)v / 2048.0);
     const int stream_above = (int)(above > 0x7fffffff ? 0x7fffffff : above);
+    const int vec = (v % 4 == 0) && ((reinterpret_cast<uintptr_t>(ssd) | (uintptr_t)(o.ssd < 0 ? -o.ssd : o.ssd)) & 15) == 0;
+    // voxels whose key the voxel kernel stored plainly keep it under the scan (it finds the same winner); listed voxels were armed to ~0
     hipLaunchKernelGGL((k_argmin_wave<PrevT>), dim3(512, nprob), dim3(256), 0, s, ssd, mesh, u, coef, K, n, v, smin, kprev, list,
-                       list_count, keys, stream_above, o);
-    {
-        const int xb = (int)cdiv64((int64_t)cdiv64((int64_t)v, 4), 256);
-        int nslices = cdiv(512, xb);
-        nslices = nslices > K ? K : (nslices < 1 ? 1 : nslices);
-        const int kslice = cdiv(K, nslices);
-        nslices = cdiv(K, kslice);
-        // voxels whose key the voxel kernel stored plainly keep it (the scan finds the same winner); listed voxels were armed to ~0
-        const int vec = (v % 4 == 0) && ((reinterpret_cast<uintptr_t>(ssd) | (uintptr_t)(o.ssd < 0 ? -o.ssd : o.ssd)) & 15) == 0;
-        hipLaunchKernelGGL(k_argmin4_stream, dim3(xb, nslices, nprob), dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, list_count, keys,
-                           stream_above, vec, o);
-    }
+                       list_count, keys, stream_above, vec, o);
     return check_last("argmin_pruned");
 }
 

@@ -57,11 +57,11 @@ def main(src, tag):
     for k, n, fe, wr, mb in rows:
         buf.write("%-44s %6d %14.1f %14.1f %18.1f\n" % (k[-44:], n, fe, wr, mb))
     open(os.path.join(prof, tag + "_pmc_hbm_traffic.txt"), "w").write(buf.getvalue())
-    stage = [r for r in rows if any(s in r[0] for s in ("k_corr_prep", "k_corr_raw", "k_corr_tail", "k_corr_box"))]
+    stage = [(r[0], r[1], r[2], r[3], r[4]) for r in rows if any(s in r[0] for s in ("k_corr_prep", "k_corr_raw", "k_corr_tail", "k_corr_box", "k_corr_fused"))]
     total = sum(r[4] for r in stage) * 1e6
     json.dump({"correlate_stage_bytes_per_launch": total, "source": "profiles/%s_pmc_hbm_traffic.txt" % tag,
                "kernels": {r[0]: r[4] * 1e6 for r in stage},
-               "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 summed over k_corr_prep, k_corr_raw, (k_corr_tail,) k_corr_box2"},
+               "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 summed over k_corr_prep, k_corr_fused (k_corr_tail_compact when the volume has an interleaved-order tail), per launch = per direction", "measured_at_commit": os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip()},
               open(os.path.join(prof, "pmc_hbm_traffic.json"), "w"), indent=1)
     sa, sc = pmc(src + "/sq")
     names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT"]
