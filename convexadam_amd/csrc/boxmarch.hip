@@ -307,6 +307,11 @@ static int launch_qpr(const float* in, float* out, int h, int w, int d, bool bac
 
 int launch_box3_march(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
                       AdamConsts ac, float* gsave, hipStream_t s) {
+    if (options().box_yt == 4) {              // 4-row tiles: 9-wave workgroups, three per CU
+        if (d <= 30) return launch_qpr<8, 4>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+        if (d <= 62) return launch_qpr<16, 4>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+        return launch_qpr<32, 4>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+    }
     if (d <= 30) return launch_qpr<8, 8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
     if (d <= 62) return launch_qpr<16, 8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
     return launch_qpr<32, 8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);

@@ -66,6 +66,7 @@ struct Options {
     long long corr_unfused;        // 1: k_corr_raw + k_corr_box2 instead of the fused correlation kernel
     long long prune_stream_above;  // pruned pass falls back to a coalesced scan above this many 256-displacement chunks (-1 = K*v/2048)
     long long cf_census;           // 1: the fused correlation kernel records per-workgroup residency in its workspace
+    long long box_yt;              // rows per tile of the marching three-box kernels: 8 (default) or 4
     long long box_wg_target;       // workgroups the z-marching three-box kernels of the Adam loop aim for (z-chunk length follows)
 };
 Options& options();
