@@ -77,32 +77,47 @@ def main():
     s20, a20 = U.correlate(f20, m20, 1, 1, (7, 5, 9), 20)
     save("correlate_c20", fix=f20[0].numpy(), mov=m20[0].numpy(), ssd=s20.numpy(), argmin=a20.numpy())
 
-    # ---- C: Adam instance optimisation (convex_adam_MIND.py:147-182), inline restatement of the
-    #         reference loop body is NOT stored; we run the reference pipeline pieces through torch.
+    # ---- C: Adam instance optimisation (convex_adam_MIND.py:147-182): the reference's own loop runs inside convex_adam_pt; its inputs,
+    #         per-iteration control grids and gradients are observed through wrappers around F.avg_pool3d and torch.optim.Adam.step
     g, lam = 2, 1.25
-    pf = F.avg_pool3d(ff, g, stride=g)
-    pm = F.avg_pool3d(fm, g, stride=g)
+    rec = dict(pooled=[], P={}, G={})
+    _pool, _step = F.avg_pool3d, torch.optim.Adam.step
+
+    def pool(x, *a, **k):
+        y = _pool(x, *a, **k)
+        if x.shape[1] == 12 and (a[0] if a else k.get("kernel_size")) == g and k.get("stride") == g:
+            rec["pooled"].append(y.detach()[0].clone())            # patch_features_fix, then patch_features_mov (:149-150)
+        return y
+
+    def step(opt, *a, **k):
+        n = len(rec["P"]) + 1
+        w = opt.param_groups[0]["params"][0]
+        rec["P"][n] = w.detach()[0].clone()                        # control grid of forward pass n (before its update)
+        rec["G"][n] = w.grad.detach()[0].clone()
+        r = _step(opt, *a, **k)
+        rec["after"] = w.detach()[0].clone()
+        return r
+
+    F.avg_pool3d, torch.optim.Adam.step = pool, step
+    try:
+        M.convex_adam_pt(fix, mov, mind_r=1, mind_d=2, lambda_weight=lam, grid_sp=gs, disp_hw=hw, selected_niter=20, grid_sp_adam=g, ic=True,
+                         dtype=torch.float32, device=CPU)
+    finally:
+        F.avg_pool3d, torch.optim.Adam.step = _pool, _step
+    pf, pm = rec["pooled"][-2][None], rec["pooled"][-1][None]
+    P0 = rec["P"][1].numpy().copy()
+
+    def disp_sample(P):                                            # (:166) three zero-padded 3^3 mean filters
+        u = P[None]
+        for _ in range(3):
+            u = F.avg_pool3d(u, 3, stride=1, padding=1)
+        return u[0].numpy().copy()
+
     out = {}
     for niter in (1, 2, 5, 20):
-        net = nn.Sequential(nn.Conv3d(3, 1, (H // g, W // g, D // g), bias=False))
-        net[0].weight.data[:] = lr.float().cpu().data / g
-        P0 = net[0].weight.data[0].numpy().copy()
-        opt = torch.optim.Adam(net.parameters(), lr=1)
-        grid0 = F.affine_grid(torch.eye(3, 4).unsqueeze(0), (1, 1, H // g, W // g, D // g), align_corners=False)
-        for it in range(niter):
-            opt.zero_grad()
-            ds = F.avg_pool3d(F.avg_pool3d(F.avg_pool3d(net[0].weight, 3, stride=1, padding=1), 3, stride=1, padding=1), 3, stride=1, padding=1).permute(0, 2, 3, 4, 1)
-            reg = lam * ((ds[0, :, 1:, :] - ds[0, :, :-1, :]) ** 2).mean() + lam * ((ds[0, 1:, :, :] - ds[0, :-1, :, :]) ** 2).mean() + lam * ((ds[0, :, :, 1:] - ds[0, :, :, :-1]) ** 2).mean()
-            sc = torch.tensor([(H // g - 1) / 2, (W // g - 1) / 2, (D // g - 1) / 2]).unsqueeze(0)
-            gd = grid0.view(-1, 3).float() + ((ds.view(-1, 3)) / sc).flip(1).float()
-            pms = F.grid_sample(pm.float(), gd.view(1, H // g, W // g, D // g, 3), align_corners=False, mode="bilinear")
-            loss = ((pms - pf).pow(2).mean(1) * 12).mean()
-            (loss + reg).backward()
-            grad = net[0].weight.grad[0].numpy().copy()
-            opt.step()
-        out["U_%d" % niter] = ds.detach().permute(0, 4, 1, 2, 3)[0].numpy().copy()
-        out["G_%d" % niter] = grad
-        out["P_%d" % niter] = net[0].weight.data[0].numpy().copy()
+        out["U_%d" % niter] = disp_sample(rec["P"][niter])
+        out["G_%d" % niter] = rec["G"][niter].numpy().copy()
+        out["P_%d" % niter] = (rec["P"][niter + 1] if niter + 1 in rec["P"] else rec["after"]).numpy().copy()
     save("adam", F2=pf[0].numpy(), M2=pm[0].numpy(), P0=P0, lam=np.float32(lam), **out)
 
     # ---- D: whole pipeline convex_adam_pt (convex_adam_MIND.py:64-202) ---------------------------
