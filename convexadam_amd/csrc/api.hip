@@ -35,7 +35,7 @@ static long long env_ll(const char* name, long long dflt) {
 Options& options() {
     static Options o = {env_ll("CVX_MIND_TILED", 0),   env_ll("CVX_MM_TX", 0),        env_ll("CVX_MM_SLOTS", 512),          env_ll("CVX_BOX_TILED", 0),
                         env_ll("CVX_NO_PRUNE", 0),     env_ll("CVX_CORR_UNFUSED", 0), env_ll("CVX_PRUNE_STREAM_ABOVE", -1), env_ll("CVX_CF_CENSUS", 0),
-                        env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 256)};
+                        env_ll("CVX_WARP_FLAT", 0),    env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 256)};
     return o;
 }
 struct OptName { const char* name; long long Options::*field; };
@@ -43,7 +43,7 @@ static const OptName kOptNames[] = {{"mind_tiled", &Options::mind_tiled},     {"
                                     {"mm_slots", &Options::mm_slots},         {"box_tiled", &Options::box_tiled},
                                     {"no_prune", &Options::no_prune},         {"corr_unfused", &Options::corr_unfused},
                                     {"prune_stream_above", &Options::prune_stream_above}, {"cf_census", &Options::cf_census},
-                                    {"box_yt", &Options::box_yt},             {"box_wg_target", &Options::box_wg_target}};
+                                    {"warp_flat", &Options::warp_flat},       {"box_yt", &Options::box_yt},             {"box_wg_target", &Options::box_wg_target}};
 
 }  // namespace cvx
 

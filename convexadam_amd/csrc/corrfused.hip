@@ -120,13 +120,7 @@ struct CFItem {
     bool active;
 };
 
-// 16-byte load through a buffer descriptor: address = descriptor base + per-lane byte offset (VGPR) + uniform byte offset (SGPR);
-// no vector address arithmetic at all (the flat form costs a 64-bit vector add per load in a loop)
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 cf_ld16(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, unsigned uni_off) {
-    const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)uni_off, 0));
-    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
-}
+__device__ __forceinline__ float4 cf_ld16(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, unsigned uni_off) { return buffer_load16(rsrc, lane_off, uni_off); }
 
 // ---- raw stage: G x 4 channel sums per thread and step ---------------------------------------------------------------------
 // CT = compile-time channel count (12: fully unrolled software pipeline, every register static) or 0 (run-time count, rolled loop)

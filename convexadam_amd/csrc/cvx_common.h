@@ -66,6 +66,7 @@ struct Options {
     long long corr_unfused;        // 1: k_corr_raw + k_corr_box2 instead of the fused correlation kernel
     long long prune_stream_above;  // pruned pass falls back to a coalesced scan above this many 256-displacement chunks (-1 = K*v/2048)
     long long cf_census;           // 1: the fused correlation kernel records per-workgroup residency in its workspace
+    long long warp_flat;           // 1: flat 64-bit gathers in k_warp_grad instead of buffer loads
     long long box_yt;              // rows per tile of the marching three-box kernels: 8 (default) or 4
     long long box_wg_target;       // workgroups the z-marching three-box kernels of the Adam loop aim for (z-chunk length follows)
 };
@@ -129,6 +130,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 __device__ __forceinline__ f32x4 lds_load4(const float* p) { return *(const volatile lds_f32x4*)p; }   // p must point into LDS
 __device__ __forceinline__ void lds_store4(float* p, f32x4 v) { *(volatile lds_f32x4*)p = v; }
+
+// 16-byte load through a buffer descriptor: address = descriptor base + per-lane byte offset (VGPR) + wave-uniform byte offset (SGPR);
+// no 64-bit vector address arithmetic and half the address registers of the flat form
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, unsigned uni_off) {
+    const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)uni_off, 0));
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) f32x2 lds_f32x2;

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void k_to_chunked(const float* __restrict__ in
     reinterpret_cast<float4*>(out)[(size_t)blockIdx.y * (V + 1) + p] = r;
 }
 
+template <bool BUF>
 __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2, const float* __restrict__ M2, int C, int CP,
                                                    int h, int w, int d, const float* __restrict__ U,
                                                    const float* __restrict__ bh, const float* __restrict__ bw,
@@ -71,17 +72,20 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
     const float bz[8] = {fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0, fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0};
     float gix = 0.f, giy = 0.f, giz = 0.f;
     const unsigned foff = p * 16u;
-    const size_t chunk_bytes = (V + 1) * 16;
-    const char* Mc = reinterpret_cast<const char*>(M2);
-    const char* Fc = reinterpret_cast<const char*>(F2);
-    for (int c0 = 0; c0 < CP / 4; ++c0, Mc += chunk_bytes, Fc += chunk_bytes) {
+    const unsigned chunk_bytes = (unsigned)(V + 1) * 16u;
+    // buffer descriptors: per-lane 32-bit offsets + the chunk offset in a scalar register (9 address registers instead of 18, no
+    // 64-bit vector adds in the loop); the launcher guarantees CP/4 * (V + 1) * 16 < 2^32
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M2), 0, (int)(chunk_bytes * (unsigned)(CP / 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(F2), 0, (int)(chunk_bytes * (unsigned)(CP / 4)), 0x00020000);
+    unsigned coff = 0;
+    for (int c0 = 0; c0 < CP / 4; ++c0, coff += chunk_bytes) {
         float vv[8][4], fv[4];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float4 q = *reinterpret_cast<const float4*>(Mc + off[k]);
+            const float4 q = BUF ? buffer_load16(mr, off[k], coff) : *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(M2) + (size_t)c0 * chunk_bytes + off[k]);
             vv[k][0] = q.x; vv[k][1] = q.y; vv[k][2] = q.z; vv[k][3] = q.w;
         }
-        const float4 fq = *reinterpret_cast<const float4*>(Fc + foff);
+        const float4 fq = BUF ? buffer_load16(fr, foff, coff) : *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(F2) + (size_t)c0 * chunk_bytes + foff);
         fv[0] = fq.x; fv[1] = fq.y; fv[2] = fq.z; fv[3] = fq.w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
 
 int launch_to_chunked(const float* in, int C, size_t V, float* out, hipStream_t s) {
     const int CP = (C + 3) / 4 * 4;
-    if ((V + 1) * 16 >= ((size_t)1 << 32)) return fail(CVX_ERR_UNSUPPORTED, "adam_run: control grid too large (%zu voxels)", V);
+    if ((size_t)(CP / 4) * (V + 1) * 16 >= ((size_t)1 << 31)) return fail(CVX_ERR_UNSUPPORTED, "adam_run: control grid too large (%zu voxels x %d channels)", V, C);
     hipLaunchKernelGGL(k_to_chunked, dim3((unsigned)cdiv64((int64_t)(V + 1), 256), CP / 4), dim3(256), 0, s, in, C, V, out);
     return check_last("to_chunked");
 }
@@ -146,7 +150,8 @@ int launch_warp_grad(const float* Fcl, const float* Mcl, int C, int h, int w, in
                      const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s) {
     const int CP = (C + 3) / 4 * 4;
     const dim3 gv((unsigned)((cdiv(d, 16) * cdiv(w, 4) * cdiv(h, 4) + 7) / 8 * 8));     // multiple of the 8 XCDs
-    hipLaunchKernelGGL(k_warp_grad, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU);
+    if (options().warp_flat) hipLaunchKernelGGL(k_warp_grad<false>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU);
+    else hipLaunchKernelGGL(k_warp_grad<true>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU);
     return check_last("warp_grad");
 }
 
