@@ -48,6 +48,7 @@ SIGNATURES = {
     "cvx_version": (_i, []),
     "cvx_last_error": (C.c_char_p, []),
     "cvx_device_count": (_i, []),
+    "cvx_set_adam_sqrt_table": (_i, [_vp]),
     "cvx_set_option": (_i, [C.c_char_p, C.c_longlong]),
     "cvx_get_option": (C.c_longlong, [C.c_char_p]),
     "cvx_affine_base_host": (None, [_i, _vp]),

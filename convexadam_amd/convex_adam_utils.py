@@ -221,6 +221,24 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
     return U
 
 
+_adam_sqrt_table = None
+
+
+def set_adam_sqrt_table(normal=None, denormal=None, device="cuda"):
+    """Adam update with the reference build's square root (torch CPU -> MKL vsSqrt: one ulp low on 0.6 % of the inputs) instead of the
+    IEEE one.  `normal`, `denormal`: the packed bit maps of tests/golden/mkl_vssqrt_low.npz; None restores the default.  With the
+    table `adam_run` is bit-identical to the reference's loop for given features (cvx_set_adam_sqrt_table)."""
+    global _adam_sqrt_table
+    if normal is None:
+        check(lib().cvx_set_adam_sqrt_table(None))
+        _adam_sqrt_table = None
+        return
+    tbl = np.concatenate([np.ascontiguousarray(normal, np.uint8), np.ascontiguousarray(denormal, np.uint8)])
+    assert tbl.size == (1 << 21) + (1 << 20), "bit maps of 2^24 + 2^23 bits expected"
+    _adam_sqrt_table = torch.from_numpy(tbl).to(device)                     # kept alive here
+    check(lib().cvx_set_adam_sqrt_table(ptr(_adam_sqrt_table)))
+
+
 def validate_image(img, dtype=float):
     """np.ndarray / torch.Tensor (and SimpleITK / nibabel images when those packages are installed) -> torch.Tensor.
     Like the reference (convex_adam_utils.py:268-279) tensors pass through unchanged and everything else is converted with

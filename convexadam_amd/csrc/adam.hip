@@ -83,7 +83,7 @@ __device__ __forceinline__ void box_pass(const float* __restrict__ src, int sy, 
                     const float mm = __builtin_fmaf(ac.w1, g - mo, mo);          // exp_avg.lerp_(grad, 1-beta1)
                     float vv = v[i] * ac.b2;                                      // exp_avg_sq.mul_(beta2)
                     vv = __builtin_fmaf(ac.omb2 * g, g, vv);                      // .addcmul_(grad, grad, value=1-beta2)
-                    const float den = fdiv(fsqrt(vv), ac.bc2s) + 1e-8f;           // (sqrt / bias_correction2_sqrt).add_(eps)
+                    const float den = fdiv(adam_sqrt(vv, ac.sqrt_tbl), ac.bc2s) + 1e-8f;   // (sqrt / bias_correction2_sqrt).add_(eps)
                     P[i] = P[i] + fdiv(ac.neg_step * mm, den);                    // addcdiv_(exp_avg, denom, value=-step_size)
                     m[i] = mm;
                     v[i] = vv;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_adam_update(const float* __restrict__ G
     const float mm = __builtin_fmaf(ac.w1, g - mo, mo);          // exp_avg.lerp_(grad, 1-beta1)
     float vv = v[i] * ac.b2;                                      // exp_avg_sq.mul_(beta2)
     vv = __builtin_fmaf(ac.omb2 * g, g, vv);                      // .addcmul_(grad, grad, value=1-beta2)
-    const float den = fdiv(fsqrt(vv), ac.bc2s) + 1e-8f;           // (sqrt / bias_correction2_sqrt).add_(eps)
+    const float den = fdiv(adam_sqrt(vv, ac.sqrt_tbl), ac.bc2s) + 1e-8f;   // (sqrt / bias_correction2_sqrt).add_(eps)
     P[i] = P[i] + fdiv(ac.neg_step * mm, den);                    // addcdiv_(exp_avg, denom, value=-step_size)
     m[i] = mm;
     v[i] = vv;
@@ -244,7 +244,7 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
         const int step = step0 + it + 1;
         const double beta1 = 0.9, beta2 = 0.999;
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-        const AdamConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)(-(1.0 / bc1))};
+        const AdamConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)(-(1.0 / bc1)), adam_sqrt_table()};
         if (fused) { if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc; }
         else if ((rc = launch_smoother(P, U, t1, 3, h, w, d, *sm, false, s))) return rc;
         const bool last = it == niter - 1;

@@ -38,6 +38,8 @@ Options& options() {
                         env_ll("CVX_WARP_FLAT", 0),    env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 256)};
     return o;
 }
+static const unsigned* g_adam_sqrt_tbl = nullptr;
+const unsigned* adam_sqrt_table() { return g_adam_sqrt_tbl; }
 struct OptName { const char* name; long long Options::*field; };
 static const OptName kOptNames[] = {{"mind_tiled", &Options::mind_tiled},     {"mm_tx", &Options::mm_tx},
                                     {"mm_slots", &Options::mm_slots},         {"box_tiled", &Options::box_tiled},
@@ -56,6 +58,11 @@ extern "C" long long cvx_get_option(const char* name) {
     for (const auto& o : cvx::kOptNames)
         if (name && strcmp(name, o.name) == 0) return cvx::options().*(o.field);
     return -1;
+}
+
+extern "C" int cvx_set_adam_sqrt_table(const void* device_bitmap) {
+    cvx::g_adam_sqrt_tbl = static_cast<const unsigned*>(device_bitmap);
+    return CVX_OK;
 }
 
 extern "C" int cvx_version(void) { return 1000 * 0 + 1; }

@@ -71,6 +71,7 @@ struct Options {
     long long box_wg_target;       // workgroups the z-marching three-box kernels of the Adam loop aim for (z-chunk length follows)
 };
 Options& options();
+const unsigned* adam_sqrt_table();       // device bit map installed by cvx_set_adam_sqrt_table (nullptr: IEEE sqrt)
 
 // ---- workgroup barrier ---------------------------------------------------------------------------------------------------------
 // Every barrier of the library goes through cvx_barrier().  The race-stress build (python -m convexadam_amd.csrc.build --jitter ->
@@ -269,12 +270,26 @@ int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H
 int launch_resize2(const float* in, int C, int h, int w, int d, int H, int W, int D, float* scratch, float* out, int h2, int w2,
                    int d2, float post_div, hipStream_t s);
 // Adam step constants of one iteration (torch.optim.Adam, lr = 1, eps = 1e-8) and the in-place update of one element
-struct AdamConsts { float w1, b2, omb2, bc2s, neg_step; };
+// sqrt_tbl: optional restatement of the reference build's sqrt (torch CPU -> MKL vsSqrt = the correctly rounded root minus one ulp
+// for the inputs marked in a bit map: bits 0 .. 2^24-1 normal inputs, key = exponent parity << 23 | mantissa; bits 2^24 .. denormal
+// inputs, key = mantissa; cvx_set_adam_sqrt_table).  nullptr (default): IEEE sqrt.
+struct AdamConsts { float w1, b2, omb2, bc2s, neg_step; const unsigned* sqrt_tbl; };
+__device__ __forceinline__ float adam_sqrt(float x, const unsigned* __restrict__ tbl) {
+    float r = fsqrt(x);
+    if (tbl) {
+        const unsigned b = __float_as_uint(x), e = b >> 23, mant = b & 0x7fffffu;
+        if (b != 0 && e < 255) {
+            const unsigned key = e ? (((e & 1u) << 23) | mant) : ((1u << 24) | mant);
+            if ((tbl[key >> 5] >> (key & 31)) & 1u) r = __uint_as_float(__float_as_uint(r) - 1u);
+        }
+    }
+    return r;
+}
 __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& v, const AdamConsts& ac) {
     const float mm = __builtin_fmaf(ac.w1, g - m, m);            // exp_avg.lerp_(grad, 1-beta1)
     float vv = v * ac.b2;                                         // exp_avg_sq.mul_(beta2)
     vv = __builtin_fmaf(ac.omb2 * g, g, vv);                      // .addcmul_(grad, grad, value=1-beta2)
-    const float den = fdiv(fsqrt(vv), ac.bc2s) + 1e-8f;           // (sqrt / bias_correction2_sqrt).add_(eps)
+    const float den = fdiv(adam_sqrt(vv, ac.sqrt_tbl), ac.bc2s) + 1e-8f;   // (sqrt / bias_correction2_sqrt).add_(eps)
     P = P + fdiv(ac.neg_step * mm, den);                          // addcdiv_(exp_avg, denom, value=-step_size)
     m = mm;
     v = vv;

@@ -178,6 +178,14 @@ int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, int w, int 
                      const int* snapshot_iters_host, int n_snap, float* snapshots, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Optional: make the Adam update use the reference BUILD's square root instead of the IEEE one.  torch's CPU Adam calls Intel MKL's
+ * vsSqrt (convex_adam_MIND.py:179), which returns the correctly rounded root minus one ulp for 0.6 % of all inputs; which ones is a
+ * pure function of (exponent parity, mantissa) and is tabulated in tests/golden/mkl_vssqrt_low.npz (make_mkl_sqrt_table.py).
+ * device_bitmap: 3 MiB on the device, kept alive by the caller -- bits 0 .. 2^24-1 normal inputs (key = parity << 23 | mantissa),
+ * bits 2^24 .. 2^24+2^23-1 denormal inputs (key = mantissa), little-endian bit order; NULL restores the IEEE sqrt (default).
+ * With the table the Adam operator is bit-identical to the reference for given features at any number of iterations. */
+int cvx_set_adam_sqrt_table(const void* device_bitmap);
+
 /* same loop with a pluggable smoother instead of the three 3^3 boxes (adam_run_withconfig_shiftSpline.py:214-230);
  * sm == NULL or the chain {3,3,3} selects the fused kernels of cvx_adam_run_f32. */
 int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m,

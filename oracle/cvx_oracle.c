@@ -669,6 +669,26 @@ ORC_API void orc_smooth(const float* in, float* out, int C, int H, int W, int D,
  *   loss = mean_x( mean_c((Wc-Fc)^2) * 12 )                                       (:176-177)
  *   backward (autograd accumulation order restated below), Adam step             (:178-179)
  * ---------------------------------------------------------------------------------------------- */
+/* Optional restatement of the reference build's sqrt (torch CPU -> MKL vsSqrt): the correctly rounded root minus one ulp for the
+ * inputs marked in the bit maps of tests/golden/mkl_vssqrt_low.npz (normal: key = exponent parity << 23 | mantissa; denormal: key =
+ * mantissa).  NULL (default) = IEEE sqrt, which is what the HIP kernels use unless they are given the same table. */
+static const uint8_t* g_sqrt_normal = NULL;
+static const uint8_t* g_sqrt_denormal = NULL;
+ORC_API void orc_set_sqrt_table(const uint8_t* normal, const uint8_t* denormal) { g_sqrt_normal = normal; g_sqrt_denormal = denormal; }
+static float orc_adam_sqrt(float x) {
+    float r = sqrtf(x);
+    if (g_sqrt_normal) {
+        uint32_t b; memcpy(&b, &x, 4);
+        const uint32_t e = b >> 23, mant = b & 0x7fffffu;
+        if (b != 0 && e < 255) {
+            const uint8_t* t = e ? g_sqrt_normal : g_sqrt_denormal;
+            const uint32_t key = e ? (((e & 1u) << 23) | mant) : mant;
+            if (t && ((t[key >> 3] >> (key & 7)) & 1)) { uint32_t rb; memcpy(&rb, &r, 4); rb -= 1; memcpy(&r, &rb, 4); }
+        }
+    }
+    return r;
+}
+
 ORC_API void orc_adam_run_smoother(const float* F2, const float* M2, int C, int h, int w, int d, float* P,
                           float* m, float* v, float lambda_weight, int niter, int step0, float cost_scale,
                           float* U, float* G, float* loss_out, const orc_smoother* sm);
@@ -774,7 +794,7 @@ ORC_API void orc_adam_run_smoother(const float* F2, const float* M2, int C, int 
             float vv = v[i] * b2;                                   /* exp_avg_sq.mul_(beta2) */
             vv = fmaf(omb2 * g, g, vv);                             /* .addcmul_(grad, grad, value=1-beta2): the ATen
                                                                        kernel rounds (value*g) and fuses the rest */
-            const float den = sqrtf(vv) / bc2s + 1e-8f;             /* (sqrt / bc2_sqrt).add_(eps) */
+            const float den = orc_adam_sqrt(vv) / bc2s + 1e-8f;      /* (sqrt / bc2_sqrt).add_(eps) */
             P[i] = P[i] + (neg_step * mm) / den;                    /* addcdiv_(exp_avg, denom, value=-step_size) */
             m[i] = mm; v[i] = vv;
         }

@@ -76,12 +76,27 @@ def lib():
         L.orc_label_features.restype = C.c_int
         L.orc_feature_transform.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_mind_tables.argtypes = [_i32p, _i32p, _i32p]
+        L.orc_set_sqrt_table.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
 
 def _f(a):
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+_sqrt_tables = None
+
+
+def set_sqrt_table(normal=None, denormal=None):
+    """MKL-vsSqrt restatement for the Adam update (tests/golden/mkl_vssqrt_low.npz bit maps); None = IEEE sqrt (default)."""
+    global _sqrt_tables
+    if normal is None:
+        _sqrt_tables = None
+        lib().orc_set_sqrt_table(None, None)
+        return
+    _sqrt_tables = (np.ascontiguousarray(normal, np.uint8), np.ascontiguousarray(denormal, np.uint8))    # keep alive
+    lib().orc_set_sqrt_table(_sqrt_tables[0].ctypes.data_as(C.c_void_p), _sqrt_tables[1].ctypes.data_as(C.c_void_p))
 
 
 def num_threads() -> int:

@@ -1020,3 +1020,30 @@ def test_translation_wrapper_and_original_moving_warp_on_metaimage_files(tmp_pat
     assert isinstance(warped, Image) and warped.array.dtype == np.float32 and warped.GetSpacing() == moving_a.GetSpacing()
     inner = (slice(4, -4),) * 3
     assert np.allclose(warped.array[inner], np.roll(moving_a.array, (-2, 0, 2), (0, 1, 2))[inner], atol=1e-4)   # 4 mm = 2 voxels along z
+
+
+def test_adam_operator_bit_identical_to_reference_with_mkl_sqrt_table(U, orc, golden):
+    """cvx_set_adam_sqrt_table: with the tabulated deviation of the reference build's sqrt (MKL vsSqrt) the HIP Adam loop reproduces
+    the REFERENCE's captured control grid, gradient and disp_sample bit for bit at every horizon of the golden file (1, 2, 5, 20
+    iterations) -- the loop's only non-restated site is then restated too -- and still equals the oracle run with the same table."""
+    g, t = golden("adam"), golden("mkl_vssqrt_low")
+    args = (dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]))
+    U.set_adam_sqrt_table(t["normal"], t["denormal"], device=DEV)
+    orc.set_sqrt_table(t["normal"], t["denormal"])
+    try:
+        for niter in (1, 2, 5, 20):
+            Ud, st = U.adam_run(*args, niter, return_state=True)
+            assert np.array_equal(host(Ud)[0], g["U_%d" % niter]) and np.array_equal(host(st["G"])[0], g["G_%d" % niter]), niter
+            assert np.array_equal(host(st["P"])[0], g["P_%d" % niter]), niter
+        r = orc.adam_run(g["F2"], g["M2"], g["P0"], float(g["lam"]), 20, want_grad=True)
+        assert np.array_equal(host(st["P"])[0], r["P"]) and np.array_equal(host(st["v"])[0], r["v"])
+        # the generic-smoother path and the tiled box kernels take the same update
+        from convexadam_amd import _lib
+        _lib.lib().cvx_set_option(b"box_tiled", 1)
+        Ut, stt = U.adam_run(*args, 5, return_state=True)
+        _lib.lib().cvx_set_option(b"box_tiled", 0)
+        assert np.array_equal(host(stt["P"])[0], g["P_5"])
+    finally:
+        U.set_adam_sqrt_table(None)
+        orc.set_sqrt_table(None)
+    assert not np.array_equal(host(U.adam_run(*args, 20, return_state=True)[1]["P"])[0], g["P_20"])   # default: IEEE sqrt

@@ -313,3 +313,20 @@ def test_correlate_variants_vs_reference_scripts(orc, golden):
         step = 7 if tag.endswith("_w") else 1
         assert np.array_equal(ssd[::step], g[tag + "_ssd"]) and np.array_equal(am, g[tag + "_argmin"]), tag
         assert float(ssd.astype(np.float64).sum()) == float(g[tag + "_ssd_sum"])
+
+
+def test_adam_loop_bit_identical_with_the_mkl_sqrt_table(orc, golden):
+    """The only non-restated site of the Adam loop is the square root of the reference BUILD (MKL vsSqrt).  Its deviation from the IEEE
+    root is tabulated (tests/golden/mkl_vssqrt_low.npz: exhaustive over all float32 inputs); with that table the oracle reproduces
+    the reference's control grid, its gradient and disp_sample BIT FOR BIT after 1, 2, 5 and 20 iterations."""
+    g, t = golden("adam"), golden("mkl_vssqrt_low")
+    assert [int(v) for v in t["counts"]] == [59788, 39167, 52462]
+    orc.set_sqrt_table(t["normal"], t["denormal"])
+    try:
+        for niter in (1, 2, 5, 20):
+            r = orc.adam_run(g["F2"], g["M2"], g["P0"], float(g["lam"]), niter, want_grad=True)
+            assert np.array_equal(r["U"], g["U_%d" % niter]) and np.array_equal(r["G"], g["G_%d" % niter]) and np.array_equal(r["P"], g["P_%d" % niter]), niter
+    finally:
+        orc.set_sqrt_table(None)
+    r = orc.adam_run(g["F2"], g["M2"], g["P0"], float(g["lam"]), 20)
+    assert not np.array_equal(r["P"], g["P_20"])                     # the IEEE root differs, which is the default everywhere
