@@ -49,6 +49,8 @@ SIGNATURES = {
     "cvx_last_error": (C.c_char_p, []),
     "cvx_device_count": (_i, []),
     "cvx_set_adam_sqrt_table": (_i, [_vp]),
+    "cvx_set_mind_exp_table": (_i, [_vp, C.c_uint, C.c_uint]),
+    "cvx_expf_f32": (_i, [_vp, _vp, _sz, _vp]),
     "cvx_set_option": (_i, [C.c_char_p, C.c_longlong]),
     "cvx_get_option": (C.c_longlong, [C.c_char_p]),
     "cvx_affine_base_host": (None, [_i, _vp]),

@@ -224,18 +224,29 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
 _adam_sqrt_table = None
 
 
-def set_adam_sqrt_table(normal=None, denormal=None, device="cuda"):
-    """Adam update with the reference build's square root (torch CPU -> MKL vsSqrt: one ulp low on 0.6 % of the inputs) instead of the
-    IEEE one.  `normal`, `denormal`: the packed bit maps of tests/golden/mkl_vssqrt_low.npz; None restores the default.  With the
-    table `adam_run` is bit-identical to the reference's loop for given features (cvx_set_adam_sqrt_table)."""
+def sqrt_codes_from_low_bitmaps(normal, denormal):
+    """Packed bit maps of the classes whose root is one ulp LOW (the layout of tests/golden/mkl_vssqrt_low.npz) -> 2-bit code table."""
+    low = np.concatenate([np.unpackbits(np.ascontiguousarray(normal, np.uint8), bitorder="little"),
+                          np.unpackbits(np.ascontiguousarray(denormal, np.uint8), bitorder="little")]).astype(np.uint8) * 2
+    c = low.reshape(-1, 4)
+    return (c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)).astype(np.uint8)
+
+
+def set_adam_sqrt_table(codes=None, denormal=None, device="cuda"):
+    """Adam update with the reference build's square root (torch CPU -> MKL vsSqrt: the IEEE root or a neighbour, a function of exponent
+    parity and mantissa) instead of the IEEE one.  `codes`: the 6 MiB 2-bit table of cvx_set_adam_sqrt_table (reference_bits.
+    build_sqrt_table), or -- with `denormal` -- the two packed bit maps of tests/golden/mkl_vssqrt_low.npz; None restores the default.
+    With the table `adam_run` is bit-identical to the reference's loop for given features."""
     global _adam_sqrt_table
-    if normal is None:
+    if codes is None:
         check(lib().cvx_set_adam_sqrt_table(None))
         _adam_sqrt_table = None
         return
-    tbl = np.concatenate([np.ascontiguousarray(normal, np.uint8), np.ascontiguousarray(denormal, np.uint8)])
-    assert tbl.size == (1 << 21) + (1 << 20), "bit maps of 2^24 + 2^23 bits expected"
-    _adam_sqrt_table = torch.from_numpy(tbl).to(device)                     # kept alive here
+    if denormal is not None:
+        codes = sqrt_codes_from_low_bitmaps(codes, denormal)
+    tbl = codes if isinstance(codes, torch.Tensor) else torch.from_numpy(np.array(codes, dtype=np.uint8, order="C"))
+    assert tbl.dtype == torch.uint8 and tbl.numel() == 3 << 21, "2-bit codes of 2^24 + 2^23 classes expected"
+    _adam_sqrt_table = tbl.to(device).contiguous()                          # kept alive here
     check(lib().cvx_set_adam_sqrt_table(ptr(_adam_sqrt_table)))
 
 

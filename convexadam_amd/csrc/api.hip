@@ -40,6 +40,12 @@ Options& options() {
 }
 static const unsigned* g_adam_sqrt_tbl = nullptr;
 const unsigned* adam_sqrt_table() { return g_adam_sqrt_tbl; }
+static ExpTable g_mind_exp_tbl = {nullptr, 0u, 0u};
+ExpTable mind_exp_table() { return g_mind_exp_tbl; }
+
+__global__ __launch_bounds__(256) void k_expf(const float* __restrict__ x, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = cvx_expf(x[i]);
+}
 struct OptName { const char* name; long long Options::*field; };
 static const OptName kOptNames[] = {{"mind_tiled", &Options::mind_tiled},     {"mm_tx", &Options::mm_tx},
                                     {"mm_slots", &Options::mm_slots},         {"box_tiled", &Options::box_tiled},
@@ -60,9 +66,21 @@ extern "C" long long cvx_get_option(const char* name) {
     return -1;
 }
 
-extern "C" int cvx_set_adam_sqrt_table(const void* device_bitmap) {
-    cvx::g_adam_sqrt_tbl = static_cast<const unsigned*>(device_bitmap);
+extern "C" int cvx_set_adam_sqrt_table(const void* device_table) {
+    cvx::g_adam_sqrt_tbl = static_cast<const unsigned*>(device_table);
     return CVX_OK;
+}
+
+extern "C" int cvx_set_mind_exp_table(const void* device_table, unsigned first_key, unsigned count) {
+    cvx::g_mind_exp_tbl = {static_cast<const unsigned char*>(device_table), first_key, device_table ? count : 0u};
+    return CVX_OK;
+}
+extern "C" int cvx_expf_f32(const float* x, float* out, size_t n, void* stream) {
+    if (n == 0) return CVX_OK;
+    if (!x || !out) return cvx::fail(CVX_ERR_INVALID_ARG, "cvx_expf_f32: null pointer");
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(cvx::k_expf, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, cvx::as_stream(stream), x, out, n);
+    return cvx::check_last("expf");
 }
 
 extern "C" int cvx_version(void) { return 1000 * 0 + 1; }

@@ -71,7 +71,7 @@ struct Options {
     long long box_wg_target;       // workgroups the z-marching three-box kernels of the Adam loop aim for (z-chunk length follows)
 };
 Options& options();
-const unsigned* adam_sqrt_table();       // device bit map installed by cvx_set_adam_sqrt_table (nullptr: IEEE sqrt)
+const unsigned* adam_sqrt_table();       // device table installed by cvx_set_adam_sqrt_table (nullptr: IEEE sqrt)
 
 // ---- workgroup barrier ---------------------------------------------------------------------------------------------------------
 // Every barrier of the library goes through cvx_barrier().  The race-stress build (python -m convexadam_amd.csrc.build --jitter ->
@@ -123,6 +123,24 @@ __device__ __forceinline__ float cvx_expf(float d) {
     if (d < -104.0f) u = 0.0f;
     if (d > 100.0f) u = __int_as_float(0x7f800000);
     return u;
+}
+
+// Optional correction of cvx_expf to the exp of one particular reference BUILD (torch CPU -> MKL vsExp differs from cvx_expf by at
+// most one ulp, position independent): two bits per argument x <= 0, keyed by the bit pattern of |x| minus `first`
+// (0 = equal, 1 = one ulp above, 2 = one ulp below); installed by cvx_set_mind_exp_table, tbl == nullptr (default) = cvx_expf.
+struct ExpTable { const unsigned char* tbl; unsigned first, count; };
+ExpTable mind_exp_table();
+// exp(-q) for q >= 0 as MINDSSC evaluates it (convex_adam_utils.py:63)
+__device__ __forceinline__ float mind_exp(float q, const ExpTable& et) {
+    float r = cvx_expf(-q);
+    if (et.tbl) {                                    // kernel argument: wave-uniform
+        const unsigned b = __float_as_uint(q) & 0x7fffffffu, k = b - et.first;
+        if (b >= et.first && k < et.count) {
+            const unsigned code = (et.tbl[k >> 2] >> ((k & 3u) * 2u)) & 3u;
+            if (code) r = __uint_as_float(__float_as_uint(r) + (code == 1u ? 1u : 0xffffffffu));
+        }
+    }
+    return r;
 }
 
 // 16-byte LDS/global vector access that the compiler must keep as ONE b128 instruction: hipcc otherwise
@@ -270,9 +288,10 @@ int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H
 int launch_resize2(const float* in, int C, int h, int w, int d, int H, int W, int D, float* scratch, float* out, int h2, int w2,
                    int d2, float post_div, hipStream_t s);
 // Adam step constants of one iteration (torch.optim.Adam, lr = 1, eps = 1e-8) and the in-place update of one element
-// sqrt_tbl: optional restatement of the reference build's sqrt (torch CPU -> MKL vsSqrt = the correctly rounded root minus one ulp
-// for the inputs marked in a bit map: bits 0 .. 2^24-1 normal inputs, key = exponent parity << 23 | mantissa; bits 2^24 .. denormal
-// inputs, key = mantissa; cvx_set_adam_sqrt_table).  nullptr (default): IEEE sqrt.
+// sqrt_tbl: optional restatement of the reference build's sqrt (torch CPU -> MKL vsSqrt = the correctly rounded root, or one ulp
+// beside it, as a function of (exponent parity, mantissa)): two bits per class, 0 = IEEE root, 1 = one ulp above, 2 = one ulp below;
+// entries 0 .. 2^24-1 normal inputs, key = exponent parity << 23 | mantissa; entries 2^24 .. 2^24+2^23-1 denormal inputs, key =
+// mantissa; 16 entries per 32-bit word, low bits first (cvx_set_adam_sqrt_table).  nullptr (default): IEEE sqrt.
 struct AdamConsts { float w1, b2, omb2, bc2s, neg_step; const unsigned* sqrt_tbl; };
 __device__ __forceinline__ float adam_sqrt(float x, const unsigned* __restrict__ tbl) {
     float r = fsqrt(x);
@@ -280,7 +299,8 @@ __device__ __forceinline__ float adam_sqrt(float x, const unsigned* __restrict__
         const unsigned b = __float_as_uint(x), e = b >> 23, mant = b & 0x7fffffu;
         if (b != 0 && e < 255) {
             const unsigned key = e ? (((e & 1u) << 23) | mant) : ((1u << 24) | mant);
-            if ((tbl[key >> 5] >> (key & 31)) & 1u) r = __uint_as_float(__float_as_uint(r) - 1u);
+            const unsigned code = (tbl[key >> 4] >> ((key & 15u) * 2u)) & 3u;
+            if (code) r = __uint_as_float(__float_as_uint(r) + (code == 1u ? 1u : 0xffffffffu));
         }
     }
     return r;

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int 
 
 // the 12 raw patch SSDs of one voxel (pre-permutation channel order) -> descriptor values, in place:
 //   exp(-(D_c - min_c D) / clamp(mean_c(D - min), lo, hi)); `tail` selects ATen's interleaved order of the channel sum
-__device__ __forceinline__ void mind_normalise(float (&r)[12], float lo, float hi, bool tail) {
+__device__ __forceinline__ void mind_normalise(float (&r)[12], float lo, float hi, bool tail, const ExpTable& et) {
     float mn = r[0];
 #pragma unroll
     for (int c = 1; c < 12; ++c) mn = fminf(mn, r[c]);
@@ -257,13 +257,13 @@ __device__ __forceinline__ void mind_normalise(float (&r)[12], float lo, float h
     var = var < lo ? lo : var;
     var = var > hi ? hi : var;
 #pragma unroll
-    for (int c = 0; c < 12; ++c) r[c] = cvx_expf(-fdiv(r[c], var));
+    for (int c = 0; c < 12; ++c) r[c] = mind_exp(fdiv(r[c], var), et);
 }
 
 // out_c(x) in place; NV voxels per thread (4 = 16-byte access).
 // The channel mean runs over the reference's PRE-permutation channel order (the permutation is applied last, :66).
 template <int NV>
-__global__ __launch_bounds__(256) void k_mind_finish(float* __restrict__ out, size_t V, const MindStats* __restrict__ st) {
+__global__ __launch_bounds__(256) void k_mind_finish(float* __restrict__ out, size_t V, const MindStats* __restrict__ st, ExpTable et) {
     float lo, hi;
     mind_bounds(st, (double)V, lo, hi);
     const size_t x = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * NV;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_mind_finish(float* __restrict__ out, si
         } else r[0][c] = src[0];
     }
 #pragma unroll
-    for (int j = 0; j < NV; ++j) mind_normalise(r[j], lo, hi, x + j >= tail_from);
+    for (int j = 0; j < NV; ++j) mind_normalise(r[j], lo, hi, x + j >= tail_from, et);
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
         float* dst = out + (size_t)MIND_INV[c] * V + x;
@@ -339,7 +339,7 @@ __device__ __forceinline__ void mp_window(const float* __restrict__ E, int c, in
 template <int GA, int GB>
 __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restrict__ raw, int H, int W, int D,
                                                             const MindStats* __restrict__ st, float* __restrict__ out1,
-                                                            float* __restrict__ out2) {
+                                                            float* __restrict__ out2, ExpTable et) {
     constexpr int T = GA;
     __shared__ __attribute__((aligned(16))) float E[12 * T * T * MP_TX];          // [c][z][y][x], final channel order
     const int tid = threadIdx.x;
@@ -360,8 +360,8 @@ __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restr
             const float2 q = *reinterpret_cast<const float2*>(raw + (size_t)MIND_INV[c] * V + lin);
             r[0][c] = q.x; r[1][c] = q.y;
         }
-        mind_normalise(r[0], lo, hi, lin >= tail_from);
-        mind_normalise(r[1], lo, hi, lin + 1 >= tail_from);
+        mind_normalise(r[0], lo, hi, lin >= tail_from, et);
+        mind_normalise(r[1], lo, hi, lin + 1 >= tail_from, et);
 #pragma unroll
         for (int c = 0; c < 12; ++c) {
             const f32x2 v = {r[0][c], r[1][c]};
@@ -462,7 +462,7 @@ int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int di
     const int ga = swap ? g2 : g1, gb = g2 > 0 ? (swap ? g1 : g2) : g1;
     float* oa = swap ? out2 : out1;
     float* ob = g2 > 0 ? (swap ? out1 : out2) : nullptr;
-#define CVX_MP(GA, GB) hipLaunchKernelGGL((k_mind_finish_pool<GA, GB>), grid, dim3(MP_NT), 0, s, raw, H, W, D, st, oa, ob)
+#define CVX_MP(GA, GB) hipLaunchKernelGGL((k_mind_finish_pool<GA, GB>), grid, dim3(MP_NT), 0, s, raw, H, W, D, st, oa, ob, mind_exp_table())
     if (ga == 6 && gb == 2) CVX_MP(6, 2);
     else if (ga == 6 && gb == 3) CVX_MP(6, 3);
     else if (ga == 6 && gb == 6) CVX_MP(6, 6);
@@ -491,8 +491,8 @@ extern "C" int cvx_mindssc_f32(const float* img, int H, int W, int D, int radius
     if ((rc = mind_stencil(img, H, W, D, radius, dilation, out, workspace, workspace_bytes, &st, s))) return rc;
     const size_t V = (size_t)H * W * D;
     if (V % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
-        hipLaunchKernelGGL(k_mind_finish<4>, dim3((unsigned)cdiv64((int64_t)(V / 4), 256)), dim3(256), 0, s, out, V, st);
+        hipLaunchKernelGGL(k_mind_finish<4>, dim3((unsigned)cdiv64((int64_t)(V / 4), 256)), dim3(256), 0, s, out, V, st, mind_exp_table());
     else
-        hipLaunchKernelGGL(k_mind_finish<1>, dim3((unsigned)cdiv64((int64_t)V, 256)), dim3(256), 0, s, out, V, st);
+        hipLaunchKernelGGL(k_mind_finish<1>, dim3((unsigned)cdiv64((int64_t)V, 256)), dim3(256), 0, s, out, V, st, mind_exp_table());
     return check_last("mind_finish");
 }

@@ -179,12 +179,24 @@ int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, int w, int 
                      size_t workspace_bytes, void* stream);
 
 /* Optional: make the Adam update use the reference BUILD's square root instead of the IEEE one.  torch's CPU Adam calls Intel MKL's
- * vsSqrt (convex_adam_MIND.py:179), which returns the correctly rounded root minus one ulp for 0.6 % of all inputs; which ones is a
- * pure function of (exponent parity, mantissa) and is tabulated in tests/golden/mkl_vssqrt_low.npz (make_mkl_sqrt_table.py).
- * device_bitmap: 3 MiB on the device, kept alive by the caller -- bits 0 .. 2^24-1 normal inputs (key = parity << 23 | mantissa),
- * bits 2^24 .. 2^24+2^23-1 denormal inputs (key = mantissa), little-endian bit order; NULL restores the IEEE sqrt (default).
+ * vsSqrt (convex_adam_MIND.py:179), which returns the correctly rounded root or a neighbour of it (Xeon / AVX-512 path: one ulp below
+ * for 0.6 % of all inputs; EPYC hosts: one ulp above or below for 17 %); which one is a pure function of (exponent parity, mantissa)
+ * and is tabulated from torch.sqrt itself (convexadam_amd/reference_bits.py; fixture of the golden host: tests/golden/mkl_vssqrt_low.npz).
+ * device_table: 6 MiB on the device, kept alive by the caller -- two bits per class (0 = IEEE root, 1 = one ulp above, 2 = one ulp
+ * below), four per byte, low bits first; entries 0 .. 2^24-1 normal inputs (key = parity << 23 | mantissa), entries 2^24 ..
+ * 2^24+2^23-1 denormal inputs (key = mantissa); NULL restores the IEEE sqrt (default).
  * With the table the Adam operator is bit-identical to the reference for given features at any number of iterations. */
-int cvx_set_adam_sqrt_table(const void* device_bitmap);
+int cvx_set_adam_sqrt_table(const void* device_table);
+
+/* Optional, same idea for the `exp` of MINDSSC (convex_adam_utils.py:63: torch CPU -> MKL vsExp, at most one ulp from the library's
+ * expf, position independent, a property of the HOST: MKL dispatches on the CPU model).  device_table: two bits per argument x <= 0,
+ * entry k = key - first_key with key = bit pattern of |x| (0 = equal to the library's expf, 1 = one ulp above, 2 = one ulp below),
+ * four entries per byte, low bits first; arguments outside [first_key, first_key + count) are left alone.  Kept alive by the caller;
+ * NULL restores the default.  With BOTH tables of a host the whole pipeline reproduces the reference run on that host bit for bit
+ * (tests/golden/fullsize.npz, 80 Adam iterations).  convexadam_amd/reference_bits.py builds the tables from torch itself. */
+int cvx_set_mind_exp_table(const void* device_table, unsigned first_key, unsigned count);
+/* the library's expf (no table), elementwise: out[i] = exp(x[i]); what a table for cvx_set_mind_exp_table is the difference to */
+int cvx_expf_f32(const float* x, float* out, size_t n, void* stream);
 
 /* same loop with a pluggable smoother instead of the three 3^3 boxes (adam_run_withconfig_shiftSpline.py:214-230);
  * sm == NULL or the chain {3,3,3} selects the fused kernels of cvx_adam_run_f32. */

@@ -30,6 +30,10 @@
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static float outer_sum_rows(const float* vals, int64_t size, int ilp);
+ORC_API float orc_torch_sum(const float* x, int64_t n, int threads, int vec);
+/* 0 (default): the global mean of MINDSSC is the exactly rounded one; T > 0: torch's own sum with T threads (reference-bits mode) */
+static int g_mean_threads = 0, g_mean_vec = 8;
+ORC_API void orc_set_mean_threads(int threads, int vec) { g_mean_threads = threads; g_mean_vec = vec > 0 ? vec : 8; }
 
 ORC_API int orc_num_threads(void) {
 #ifdef _OPENMP
@@ -78,7 +82,29 @@ ORC_API float orc_expf(float d) {
     return u;
 }
 ORC_API void orc_expf_array(const float* in, float* out, int64_t n) {
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) out[i] = orc_expf(in[i]);
+}
+/* Optional restatement of the reference build's exp at MINDSSC (torch CPU -> MKL vsExp): orc_expf corrected by the tabulated
+ * difference to the host's torch.exp.  Two bits per argument x <= 0, keyed by the bit pattern of |x| minus `first` (0 = equal,
+ * 1 = one ulp above orc_expf, 2 = one ulp below); arguments outside [first, first + count) keep orc_expf.  The table is built at run
+ * time from torch.exp itself (tests/mkl_tables.py) -- it is the exhaustive list of the 1-ulp differences, not an algorithm.
+ * NULL (default) = orc_expf, which is what the HIP kernels use unless they are given the same table. */
+static const uint8_t* g_exp_tbl = NULL;
+static uint32_t g_exp_first = 0, g_exp_count = 0;
+ORC_API void orc_set_exp_table(const uint8_t* tbl, uint32_t first, uint32_t count) { g_exp_tbl = tbl; g_exp_first = first; g_exp_count = count; }
+static inline float orc_mind_exp(float negx) {       /* negx = -x >= 0 (or -0.0) */
+    float r = orc_expf(-negx);
+    if (g_exp_tbl) {
+        uint32_t b; memcpy(&b, &negx, 4);
+        b &= 0x7fffffffu;
+        const uint32_t k = b - g_exp_first;
+        if (b >= g_exp_first && k < g_exp_count) {
+            const uint32_t code = (g_exp_tbl[k >> 2] >> ((k & 3) * 2)) & 3u;
+            if (code) { uint32_t rb; memcpy(&rb, &r, 4); rb += (code == 1) ? 1u : 0xffffffffu; memcpy(&r, &rb, 4); }
+        }
+    }
+    return r;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -299,7 +325,8 @@ ORC_API void orc_mindssc(const float* img, int H, int W, int D, int radius, int 
     const orc_split_t sp = orc_split_make(range * range, (double)V);
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (size_t x = 0; x < V; ++x) orc_split_add(&sp, (double)var[x], &a1, &a2, &a3);
-    const float gmean = (float)((a1 + (a2 + a3)) / (double)V);
+    float gmean = (float)((a1 + (a2 + a3)) / (double)V);
+    if (g_mean_threads > 0) gmean = orc_torch_sum(var, (int64_t)V, g_mean_threads, g_mean_vec) / (float)V;   /* sum_out(..).div_(numel) */
     if (mean_out) *mean_out = gmean;
     const float lo = (float)((double)gmean * 0.001), hi = (float)((double)gmean * 1000.0);
     /* :61-66 clamp, divide, exp(-x), permute */
@@ -310,7 +337,7 @@ ORC_API void orc_mindssc(const float* img, int H, int W, int D, int radius, int 
         v = v > hi ? hi : v;
         for (int j = 0; j < 12; ++j) {
             const float m = ssd[(size_t)MIND_PERM[j] * V + x] / v;
-            out[(size_t)j * V + x] = orc_expf(-m);
+            out[(size_t)j * V + x] = orc_mind_exp(m);
         }
     }
     free(ssd); free(var);
@@ -354,6 +381,55 @@ static float outer_sum_rows(const float* vals, int64_t size, int ilp) {
     return p[0];
 }
 ORC_API float orc_outer_sum_rows(const float* vals, int64_t size, int ilp) { return outer_sum_rows(vals, size, ilp); }
+
+/* ------------------------------------------------------------------------------------------------
+ * torch.sum of a whole contiguous float tensor as ATen's CPU kernel evaluates it with `threads` threads and `vec`-float vectors
+ * (8 in the torch 2.10 build, also where the CPU capability is AVX-512: pinned empirically).  TensorIteratorReduce two_pass_reduction: at::parallel_for splits the n elements into
+ * nt = min(threads, ceil(n / 32768)) chunks of ceil(n / nt); chunk t is reduced into slot t of a `threads`-long buffer, the buffer
+ * is then reduced by the same kernel.  One chunk (SumKernel.cpp vectorized_inner_sum / row_sum): the vectors of the chunk are summed
+ * lane-wise with 4 interleaved cascade accumulators (vector i goes to partial i mod 4; leftover vectors to partial 0; then
+ * ((p0 + p1) + p2) + p3), the scalar tail (n mod vec) is summed first into the final accumulator, then the lanes are added in
+ * order; fewer than `vec` elements: the same scheme on scalars.  This is the one site whose value depends on the reference's THREAD
+ * COUNT -- `mind_var.mean()` (convex_adam_utils.py:61) -- and only matters where the variance is clamped to its bounds.
+ * Pinned against torch.sum itself for 1..16 threads, tests/test_host_logic.py::test_torch_full_sum_restatement.
+ * ---------------------------------------------------------------------------------------------- */
+static float torch_row_sum_scalar(const float* x, int64_t n) {      /* row_sum<float> : 4-way ilp on scalars */
+    const int64_t n4 = n / 4;
+    float p[4];
+    for (int k = 0; k < 4; ++k) p[k] = cascade_sum_strided(x + k, 4, n4);
+    for (int64_t i = n4 * 4; i < n; ++i) p[0] += x[i];
+    for (int k = 1; k < 4; ++k) p[0] += p[k];
+    return p[0];
+}
+static float torch_inner_sum(const float* x, int64_t n, int vec) {
+    if (n < vec) return torch_row_sum_scalar(x, n);
+    const int64_t nv = n / vec, nv4 = nv / 4;
+    float fin = 0.0f;
+    for (int64_t k = nv * vec; k < n; ++k) fin += x[k];
+    for (int lane = 0; lane < vec; ++lane) {
+        float p[4];
+        for (int k = 0; k < 4; ++k) p[k] = cascade_sum_strided(x + (int64_t)k * vec + lane, (int64_t)4 * vec, nv4);
+        for (int64_t i = nv4 * 4; i < nv; ++i) p[0] += x[i * vec + lane];
+        for (int k = 1; k < 4; ++k) p[0] += p[k];
+        fin += p[0];
+    }
+    return fin;
+}
+ORC_API float orc_torch_sum(const float* x, int64_t n, int threads, int vec) {
+    if (threads < 1) threads = 1;
+    if (n < 32768 || threads == 1) return 0.0f + torch_inner_sum(x, n, vec);
+    float buf[1024];
+    if (threads > 1024) threads = 1024;
+    for (int t = 0; t < threads; ++t) buf[t] = 0.0f;
+    int64_t nt = (n + 32767) / 32768; if (nt > threads) nt = threads;
+    const int64_t chunk = (n + nt - 1) / nt;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < nt; ++t) {
+        const int64_t b = t * chunk, e = b + chunk < n ? b + chunk : n;
+        if (b < e) buf[t] += torch_inner_sum(x + b, e - b, vec);
+    }
+    return 0.0f + torch_inner_sum(buf, threads, vec);
+}
 
 /* ------------------------------------------------------------------------------------------------
  * correlate(), convex_adam_utils.py:72-89.
@@ -669,21 +745,22 @@ ORC_API void orc_smooth(const float* in, float* out, int C, int H, int W, int D,
  *   loss = mean_x( mean_c((Wc-Fc)^2) * 12 )                                       (:176-177)
  *   backward (autograd accumulation order restated below), Adam step             (:178-179)
  * ---------------------------------------------------------------------------------------------- */
-/* Optional restatement of the reference build's sqrt (torch CPU -> MKL vsSqrt): the correctly rounded root minus one ulp for the
- * inputs marked in the bit maps of tests/golden/mkl_vssqrt_low.npz (normal: key = exponent parity << 23 | mantissa; denormal: key =
- * mantissa).  NULL (default) = IEEE sqrt, which is what the HIP kernels use unless they are given the same table. */
-static const uint8_t* g_sqrt_normal = NULL;
-static const uint8_t* g_sqrt_denormal = NULL;
-ORC_API void orc_set_sqrt_table(const uint8_t* normal, const uint8_t* denormal) { g_sqrt_normal = normal; g_sqrt_denormal = denormal; }
+/* Optional restatement of the reference build's sqrt (torch CPU -> MKL vsSqrt): the correctly rounded root or a neighbour of it as
+ * tabulated from torch.sqrt itself -- two bits per (exponent parity, mantissa) class, 0 = IEEE root, 1 = one ulp above, 2 = one ulp
+ * below; entries 0 .. 2^24-1 normal inputs (key = parity << 23 | mantissa), then 2^23 denormal inputs (key = mantissa); four per
+ * byte (tests/mkl_tables.py; tests/golden/mkl_vssqrt_low.npz holds the golden host's table as bit maps of the low classes).
+ * NULL (default) = IEEE sqrt, which is what the HIP kernels use unless they are given the same table. */
+static const uint8_t* g_sqrt_codes = NULL;
+ORC_API void orc_set_sqrt_table(const uint8_t* codes) { g_sqrt_codes = codes; }
 static float orc_adam_sqrt(float x) {
     float r = sqrtf(x);
-    if (g_sqrt_normal) {
+    if (g_sqrt_codes) {
         uint32_t b; memcpy(&b, &x, 4);
         const uint32_t e = b >> 23, mant = b & 0x7fffffu;
         if (b != 0 && e < 255) {
-            const uint8_t* t = e ? g_sqrt_normal : g_sqrt_denormal;
-            const uint32_t key = e ? (((e & 1u) << 23) | mant) : mant;
-            if (t && ((t[key >> 3] >> (key & 7)) & 1)) { uint32_t rb; memcpy(&rb, &r, 4); rb -= 1; memcpy(&r, &rb, 4); }
+            const uint32_t key = e ? (((e & 1u) << 23) | mant) : ((1u << 24) | mant);
+            const uint32_t code = (g_sqrt_codes[key >> 2] >> ((key & 3u) * 2u)) & 3u;
+            if (code) { uint32_t rb; memcpy(&rb, &r, 4); rb += (code == 1u) ? 1u : 0xffffffffu; memcpy(&r, &rb, 4); }
         }
     }
     return r;

@@ -76,7 +76,11 @@ def lib():
         L.orc_label_features.restype = C.c_int
         L.orc_feature_transform.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_mind_tables.argtypes = [_i32p, _i32p, _i32p]
-        L.orc_set_sqrt_table.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_set_sqrt_table.argtypes = [C.c_void_p]
+        L.orc_set_exp_table.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.orc_set_mean_threads.argtypes = [C.c_int, C.c_int]
+        L.orc_torch_sum.argtypes = [_f32p, C.c_int64, C.c_int, C.c_int]
+        L.orc_torch_sum.restype = C.c_float
         _lib = L
     return _lib
 
@@ -88,15 +92,51 @@ def _f(a):
 _sqrt_tables = None
 
 
-def set_sqrt_table(normal=None, denormal=None):
-    """MKL-vsSqrt restatement for the Adam update (tests/golden/mkl_vssqrt_low.npz bit maps); None = IEEE sqrt (default)."""
+def sqrt_codes_from_low_bitmaps(normal, denormal):
+    """Packed bit maps of the classes whose root is one ulp LOW (tests/golden/mkl_vssqrt_low.npz) -> the 2-bit code table."""
+    low = np.concatenate([np.unpackbits(np.ascontiguousarray(normal, np.uint8), bitorder="little"),
+                          np.unpackbits(np.ascontiguousarray(denormal, np.uint8), bitorder="little")]).astype(np.uint8) * 2
+    c = low.reshape(-1, 4)
+    return (c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)).astype(np.uint8)
+
+
+def set_sqrt_table(codes=None, denormal=None):
+    """Reference-build sqrt for the Adam update: `codes` = 2-bit table (orc_set_sqrt_table), or (normal, denormal) low bit maps of
+    tests/golden/mkl_vssqrt_low.npz; None = IEEE sqrt (default)."""
     global _sqrt_tables
-    if normal is None:
+    if codes is None:
         _sqrt_tables = None
-        lib().orc_set_sqrt_table(None, None)
+        lib().orc_set_sqrt_table(None)
         return
-    _sqrt_tables = (np.ascontiguousarray(normal, np.uint8), np.ascontiguousarray(denormal, np.uint8))    # keep alive
-    lib().orc_set_sqrt_table(_sqrt_tables[0].ctypes.data_as(C.c_void_p), _sqrt_tables[1].ctypes.data_as(C.c_void_p))
+    if denormal is not None:
+        codes = sqrt_codes_from_low_bitmaps(codes, denormal)
+    _sqrt_tables = np.ascontiguousarray(codes, np.uint8)                                   # keep alive
+    assert _sqrt_tables.size == 3 << 21
+    lib().orc_set_sqrt_table(_sqrt_tables.ctypes.data_as(C.c_void_p))
+
+
+_exp_table = None
+
+
+def set_exp_table(table=None, first=0, count=0):
+    """MKL-vsExp correction for MINDSSC: 2 bits per argument (see orc_set_exp_table); None = orc_expf (default)."""
+    global _exp_table
+    if table is None:
+        _exp_table = None
+        lib().orc_set_exp_table(None, 0, 0)
+        return
+    _exp_table = np.ascontiguousarray(table, np.uint8)
+    lib().orc_set_exp_table(_exp_table.ctypes.data_as(C.c_void_p), int(first), int(count))
+
+
+def set_mean_threads(threads=0, vec=8):
+    """MINDSSC's global mean as torch evaluates it with `threads` threads (0 = the exactly rounded mean, default)."""
+    lib().orc_set_mean_threads(int(threads), int(vec))
+
+
+def torch_sum(x, threads, vec=8):
+    x = _f(x).reshape(-1)
+    return float(lib().orc_torch_sum(x, x.size, int(threads), int(vec)))
 
 
 def num_threads() -> int:

@@ -35,3 +35,25 @@ def orc():
 
     oracle.build()
     return oracle
+
+
+@pytest.fixture(scope="session")
+def mkl():
+    """tests/mkl_tables.py: the reference build's exp / sqrt deviations as tables (golden host fixtures, or built from this host's torch)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mkl_tables
+
+    return mkl_tables
+
+
+@pytest.fixture()
+def orc_reference_bits(orc, mkl):
+    """The oracle with the golden host's two MKL tables installed: bit-identical to the reference goldens everywhere."""
+    t = mkl.golden_tables()
+    orc.set_exp_table(t["exp"], t["exp_first"], t["exp_count"])
+    orc.set_sqrt_table(t["sqrt"])
+    orc.set_mean_threads(8)                    # every golden was captured with torch.set_num_threads(8)
+    yield orc
+    orc.set_exp_table(None)
+    orc.set_sqrt_table(None)
+    orc.set_mean_threads(0)

@@ -1047,3 +1047,79 @@ def test_adam_operator_bit_identical_to_reference_with_mkl_sqrt_table(U, orc, go
         U.set_adam_sqrt_table(None)
         orc.set_sqrt_table(None)
     assert not np.array_equal(host(U.adam_run(*args, 20, return_state=True)[1]["P"])[0], g["P_20"])   # default: IEEE sqrt
+
+
+# ---- reference-bits mode: the reference build's exp / sqrt as tables (convexadam_amd/reference_bits.py, tests/mkl_tables.py) --------
+@pytest.fixture()
+def reference_bits(orc, mkl):
+    """HIP library AND oracle with the tables of the host that produced the goldens."""
+    from convexadam_amd import reference_bits as rb
+    t = mkl.golden_tables()
+    rb.set_mind_exp_table(t["exp"], t["exp_first"], t["exp_count"], device=DEV)
+    rb.set_adam_sqrt_table(t["sqrt"], device=DEV)
+    orc.set_exp_table(t["exp"], t["exp_first"], t["exp_count"])
+    orc.set_sqrt_table(t["sqrt"])
+    yield rb
+    rb.disable()
+    orc.set_exp_table(None)
+    orc.set_sqrt_table(None)
+
+
+def test_reference_bits_tables_built_by_the_product_equal_the_test_infrastructure(orc, mkl):
+    """reference_bits.build_exp_table tabulates (this host's torch.exp) - (the DEVICE expf) over all 310 M arguments of the domain;
+    tests/mkl_tables.py does the same against the oracle's expf on the CPU.  Equal tables = the device expf equals the oracle's for
+    every argument MINDSSC can produce, and the product's builder is right.  Same for the sqrt bit maps."""
+    from convexadam_amd import reference_bits as rb
+    t = mkl.host_tables(orc)
+    assert (rb.EXP_FIRST, rb.EXP_COUNT) == (t["exp_first"], t["exp_count"])
+    assert np.array_equal(host(rb.build_exp_table(DEV)), t["exp"])
+    assert np.array_equal(rb.build_sqrt_table(), t["sqrt"])
+    x = -torch.rand(100000, device=DEV) * 110.0
+    assert np.array_equal(host(rb.device_expf(x)), orc.expf(host(x)))
+
+
+def test_mindssc_bit_identical_to_reference_with_exp_table(U, orc, golden, reference_bits):
+    """With the golden host's exp table MINDSSC equals the reference golden exactly (default: <= 1 ulp), for every radius / dilation of
+    the golden file, through the marching, the tiled and the pooled kernels; ragged shapes against the oracle with the same table."""
+    from convexadam_amd.phantom import phantom
+    from convexadam_amd import _lib
+    g = golden("mind")
+    for key, r, d in (("mind_r1d2", 1, 2), ("mind_r2d2", 2, 2), ("mind_r1d1", 1, 1)):
+        assert np.array_equal(host(U.MINDSSC(dev(g["img"])[None, None], r, d, device=DEV))[0], g[key]), key
+    _lib.lib().cvx_set_option(b"mind_tiled", 1)
+    assert np.array_equal(host(U.MINDSSC(dev(g["img"])[None, None], 1, 2, device=DEV))[0], g["mind_r1d2"])
+    _lib.lib().cvx_set_option(b"mind_tiled", 0)
+    for shape in ((20, 18, 23), (33, 40, 70), (9, 70, 8)):
+        img = phantom(shape, 3, 30)
+        img[: shape[0] // 2] *= 1e-3                                   # small variances: clamped voxels, large arguments of exp
+        assert np.array_equal(host(U.MINDSSC(img[None, None].to(DEV), 1, 2, device=DEV))[0], orc.mindssc(img.numpy(), 1, 2)), shape
+
+
+def test_pipeline_goldens_bit_identical_to_reference_with_mkl_tables(M, golden, reference_bits):
+    """Whole pipelines of tests/golden/pipeline.npz (convex only, 1 / 5 / 20 Adam iterations, final smoothing, no ic): exact."""
+    g = golden("pipeline")
+    kw = dict(mind_r=1, mind_d=2, grid_sp=4, disp_hw=3, grid_sp_adam=2)
+    for key, extra in (("convex_only_ic", dict(lambda_weight=0, ic=True)), ("adam_1", dict(lambda_weight=1.25, selected_niter=1, ic=True)),
+                       ("adam_5", dict(lambda_weight=1.25, selected_niter=5, ic=True)), ("adam_20", dict(lambda_weight=1.25, selected_niter=20, ic=True)),
+                       ("adam_5_smooth3", dict(lambda_weight=1.25, selected_niter=5, selected_smooth=3, ic=True)),
+                       ("adam_5_noic", dict(lambda_weight=1.25, selected_niter=5, ic=False))):
+        out = host(M.register_pair_device(dev(g["fix"]), dev(g["mov"]), **kw, **extra))
+        assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), g[key]), key
+
+
+def test_full_size_benchmark_pair_bit_identical_to_the_reference_with_mkl_tables(M, golden, reference_bits):
+    """THE headline configuration (BASELINE configs[1], the pair bench.py times: 160x192x224, hw 6, gs 6, ic, 80 Adam iterations): with
+    the two tables of the golden host the HIP pipeline's field equals the field captured from the reference itself -- every 8th voxel
+    per axis bit for bit at 1, 20, 40 and 80 iterations, float64 sums of the whole field and of its squares to 1e-14."""
+    from convexadam_amd.phantom import deformed_pair
+    g = golden("fullsize")
+    s = int(g["sub"])
+    shape = (160, 192, 224)
+    fix, mov = deformed_pair(shape, 0, 4.0)
+    kw = dict(mind_r=1, mind_d=2, grid_sp=6, disp_hw=6, grid_sp_adam=2, ic=True, lambda_weight=1.25)
+    for niter in (int(v) for v in g["c1_snaps"]):
+        f = M.register_pair_device(fix.to(DEV), mov.to(DEV), selected_niter=niter, **kw)
+        assert np.array_equal(host(f[:, ::s, ::s, ::s]), g["c1_adam_%d_sub" % niter]), niter
+        fd = f.cpu().double()
+        assert np.allclose(fd.sum((1, 2, 3)).numpy(), g["c1_adam_%d_sum" % niter], rtol=1e-14, atol=0)
+        assert np.allclose(fd.square().sum((1, 2, 3)).numpy(), g["c1_adam_%d_sumsq" % niter], rtol=1e-14, atol=0)
