@@ -53,6 +53,45 @@ def pmc_traffic():
         return None
 
 
+def reference_bits_check(fix, mov, dev):
+    """Outside every timed region of `value`: the same pair in reference-bits mode -- the reference build's exp / sqrt as tables of the
+    host that produced tests/golden (fixtures: mkl_vsexp_codes.xz, mkl_vssqrt_low.npz) and torch's 8-thread mean -- compared with the
+    field captured from the reference itself (tests/golden/fullsize.npz, every 8th voxel per axis + float64 sums).  Data files only."""
+    import lzma
+    import numpy as np
+    from convexadam_amd import reference_bits as rb
+    from convexadam_amd.convex_adam_MIND import register_pair_device
+    from convexadam_amd.convex_adam_utils import sqrt_codes_from_low_bitmaps
+    gd = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(gd, "mkl_vsexp_codes.xz"), "rb") as f:
+        exp_tbl = np.frombuffer(lzma.decompress(f.read()), np.uint8)
+    q = np.load(os.path.join(gd, "mkl_vssqrt_low.npz"))
+    g = np.load(os.path.join(gd, "fullsize.npz"))
+    rb.set_mind_exp_table(exp_tbl, device=dev)
+    rb.set_adam_sqrt_table(sqrt_codes_from_low_bitmaps(q["normal"], q["denormal"]), device=dev)
+    rb.set_mean_threads(8)
+    try:
+        for _ in range(2):
+            f = register_pair_device(fix, mov, **CFG)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            f = register_pair_device(fix, mov, **CFG)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+    finally:
+        rb.disable()
+    s = int(g["sub"])
+    sub_equal = bool(np.array_equal(f[:, ::s, ::s, ::s].cpu().numpy(), g["c1_adam_80_sub"]))
+    fd = f.cpu().double()
+    sums_equal = bool(np.allclose(fd.sum((1, 2, 3)).numpy(), g["c1_adam_80_sum"], rtol=1e-14, atol=0)
+                      and np.allclose(fd.square().sum((1, 2, 3)).numpy(), g["c1_adam_80_sumsq"], rtol=1e-14, atol=0))
+    return dict(bit_identical_to_reference_capture=sub_equal and sums_equal, ms_per_pair=ms,
+                note="opt-in mode (convexadam_amd/reference_bits.py): MKL vsExp / vsSqrt of the golden host as tables + torch's 8-thread "
+                     "mean; compared with the field captured from the reference at 80 iterations (tests/golden/fullsize.npz: every 8th "
+                     "voxel per axis bit for bit, float64 sum and sum of squares of the whole field to 1e-14)")
+
+
 def cpu_baseline(fix, mov, hip_field):
     """Times the C oracle (oracle/, the parity checker) on the host cores for one full pair and -- outside every timed region --
     compares the field the timed HIP loop produced for the same pair with the oracle's field."""
@@ -68,7 +107,7 @@ def cpu_baseline(fix, mov, hip_field):
     parity = dict(epe_vs_oracle=epe, bit_identical=bool(np.array_equal(got, ref)), max_abs_diff=float(np.abs(got - ref).max()),
                   note="field of the last timed step vs oracle/cvx_oracle.c on the same pair, full size; oracle vs the reference itself: "
                        "tests/golden/fullsize.npz (bit-identical convex stage, mean EPE 1.2e-3 after 80 iterations = below the reference's "
-                       "own 1-ulp sensitivity of 1.6e-3)")
+                       "own 1-ulp sensitivity of 1.6e-3; in reference-bits mode bit-identical, see reference_bits_mode)")
     base = dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port", seconds_per_pair=dt,
                 sample="1 full 160x192x224 pair (MIND r1 d2, gs6, hw6, ic, 80 Adam its) with oracle/cvx_oracle.c, "
                        "OpenMP over %d threads; reference PyTorch-CPU figure from BASELINE.md: 77.4 s/pair on 8 cores" % cores)
@@ -229,6 +268,7 @@ def main():
                                                 "flat cost regions; a pruned pass whose large candidate boxes exceed the cost of a coalesced scan streams the volume instead (bounded worst case)"}
         if n == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"], res["parity"] = cpu_baseline(fix.cpu().numpy(), mov.cpu().numpy(), field_of_timed_loop)
+            res["parity"]["reference_bits_mode"] = reference_bits_check(fix, mov, dev)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

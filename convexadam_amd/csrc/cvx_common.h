@@ -69,6 +69,8 @@ struct Options {
     long long warp_flat;           // 1: flat 64-bit gathers in k_warp_grad instead of buffer loads
     long long box_yt;              // rows per tile of the marching three-box kernels: 8 (default) or 4
     long long box_wg_target;       // workgroups the z-marching three-box kernels of the Adam loop aim for (z-chunk length follows)
+    long long mind_mean_threads;   // 0: exactly rounded global mean in MINDSSC (default); T > 0: torch's own float sum with T threads
+                                   //    (reference-bits mode; NOT a bit-identical variant -- it changes the clamp bounds by ulps)
 };
 Options& options();
 const unsigned* adam_sqrt_table();       // device table installed by cvx_set_adam_sqrt_table (nullptr: IEEE sqrt)

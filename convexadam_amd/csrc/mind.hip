@@ -77,11 +77,13 @@ __global__ __launch_bounds__(256) void k_mind_stats_init(const float* part, int 
     st->a1 = st->a2 = st->a3 = 0.0;
     st->imin = mn;
     st->imax = mx;
+    st->mean_override = 0.0f;
+    st->use_override = 0;
 }
 // clamp bounds of the normalisation from the exact partial sums (every consumer evaluates them itself: a handful of scalar
 // operations instead of a one-thread launch between the two passes)
 __device__ __forceinline__ void mind_bounds(const MindStats* __restrict__ st, double count, float& lo, float& hi) {
-    const float gm = (float)((st->a1 + (st->a2 + st->a3)) / count);
+    const float gm = st->use_override ? st->mean_override : (float)((st->a1 + (st->a2 + st->a3)) / count);
     lo = (float)((double)gm * 0.001);      // python: mind_var.mean().item()*0.001   (:61)
     hi = (float)((double)gm * 1000.0);
 }
@@ -260,6 +262,160 @@ __device__ __forceinline__ void mind_normalise(float (&r)[12], float lo, float h
     for (int c = 0; c < 12; ++c) r[c] = mind_exp(fdiv(r[c], var), et);
 }
 
+// ---- reference-bits mode: `mind_var.mean()` exactly as torch evaluates it (option mind_mean_threads = T > 0) -------------------
+// The default global mean is the exactly rounded one (order independent).  The reference's own value is ATen's float32 sum of the
+// V per-voxel variances with T threads (convex_adam_utils.py:61): TensorIteratorReduce's two_pass_reduction splits the elements into
+// nt = min(T, ceil(V / 32768)) chunks of ceil(V / nt); a chunk is summed by SumKernel's vectorized_inner_sum -- 8-float vectors,
+// vector i of the chunk to one of 4 interleaved accumulators (i mod 4) which are cascade sums (4 levels, 16 or more rows per level),
+// leftover vectors to accumulator 0, ((p0 + p1) + p2) + p3 per lane, then the scalar tail and the 8 lanes in order; the T slots are
+// reduced by the same routine.  Restated here (and in oracle/cvx_oracle.c::orc_torch_sum, which is pinned against torch.sum for
+// 1..128 threads): it only matters for voxels whose variance is clamped to its bounds.
+//   k_mind_var          var[x] exactly as mind_normalise computes it
+//   k_torch_sum_level   the cascade levels as a parallel radix-16 tree: chain L < 32 of a chunk = (accumulator L / 8, vector lane
+//                       L % 8) owns elements 32 i + L; k_torch_sum_chunks folds the top level, the remainders and the lanes
+//   k_torch_sum_final   the slots -> mean -> MindStats::mean_override
+__device__ __forceinline__ int ceil_log2_ll(long long x) { int r = 0; long long v = 1; while (v < x) { v <<= 1; ++r; } return r; }
+// ATen multi_row_sum for one row set: elements x[i * stride], i < size, 4 cascade levels
+__device__ float cascade_sum_dev(const float* __restrict__ x, long long stride, long long size) {
+    int level_power = ceil_log2_ll(size) / 4;
+    if (level_power < 4) level_power = 4;
+    const long long level_step = 1ll << level_power, level_mask = level_step - 1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    long long i = 0;
+    for (; i + level_step <= size;) {
+        for (long long j = 0; j < level_step; j += 16) {                  // level_step is a multiple of 16: 16 loads in flight
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = x[(i + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[0] += v[u];
+            i += 16;
+        }
+        for (int l = 1; l < 4; ++l) {
+            acc[l] += acc[l - 1];
+            acc[l - 1] = 0.f;
+            const long long mask = level_mask << (l * level_power);
+            if ((i & mask) != 0) break;
+        }
+    }
+    for (; i < size; ++i) acc[0] += x[i * stride];
+    for (int l = 1; l < 4; ++l) acc[0] += acc[l];
+    return acc[0];
+}
+// one thread: SumKernel's inner sum of n contiguous floats (any n; used for the T slots and for tiny volumes)
+__device__ float torch_inner_sum_serial(const float* __restrict__ x, long long n) {
+    if (n < 8) {
+        const long long n4 = n / 4;
+        float p[4];
+        for (int k = 0; k < 4; ++k) p[k] = cascade_sum_dev(x + k, 4, n4);
+        for (long long i = n4 * 4; i < n; ++i) p[0] += x[i];
+        for (int k = 1; k < 4; ++k) p[0] += p[k];
+        return p[0];
+    }
+    const long long nv = n / 8, nv4 = nv / 4;
+    float fin = 0.0f;
+    for (long long k = nv * 8; k < n; ++k) fin += x[k];
+    for (int lane = 0; lane < 8; ++lane) {
+        float p[4];
+        for (int k = 0; k < 4; ++k) p[k] = cascade_sum_dev(x + k * 8 + lane, 32, nv4);
+        for (long long i = nv4 * 4; i < nv; ++i) p[0] += x[i * 8 + lane];
+        for (int k = 1; k < 4; ++k) p[0] += p[k];
+        fin += p[0];
+    }
+    return fin;
+}
+__global__ __launch_bounds__(256) void k_mind_var(const float* __restrict__ raw, size_t V, float* __restrict__ var) {
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= V) return;
+    float r[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) r[c] = raw[(size_t)MIND_INV[c] * V + x];
+    float mn = r[0];
+#pragma unroll
+    for (int c = 1; c < 12; ++c) mn = fminf(mn, r[c]);
+#pragma unroll
+    for (int c = 0; c < 12; ++c) r[c] = r[c] - mn;
+    const float sum = x >= (V / 32) * 32 ? outer_sum_ilp<12>(r) : cascade_seq<12>(r);
+    var[x] = fdiv(sum, 12.0f);
+}
+// geometry of chunk c of the two-pass reduction: n elements from b; nv4 rows of 32 floats feed the 32 cascade chains
+struct TSChunk { long long b, n, nv, nv4; int power; long long step, n0, n1, n2; };
+__device__ __forceinline__ TSChunk ts_chunk(long long V, long long chunk, int c) {
+    TSChunk t;
+    t.b = (long long)c * chunk;
+    t.n = (t.b + chunk < V ? t.b + chunk : V) - t.b;
+    if (t.n < 0) t.n = 0;
+    t.nv = t.n / 8;
+    t.nv4 = t.nv / 4;
+    t.power = ceil_log2_ll(t.nv4) / 4;
+    if (t.power < 4) t.power = 4;
+    t.step = 1ll << t.power;
+    t.n0 = t.nv4 / t.step; t.n1 = t.n0 / t.step; t.n2 = t.n1 / t.step;
+    return t;
+}
+// One cascade level for every chain of every chunk in parallel: the cascade is a radix-`step` tree (level l+1 adds `step` level-l sums
+// in order, starting from 0), so out[j][L] = ((0 + in[j*step][L]) + in[j*step+1][L]) + ...  LEVEL 0 reads the variances themselves
+// (row i of chunk c = var[b + 32 i + L]), levels 1, 2 read the previous level's rows; rows are 32 floats = one coalesced access.
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_torch_sum_level(const float* __restrict__ in, float* __restrict__ out, long long V, long long chunk,
+                                                         long long in_stride, long long out_stride) {
+    const TSChunk t = ts_chunk(V, chunk, blockIdx.y);
+    const long long nout = LEVEL == 0 ? t.n0 : (LEVEL == 1 ? t.n1 : t.n2);
+    const long long j = ((long long)blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int L = threadIdx.x & 31;
+    if (j >= nout) return;
+    const float* src = (LEVEL == 0 ? in + t.b : in + (long long)blockIdx.y * in_stride) + j * t.step * 32 + L;
+    float acc = 0.0f;
+    for (long long u = 0; u < t.step; u += 16) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = src[(u + q) * 32];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += v[q];
+    }
+    out[(long long)blockIdx.y * out_stride + j * 32 + L] = acc;
+}
+// per chunk: the top level and the ragged remainders of every level in order, ((acc0 + acc1) + acc2) + acc3 per chain, leftover
+// vectors, the four accumulators of a vector lane, the scalar tail and the eight lanes -> the chunk's slot
+__global__ __launch_bounds__(64) void k_torch_sum_chunks(const float* __restrict__ var, const float* __restrict__ B0, const float* __restrict__ B1,
+                                                         const float* __restrict__ B2, long long V, long long chunk, long long s0, long long s1,
+                                                         long long s2, float* __restrict__ slots) {
+    const TSChunk t = ts_chunk(V, chunk, blockIdx.x);
+    const int L = threadIdx.x;
+    __shared__ float part[32];
+    if (t.n <= 0) return;                                                // (slot keeps the identity)
+    if (t.n < 64) {                                                      // tiny chunk: one thread
+        if (L == 0) slots[blockIdx.x] = 0.0f + torch_inner_sum_serial(var + t.b, t.n);
+        return;
+    }
+    if (L < 32) {
+        const float* x = var + t.b + L;
+        const float* b0 = B0 + (long long)blockIdx.x * s0 + L;
+        const float* b1 = B1 + (long long)blockIdx.x * s1 + L;
+        const float* b2 = B2 + (long long)blockIdx.x * s2 + L;
+        float a3 = 0.f, a2 = 0.f, a1 = 0.f, a0 = 0.f;
+        for (long long j = 0; j < t.n2; ++j) a3 += b2[j * 32];
+        for (long long j = t.n2 * t.step; j < t.n1; ++j) a2 += b1[j * 32];
+        for (long long j = t.n1 * t.step; j < t.n0; ++j) a1 += b0[j * 32];
+        for (long long i = t.n0 * t.step; i < t.nv4; ++i) a0 += x[i * 32];
+        float p = ((a0 + a1) + a2) + a3;
+        if (L < 8) for (long long i = t.nv4 * 4; i < t.nv; ++i) p += var[t.b + i * 8 + L];   // leftover vectors -> accumulator 0
+        part[L] = p;
+    }
+    cvx_barrier();
+    if (L == 0) {
+        float fin = 0.0f;
+        for (long long k = t.nv * 8; k < t.n; ++k) fin += var[t.b + k];
+        for (int lane = 0; lane < 8; ++lane) fin += ((part[lane] + part[8 + lane]) + part[16 + lane]) + part[24 + lane];
+        slots[blockIdx.x] = 0.0f + fin;
+    }
+}
+__global__ void k_torch_sum_final(const float* __restrict__ slots, int nslots, int two_pass, long long V, MindStats* __restrict__ st) {
+    const float sum = two_pass ? 0.0f + torch_inner_sum_serial(slots, nslots) : slots[0];
+    st->mean_override = fdiv(sum, (float)V);                             // sum_out(..).div_(numel)
+    st->use_override = 1;
+}
+
 // out_c(x) in place; NV voxels per thread (4 = 16-byte access).
 // The channel mean runs over the reference's PRE-permutation channel order (the permutation is applied last, :66).
 template <int NV>
@@ -416,11 +572,41 @@ static int mind_stencil(const float* img, int H, int W, int D, int radius, int d
     const int nb = (int)(V / 4096 + 1 < 1024 ? V / 4096 + 1 : 1024);
     hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(256), 0, s, img, V, part);
     hipLaunchKernelGGL(k_mind_stats_init, dim3(1), dim3(256), 0, s, part, nb, (double)V, st);
+    int rc;
     switch (radius) {
-        case 1: return mind_launch_r<1>(img, H, W, D, dilation, st, raw, s);
-        case 2: return mind_launch_r<2>(img, H, W, D, dilation, st, raw, s);
-        default: return mind_launch_r<3>(img, H, W, D, dilation, st, raw, s);
+        case 1: rc = mind_launch_r<1>(img, H, W, D, dilation, st, raw, s); break;
+        case 2: rc = mind_launch_r<2>(img, H, W, D, dilation, st, raw, s); break;
+        default: rc = mind_launch_r<3>(img, H, W, D, dilation, st, raw, s); break;
     }
+    const long long T = options().mind_mean_threads;
+    if (rc || T <= 0) return rc;
+    // reference-bits mode: torch's own mean instead of the exactly rounded one
+    const int threads = (int)(T > 1024 ? 1024 : T);
+    float* var = cv.take<float>(V);
+    float* slots = cv.take<float>(1024);
+    const bool two_pass = V >= 32768 && threads > 1;
+    long long nt = 1, chunk = (long long)V;
+    if (two_pass) {
+        nt = ((long long)V + 32767) / 32768;
+        if (nt > threads) nt = threads;
+        chunk = ((long long)V + nt - 1) / nt;
+    }
+    // level buffers: at most nv4 / 16, / 256, / 4096 rows of 32 floats per chunk
+    const long long rows = chunk / 32 + 1;
+    const long long s0 = (rows / 16 + 1) * 32, s1 = (rows / 256 + 1) * 32, s2 = (rows / 4096 + 1) * 32;
+    float* B0 = cv.take<float>((size_t)(s0 * nt));
+    float* B1 = cv.take<float>((size_t)(s1 * nt));
+    float* B2 = cv.take<float>((size_t)(s2 * nt));
+    if (!cv.ok()) return fail(CVX_ERR_WORKSPACE, "mindssc: workspace too small for mind_mean_threads (query the size after setting the option)");
+    hipLaunchKernelGGL(k_mind_var, dim3((unsigned)cdiv64((int64_t)V, 256)), dim3(256), 0, s, raw, V, var);
+    if (two_pass) (void)hipMemsetAsync(slots, 0, 1024 * sizeof(float), s);              // unused slots keep the identity
+    auto blocks = [](long long nrows) { return (unsigned)((nrows * 32 + 255) / 256 > 0 ? (nrows * 32 + 255) / 256 : 1); };
+    hipLaunchKernelGGL(k_torch_sum_level<0>, dim3(blocks(rows / 16 + 1), (unsigned)nt), dim3(256), 0, s, var, B0, (long long)V, chunk, 0ll, s0);
+    hipLaunchKernelGGL(k_torch_sum_level<1>, dim3(blocks(rows / 256 + 1), (unsigned)nt), dim3(256), 0, s, B0, B1, (long long)V, chunk, s0, s1);
+    hipLaunchKernelGGL(k_torch_sum_level<2>, dim3(blocks(rows / 4096 + 1), (unsigned)nt), dim3(256), 0, s, B1, B2, (long long)V, chunk, s1, s2);
+    hipLaunchKernelGGL(k_torch_sum_chunks, dim3((unsigned)nt), dim3(64), 0, s, var, B0, B1, B2, (long long)V, chunk, s0, s1, s2, slots);
+    hipLaunchKernelGGL(k_torch_sum_final, dim3(1), dim3(1), 0, s, slots, threads, two_pass ? 1 : 0, (long long)V, st);
+    return check_last("mind_mean");
 }
 
 static int mind_check(const float* img, const float* out, const void* workspace, int H, int W, int D, int radius, int dilation,
@@ -478,8 +664,11 @@ int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int di
 using namespace cvx;
 
 extern "C" size_t cvx_mindssc_workspace_bytes(int H, int W, int D, int radius, int dilation) {
-    (void)H; (void)W; (void)D; (void)radius; (void)dilation;
-    return 256 + 2 * 1024 * sizeof(float) + 256 + sizeof(MindStats) + 256;
+    (void)radius; (void)dilation;
+    size_t n = 256 + 2 * 1024 * sizeof(float) + 256 + sizeof(MindStats) + 256;
+    if (options().mind_mean_threads > 0)                                       // var, thread slots, three cascade levels (< V / 14 floats)
+        n += 256 + (size_t)H * W * D * sizeof(float) + 256 + 1024 * sizeof(float) + (size_t)H * W * D / 14 * sizeof(float) + 3 * (256 + 1024 * 64 * sizeof(float));
+    return n;
 }
 
 extern "C" int cvx_mindssc_f32(const float* img, int H, int W, int D, int radius, int dilation, float* out,

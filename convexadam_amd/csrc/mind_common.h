@@ -19,6 +19,8 @@ struct MindStats {
     double m1, m2, m3;     // split grids (see oracle orc_split_make)
     double a1, a2, a3;     // exact partial sums
     float imin, imax;
+    float mean_override;   // reference-bits mode (option mind_mean_threads): torch's own mean, see k_torch_sum_* in mind.hip
+    int use_override;
 };
 
 // z-marching stencil (mindmarch.hip): radius 1, dilation 2, rows of a multiple of 4 voxels, 16-byte aligned pointers

@@ -1,7 +1,8 @@
 """Reproducing the bits of a reference run on a given host (opt-in).
 
-Every operation of the hot path is restated in the reference's own evaluation order except two library calls of
-the reference BUILD: `torch.exp` at MINDSSC (src/convexAdam/convex_adam_utils.py:63) and the `sqrt` inside `torch.optim.Adam`
+Every operation of the hot path is restated in the reference's own evaluation order except a global mean whose
+rounding depends on the reference's thread count (set_mean_threads below restates torch's sum for a given count) and two library
+calls of the reference BUILD: `torch.exp` at MINDSSC (src/convexAdam/convex_adam_utils.py:63) and the `sqrt` inside `torch.optim.Adam`
 (src/convexAdam/convex_adam_MIND.py:179).  On the CPU torch evaluates both with Intel MKL VML (vsExp / vsSqrt), whose results are
 at most one ulp from this library's (`cvx_expf_f32`, IEEE sqrt), do not depend on the position in the tensor, and DO depend on the
 host: MKL picks its code path by CPU model (a Xeon and an EPYC host of the same image give different tables).  Because the deviation
@@ -10,8 +11,9 @@ is a pure function of the argument it can be tabulated from torch itself, exhaus
     sqrt: 2 x 2^23 normal (exponent parity, mantissa) classes + 2^23 denormals  -> 6 MiB of 2-bit codes, < 1 s
     exp : every float32 argument with |x| in [2^-30, 128) -> 310 M two-bit entries, 74 MiB on the device, ~15 s
 
-With both tables installed the pipeline's output equals the reference's bit for bit -- checked at the full benchmark size through
-80 Adam iterations against fields captured from the reference (tests/golden/fullsize.npz; tests/test_gpu_parity.py).  The default
+With both tables installed (and the thread count of the reference run) the pipeline's output equals the reference's bit for bit --
+checked at the full benchmark size through 80 Adam iterations and on the masked large-motion configuration against fields captured
+from the reference (tests/golden/fullsize.npz; tests/test_gpu_parity.py).  The default
 (no tables) is within one ulp at those two sites, which the Adam loop amplifies to 1e-3 voxels after 80 iterations (the reference
 differs by as much from itself across hosts).  Cost when installed: a dependent 2-bit lookup per exp and per sqrt.
 
@@ -102,12 +104,22 @@ def set_mind_exp_table(table=None, first=EXP_FIRST, count=EXP_COUNT, device="cud
     check(lib().cvx_set_mind_exp_table(ptr(t), int(first), int(count)))
 
 
-def enable(device="cuda"):
-    """Builds this host's tables from torch and installs both."""
+def set_mean_threads(threads=0):
+    """MINDSSC's global mean (`mind_var.mean()`, convex_adam_utils.py:61) as torch's CPU kernel evaluates it with `threads` threads
+    instead of the exactly rounded, order-independent mean (0, default).  The value differs by a few ulps and only reaches the result
+    through voxels whose variance is clamped to [mean / 1000, 1000 mean] (flat regions, e.g. masked images)."""
+    check(lib().cvx_set_option(b"mind_mean_threads", int(threads)))
+
+
+def enable(device="cuda", threads=None):
+    """Builds this host's tables from torch and installs them; `threads`: the thread count of the reference run to reproduce
+    (default: torch.get_num_threads() of this process)."""
     set_mind_exp_table(build_exp_table(device), device=device)
     set_adam_sqrt_table(build_sqrt_table(), device=device)
+    set_mean_threads(torch.get_num_threads() if threads is None else threads)
 
 
 def disable():
     set_mind_exp_table(None)
     set_adam_sqrt_table(None)
+    set_mean_threads(0)

@@ -1057,12 +1057,15 @@ def reference_bits(orc, mkl):
     t = mkl.golden_tables()
     rb.set_mind_exp_table(t["exp"], t["exp_first"], t["exp_count"], device=DEV)
     rb.set_adam_sqrt_table(t["sqrt"], device=DEV)
+    rb.set_mean_threads(8)                      # every golden was captured with torch.set_num_threads(8)
     orc.set_exp_table(t["exp"], t["exp_first"], t["exp_count"])
     orc.set_sqrt_table(t["sqrt"])
+    orc.set_mean_threads(8)
     yield rb
     rb.disable()
     orc.set_exp_table(None)
     orc.set_sqrt_table(None)
+    orc.set_mean_threads(0)
 
 
 def test_reference_bits_tables_built_by_the_product_equal_the_test_infrastructure(orc, mkl):
@@ -1123,3 +1126,43 @@ def test_full_size_benchmark_pair_bit_identical_to_the_reference_with_mkl_tables
         fd = f.cpu().double()
         assert np.allclose(fd.sum((1, 2, 3)).numpy(), g["c1_adam_%d_sum" % niter], rtol=1e-14, atol=0)
         assert np.allclose(fd.square().sum((1, 2, 3)).numpy(), g["c1_adam_%d_sumsq" % niter], rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("threads", [1, 2, 8, 128])
+def test_mindssc_with_torch_mean_vs_oracle(U, orc, reference_bits, threads):
+    """Option mind_mean_threads: the global mean as torch sums it with T threads (two-pass reduction over chunks, 8-float vectors, 4
+    interleaved cascade accumulators) -- HIP vs the oracle's restatement (itself pinned against torch.sum for 1..128 threads,
+    tests/test_host_logic.py) on volumes with clamped voxels, below and above the 32768-element threshold of the parallel path."""
+    from convexadam_amd.phantom import phantom
+    reference_bits.set_mean_threads(threads)
+    orc.set_mean_threads(threads)
+    for shape in ((20, 18, 23), (33, 40, 70), (64, 72, 60)):
+        img = phantom(shape, 3, 30)
+        img[: shape[0] // 2] *= 1e-3
+        out, mean = orc.mindssc(img.numpy(), 1, 2, return_mean=True)
+        assert np.array_equal(host(U.MINDSSC(img[None, None].to(DEV), 1, 2, device=DEV))[0], out), (shape, threads)
+
+
+def test_masked_goldens_bit_identical_to_reference_in_reference_bits_mode(M, golden, reference_bits):
+    """extract_features(use_mask=True) of tests/golden/masked.npz: exact (flat filled regions -> clamped variances -> the mean's last bits)."""
+    g = golden("masked")
+    ff, fm = M.extract_features(dev(g["img_fix"]), dev(g["img_mov"]), 1, 2, True, dev(g["mask_fix"]), dev(g["mask_mov"]), device=torch.device(DEV),
+                                dtype=torch.float32)
+    assert np.array_equal(host(ff)[0], g["feat_fix"]) and np.array_equal(host(fm)[0], g["feat_mov"])
+
+
+def test_full_size_masked_config3_bit_identical_to_the_reference(M, golden, reference_bits):
+    """BASELINE configs[2] (224x192x224, masks, disp_hw 8, 20 Adam iterations) in reference-bits mode: equal to the reference capture."""
+    from convexadam_amd.phantom import deformed_pair, ellipsoid_mask
+    g = golden("fullsize")
+    s = int(g["sub"])
+    shape = (224, 192, 224)
+    fix, mov = deformed_pair(shape, 3, 10.0)
+    mf, mm = ellipsoid_mask(shape, 0.35), ellipsoid_mask(shape, 0.35, shift=(4, -3, 5))
+    ff, fm = M.extract_features(fix, mov, 1, 2, True, mf, mm, device=torch.device(DEV), dtype=torch.float32)
+    f = M.register_pair_device(feat_fixed=ff[0], feat_moving=fm[0], lambda_weight=1.25, grid_sp=6, disp_hw=8, selected_niter=20,
+                               selected_smooth=0, grid_sp_adam=2, ic=True)
+    assert np.array_equal(host(f[:, ::s, ::s, ::s]), g["c3_adam_20_sub"])
+    fd = f.cpu().double()
+    assert np.allclose(fd.sum((1, 2, 3)).numpy(), g["c3_adam_20_sum"], rtol=1e-14, atol=0)
+    assert np.allclose(fd.square().sum((1, 2, 3)).numpy(), g["c3_adam_20_sumsq"], rtol=1e-14, atol=0)

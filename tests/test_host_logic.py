@@ -323,3 +323,23 @@ def test_rescale_displacement_field_and_translation_without_simpleitk():
     moved = apply_translation(moving, (1.0, 2.0, 3.0))
     assert np.allclose(np.array(moving.GetOrigin()) - np.array(moved.GetOrigin()), Rz @ np.array([1.0, 2.0, 3.0])) and moving.GetOrigin() == (6.0, 0.0, 0.0)
     assert field_to_translation(field, (0.5, 0.5, 2.5)) == (0.5, -1.0, 2.5)            # whole voxels of the moving image, in mm (x, y, z)
+
+
+def test_torch_full_sum_restatement():
+    """oracle.torch_sum = ATen's float32 sum of a whole contiguous tensor for a given thread count (two-pass reduction, 8-float vectors,
+    4 interleaved cascade accumulators): the one quantity of the hot path whose bits depend on the reference's thread count
+    (`mind_var.mean()`, convex_adam_utils.py:61).  Pinned against torch.sum itself."""
+    import numpy as np
+    import torch
+    from oracle import oracle as orc
+    orc.build()
+    rng = np.random.default_rng(1)
+    old = torch.get_num_threads()
+    try:
+        for T in (1, 2, 3, 8, 16):
+            torch.set_num_threads(T)
+            for n in (1, 5, 7, 8, 9, 31, 32, 33, 63, 64, 65, 1000, 4097, 32767, 32768, 32769, 65537, 100000, 262147, 1000003):
+                x = (rng.random(n, dtype=np.float32) ** 4 * 1e3).astype(np.float32)
+                assert float(torch.from_numpy(x).sum()) == orc.torch_sum(x, T), (T, n)
+    finally:
+        torch.set_num_threads(old)

@@ -379,6 +379,29 @@ def test_full_size_bit_identical_to_reference_with_mkl_tables(orc_reference_bits
     assert np.allclose(ft.square().sum((1, 2, 3)).numpy(), g["c1_adam_80_sumsq"], rtol=1e-14, atol=0)
 
 
+def test_full_size_masked_config3_bit_identical_to_reference(orc_reference_bits, golden):
+    """BASELINE configs[2] (224x192x224, ellipsoid masks, disp_hw 8, 20 Adam iterations): equal to the reference capture.  The masked
+    images have flat filled regions whose variance is clamped to mean / 1000, so this also needs the reference's `mind_var.mean()` to
+    the last bit: torch's float sum with the capture's 8 threads, restated in orc_torch_sum."""
+    from convexadam_amd.phantom import deformed_pair, ellipsoid_mask
+    import torch
+    orc, g = orc_reference_bits, golden("fullsize")
+    s = int(g["sub"])
+    shape = (224, 192, 224)
+    fix, mov = deformed_pair(shape, 3, 10.0)
+    mf, mm = ellipsoid_mask(shape, 0.35), ellipsoid_mask(shape, 0.35, shift=(4, -3, 5))
+    filled_f, _ = orc.replicate_fill(fix.numpy(), mf.numpy())
+    filled_m, _ = orc.replicate_fill(mov.numpy(), mm.numpy())
+    feats = (orc.mindssc(filled_f, 1, 2), orc.mindssc(filled_m, 1, 2))
+    out = orc.convex_adam_pipeline(None, None, features=feats, lambda_weight=1.25, grid_sp=6, disp_hw=8, selected_niter=20, selected_smooth=0,
+                                   grid_sp_adam=2, ic=True)
+    f = np.moveaxis(out, -1, 0).astype(np.float32)
+    assert np.array_equal(f[:, ::s, ::s, ::s], g["c3_adam_20_sub"])
+    ft = torch.from_numpy(np.ascontiguousarray(f)).double()
+    assert np.allclose(ft.sum((1, 2, 3)).numpy(), g["c3_adam_20_sum"], rtol=1e-14, atol=0)
+    assert np.allclose(ft.square().sum((1, 2, 3)).numpy(), g["c3_adam_20_sumsq"], rtol=1e-14, atol=0)
+
+
 def test_host_tables_match_the_fixtures_on_the_golden_host(orc, mkl):
     """The fixtures are nothing but torch.exp / torch.sqrt of the host that produced the goldens, tabulated: rebuilt from torch here
     they are identical.  Another CPU model makes MKL take another code path (the GPU boxes' EPYC hosts do): skipped there."""
