@@ -1166,3 +1166,30 @@ def test_full_size_masked_config3_bit_identical_to_the_reference(M, golden, refe
     fd = f.cpu().double()
     assert np.allclose(fd.sum((1, 2, 3)).numpy(), g["c3_adam_20_sum"], rtol=1e-14, atol=0)
     assert np.allclose(fd.square().sum((1, 2, 3)).numpy(), g["c3_adam_20_sumsq"], rtol=1e-14, atol=0)
+
+
+def test_reference_bits_enable_with_this_hosts_own_tables_vs_oracle(M, orc, mkl, golden):
+    """reference_bits.enable() tabulates THIS host's torch.exp / torch.sqrt (on the GPU boxes an EPYC, whose MKL code path deviates from
+    the IEEE root in BOTH directions and from the golden host's exp in 40 % of the deviating arguments) and installs torch's mean for
+    this process's thread count.  The HIP pipeline then equals the oracle given the tables tests/mkl_tables.py builds from the same
+    host -- i.e. what the reference would compute HERE -- and differs from the golden host's result."""
+    from convexadam_amd import reference_bits as rb
+    t = mkl.host_tables(orc)
+    g = golden("pipeline")
+    kw = dict(mind_r=1, mind_d=2, grid_sp=4, disp_hw=3, grid_sp_adam=2, lambda_weight=1.25, selected_niter=20, ic=True)
+    threads = torch.get_num_threads()
+    rb.enable(DEV)
+    orc.set_exp_table(t["exp"], t["exp_first"], t["exp_count"])
+    orc.set_sqrt_table(t["sqrt"])
+    orc.set_mean_threads(threads)
+    try:
+        out = host(M.register_pair_device(dev(g["fix"]), dev(g["mov"]), **kw))
+        ref = orc.convex_adam_pipeline(g["fix"], g["mov"], **kw)
+    finally:
+        rb.disable()
+        orc.set_exp_table(None)
+        orc.set_sqrt_table(None)
+        orc.set_mean_threads(0)
+    assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), ref)
+    if not t["matches_golden_host"]:
+        assert not np.array_equal(ref, g["adam_20"])            # another host, another reference result
