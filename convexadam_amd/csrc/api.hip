@@ -35,8 +35,8 @@ static long long env_ll(const char* name, long long dflt) {
 Options& options() {
     static Options o = {env_ll("CVX_MIND_TILED", 0),   env_ll("CVX_MM_TX", 0),        env_ll("CVX_MM_SLOTS", 512),          env_ll("CVX_BOX_TILED", 0),
                         env_ll("CVX_NO_PRUNE", 0),     env_ll("CVX_CORR_UNFUSED", 0), env_ll("CVX_PRUNE_STREAM_ABOVE", -1), env_ll("CVX_CF_CENSUS", 0),
-                        env_ll("CVX_WARP_FLAT", 0),    env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 256),
-                        env_ll("CVX_MIND_MEAN_THREADS", 0)};
+                        env_ll("CVX_WARP_FLAT", 0),    env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 0),
+                        env_ll("CVX_BOX_XSPLIT", -1),  env_ll("CVX_MIND_MEAN_THREADS", 0)};
     return o;
 }
 static const unsigned* g_adam_sqrt_tbl = nullptr;
@@ -53,7 +53,7 @@ static const OptName kOptNames[] = {{"mind_tiled", &Options::mind_tiled},     {"
                                     {"no_prune", &Options::no_prune},         {"corr_unfused", &Options::corr_unfused},
                                     {"prune_stream_above", &Options::prune_stream_above}, {"cf_census", &Options::cf_census},
                                     {"warp_flat", &Options::warp_flat},       {"box_yt", &Options::box_yt},             {"box_wg_target", &Options::box_wg_target},
-                                    {"mind_mean_threads", &Options::mind_mean_threads}};
+                                    {"box_xsplit", &Options::box_xsplit},     {"mind_mean_threads", &Options::mind_mean_threads}};
 
 }  // namespace cvx
 

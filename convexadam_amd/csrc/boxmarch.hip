@@ -35,6 +35,8 @@ struct BMCtx {
     float *oc, *Pc, *mc, *vc, *gs;          // output channel / Adam state / saved gradient (may be null)
     float *S0, *S1, *S2, *S3;               // S3: plain adjoint sums of the newest output plane (Adam variant only)
     int h, w, d, z0, y0, zn, nsteps;
+    int xl0;                                // global column of local column 0 (0, or x tile start - 4: an aligned halo of one quad)
+    int ox0, ox1;                           // global columns this workgroup writes: [ox0, ox1)
     size_t wd;                              // plane stride w*d
     unsigned e_off[2];                      // Adam variant: offset (y0+row)*d + col inside a plane of the <= 2 elements this thread updates
     unsigned e_lds[2];                      //               and their index in an S3 slot; 0xffffffff = none
@@ -134,11 +136,12 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     const bool rowok = active && gy >= 0 && gy < c.w;
     bool ok[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ok[j] = rowok && c0 + j >= 0 && c0 + j < c.d;
+    for (int j = 0; j < 4; ++j) ok[j] = rowok && c.xl0 + c0 + j >= 0 && c.xl0 + c0 + j < c.d;
     const float* src = (K == 1 ? c.S0 : (K == 2 ? c.S1 : c.S2)) + r * G::RS + 4 * q + 4;
     float* dst = (K == 1 ? c.S1 : c.S2) + r * G::RS + 4 * q + 4;
-    const int ncol = c.d - 4 * q;                                        // pass 3: valid columns of this quad
-    const unsigned rowbase = (unsigned)((gy < 0 ? 0 : gy) * c.d + 4 * q);
+    const int gx = c.xl0 + 4 * q;                                        // pass 3: first global column of this quad
+    const int ncol = gx >= c.ox0 ? c.ox1 - gx : 0;                       //         and how many of its columns this workgroup owns
+    const unsigned rowbase = (unsigned)((gy < 0 ? 0 : gy) * c.d + (gx < 0 ? 0 : gx));
     const int tlast = c.zn + 5 + K;
 
     BMAdamPre apre = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -223,18 +226,18 @@ template <int QPR, int YT, bool BACKWARD, bool ADAM>
 __global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
                                                                 int w, int d, int zc, int nzc, int nyt, float* __restrict__ P,
                                                                 float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
-                                                                float* __restrict__ gsave, int vec_ok) {
+                                                                float* __restrict__ gsave, int vec_ok, int nxt, int tw) {
     using G = BMGeomT<QPR, YT>;
     constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
     __shared__ __attribute__((aligned(16))) float S0[2 * SLOT0];
     __shared__ __attribute__((aligned(16))) float S1[2 * SLOT1];
     __shared__ __attribute__((aligned(16))) float S2[2 * SLOT2];
     __shared__ __attribute__((aligned(16))) float S3[ADAM ? 2 * G::ROWS3 * G::RS : 4];
-    // XCD-aware order: XCD q (workgroups q, q+8, ..) takes the q-th contiguous run of (channel, y tile, z chunk) triples
-    const int nblk = 3 * nyt * nzc;
+    // XCD-aware order: XCD q (workgroups q, q+8, ..) takes the q-th contiguous run of (channel, y tile, x tile, z chunk) tuples
+    const int nblk = 3 * nyt * nxt * nzc;
     const int b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     if (b >= nblk) return;
-    const int zi = b % nzc, yi = (b / nzc) % nyt, ch = b / (nzc * nyt);
+    const int zi = b % nzc, xi = (b / nzc) % nxt, yi = (b / (nzc * nxt)) % nyt, ch = b / (nzc * nxt * nyt);
     const size_t V = (size_t)h * w * d;
     BMCtx c;
     c.ic = in + (size_t)ch * V;
@@ -246,6 +249,11 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const flo
     c.S0 = S0; c.S1 = S1; c.S2 = S2; c.S3 = S3;
     c.wd = (size_t)w * d;
     c.h = h; c.w = w; c.d = d; c.z0 = zi * zc; c.y0 = yi * YT;
+    // x tiles (nxt > 1): tw columns each plus one quad of halo on either side, so that every 16-byte access stays aligned; the three
+    // passes lose one column per side each, the tile's own columns are local 4 .. 4 + tw - 1
+    c.xl0 = nxt > 1 ? xi * tw - 4 : 0;
+    c.ox0 = nxt > 1 ? xi * tw : 0;
+    c.ox1 = nxt > 1 ? min(d, (xi + 1) * tw) : d;
     c.zn = min(zc, h - c.z0);
     c.nsteps = c.zn + (ADAM ? 10 : 9);
     c.vec = vec_ok != 0;
@@ -259,11 +267,12 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const flo
     if (ADAM) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int e = tid + k * G::NT;                           // 8 rows x d columns <= 1008 elements <= 2 per thread
-            const int row = e / d, col = e - row * d;
+            const int e = tid + k * G::NT;                           // 8 rows x (<= 126) columns <= 1008 elements <= 2 per thread
+            const int ow = c.ox1 - c.ox0;
+            const int row = e / ow, col = e - row * ow;
             const bool have = row < YT && c.y0 + row < w;
-            c.e_off[k] = (unsigned)((c.y0 + row) * d + col);
-            c.e_lds[k] = have ? (unsigned)(row * G::RS + col + 4) : 0xffffffffu;
+            c.e_off[k] = (unsigned)((c.y0 + row) * d + c.ox0 + col);
+            c.e_lds[k] = have ? (unsigned)(row * G::RS + (c.ox0 - c.xl0) + col + 4) : 0xffffffffu;
         }
     }
     BMLoader L;
@@ -271,8 +280,9 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const flo
     const int lr = tid / QPR;
     L.lq = tid % QPR;
     const int lgy = c.y0 - 3 + lr;
-    L.lrow = L.ldr && lgy >= 0 && lgy < w && 4 * L.lq < d;
-    L.loff = (unsigned)((lgy < 0 ? 0 : lgy) * d + 4 * L.lq);
+    const int lgx = c.xl0 + 4 * L.lq;
+    L.lrow = L.ldr && lgy >= 0 && lgy < w && lgx >= 0 && lgx < d;
+    L.loff = (unsigned)((lgy < 0 ? 0 : lgy) * d + (lgx < 0 ? 0 : lgx));
     L.lds0 = S0 + lr * G::RS + 4 * L.lq + 7;
     bm_issue<BACKWARD>(c, L, c.z0 - 3);
     cvx_barrier();
@@ -287,34 +297,50 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const flo
 bool box3_march_supported(int d) { return d <= 126; }
 
 template <int QPR, int YT>
-static int launch_qpr(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
+static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt, int tw, bool backward, float* P, float* m, float* v,
                       AdamConsts ac, float* gsave, hipStream_t s) {
     using G = BMGeomT<QPR, YT>;
     const int nyt = cdiv(w, YT);
-    const int wg_target = (int)options().box_wg_target;                       // workgroups to aim for (z chunks follow from it)
-    const int nz_target = wg_target / (3 * nyt) > 0 ? wg_target / (3 * nyt) : 1;
+    long long wg_target = options().box_wg_target;                            // workgroups to aim for (z chunks follow from it);
+    if (wg_target <= 0) wg_target = nxt > 1 ? 512 : 256;                      // 0 = automatic: two x-tile workgroups share a CU
+    const int nz_target = wg_target / (3 * nyt * nxt) > 0 ? (int)(wg_target / (3 * nyt * nxt)) : 1;
     int zc = cdiv(h, nz_target);
     if (zc < 4) zc = 4;
     const int nzc = cdiv(h, zc);
-    const unsigned grid = (unsigned)((3 * nyt * nzc + 7) / 8 * 8);
+    const unsigned grid = (unsigned)((3 * nyt * nxt * nzc + 7) / 8 * 8);
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec = (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave);
-    if (!backward) hipLaunchKernelGGL((k_box3_march<QPR, YT, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
-    else if (!P) hipLaunchKernelGGL((k_box3_march<QPR, YT, true, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
-    else hipLaunchKernelGGL((k_box3_march<QPR, YT, true, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec);
+    if (!backward) hipLaunchKernelGGL((k_box3_march<QPR, YT, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw);
+    else if (!P) hipLaunchKernelGGL((k_box3_march<QPR, YT, true, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw);
+    else hipLaunchKernelGGL((k_box3_march<QPR, YT, true, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw);
     return check_last("box3_march");
 }
 
 int launch_box3_march(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
                       AdamConsts ac, float* gsave, hipStream_t s) {
-    if (options().box_yt == 4) {              // 4-row tiles: 9-wave workgroups, three per CU
-        if (d <= 30) return launch_qpr<8, 4>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
-        if (d <= 62) return launch_qpr<16, 4>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
-        return launch_qpr<32, 4>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+    // Long rows are cut into x tiles of <= 56 columns (+ 2 x 4 of halo = 16 quads): twice as many workgroups of half the size, two of
+    // which share a CU and run out of step, so that the LDS phase of one overlaps the VALU phase of the other.
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave);
+    const long long xs = options().box_xsplit;                                 // -1 automatic, 0 off, n >= 2: that many x tiles
+    int nxt = 1, tw = d;
+    if (vec && d > 62 && xs != 0) {
+        nxt = xs > 1 ? (int)xs : cdiv(d, 56);
+        tw = (cdiv(d, nxt) + 3) / 4 * 4;
+        if (tw > 56 || tw < 8) { nxt = 1; tw = d; }
     }
-    if (d <= 30) return launch_qpr<8, 8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
-    if (d <= 62) return launch_qpr<16, 8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
-    return launch_qpr<32, 8>(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
+    if (nxt > 1) {
+        if (options().box_yt == 4) return launch_qpr<16, 4>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);
+        return launch_qpr<16, 8>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);
+    }
+    if (options().box_yt == 4) {              // 4-row tiles: 9-wave workgroups, three per CU
+        if (d <= 30) return launch_qpr<8, 4>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
+        if (d <= 62) return launch_qpr<16, 4>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
+        return launch_qpr<32, 4>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
+    }
+    if (d <= 30) return launch_qpr<8, 8>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
+    if (d <= 62) return launch_qpr<16, 8>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
+    return launch_qpr<32, 8>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
 }
 
 }  // namespace cvx

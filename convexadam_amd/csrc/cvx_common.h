@@ -68,7 +68,8 @@ struct Options {
     long long cf_census;           // 1: the fused correlation kernel records per-workgroup residency in its workspace
     long long warp_flat;           // 1: flat 64-bit gathers in k_warp_grad instead of buffer loads
     long long box_yt;              // rows per tile of the marching three-box kernels: 8 (default) or 4
-    long long box_wg_target;       // workgroups the z-marching three-box kernels of the Adam loop aim for (z-chunk length follows)
+    long long box_wg_target;       // workgroups the z-marching three-box kernels of the Adam loop aim for (z-chunk length follows); 0 = automatic
+    long long box_xsplit;          // x tiles of the marching three-box kernels: -1 automatic (rows > 62 columns: tiles of <= 56), 0 off
     long long mind_mean_threads;   // 0: exactly rounded global mean in MINDSSC (default); T > 0: torch's own float sum with T threads
                                    //    (reference-bits mode; NOT a bit-identical variant -- it changes the clamp bounds by ulps)
 };

@@ -285,6 +285,35 @@ def test_adam_grid_shapes_vs_oracle(U, orc, shape):
     assert np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
 
 
+@pytest.mark.parametrize("xsplit", [-1, 0, 2, 3])
+@pytest.mark.parametrize("shape", [(5, 9, 64), (30, 20, 112), (4, 9, 100), (13, 8, 68)])
+def test_adam_x_tiles_vs_oracle(U, orc, shape, xsplit):
+    """Rows longer than 62 voxels: the marching three-box kernels cut them into x tiles (<= 56 columns + a 4-column halo per side,
+    two half-size workgroups per CU); option box_xsplit: -1 automatic, 0 one tile per row, n tiles.  Forward boxes, adjoint boxes and
+    the fused Adam update against the oracle, tile edges inside and at the border of the volume, several z chunks."""
+    from convexadam_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(sum(shape) + xsplit)
+    C = 4
+    F2 = rng.random((C,) + shape, dtype=np.float32)
+    M2 = rng.random((C,) + shape, dtype=np.float32)
+    P0 = (0.7 * rng.standard_normal((3,) + shape)).astype(np.float32)
+    old = L.cvx_get_option(b"box_xsplit")
+    L.cvx_set_option(b"box_xsplit", xsplit)
+    try:
+        Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.25, 3, return_state=True)
+        sm = host(U.box_smooth(dev(P0)[None], 3, 3))[0]
+    finally:
+        L.cvx_set_option(b"box_xsplit", old)
+    r = orc.adam_run(F2, M2, P0, 1.25, 3, want_grad=True)
+    assert np.array_equal(host(Ud)[0], r["U"]) and np.array_equal(host(st["G"])[0], r["G"])
+    assert np.array_equal(host(st["P"])[0], r["P"]) and np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
+    b = P0
+    for _ in range(3):
+        b = orc.box_zero(b, 3)
+    assert np.array_equal(sm, b)
+
+
 def test_adam_snapshots_and_resume(U, orc, golden):
     g = golden("adam")
     args = (dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]))
@@ -953,7 +982,7 @@ def test_full_size_sweep_extreme_settings(M):
 
 # ---- (9) every selectable kernel variant -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opt,val", [("mind_tiled", 1), ("mm_tx", 32), ("mm_tx", 64), ("mm_slots", 64), ("box_tiled", 1), ("no_prune", 1),
-                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700)])
+                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0)])
 def test_kernel_variants_agree(M, U, orc, golden, opt, val):
     """The library's run-time switches (cvx_set_option / CVX_* environment variables) select alternative kernels for the same
     operators; every one of them is bit-identical to the oracle: marching vs tiled MIND stencil and its tile shapes, marching vs tiled
