@@ -61,3 +61,32 @@ def test_whole_pipeline_convex_stage_on_fresh_pair(ref, orc):
     mine = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), **kw)
     epe = float(np.sqrt(((out - mine) ** 2).sum(-1)).mean())
     assert epe <= 1e-5, epe                          # exp differs by <= 1 ulp; everything downstream is restated exactly
+
+
+@pytest.mark.parametrize("threads", [3, 8])
+def test_whole_pipeline_bit_identical_in_reference_bits_mode_on_fresh_pairs(ref, orc, mkl, threads):
+    """LIVE: the reference runs here on pairs that are in no golden file (a textured pair with a zero background -- flat regions whose
+    variance is clamped, so the thread-count dependent mean matters -- 25 Adam iterations, final smoothing) and the oracle, given THIS
+    host's MKL tables (tests/mkl_tables.py, built from torch.exp / torch.sqrt) and the run's thread count, returns the same bits."""
+    _, mind = ref
+    from convexadam_amd.phantom import ellipsoid_mask, phantom
+    t = mkl.host_tables(orc)
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    orc.set_exp_table(t["exp"], t["exp_first"], t["exp_count"])
+    orc.set_sqrt_table(t["sqrt"])
+    orc.set_mean_threads(threads)
+    try:
+        for shape, seed, kw in (((44, 40, 48), 5, dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=4, disp_hw=3, selected_niter=25, selected_smooth=3, grid_sp_adam=2, ic=True)),
+                                ((40, 48, 36), 9, dict(mind_r=2, mind_d=1, lambda_weight=0.5, grid_sp=3, disp_hw=2, selected_niter=12, selected_smooth=0, grid_sp_adam=1, ic=False))):
+            m = ellipsoid_mask(shape, 0.35)
+            fix = phantom(shape, seed, 41) * m
+            mov = torch.roll(phantom(shape, seed, 42), (2, -1, 1), (0, 1, 2)) * m
+            out = mind.convex_adam_pt(fix, mov, dtype=torch.float32, device=torch.device("cpu"), **kw)
+            mine = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), **kw)
+            assert np.array_equal(out, mine), (shape, float(np.abs(out - mine).max()))
+    finally:
+        torch.set_num_threads(old)
+        orc.set_exp_table(None)
+        orc.set_sqrt_table(None)
+        orc.set_mean_threads(0)
