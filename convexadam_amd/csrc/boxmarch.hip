@@ -56,12 +56,12 @@ struct BMLoader {
 // x / 27 correctly rounded for every float including -0.0 (IEEE: -0.0 / 27 = -0.0)
 __device__ __forceinline__ float div27_signed(float x) { return x == 0.0f ? x : div_exact<27>(x); }
 
-template <bool BACKWARD>
+template <bool BACKWARD, bool VEC>
 __device__ __forceinline__ void bm_issue(const BMCtx& c, BMLoader& L, int gz) {
     L.reg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (L.lrow && gz >= 0 && gz < c.h) {
         const float* rowp = c.ic + (size_t)gz * c.wd + L.loff;
-        if (c.vec) L.reg = *reinterpret_cast<const float4*>(rowp);
+        if (VEC) L.reg = *reinterpret_cast<const float4*>(rowp);
         else {
             L.reg.x = rowp[0];
             if (4 * L.lq + 1 < c.d) L.reg.y = rowp[1];
@@ -74,7 +74,7 @@ __device__ __forceinline__ void bm_issue(const BMCtx& c, BMLoader& L, int gz) {
 }
 
 // loader part of step t: publish the plane fetched during the previous step, start fetching the next one
-template <int SLOT0, bool BACKWARD>
+template <int SLOT0, bool BACKWARD, bool VEC>
 __device__ __forceinline__ void bm_load_step(const BMCtx& c, BMLoader& L, int t) {
     if (L.ldr && t <= c.zn + 5) {
         float* p = L.lds0 + (t & 1) * SLOT0;                         // indices 4lq+7 .. 4lq+10: b32 + b64 + b32
@@ -82,7 +82,7 @@ __device__ __forceinline__ void bm_load_step(const BMCtx& c, BMLoader& L, int t)
         const f32x2 mid = {L.reg.y, L.reg.z};
         lds_store2(p + 1, mid);
         p[3] = L.reg.w;
-        if (t + 1 <= c.zn + 5) bm_issue<BACKWARD>(c, L, c.z0 - 3 + t + 1);
+        if (t + 1 <= c.zn + 5) bm_issue<BACKWARD, VEC>(c, L, c.z0 - 3 + t + 1);
     }
 }
 
@@ -122,7 +122,7 @@ __device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int
 // The whole march of one role.  Every role executes exactly nsteps barriers.  Lanes beyond the role's last row
 // compute on a clamped row and only their stores are masked, so that the window registers never pass through a
 // divergent merge (no register copies).
-template <int K, int QPR, int YT, bool BACKWARD, bool ADAM>
+template <int K, int QPR, int YT, bool BACKWARD, bool ADAM, bool VEC>
 __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int lane) {
     using G = BMGeomT<QPR, YT>;
     constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
@@ -153,7 +153,7 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     // one step; n = t - (3K-2) counts the input planes of this role; EMIT: n >= 2, an output plane is due
     auto step = [&](auto emit, int t) {
         constexpr bool EMIT = decltype(emit)::value;
-        bm_load_step<SLOT0, BACKWARD>(c, L, t);
+        bm_load_step<SLOT0, BACKWARD, VEC>(c, L, t);
         const float* sp = src + ((t - 1) & 1) * SRC_SLOT;
         float f[4], m[4], p[4];
 #pragma unroll
@@ -197,7 +197,7 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
                 float g[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = BACKWARD ? s[j] : div_exact<27>(s[j]);
-                if (c.vec) *reinterpret_cast<float4*>(oz + rowbase) = make_float4(g[0], g[1], g[2], g[3]);
+                if (VEC) *reinterpret_cast<float4*>(oz + rowbase) = make_float4(g[0], g[1], g[2], g[3]);
                 else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (j < ncol) oz[rowbase + j] = g[j];
@@ -210,19 +210,19 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
     int t = 0;
-    for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD>(c, L, t); cvx_barrier(); }                    // (Adam starts at t = 10)
+    for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD, VEC>(c, L, t); cvx_barrier(); }                    // (Adam starts at t = 10)
     step(No{}, t); ++t;                                 // t = 3K-2: input plane 0
     step(No{}, t); ++t;                                 // t = 3K-1: input plane 1
 #pragma unroll 1
     for (; t <= tlast; ++t) step(Yes{}, t);             // t = 3K ..: output planes
     for (; t < c.nsteps; ++t) {
-        bm_load_step<SLOT0, BACKWARD>(c, L, t);
+        bm_load_step<SLOT0, BACKWARD, VEC>(c, L, t);
         if (ADAM) bm_adam_step<QPR, YT>(c, apre, t);
         cvx_barrier();
     }
 }
 
-template <int QPR, int YT, bool BACKWARD, bool ADAM>
+template <int QPR, int YT, bool BACKWARD, bool ADAM, bool VEC>
 __global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
                                                                 int w, int d, int zc, int nzc, int nyt, float* __restrict__ P,
                                                                 float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
@@ -284,14 +284,14 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const flo
     L.lrow = L.ldr && lgy >= 0 && lgy < w && lgx >= 0 && lgx < d;
     L.loff = (unsigned)((lgy < 0 ? 0 : lgy) * d + (lgx < 0 ? 0 : lgx));
     L.lds0 = S0 + lr * G::RS + 4 * L.lq + 7;
-    bm_issue<BACKWARD>(c, L, c.z0 - 3);
+    bm_issue<BACKWARD, VEC>(c, L, c.z0 - 3);
     cvx_barrier();
 
     // role of this wavefront (wave-uniform, kept in a scalar register)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    if (wave < G::NW1) bm_run<1, QPR, YT, BACKWARD, ADAM>(c, L, wave, lane);
-    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, BACKWARD, ADAM>(c, L, wave - G::NW1, lane);
-    else bm_run<3, QPR, YT, BACKWARD, ADAM>(c, L, wave - G::NW1 - G::NW2, lane);
+    if (wave < G::NW1) bm_run<1, QPR, YT, BACKWARD, ADAM, VEC>(c, L, wave, lane);
+    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, BACKWARD, ADAM, VEC>(c, L, wave - G::NW1, lane);
+    else bm_run<3, QPR, YT, BACKWARD, ADAM, VEC>(c, L, wave - G::NW1 - G::NW2, lane);
 }
 
 bool box3_march_supported(int d) { return d <= 126; }
@@ -310,9 +310,15 @@ static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt,
     const unsigned grid = (unsigned)((3 * nyt * nxt * nzc + 7) / 8 * 8);
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec = (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave);
-    if (!backward) hipLaunchKernelGGL((k_box3_march<QPR, YT, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw);
-    else if (!P) hipLaunchKernelGGL((k_box3_march<QPR, YT, true, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw);
-    else hipLaunchKernelGGL((k_box3_march<QPR, YT, true, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw);
+#define CVX_BM_LAUNCH(B, A)                                                                                                                        \
+    do {                                                                                                                                           \
+        if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, B, A, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw); \
+        else hipLaunchKernelGGL((k_box3_march<QPR, YT, B, A, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw); \
+    } while (0)
+    if (!backward) CVX_BM_LAUNCH(false, false);
+    else if (!P) CVX_BM_LAUNCH(true, false);
+    else CVX_BM_LAUNCH(true, true);
+#undef CVX_BM_LAUNCH
     return check_last("box3_march");
 }
 
