@@ -11,7 +11,12 @@
  * Each function cites the reference lines (relative to /root/reference) it follows.
  *
  * Pinning: the oracle is checked (tests/test_oracle_vs_golden.py) against golden vectors produced
- * by importing and running the reference in the build container (tests/golden/make_golden.py).
+ * by importing and running the reference in the build container (tests/golden/make_golden*.py), and
+ * live against the reference itself where it is mounted (tests/test_oracle_vs_reference_live.py).
+ * By default three sites are not the reference's own bits (a SLEEF-style expf, the IEEE sqrt, an exactly
+ * rounded global mean: <= 1 ulp each); with the optional tables / thread count of orc_set_exp_table,
+ * orc_set_sqrt_table and orc_set_mean_threads (tests/mkl_tables.py) the oracle equals the reference
+ * BIT FOR BIT end to end, including the full-size benchmark pair after 80 Adam iterations.
  *
  * Plain C99, scalar IEEE-754 binary32 arithmetic, compiled with -ffp-contract=off so that no
  * multiply-add is fused unless written as fmaf().  OpenMP is used only over independent outputs
