@@ -298,13 +298,16 @@ def test_adam_x_tiles_vs_oracle(U, orc, shape, xsplit):
     F2 = rng.random((C,) + shape, dtype=np.float32)
     M2 = rng.random((C,) + shape, dtype=np.float32)
     P0 = (0.7 * rng.standard_normal((3,) + shape)).astype(np.float32)
-    old = L.cvx_get_option(b"box_xsplit")
+    old, old_yt = L.cvx_get_option(b"box_xsplit"), L.cvx_get_option(b"box_yt")
     L.cvx_set_option(b"box_xsplit", xsplit)
+    if shape[0] == 13:
+        L.cvx_set_option(b"box_yt", 4)                          # 4-row tiles combined with x tiles
     try:
         Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.25, 3, return_state=True)
         sm = host(U.box_smooth(dev(P0)[None], 3, 3))[0]
     finally:
         L.cvx_set_option(b"box_xsplit", old)
+        L.cvx_set_option(b"box_yt", old_yt)
     r = orc.adam_run(F2, M2, P0, 1.25, 3, want_grad=True)
     assert np.array_equal(host(Ud)[0], r["U"]) and np.array_equal(host(st["G"])[0], r["G"])
     assert np.array_equal(host(st["P"])[0], r["P"]) and np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
