@@ -68,8 +68,6 @@ __device__ __forceinline__ void bm_issue(const BMCtx& c, BMLoader& L, int gz) {
             if (4 * L.lq + 2 < c.d) L.reg.z = rowp[2];
             if (4 * L.lq + 3 < c.d) L.reg.w = rowp[3];
         }
-        // backward: every tap is gradOut / 27; the dividend may be -0.0 here, which div_exact maps to +0.0 -> sign fix
-        if (BACKWARD) { L.reg.x = div27_signed(L.reg.x); L.reg.y = div27_signed(L.reg.y); L.reg.z = div27_signed(L.reg.z); L.reg.w = div27_signed(L.reg.w); }
     }
 }
 
@@ -78,10 +76,18 @@ template <int SLOT0, bool BACKWARD, bool VEC>
 __device__ __forceinline__ void bm_load_step(const BMCtx& c, BMLoader& L, int t) {
     if (L.ldr && t <= c.zn + 5) {
         float* p = L.lds0 + (t & 1) * SLOT0;                         // indices 4lq+7 .. 4lq+10: b32 + b64 + b32
-        p[0] = L.reg.x;
-        const f32x2 mid = {L.reg.y, L.reg.z};
+        // the 8-byte store needs an even-aligned register pair, the middle of a 16-byte load is an odd one: without the barrier below
+        // the compiler carries the PAIR through the loop and copies into it right after the load is issued, i.e. it waits for the
+        // prefetch in the step that requested it.  New values defined here keep the copies (and the wait) on this side of the step.
+        float mx = L.reg.x, my = L.reg.y, mz = L.reg.z, mw = L.reg.w;
+        asm volatile("" : "+v"(my), "+v"(mz));
+        // backward: every tap is gradOut / 27 (divided here, when the plane is published -- not when it is requested, which would wait
+        // for the load at once); the dividend may be -0.0, which div_exact maps to +0.0 -> sign fix
+        if (BACKWARD) { mx = div27_signed(mx); my = div27_signed(my); mz = div27_signed(mz); mw = div27_signed(mw); }
+        p[0] = mx;
+        const f32x2 mid = {my, mz};
         lds_store2(p + 1, mid);
-        p[3] = L.reg.w;
+        p[3] = mw;
         if (t + 1 <= c.zn + 5) bm_issue<BACKWARD, VEC>(c, L, c.z0 - 3 + t + 1);
     }
 }
