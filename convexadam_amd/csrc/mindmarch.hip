@@ -55,8 +55,13 @@ template <int PLANE>
 __device__ __forceinline__ void mm_publish(const MMLoader& L, float* ring, int l, const float4& v) {
     if (!L.on) return;
     float* p = L.dst + ((l + 12) % 6) * PLANE;           // odd index: b32 + b64 + b32
+    // the 8-byte store needs an even-aligned register pair and the middle of a 16-byte load is an odd one: without re-defining the two
+    // values HERE the compiler carries the pair through the loop and copies into it right after the load is issued -- i.e. it waits
+    // for the prefetched plane in the step that requested it (same fix as in boxmarch.hip)
+    float my = v.y, mz = v.z;
+    asm volatile("" : "+v"(my), "+v"(mz));
     p[0] = v.x;
-    const f32x2 mid = {v.y, v.z};
+    const f32x2 mid = {my, mz};
     lds_store2(p + 1, mid);
     p[3] = v.w;
 }
