@@ -133,18 +133,7 @@ __device__ __forceinline__ float cvx_expf(float d) {
 // (0 = equal, 1 = one ulp above, 2 = one ulp below); installed by cvx_set_mind_exp_table, tbl == nullptr (default) = cvx_expf.
 struct ExpTable { const unsigned char* tbl; unsigned first, count; };
 ExpTable mind_exp_table();
-// exp(-q) for q >= 0 as MINDSSC evaluates it (convex_adam_utils.py:63)
-__device__ __forceinline__ float mind_exp(float q, const ExpTable& et) {
-    float r = cvx_expf(-q);
-    if (et.tbl) {                                    // kernel argument: wave-uniform
-        const unsigned b = __float_as_uint(q) & 0x7fffffffu, k = b - et.first;
-        if (b >= et.first && k < et.count) {
-            const unsigned code = (et.tbl[k >> 2] >> ((k & 3u) * 2u)) & 3u;
-            if (code) r = __uint_as_float(__float_as_uint(r) + (code == 1u ? 1u : 0xffffffffu));
-        }
-    }
-    return r;
-}
+// (applied in mind.hip::mind_normalise: the 12 table bytes of a voxel are requested together)
 
 // 16-byte LDS/global vector access that the compiler must keep as ONE b128 instruction: hipcc otherwise
 // re-splits an aligned float4 LDS load into two ds_read2_b32 (4-way bank conflicts for 16-byte lane strides).

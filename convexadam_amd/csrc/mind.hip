@@ -258,8 +258,28 @@ __device__ __forceinline__ void mind_normalise(float (&r)[12], float lo, float h
     float var = fdiv(sum, 12.0f);
     var = var < lo ? lo : var;
     var = var > hi ? hi : var;
+    if (!et.tbl) {                                   // kernel argument: wave-uniform
 #pragma unroll
-    for (int c = 0; c < 12; ++c) r[c] = mind_exp(fdiv(r[c], var), et);
+        for (int c = 0; c < 12; ++c) r[c] = cvx_expf(-fdiv(r[c], var));
+        return;
+    }
+    // reference-bits mode: the 12 table bytes are requested together (clamped index, no branch around the loads) and applied
+    // afterwards -- one memory round trip per voxel instead of twelve dependent ones
+    unsigned key[12], byte[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+        const float q = fdiv(r[c], var);
+        r[c] = cvx_expf(-q);
+        const unsigned b = __float_as_uint(q) & 0x7fffffffu, k = b - et.first;
+        key[c] = (b >= et.first && k < et.count) ? k : 0xffffffffu;
+    }
+#pragma unroll
+    for (int c = 0; c < 12; ++c) byte[c] = et.tbl[key[c] != 0xffffffffu ? (key[c] >> 2) : 0u];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+        const unsigned code = key[c] != 0xffffffffu ? (byte[c] >> ((key[c] & 3u) * 2u)) & 3u : 0u;
+        if (code) r[c] = __uint_as_float(__float_as_uint(r[c]) + (code == 1u ? 1u : 0xffffffffu));
+    }
 }
 
 // ---- reference-bits mode: `mind_var.mean()` exactly as torch evaluates it (option mind_mean_threads = T > 0) -------------------
