@@ -11,8 +11,9 @@
 // Rows are stored with a per-stage shift (stage 0: column c at index c+7, stage 1: c+6, stage 2: c+5) so that
 // every window read is one aligned ds_read_b128 + ds_read_b64 at the same index 4q+4 and every stage write one
 // aligned ds_write_b128; pass k evaluates columns 4q-3+k .. 4q+k, the last pass lands on 16-byte aligned rows of
-// the output (and of P, m, v for the fused Adam update).  No halo along x (the row pads are the zero padding of
-// avg_pool3d), 3 rows of halo along y, 3 planes (+ pipeline fill) along z.
+// the output (and of P, m, v for the fused Adam update).  Rows of up to 62 voxels: no halo along x (the row pads are the zero padding
+// of avg_pool3d); longer rows are cut into x tiles of <= 56 columns plus one aligned quad of halo per side (two half-size
+// workgroups per CU that run out of step); 3 rows of halo along y, 3 planes (+ pipeline fill) along z.
 //   forward  (ATen avg_pool3d):           out = (raster sum of 27 taps) / 27            at every pass
 //   backward (ATen avg_pool3d_backward):  out = raster sum of (tap / 27): taps are divided when they are staged
 //                                          (IEEE division, the dividend may be -0.0), the last pass stores the sum
