@@ -38,7 +38,7 @@ class PairParams(C.Structure):
                 ("lambda_weight", C.c_float), ("grid_sp", C.c_int), ("disp_hw", C.c_int), ("selected_niter", C.c_int),
                 ("selected_smooth", C.c_int), ("grid_sp_adam", C.c_int), ("ic", C.c_int), ("n_feat", C.c_int),
                 ("cost_scale", C.c_float), ("cost", C.c_int), ("n_box", C.c_int), ("n_spline_pools", C.c_int), ("corr_fast", C.c_int),
-                ("fp16_storage", C.c_int)]
+                ("fp16_storage", C.c_int), ("ctx", C.c_void_p)]
 
 
 _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -48,6 +48,13 @@ SIGNATURES = {
     "cvx_version": (_i, []),
     "cvx_last_error": (C.c_char_p, []),
     "cvx_device_count": (_i, []),
+    "cvx_context_create": (_vp, []),
+    "cvx_context_destroy": (None, [_vp]),
+    "cvx_context_bind": (_vp, [_vp]),
+    "cvx_context_set_option": (_i, [_vp, C.c_char_p, C.c_longlong]),
+    "cvx_context_get_option": (C.c_longlong, [_vp, C.c_char_p]),
+    "cvx_context_set_adam_sqrt_table": (_i, [_vp, _vp, _vp]),
+    "cvx_context_set_mind_exp_table": (_i, [_vp, _vp, C.c_uint, C.c_uint, _vp]),
     "cvx_set_adam_sqrt_table": (_i, [_vp]),
     "cvx_set_mind_exp_table": (_i, [_vp, C.c_uint, C.c_uint]),
     "cvx_expf_f32": (_i, [_vp, _vp, _sz, _vp]),

@@ -246,8 +246,10 @@ def set_adam_sqrt_table(codes=None, denormal=None, device="cuda"):
         codes = sqrt_codes_from_low_bitmaps(codes, denormal)
     tbl = codes if isinstance(codes, torch.Tensor) else torch.from_numpy(np.array(codes, dtype=np.uint8, order="C"))
     assert tbl.dtype == torch.uint8 and tbl.numel() == 3 << 21, "2-bit codes of 2^24 + 2^23 classes expected"
-    _adam_sqrt_table = tbl.to(device).contiguous()                          # kept alive here
-    check(lib().cvx_set_adam_sqrt_table(ptr(_adam_sqrt_table)))
+    _adam_sqrt_table = tbl.to(device).contiguous()                          # (the library keeps its own copy)
+    with torch.cuda.device(_adam_sqrt_table.device):
+        check(lib().cvx_context_set_adam_sqrt_table(None, ptr(_adam_sqrt_table), stream_ptr(_adam_sqrt_table.device)))
+    _adam_sqrt_table = None
 
 
 def validate_image(img, dtype=float):

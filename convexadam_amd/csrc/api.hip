@@ -2,6 +2,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <new>
 
 #include "cvx_common.h"
 
@@ -32,17 +33,78 @@ static long long env_ll(const char* name, long long dflt) {
     const char* e = getenv(name);
     return e ? atoll(e) : dflt;
 }
-Options& options() {
-    static Options o = {env_ll("CVX_MIND_TILED", 0),   env_ll("CVX_MM_TX", 0),        env_ll("CVX_MM_SLOTS", 512),          env_ll("CVX_BOX_TILED", 0),
-                        env_ll("CVX_NO_PRUNE", 0),     env_ll("CVX_CORR_UNFUSED", 0), env_ll("CVX_PRUNE_STREAM_ABOVE", -1), env_ll("CVX_CF_CENSUS", 0),
-                        env_ll("CVX_WARP_FLAT", 0),    env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 0),
-                        env_ll("CVX_BOX_XSPLIT", -1),  env_ll("CVX_MIND_MEAN_THREADS", 0)};
-    return o;
+
+// ---- contexts: variant switches + reference-build tables, per caller ------------------------------------------------------------
+// Every entry point reads its switches and tables from the context bound to the CALLING THREAD (cvx_context_bind; the whole-pair
+// entry points also accept one in cvx_pair_params.ctx) and passes them to its kernels by value at enqueue time, so two threads
+// driving two streams with different settings never see each other's state.  No context bound = the process default context
+// (what cvx_set_option and the legacy table setters modify).  Tables are COPIED into device memory the context owns: the caller
+// may free its buffer as soon as the setter returns, and the copy lives until the context is destroyed or the table replaced,
+// both of which wait for the device first (enqueued work keeps a valid table).
+}  // namespace cvx
+struct cvx_context {
+    cvx::Options opt;
+    unsigned* sqrt_tbl = nullptr;              // owned, 6 MiB (nullptr: IEEE sqrt)
+    unsigned char* exp_tbl = nullptr;          // owned (nullptr: the library's expf)
+    unsigned exp_first = 0, exp_count = 0;
+    int tbl_device = -1;                       // device the owned tables live on
+};
+namespace cvx {
+static Options env_options() {
+    return {env_ll("CVX_MIND_TILED", 0),   env_ll("CVX_MM_TX", 0),        env_ll("CVX_MM_SLOTS", 512),          env_ll("CVX_BOX_TILED", 0),
+            env_ll("CVX_NO_PRUNE", 0),     env_ll("CVX_CORR_UNFUSED", 0), env_ll("CVX_PRUNE_STREAM_ABOVE", -1), env_ll("CVX_CF_CENSUS", 0),
+            env_ll("CVX_WARP_FLAT", 0),    env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 0),
+            env_ll("CVX_BOX_XSPLIT", -1),  env_ll("CVX_MIND_MEAN_THREADS", 0)};
 }
-static const unsigned* g_adam_sqrt_tbl = nullptr;
-const unsigned* adam_sqrt_table() { return g_adam_sqrt_tbl; }
-static ExpTable g_mind_exp_tbl = {nullptr, 0u, 0u};
-ExpTable mind_exp_table() { return g_mind_exp_tbl; }
+static cvx_context& default_context() {
+    static cvx_context c = [] { cvx_context d; d.opt = env_options(); return d; }();
+    return c;
+}
+static thread_local cvx_context* t_bound = nullptr;
+static cvx_context& current_context() { return t_bound ? *t_bound : default_context(); }
+Options& options() { return current_context().opt; }
+const unsigned* adam_sqrt_table() { return current_context().sqrt_tbl; }
+ExpTable mind_exp_table() {
+    const cvx_context& c = current_context();
+    return {c.exp_tbl, c.exp_first, c.exp_tbl ? c.exp_count : 0u};
+}
+ContextScope::ContextScope(const cvx_context* c) : prev_(t_bound), active_(c != nullptr) {
+    if (active_) t_bound = const_cast<cvx_context*>(c);
+}
+ContextScope::~ContextScope() {
+    if (active_) t_bound = static_cast<cvx_context*>(prev_);
+}
+
+static void drop_table(cvx_context& c, void** slot) {
+    if (!*slot) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (c.tbl_device >= 0 && c.tbl_device != cur) (void)hipSetDevice(c.tbl_device);
+    (void)hipDeviceSynchronize();              // work already enqueued may still read the table
+    (void)hipFree(*slot);
+    if (c.tbl_device >= 0 && c.tbl_device != cur) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+    *slot = nullptr;
+}
+// device copy of `bytes` bytes at `src` (device memory of the current device) owned by the context
+static int adopt_table(cvx_context& c, const void* src, size_t bytes, void** slot, hipStream_t s, const char* what) {
+    drop_table(c, slot);
+    if (!src) return CVX_OK;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (c.tbl_device >= 0 && c.tbl_device != cur && (c.sqrt_tbl || c.exp_tbl))
+        return fail(CVX_ERR_INVALID_ARG, "%s: the context already holds a table on device %d (current device %d)", what, c.tbl_device, cur);
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(CVX_ERR_LAUNCH, "%s: cannot allocate %zu bytes for the table copy", what, bytes); }
+    if (hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFree(p);
+        return fail(CVX_ERR_LAUNCH, "%s: table copy failed", what);
+    }
+    c.tbl_device = cur;
+    *slot = p;
+    return CVX_OK;
+}
+constexpr size_t kSqrtTableBytes = ((size_t)(1u << 24) + (1u << 23)) / 4;     // two bits per class
 
 __global__ __launch_bounds__(256) void k_expf(const float* __restrict__ x, float* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = cvx_expf(x[i]);
@@ -57,25 +119,64 @@ static const OptName kOptNames[] = {{"mind_tiled", &Options::mind_tiled},     {"
 
 }  // namespace cvx
 
-extern "C" int cvx_set_option(const char* name, long long value) {
+static int set_option_of(cvx_context& c, const char* name, long long value) {
     for (const auto& o : cvx::kOptNames)
-        if (name && strcmp(name, o.name) == 0) { cvx::options().*(o.field) = value; return CVX_OK; }
+        if (name && strcmp(name, o.name) == 0) {
+            if (strcmp(name, "box_xsplit") == 0 && value > 32) return cvx::fail(CVX_ERR_INVALID_ARG, "box_xsplit %lld: at most 32 x tiles", value);
+            c.opt.*(o.field) = value;
+            return CVX_OK;
+        }
     return cvx::fail(CVX_ERR_INVALID_ARG, "cvx_set_option: unknown option '%s'", name ? name : "(null)");
 }
-extern "C" long long cvx_get_option(const char* name) {
+static long long get_option_of(const cvx_context& c, const char* name) {
     for (const auto& o : cvx::kOptNames)
-        if (name && strcmp(name, o.name) == 0) return cvx::options().*(o.field);
+        if (name && strcmp(name, o.name) == 0) return c.opt.*(o.field);
     return -1;
 }
 
-extern "C" int cvx_set_adam_sqrt_table(const void* device_table) {
-    cvx::g_adam_sqrt_tbl = static_cast<const unsigned*>(device_table);
-    return CVX_OK;
+extern "C" cvx_context* cvx_context_create(void) {
+    cvx_context* c = new (std::nothrow) cvx_context();
+    if (!c) { cvx::set_error("cvx_context_create: out of memory"); return nullptr; }
+    c->opt = cvx::default_context().opt;
+    return c;
+}
+extern "C" void cvx_context_destroy(cvx_context* c) {
+    if (!c) return;
+    if (cvx::t_bound == c) cvx::t_bound = nullptr;
+    cvx::drop_table(*c, reinterpret_cast<void**>(&c->sqrt_tbl));
+    cvx::drop_table(*c, reinterpret_cast<void**>(&c->exp_tbl));
+    delete c;
+}
+extern "C" cvx_context* cvx_context_bind(cvx_context* c) {
+    cvx_context* prev = cvx::t_bound;
+    cvx::t_bound = c;
+    return prev;
+}
+extern "C" int cvx_context_set_option(cvx_context* c, const char* name, long long value) {
+    return set_option_of(c ? *c : cvx::default_context(), name, value);
+}
+extern "C" long long cvx_context_get_option(const cvx_context* c, const char* name) {
+    return get_option_of(c ? *c : cvx::default_context(), name);
+}
+extern "C" int cvx_context_set_adam_sqrt_table(cvx_context* c, const void* device_table, void* stream) {
+    cvx_context& x = c ? *c : cvx::default_context();
+    return cvx::adopt_table(x, device_table, cvx::kSqrtTableBytes, reinterpret_cast<void**>(&x.sqrt_tbl), cvx::as_stream(stream), "cvx_context_set_adam_sqrt_table");
+}
+extern "C" int cvx_context_set_mind_exp_table(cvx_context* c, const void* device_table, unsigned first_key, unsigned count, void* stream) {
+    cvx_context& x = c ? *c : cvx::default_context();
+    if (device_table && count == 0) return cvx::fail(CVX_ERR_INVALID_ARG, "cvx_context_set_mind_exp_table: empty table");
+    const int rc = cvx::adopt_table(x, device_table, ((size_t)count + 3) / 4, reinterpret_cast<void**>(&x.exp_tbl), cvx::as_stream(stream), "cvx_context_set_mind_exp_table");
+    x.exp_first = device_table && rc == CVX_OK ? first_key : 0u;
+    x.exp_count = device_table && rc == CVX_OK ? count : 0u;
+    return rc;
 }
 
+// process default context (also what a thread without a bound context uses)
+extern "C" int cvx_set_option(const char* name, long long value) { return set_option_of(cvx::default_context(), name, value); }
+extern "C" long long cvx_get_option(const char* name) { return get_option_of(cvx::default_context(), name); }
+extern "C" int cvx_set_adam_sqrt_table(const void* device_table) { return cvx_context_set_adam_sqrt_table(nullptr, device_table, nullptr); }
 extern "C" int cvx_set_mind_exp_table(const void* device_table, unsigned first_key, unsigned count) {
-    cvx::g_mind_exp_tbl = {static_cast<const unsigned char*>(device_table), first_key, device_table ? count : 0u};
-    return CVX_OK;
+    return cvx_context_set_mind_exp_table(nullptr, device_table, first_key, count, nullptr);
 }
 extern "C" int cvx_expf_f32(const float* x, float* out, size_t n, void* stream) {
     if (n == 0) return CVX_OK;

@@ -340,7 +340,7 @@ int launch_box3_march(const float* in, float* out, int h, int w, int d, bool bac
     if (vec && d > 62 && xs != 0) {
         nxt = xs > 1 ? (int)xs : cdiv(d, 56);
         tw = (cdiv(d, nxt) + 3) / 4 * 4;
-        if (tw > 56 || tw < 8) { nxt = 1; tw = d; }
+        if (tw > 56 || tw < 8 || (nxt - 1) * tw >= d) { nxt = 1; tw = d; }      // (a requested split that would leave a tile empty is ignored)
     }
     if (nxt > 1) {
         if (options().box_yt == 4) return launch_qpr<16, 4>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);

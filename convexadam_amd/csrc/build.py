@@ -36,15 +36,13 @@ def _stale(target, deps):
 def build(force=False, verbose=False, jitter=False):
     """jitter=True: the race-stress variant (random per-wavefront delays around every barrier, cvx_common.h) as
     libconvexadam_hip_jitter.so; select it at run time with CONVEXADAM_HIP_LIB=<path>."""
-    global OBJDIR, LIB
-    if jitter:
-        OBJDIR, LIB = os.path.join(HERE, "build_jitter"), os.path.join(HERE, "libconvexadam_hip_jitter.so")
-    os.makedirs(OBJDIR, exist_ok=True)
+    objdir, lib = (os.path.join(HERE, "build_jitter"), os.path.join(HERE, "libconvexadam_hip_jitter.so")) if jitter else (OBJDIR, LIB)
+    os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith(".h")] + [os.path.join(ROOT, "include", "convexadam_hip.h"), os.path.abspath(__file__)]
     jobs = []
     for src in SOURCES:
         s = os.path.join(HERE, src)
-        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
             jobs.append([hipcc()] + FLAGS + PER_FILE_FLAGS.get(src, []) + ["-DCVX_BUILDING=1"] + (["-DCVX_RACE_JITTER=1"] if jitter else []) + ["-c", s, "-o", o])
 
@@ -62,10 +60,10 @@ def build(force=False, verbose=False, jitter=False):
         for o in outs:
             if o.strip():
                 print(o)
-    objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(lib, objs):
+        run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":

@@ -9,6 +9,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <mutex>
+
 #include "convexadam_hip.h"
 
 namespace cvx {
@@ -31,6 +33,8 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // opt in to more than 64 KiB of dynamic LDS for `kernel` (idempotent; never leaves a sticky error)
 template <typename KernelT>
 static inline void ensure_dynamic_lds(KernelT kernel, size_t bytes, size_t& granted) {
+    static std::mutex mu;                       // `granted` is a function-local static of the caller shared by all threads
+    std::lock_guard<std::mutex> lock(mu);
     if (bytes > granted) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         (void)hipGetLastError();
@@ -54,9 +58,9 @@ struct Carver {
 static inline size_t carve_size(size_t used, size_t bytes) { return align_up(used, 256) + bytes; }
 
 // ---- run-time switches between kernel variants ---------------------------------------------------------------------------------
-// One process-wide table, initialised once from the environment (CVX_<NAME IN CAPITALS>, e.g. CVX_MIND_TILED=1) and changeable through
-// cvx_set_option(); every selectable path is bit-identical, the switches exist for A/B timing and so that the test-suite can run
-// every variant (tests/test_gpu_parity.py::test_kernel_variants_agree).
+// One table per context (cvx_context_*); the default context is initialised once from the environment (CVX_<NAME IN CAPITALS>, e.g.
+// CVX_MIND_TILED=1) and changeable through cvx_set_option(); every selectable path except mind_mean_threads is bit-identical, the
+// switches exist for A/B timing and so that the test-suite can run every variant (tests/test_gpu_parity.py::test_kernel_variants_agree).
 struct Options {
     long long mind_tiled;          // 1: tiled MIND stencil instead of the z-marching one
     long long mm_tx;               // 32 / 64: tile width of the marching MIND stencil (0 = automatic)
@@ -73,8 +77,21 @@ struct Options {
     long long mind_mean_threads;   // 0: exactly rounded global mean in MINDSSC (default); T > 0: torch's own float sum with T threads
                                    //    (reference-bits mode; NOT a bit-identical variant -- it changes the clamp bounds by ulps)
 };
+// All three read the context bound to the calling thread (cvx_context_bind / cvx_pair_params.ctx), else the process default context;
+// launchers copy what they need into kernel arguments at enqueue time (api.hip).
 Options& options();
-const unsigned* adam_sqrt_table();       // device table installed by cvx_set_adam_sqrt_table (nullptr: IEEE sqrt)
+const unsigned* adam_sqrt_table();       // device table of the current context (nullptr: IEEE sqrt)
+// binds a context to the calling thread for the lifetime of the object (no-op for nullptr)
+class ContextScope {
+public:
+    explicit ContextScope(const cvx_context* c);
+    ~ContextScope();
+    ContextScope(const ContextScope&) = delete;
+    ContextScope& operator=(const ContextScope&) = delete;
+private:
+    void* prev_;
+    bool active_;
+};
 
 // ---- workgroup barrier ---------------------------------------------------------------------------------------------------------
 // Every barrier of the library goes through cvx_barrier().  The race-stress build (python -m convexadam_amd.csrc.build --jitter ->

@@ -188,6 +188,7 @@ extern "C" int cvx_last_pair_profile(const char** names_host, float* ms_host, in
 
 extern "C" size_t cvx_register_pair_workspace_bytes(const cvx_pair_params* p) {
     if (validate(p) != CVX_OK) return 0;
+    const ContextScope scope(p->ctx);
     return pair_layout(*p).total;
 }
 
@@ -213,6 +214,7 @@ extern "C" int cvx_register_pair_f32(const float* img_fixed, const float* img_mo
 
 extern "C" size_t cvx_register_pair_snapshots_workspace_bytes(const cvx_pair_params* p, int n_snap, const int* smooth_host, int n_smooth) {
     if (validate(p) != CVX_OK || n_snap < 1 || n_smooth < 1 || !smooth_host) return 0;
+    const ContextScope scope(p->ctx);
     return pair_layout(*p, n_snap, smooth_max(smooth_host, n_smooth)).total;
 }
 
@@ -238,6 +240,7 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
                                    const int* smooth_host, int n_smooth, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = validate(p);
     if (rc) return rc;
+    const ContextScope scope(p->ctx);           // switches and tables of this call (cvx_pair_params.ctx; nullptr keeps the thread's)
     CVX_REQUIRE(out_field && workspace, "cvx_register_pair_f32: null pointer");
     if (p->n_feat == 0) CVX_REQUIRE(img_fixed && img_moving, "cvx_register_pair_f32: images missing");
     else CVX_REQUIRE(feat_fixed && feat_moving, "cvx_register_pair_f32: feature volumes missing");

@@ -100,8 +100,8 @@ def set_mind_exp_table(table=None, first=EXP_FIRST, count=EXP_COUNT, device="cud
     t = table if isinstance(table, torch.Tensor) else torch.from_numpy(np.array(table, dtype=np.uint8, order="C"))
     t = t.to(device).contiguous()
     assert t.dtype == torch.uint8 and t.numel() * 4 >= count
-    _exp_table = t                                                                   # kept alive here
-    check(lib().cvx_set_mind_exp_table(ptr(t), int(first), int(count)))
+    with torch.cuda.device(t.device):                                                # (the library keeps its own copy)
+        check(lib().cvx_context_set_mind_exp_table(None, ptr(t), int(first), int(count), stream_ptr(t.device)))
 
 
 def set_mean_threads(threads=0):
@@ -123,3 +123,14 @@ def disable():
     set_mind_exp_table(None)
     set_adam_sqrt_table(None)
     set_mean_threads(0)
+
+
+def context(device="cuda", threads=None, exp_table=None, sqrt_table=None, exp_first=EXP_FIRST, exp_count=EXP_COUNT):
+    """A `convexadam_amd.context.Context` in reference-bits mode, leaving the process default context alone: `with context(...):`
+    around the calls of one thread.  Tables default to this host's (built from torch, ~15 s); pass recorded ones to reproduce another
+    host (tests/golden/mkl_vsexp_codes.xz, mkl_vssqrt_low.npz through convex_adam_utils.sqrt_codes_from_low_bitmaps)."""
+    from .context import Context
+    ctx = Context(mind_mean_threads=torch.get_num_threads() if threads is None else threads)
+    ctx.set_mind_exp_table(build_exp_table(device) if exp_table is None else exp_table, exp_first, exp_count, device=device)
+    ctx.set_adam_sqrt_table(build_sqrt_table() if sqrt_table is None else sqrt_table, device=device)
+    return ctx

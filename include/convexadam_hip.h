@@ -21,7 +21,8 @@
  *   - floating-point evaluation order follows the ATen CPU kernels the reference calls, so results
  *     are reproducible bit-for-bit against the CPU oracle (oracle/cvx_oracle.c);
  *   - state kept by the library: the thread-local error message, the optional per-thread stage timing (cvx_set_profiling), the
- *     internal stream pool of cvx_register_pairs_f32 and the process-wide variant switches of cvx_set_option -- nothing else.
+ *     per-thread internal stream pool of the whole-pair entry points, the per-thread context binding and the default context
+ *     (see "State model" below) -- nothing else; entry points are re-entrant per (thread, stream).
  */
 #ifndef CONVEXADAM_HIP_H
 #define CONVEXADAM_HIP_H
@@ -47,9 +48,38 @@ int cvx_version(void);                 /* 1000*major + minor */
 const char* cvx_last_error(void);      /* message of the last failing call on this thread */
 int cvx_device_count(void);            /* number of visible HIP devices (0 on a CPU-only host) */
 
-/* run-time switches between bit-identical kernel variants (A/B timing, variant coverage in the tests): "mind_tiled", "mm_tx", "mm_slots",
- * "box_tiled", "no_prune", "corr_unfused", "prune_stream_above", "cf_census"; initial values come from CVX_<NAME> environment variables.
- * Process-wide: set them while no call is in flight.  cvx_get_option returns -1 for an unknown name. */
+/* Run-time switches between kernel variants (A/B timing, variant coverage in the tests).  Every variant is bit-identical except
+ * "mind_mean_threads", which changes MINDSSC's clamp bounds by ulps (reference-bits mode).  Names:
+ *   mind_tiled          1: tiled MIND stencil instead of the z-marching one
+ *   mm_tx, mm_slots     tile width (32 / 64, 0 = automatic) and workgroup budget (512) of the marching MIND stencil
+ *   box_tiled           1: tiled three-box kernels in the Adam loop instead of the z-marching ones
+ *   box_yt              rows per tile of the marching three-box kernels: 8 (default) or 4
+ *   box_wg_target       workgroups the marching three-box kernels aim for (z-chunk length follows); 0 = automatic
+ *   box_xsplit          x tiles of the marching three-box kernels: -1 automatic, 0 off, 2..32 that many (ignored when a tile would be empty)
+ *   warp_flat           1: flat 64-bit gathers in the warp kernel instead of buffer loads
+ *   no_prune            1: streaming coupled-convex passes instead of branch and bound
+ *   prune_stream_above  chunk budget above which a pruned pass scans the volume (-1 = automatic)
+ *   corr_unfused        1: separate raw-SSD and box kernels instead of the fused correlation kernel
+ *   cf_census           1: the fused correlation kernel records per-workgroup residency in its workspace
+ *   mind_mean_threads   0: exactly rounded global mean in MINDSSC; T > 0: torch's float32 sum with T threads
+ * Workspace sizes (cvx_*_workspace_bytes) depend on some switches: query them with the same context / options the call will use.
+ *
+ * State model.  Switches and the two reference-build tables below live in a CONTEXT.  Every entry point uses the context bound to the
+ * calling thread (cvx_context_bind), the whole-pair entry points alternatively the one named in cvx_pair_params.ctx; settings are
+ * read when a call enqueues its kernels and travel with them, so threads that drive different streams with different contexts are
+ * independent.  A thread without a bound context uses the process default context, whose initial switch values come from CVX_<NAME>
+ * environment variables; cvx_set_option / cvx_get_option and the legacy table setters address that default context (set them while no
+ * other thread is inside the library).  cvx_get_option returns -1 for an unknown name.
+ *   cvx_context_create     new context; switches start as a copy of the default context's, no tables
+ *   cvx_context_destroy    waits for the device, frees the context and the table copies it owns
+ *   cvx_context_bind       binds ctx (NULL = default) to the calling thread, returns the previously bound one
+ *   cvx_context_set_*      ctx == NULL addresses the default context */
+typedef struct cvx_context cvx_context;
+cvx_context* cvx_context_create(void);
+void cvx_context_destroy(cvx_context* ctx);
+cvx_context* cvx_context_bind(cvx_context* ctx);
+int cvx_context_set_option(cvx_context* ctx, const char* name, long long value);
+long long cvx_context_get_option(const cvx_context* ctx, const char* name);
 int cvx_set_option(const char* name, long long value);
 long long cvx_get_option(const char* name);
 
@@ -182,19 +212,22 @@ int cvx_adam_run_f32(const float* F2, const float* M2, int C, int h, int w, int 
  * vsSqrt (convex_adam_MIND.py:179), which returns the correctly rounded root or a neighbour of it (Xeon / AVX-512 path: one ulp below
  * for 0.6 % of all inputs; EPYC hosts: one ulp above or below for 17 %); which one is a pure function of (exponent parity, mantissa)
  * and is tabulated from torch.sqrt itself (convexadam_amd/reference_bits.py; fixture of the golden host: tests/golden/mkl_vssqrt_low.npz).
- * device_table: 6 MiB on the device, kept alive by the caller -- two bits per class (0 = IEEE root, 1 = one ulp above, 2 = one ulp
+ * device_table: 6 MiB on the current device, COPIED into memory the context owns (the caller may free it after the call; the
+ * copy is released when the table is replaced or the context destroyed, after a device synchronisation) -- two bits per class (0 = IEEE root, 1 = one ulp above, 2 = one ulp
  * below), four per byte, low bits first; entries 0 .. 2^24-1 normal inputs (key = parity << 23 | mantissa), entries 2^24 ..
  * 2^24+2^23-1 denormal inputs (key = mantissa); NULL restores the IEEE sqrt (default).
  * With the table the Adam operator is bit-identical to the reference for given features at any number of iterations. */
-int cvx_set_adam_sqrt_table(const void* device_table);
+int cvx_context_set_adam_sqrt_table(cvx_context* ctx, const void* device_table, void* stream);
+int cvx_set_adam_sqrt_table(const void* device_table);                 /* default context, default stream */
 
 /* Optional, same idea for the `exp` of MINDSSC (convex_adam_utils.py:63: torch CPU -> MKL vsExp, at most one ulp from the library's
  * expf, position independent, a property of the HOST: MKL dispatches on the CPU model).  device_table: two bits per argument x <= 0,
  * entry k = key - first_key with key = bit pattern of |x| (0 = equal to the library's expf, 1 = one ulp above, 2 = one ulp below),
- * four entries per byte, low bits first; arguments outside [first_key, first_key + count) are left alone.  Kept alive by the caller;
- * NULL restores the default.  With BOTH tables of a host the whole pipeline reproduces the reference run on that host bit for bit
+ * four entries per byte, low bits first; arguments outside [first_key, first_key + count) are left alone.  Copied like the sqrt
+ * table; NULL restores the default.  With BOTH tables of a host the whole pipeline reproduces the reference run on that host bit for bit
  * (tests/golden/fullsize.npz, 80 Adam iterations).  convexadam_amd/reference_bits.py builds the tables from torch itself. */
-int cvx_set_mind_exp_table(const void* device_table, unsigned first_key, unsigned count);
+int cvx_context_set_mind_exp_table(cvx_context* ctx, const void* device_table, unsigned first_key, unsigned count, void* stream);
+int cvx_set_mind_exp_table(const void* device_table, unsigned first_key, unsigned count);      /* default context, default stream */
 /* the library's expf (no table), elementwise: out[i] = exp(x[i]); what a table for cvx_set_mind_exp_table is the difference to */
 int cvx_expf_f32(const float* x, float* out, size_t n, void* stream);
 
@@ -227,6 +260,7 @@ typedef struct cvx_pair_params {
     int corr_fast;       /* 1: fast correlation mode (see cvx_corr_opts) */
     int fp16_storage;    /* 1: pooled features and cost volume rounded to half precision, float32 accumulation
                             (the reference's GPU default dtype, convex_adam_MIND.py:79; graded by end-point error) */
+    const cvx_context* ctx;  /* switches + tables for this call; NULL: the context bound to the calling thread (else the default one) */
 } cvx_pair_params;
 
 size_t cvx_register_pair_workspace_bytes(const cvx_pair_params* p);

@@ -122,3 +122,38 @@ def test_option_table(L):
         assert L.cvx_set_option(name, 7) == 0 and L.cvx_get_option(name) == 7
         assert L.cvx_set_option(name, old) == 0
     assert L.cvx_set_option(b"bogus", 1) != 0 and L.cvx_get_option(b"bogus") == -1
+
+
+def test_contexts_are_per_caller(L):
+    """cvx_context_*: switches live in a context; a context bound to one thread is invisible to another thread and to the default
+    context; cvx_pair_params.ctx names one per call (no GPU needed: workspace queries depend on mind_mean_threads)."""
+    import threading
+    from convexadam_amd._lib import PairParams
+    from convexadam_amd.context import Context
+    base = L.cvx_mindssc_workspace_bytes(32, 32, 32, 1, 2)
+    ctx = Context(mind_mean_threads=8, box_yt=4)
+    assert ctx.get_option("mind_mean_threads") == 8 and L.cvx_get_option(b"mind_mean_threads") == 0
+    assert L.cvx_context_set_option(ctx.handle, b"bogus", 1) != 0 and L.cvx_context_get_option(ctx.handle, b"bogus") == -1
+    seen = {}
+
+    def other_thread():
+        seen["other"] = L.cvx_mindssc_workspace_bytes(32, 32, 32, 1, 2)
+
+    with ctx:
+        big = L.cvx_mindssc_workspace_bytes(32, 32, 32, 1, 2)
+        th = threading.Thread(target=other_thread)
+        th.start(); th.join()
+        with Context(mind_mean_threads=0):                       # nesting restores the outer binding
+            assert L.cvx_mindssc_workspace_bytes(32, 32, 32, 1, 2) == base
+        assert L.cvx_mindssc_workspace_bytes(32, 32, 32, 1, 2) == big
+    assert big > base and seen["other"] == base and L.cvx_mindssc_workspace_bytes(32, 32, 32, 1, 2) == base
+    # per call through cvx_pair_params.ctx
+    p = PairParams(64, 64, 64, 1, 2, 1.25, 4, 3, 5, 0, 2, 1, 0, 12.0)
+    n0 = L.cvx_register_pair_workspace_bytes(C.byref(p))
+    p.ctx = ctx.handle
+    assert L.cvx_register_pair_workspace_bytes(C.byref(p)) > n0
+    assert L.cvx_mindssc_workspace_bytes(32, 32, 32, 1, 2) == base   # the scope ended with the call
+    # tables: NULL restores the default without touching a device
+    assert L.cvx_context_set_adam_sqrt_table(ctx.handle, None, None) == 0
+    assert L.cvx_context_set_mind_exp_table(ctx.handle, None, 0, 0, None) == 0
+    ctx.close()

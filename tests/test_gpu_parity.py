@@ -1130,6 +1130,68 @@ def test_mindssc_bit_identical_to_reference_with_exp_table(U, orc, golden, refer
         assert np.array_equal(host(U.MINDSSC(img[None, None].to(DEV), 1, 2, device=DEV))[0], orc.mindssc(img.numpy(), 1, 2)), shape
 
 
+def test_two_threads_with_different_contexts_run_concurrently(M, orc, mkl):
+    """the C ABI is re-entrant per stream and holds no shared mutable state.  Two Python threads register the same pair
+    at the same time on two streams -- one with the default context, one inside a reference-bits context (golden host's exp / sqrt
+    tables, torch's 8-thread mean, another box-kernel variant) -- and each gets exactly its own mode's field, which is the oracle's
+    field for that mode.  A third context selected per call through cvx_pair_params.ctx-style binding is nested inside."""
+    import threading
+    from convexadam_amd import reference_bits as rb
+    from convexadam_amd.context import Context
+    from convexadam_amd.phantom import deformed_pair, ellipsoid_mask
+    t = mkl.golden_tables()
+    shape = (48, 56, 64)
+    fix, mov = deformed_pair(shape, 5, 3.0)
+    m = ellipsoid_mask(shape, 0.4)
+    fix, mov = (fix * m).contiguous(), (mov * m).contiguous()          # flat background: clamped variances -> the mean matters
+    kw = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=4, disp_hw=3, selected_niter=12, selected_smooth=0, grid_sp_adam=2, ic=True)
+    want_default = np.moveaxis(orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), **kw), -1, 0).astype(np.float32)
+    orc.set_exp_table(t["exp"], t["exp_first"], t["exp_count"]); orc.set_sqrt_table(t["sqrt"]); orc.set_mean_threads(8)
+    try:
+        want_bits = np.moveaxis(orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), **kw), -1, 0).astype(np.float32)
+    finally:
+        orc.set_exp_table(None); orc.set_sqrt_table(None); orc.set_mean_threads(0)
+    assert not np.array_equal(want_default, want_bits), "the two modes must differ for this test to mean anything"
+    ctx = rb.context(DEV, threads=8, exp_table=t["exp"], sqrt_table=t["sqrt"], exp_first=t["exp_first"], exp_count=t["exp_count"])
+    ctx.set_option("box_tiled", 1)
+    fd, md = fix.to(DEV), mov.to(DEV)
+    results, errors = {}, []
+    start = threading.Barrier(2)
+
+    def worker(name, context, n):
+        try:
+            s = torch.cuda.Stream(DEV)
+            outs = []
+            start.wait()
+            with torch.cuda.stream(s):
+                for _ in range(n):
+                    if context is None:
+                        outs.append(M.register_pair_device(fd, md, **kw).clone())
+                    else:
+                        with context:
+                            outs.append(M.register_pair_device(fd, md, **kw).clone())
+                s.synchronize()
+            results[name] = [host(o) for o in outs]
+        except Exception as e:                                   # surfaced by the assertion below
+            errors.append((name, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=("default", None, 6)), threading.Thread(target=worker, args=("bits", ctx, 6))]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    for o in results["default"]:
+        assert np.array_equal(o, want_default)
+    for o in results["bits"]:
+        assert np.array_equal(o, want_bits)
+    # the default context was never touched
+    from convexadam_amd import _lib
+    assert _lib.lib().cvx_get_option(b"mind_mean_threads") == 0 and _lib.lib().cvx_get_option(b"box_tiled") == 0
+    assert np.array_equal(host(M.register_pair_device(fd, md, **kw)), want_default)
+    ctx.close()
+
+
 def test_pipeline_goldens_bit_identical_to_reference_with_mkl_tables(M, golden, reference_bits):
     """Whole pipelines of tests/golden/pipeline.npz (convex only, 1 / 5 / 20 Adam iterations, final smoothing, no ic): exact."""
     g = golden("pipeline")

@@ -32,6 +32,16 @@ def pmc(d):
     return acc, cnt
 
 
+def corr_sha():
+    """sha256 over the correlation-stage sources (bench.py compares it with the tree it runs on -> roofline.traffic_stale)."""
+    import hashlib                              # (same recipe as bench.py::corr_sources_sha)
+    h = hashlib.sha256()
+    for name in ("corrfused.hip", "correlate.hip", "corrbox.hip"):
+        with open(os.path.join(ROOT, "convexadam_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def main(src, tag):
     prof = os.path.join(ROOT, "profiles")
     db = glob.glob(src + "/stats/**/*_results.db", recursive=True)
@@ -61,7 +71,8 @@ def main(src, tag):
     total = sum(r[4] for r in stage) * 1e6
     json.dump({"correlate_stage_bytes_per_launch": total, "source": "profiles/%s_pmc_hbm_traffic.txt" % tag,
                "kernels": {r[0]: r[4] * 1e6 for r in stage},
-               "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 summed over k_corr_prep, k_corr_fused (k_corr_tail_compact when the volume has an interleaved-order tail), per launch = per direction", "measured_at_commit": os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip()},
+               "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 summed over k_corr_prep, k_corr_fused (k_corr_tail_compact when the volume has an interleaved-order tail), per launch = per direction", "measured_at_commit": os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip(),
+               "corr_sources_sha16": corr_sha()},
               open(os.path.join(prof, "pmc_hbm_traffic.json"), "w"), indent=1)
     sa, sc = pmc(src + "/sq")
     names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT"]
