@@ -46,6 +46,15 @@ def mkl():
     return mkl_tables
 
 
+@pytest.fixture(scope="session")
+def nnunet():
+    """tests/nnunet_golden.py: rebuilds the reference's label features of nnunet.npz and compares fields with its captures."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import nnunet_golden
+
+    return nnunet_golden
+
+
 @pytest.fixture()
 def orc_reference_bits(orc, mkl):
     """The oracle with the golden host's two MKL tables installed: bit-identical to the reference goldens everywhere."""

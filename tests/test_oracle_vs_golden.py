@@ -168,6 +168,34 @@ def test_label_features(orc, golden):
     assert np.allclose(orc.avgpool_stride(ff, 2), g["feat_fix_pool2"], rtol=2e-6, atol=1e-7)
 
 
+def test_nnunet_pipeline_vs_reference_golden(orc, golden, nnunet):
+    """BASELINE configs[3] end to end (convex_adam_nnUNet.py:41-159 run by tests/golden/make_golden_nnunet.py, 18 channels: ATen's
+    cascade channel sum): label features -> correlation, coupled convex, inverse consistency -> Adam.  The oracle's own label
+    weights agree to 2e-6 (libm powf vs ATen's vectorised pow); FROM THE REFERENCE'S FEATURE VALUES the oracle reproduces the convex
+    stage bit for bit, the Adam horizons within the sqrt-ulp sensitivity, and -- with the golden host's sqrt table -- every horizon
+    bit for bit (no exp and no global mean on this path)."""
+    g = golden("nnunet")
+    gs, hw, gsa = (int(v) for v in g["cfg"])
+    lf, lm, ff, fm = nnunet.features(g)
+    of, om, _ = orc.label_features(lf, lm, 10.0)
+    assert of.shape == ff.shape and np.allclose(of.reshape(of.shape[0], -1).max(1), g["feat_max"], rtol=2e-6)
+    kw = dict(grid_sp=gs, disp_hw=hw, grid_sp_adam=gsa, ic=True, features=(ff, fm))
+    conv = orc.convex_adam_pipeline(None, None, lambda_weight=0, **kw)
+    nnunet.field_checks(g, "convex", conv, exact=True)
+    assert np.abs(conv).mean() > 0.3                                   # a real displacement, not the identity
+    for niter, tol in ((1, 1e-6), (5, 1e-5), (20, 1e-3)):
+        out = orc.convex_adam_pipeline(None, None, lambda_weight=1.25, selected_niter=niter, **kw)
+        assert nnunet.field_checks(g, "adam_%d" % niter, out, exact=False) < tol, niter
+    q = golden("mkl_vssqrt_low")
+    orc.set_sqrt_table(q["normal"], q["denormal"])
+    try:
+        for niter in (1, 5, 20):
+            out = orc.convex_adam_pipeline(None, None, lambda_weight=1.25, selected_niter=niter, **kw)
+            nnunet.field_checks(g, "adam_%d" % niter, out, exact=True)
+    finally:
+        orc.set_sqrt_table(None)
+
+
 def test_masked_feature_extraction(orc, golden):
     """extract_features(use_mask=True), convex_adam_MIND.py:36-54: eroded mask, half-resolution nearest-in-mask fill
     (scipy EDT on the host, as in the reference), x2 trilinear up-sampling, MIND-SSC of the filled image."""
