@@ -21,9 +21,14 @@
 
 namespace cvx {
 
-template <int QPR, int YT>
+// QPR = quads (16-byte slots) per LDS row, YT = output rows per tile, CPT = output columns per thread (4, or 2: twice the wavefronts
+// with half the per-step instruction stream each -- a step is bound by the serial issue of ONE wavefront)
+template <int QPR, int YT, int CPT = 4>
 struct BMGeomT {
-    static constexpr int RPW = 64 / QPR;                                   // rows per wavefront
+    static constexpr int TPR = QPR * 4 / CPT;                              // threads per row
+    static constexpr int RPW = 64 / TPR;                                   // rows per wavefront
+    static_assert(CPT == 4 || CPT == 2, "4 or 2 columns per thread");
+    static_assert(TPR <= 64 && 64 % TPR == 0, "a row must not straddle wavefronts");
     static constexpr int ROWS0 = YT + 6, ROWS1 = YT + 4, ROWS2 = YT + 2, ROWS3 = YT;
     static constexpr int NW1 = (ROWS1 + RPW - 1) / RPW, NW2 = (ROWS2 + RPW - 1) / RPW, NW3 = (ROWS3 + RPW - 1) / RPW;
     static constexpr int NT = 64 * (NW1 + NW2 + NW3);
@@ -41,6 +46,7 @@ struct BMCtx {
     size_t wd;                              // plane stride w*d
     unsigned e_off[2];                      // Adam variant: offset (y0+row)*d + col inside a plane of the <= 2 elements this thread updates
     unsigned e_lds[2];                      //               and their index in an S3 slot; 0xffffffff = none
+    int prio_par;                           // -1: no priority play; 0 / 1: this workgroup issues at raised priority on even / odd steps
     bool vec;
     AdamConsts ac;
 };
@@ -99,9 +105,9 @@ __device__ __forceinline__ void bm_load_step(const BMCtx& c, BMLoader& L, int t)
 // not on the critical path of the step barrier.
 struct BMAdamPre { float p[2], m[2], v[2]; };
 
-template <int QPR, int YT>
+template <int QPR, int YT, int CPT>
 __device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int t) {
-    using G = BMGeomT<QPR, YT>;
+    using G = BMGeomT<QPR, YT, CPT>;
     constexpr int SLOT3 = G::ROWS3 * G::RS;
     if (t >= 10 && t <= c.zn + 9) {
         const size_t po = (size_t)(c.z0 + t - 10) * c.wd;             // uniform plane offset
@@ -129,24 +135,26 @@ __device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int
 // The whole march of one role.  Every role executes exactly nsteps barriers.  Lanes beyond the role's last row
 // compute on a clamped row and only their stores are masked, so that the window registers never pass through a
 // divergent merge (no register copies).
-template <int K, int QPR, int YT, bool BACKWARD, bool ADAM, bool VEC>
+template <int K, int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC>
 __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int lane) {
-    using G = BMGeomT<QPR, YT>;
+    using G = BMGeomT<QPR, YT, CPT>;
     constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
     constexpr int ROWS = YT + 6 - 2 * K;
     constexpr int SRC_SLOT = K == 1 ? SLOT0 : (K == 2 ? SLOT1 : SLOT2), DST_SLOT = K == 1 ? SLOT1 : SLOT2;
-    const int r_raw = wk * G::RPW + lane / QPR, q = lane % QPR;
+    constexpr int WIN = CPT + 2;                                         // window columns per row
+    const int r_raw = wk * G::RPW + lane / G::TPR, q = lane % G::TPR;
     const bool active = r_raw < ROWS;
     const int r = active ? r_raw : ROWS - 1;
-    const int c0 = 4 * q - 3 + K;
+    const int c0 = CPT * q - 3 + K;                                      // first output column (local)
     const int gy = c.y0 - 3 + K + r;
     const bool rowok = active && gy >= 0 && gy < c.w;
-    bool ok[4];
+    bool ok[CPT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ok[j] = rowok && c.xl0 + c0 + j >= 0 && c.xl0 + c0 + j < c.d;
-    const float* src = (K == 1 ? c.S0 : (K == 2 ? c.S1 : c.S2)) + r * G::RS + 4 * q + 4;
-    float* dst = (K == 1 ? c.S1 : c.S2) + r * G::RS + 4 * q + 4;
-    const int gx = c.xl0 + 4 * q;                                        // pass 3: first global column of this quad
+    for (int j = 0; j < CPT; ++j) ok[j] = rowok && c.xl0 + c0 + j >= 0 && c.xl0 + c0 + j < c.d;
+    // window of pass K = columns c0-1 .. c0+CPT of stage K-1 = indices CPT*q+4 .. (stage shifts 7, 6, 5); outputs at CPT*q+4 .. of stage K
+    const float* src = (K == 1 ? c.S0 : (K == 2 ? c.S1 : c.S2)) + r * G::RS + CPT * q + 4;
+    float* dst = (K == 1 ? c.S1 : c.S2) + r * G::RS + CPT * q + 4;
+    const int gx = c.xl0 + CPT * q;                                      // pass 3: first global column of this thread
     const int ncol = gx >= c.ox0 ? c.ox1 - gx : 0;                       //         and how many of its columns this workgroup owns
     const unsigned rowbase = (unsigned)((gy < 0 ? 0 : gy) * c.d + (gx < 0 ? 0 : gx));
     const int tlast = c.zn + 5 + K;
@@ -155,63 +163,81 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     // Register state: two running sums per output column.  The 27-tap raster-order sum of output plane z is
     // ((0 + taps(z-1)) + taps(z)) + taps(z+1); when input plane n arrives the thread finishes plane n-1 from `mid` (= prefix of
     // planes n-2, n-1), advances `mid` from `pre` (= taps of plane n-1 added to +0.0) and restarts `pre`: every tap is read once
-    // and only the newest plane's 3 x 6 window is live (the rows are a rolled loop: 6 window registers).
-    float mid[4] = {0.f, 0.f, 0.f, 0.f}, pre[4] = {0.f, 0.f, 0.f, 0.f};
+    // and only the newest plane's 3 x WIN window is live.
+    float mid[CPT], pre[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) { mid[j] = 0.f; pre[j] = 0.f; }
     // one step; n = t - (3K-2) counts the input planes of this role; EMIT: n >= 2, an output plane is due
     auto step = [&](auto emit, int t) {
         constexpr bool EMIT = decltype(emit)::value;
+        if (c.prio_par >= 0) {                         // (wave-uniform) the two workgroups of a CU take turns at the issue arbitration
+            if ((t + c.prio_par) & 1) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         bm_load_step<SLOT0, BACKWARD, VEC>(c, L, t);
         const float* sp = src + ((t - 1) & 1) * SRC_SLOT;
-        float f[4], m[4], p[4];
+        float f[CPT], m[CPT], p[CPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { f[j] = mid[j]; m[j] = pre[j]; p[j] = 0.0f; }       // (+0.0 + tap: a -0.0 tap must not survive, like ATen's sum)
-        float win[3][6];
+        for (int j = 0; j < CPT; ++j) { f[j] = mid[j]; m[j] = pre[j]; p[j] = 0.0f; }       // (+0.0 + tap: a -0.0 tap must not survive, like ATen's sum)
+        float win[3][WIN];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {                 // all three rows in flight: one LDS round trip per step
-            const f32x4 a = lds_load4(sp + i * G::RS);
-            const f32x2 b = lds_load2(sp + i * G::RS + 4);
-            win[i][0] = a.x; win[i][1] = a.y; win[i][2] = a.z; win[i][3] = a.w; win[i][4] = b.x; win[i][5] = b.y;
+            if (CPT == 4) {
+                const f32x4 a = lds_load4(sp + i * G::RS);
+                const f32x2 b = lds_load2(sp + i * G::RS + 4);
+                win[i][0] = a.x; win[i][1] = a.y; win[i][2] = a.z; win[i][3] = a.w; win[i][WIN - 2] = b.x; win[i][WIN - 1] = b.y;
+            } else {
+                const f32x2 a = lds_load2(sp + i * G::RS);
+                const f32x2 b = lds_load2(sp + i * G::RS + 2);
+                win[i][0] = a.x; win[i][1] = a.y; win[i][WIN - 2] = b.x; win[i][WIN - 1] = b.y;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float (&w)[6] = win[i];
+            const float (&w)[WIN] = win[i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < CPT; ++j) {
                 f[j] += w[j]; m[j] += w[j]; p[j] += w[j];
                 f[j] += w[j + 1]; m[j] += w[j + 1]; p[j] += w[j + 1];
                 f[j] += w[j + 2]; m[j] += w[j + 2]; p[j] += w[j + 2];
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { mid[j] = m[j]; pre[j] = p[j]; }
-        const float (&s)[4] = f;
+        for (int j = 0; j < CPT; ++j) { mid[j] = m[j]; pre[j] = p[j]; }
+        const float (&s)[CPT] = f;
         if (EMIT) {
             const int gz = c.z0 - (2 * K + 3) + t;
             const bool planeok = gz >= 0 && gz < c.h;
             if (K < 3) {
-                f32x4 o;
-                o.x = (planeok && ok[0]) ? div_exact<27>(s[0]) : 0.0f;
-                o.y = (planeok && ok[1]) ? div_exact<27>(s[1]) : 0.0f;
-                o.z = (planeok && ok[2]) ? div_exact<27>(s[2]) : 0.0f;
-                o.w = (planeok && ok[3]) ? div_exact<27>(s[3]) : 0.0f;
-                if (active) lds_store4(dst + (t & 1) * DST_SLOT, o);
+                float o[CPT];
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) o[j] = (planeok && ok[j]) ? div_exact<27>(s[j]) : 0.0f;
+                if (active) {
+                    if (CPT == 4) lds_store4(dst + (t & 1) * DST_SLOT, f32x4{o[0], o[1], o[CPT - 2], o[CPT - 1]});
+                    else lds_store2(dst + (t & 1) * DST_SLOT, f32x2{o[0], o[1]});
+                }
             } else if (ADAM) {
                 // plain adjoint sums of this plane -> S3 (index = column + 4); consumed by bm_adam_step of the next step
-                const f32x4 o = {s[0], s[1], s[2], s[3]};
-                if (active) lds_store4(c.S3 + (t & 1) * (G::ROWS3 * G::RS) + r * G::RS + 4 * q + 4, o);
+                float* o3 = c.S3 + (t & 1) * (G::ROWS3 * G::RS) + r * G::RS + CPT * q + 4;
+                if (active) {
+                    if (CPT == 4) lds_store4(o3, f32x4{s[0], s[1], s[CPT - 2], s[CPT - 1]});
+                    else lds_store2(o3, f32x2{s[0], s[1]});
+                }
             } else if (planeok && rowok && ncol > 0) {
                 float* oz = c.oc + (size_t)gz * c.wd;
-                float g[4];
+                float g[CPT];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = BACKWARD ? s[j] : div_exact<27>(s[j]);
-                if (VEC) *reinterpret_cast<float4*>(oz + rowbase) = make_float4(g[0], g[1], g[2], g[3]);
-                else {
+                for (int j = 0; j < CPT; ++j) g[j] = BACKWARD ? s[j] : div_exact<27>(s[j]);
+                if (VEC) {
+                    if (CPT == 4) *reinterpret_cast<float4*>(oz + rowbase) = make_float4(g[0], g[1], g[CPT - 2], g[CPT - 1]);
+                    else *reinterpret_cast<float2*>(oz + rowbase) = make_float2(g[0], g[1]);
+                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (j < ncol) oz[rowbase + j] = g[j];
+                    for (int j = 0; j < CPT; ++j) if (j < ncol) oz[rowbase + j] = g[j];
                 }
             }
         }
-        if (ADAM) bm_adam_step<QPR, YT>(c, apre, t);
+        if (ADAM) bm_adam_step<QPR, YT, CPT>(c, apre, t);
         cvx_barrier();
     };
     using Yes = std::integral_constant<bool, true>;
@@ -224,17 +250,22 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     for (; t <= tlast; ++t) step(Yes{}, t);             // t = 3K ..: output planes
     for (; t < c.nsteps; ++t) {
         bm_load_step<SLOT0, BACKWARD, VEC>(c, L, t);
-        if (ADAM) bm_adam_step<QPR, YT>(c, apre, t);
+        if (ADAM) bm_adam_step<QPR, YT, CPT>(c, apre, t);
         cvx_barrier();
     }
 }
 
-template <int QPR, int YT, bool BACKWARD, bool ADAM, bool VEC>
-__global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
+template <int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC>
+__global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
                                                                 int w, int d, int zc, int nzc, int nyt, float* __restrict__ P,
                                                                 float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
-                                                                float* __restrict__ gsave, int vec_ok, int nxt, int tw) {
-    using G = BMGeomT<QPR, YT>;
+                                                                float* __restrict__ gsave, int vec_ok, int nxt, int tw,
+                                                                unsigned long long* __restrict__ census, int prio_mode) {
+    using G = BMGeomT<QPR, YT, CPT>;
+    if (census && threadIdx.x == 0) {
+        census[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        census[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+    }
     constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
     __shared__ __attribute__((aligned(16))) float S0[2 * SLOT0];
     __shared__ __attribute__((aligned(16))) float S1[2 * SLOT1];
@@ -265,6 +296,9 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const flo
     c.nsteps = c.zn + (ADAM ? 10 : 9);
     c.vec = vec_ok != 0;
     c.ac = ac;
+    // prio_mode 1: alternate by step, phase from the workgroup's slot id on its CU (HW_ID.TG_ID); 2: the same from the block index
+    c.prio_par = prio_mode == 1 ? (int)((__builtin_amdgcn_s_getreg((4 << 0) | (16 << 6) | (3 << 11))) & 1u)
+               : prio_mode == 2 ? (int)((blockIdx.x >> 8) & 1u) : -1;
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * SLOT0; i += G::NT) S0[i] = 0.0f;
     for (int i = tid; i < 2 * SLOT1; i += G::NT) S1[i] = 0.0f;
@@ -293,20 +327,26 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT>::NT)) void k_box3_march(const flo
     L.lds0 = S0 + lr * G::RS + 4 * L.lq + 7;
     bm_issue<BACKWARD, VEC>(c, L, c.z0 - 3);
     cvx_barrier();
+    if (census) {                                        // arrival of the first input plane
+        const float4 probe = L.reg;
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(probe.x));
+        if (threadIdx.x == 0) census[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 
     // role of this wavefront (wave-uniform, kept in a scalar register)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    if (wave < G::NW1) bm_run<1, QPR, YT, BACKWARD, ADAM, VEC>(c, L, wave, lane);
-    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, BACKWARD, ADAM, VEC>(c, L, wave - G::NW1, lane);
-    else bm_run<3, QPR, YT, BACKWARD, ADAM, VEC>(c, L, wave - G::NW1 - G::NW2, lane);
+    if (wave < G::NW1) bm_run<1, QPR, YT, CPT, BACKWARD, ADAM, VEC>(c, L, wave, lane);
+    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, CPT, BACKWARD, ADAM, VEC>(c, L, wave - G::NW1, lane);
+    else bm_run<3, QPR, YT, CPT, BACKWARD, ADAM, VEC>(c, L, wave - G::NW1 - G::NW2, lane);
+    if (census && threadIdx.x == 0) census[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
 bool box3_march_supported(int d) { return d <= 126; }
 
-template <int QPR, int YT>
+template <int QPR, int YT, int CPT = 4>
 static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt, int tw, bool backward, float* P, float* m, float* v,
                       AdamConsts ac, float* gsave, hipStream_t s) {
-    using G = BMGeomT<QPR, YT>;
+    using G = BMGeomT<QPR, YT, CPT>;
     const int nyt = cdiv(w, YT);
     long long wg_target = options().box_wg_target;                            // workgroups to aim for (z chunks follow from it);
     if (wg_target <= 0) wg_target = nxt > 1 ? 512 : 256;                      // 0 = automatic: two x-tile workgroups share a CU
@@ -317,10 +357,13 @@ static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt,
     const unsigned grid = (unsigned)((3 * nyt * nxt * nzc + 7) / 8 * 8);
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec = (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave);
+    // debugging aid (option census_ptr): forward kernel -> slots [0, 4096), adjoint kernel -> [4096, 8192)
+    unsigned long long* census = reinterpret_cast<unsigned long long*>(options().census_ptr);
+    if (census && backward) census += 4 * 1024;
 #define CVX_BM_LAUNCH(B, A)                                                                                                                        \
     do {                                                                                                                                           \
-        if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, B, A, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw); \
-        else hipLaunchKernelGGL((k_box3_march<QPR, YT, B, A, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw); \
+        if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio); \
+        else hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio); \
     } while (0)
     if (!backward) CVX_BM_LAUNCH(false, false);
     else if (!P) CVX_BM_LAUNCH(true, false);
@@ -342,8 +385,11 @@ int launch_box3_march(const float* in, float* out, int h, int w, int d, bool bac
         tw = (cdiv(d, nxt) + 3) / 4 * 4;
         if (tw > 56 || tw < 8 || (nxt - 1) * tw >= d) { nxt = 1; tw = d; }      // (a requested split that would leave a tile empty is ignored)
     }
+    const bool cpt2 = options().box_cpt == 2;                                    // two columns per thread (x tiles / short rows only)
     if (nxt > 1) {
         if (options().box_yt == 4) return launch_qpr<16, 4>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);
+        if (cpt2) return launch_qpr<16, 8, 2>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);
+        if (options().box_yt == 16) return launch_qpr<16, 16>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);
         return launch_qpr<16, 8>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);
     }
     if (options().box_yt == 4) {              // 4-row tiles: 9-wave workgroups, three per CU
@@ -351,8 +397,8 @@ int launch_box3_march(const float* in, float* out, int h, int w, int d, bool bac
         if (d <= 62) return launch_qpr<16, 4>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
         return launch_qpr<32, 4>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
     }
-    if (d <= 30) return launch_qpr<8, 8>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
-    if (d <= 62) return launch_qpr<16, 8>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
+    if (d <= 30) return cpt2 ? launch_qpr<8, 8, 2>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s) : launch_qpr<8, 8>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
+    if (d <= 62) return cpt2 ? launch_qpr<16, 8, 2>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s) : launch_qpr<16, 8>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
     return launch_qpr<32, 8>(in, out, h, w, d, 1, d, backward, P, m, v, ac, gsave, s);
 }
 

@@ -74,6 +74,10 @@ struct Options {
     long long box_yt;              // rows per tile of the marching three-box kernels: 8 (default) or 4
     long long box_wg_target;       // workgroups the z-marching three-box kernels of the Adam loop aim for (z-chunk length follows); 0 = automatic
     long long box_xsplit;          // x tiles of the marching three-box kernels: -1 automatic (rows > 62 columns: tiles of <= 56), 0 off
+    long long box_cpt;             // output columns per thread of the marching three-box kernels: 4, or 2 (x tiles / rows <= 62 columns only)
+    long long box_prio;            // marching three-box kernels: 1 / 2 = the workgroups sharing a CU alternate their issue priority step by step
+    long long census_ptr;          // debugging aid: device address of a uint64 buffer; the Adam-loop kernels record per workgroup
+                                   //    {start, first data, end} in 100 MHz ticks (s_memrealtime) + placement there (0 = off)
     long long mind_mean_threads;   // 0: exactly rounded global mean in MINDSSC (default); T > 0: torch's own float sum with T threads
                                    //    (reference-bits mode; NOT a bit-identical variant -- it changes the clamp bounds by ulps)
 };

@@ -32,8 +32,12 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
                                                    int h, int w, int d, const float* __restrict__ U,
                                                    const float* __restrict__ bh, const float* __restrict__ bw,
                                                    const float* __restrict__ bd, float gsc, float cH, float cW, float cD,
-                                                   float* __restrict__ gU) {
+                                                   float* __restrict__ gU, unsigned long long* __restrict__ census) {
     const size_t V = (size_t)h * w * d;
+    if (census && threadIdx.x == 0) {                   // debugging aid (option census_ptr, tools/adam_census.py)
+        census[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        census[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+    }
     // 4 x 4 x 16 voxel tile per workgroup: the 8-corner footprints of a tile overlap in L1 (each moving-feature
     // record is fetched from L2 about 1.7x instead of 4x with a linear mapping)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so XCD q takes the q-th contiguous slab of
@@ -136,6 +140,7 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
         t = acc +  (cW * (2.0f * (uc - nb[a][5]))); acc = y > 0 ? t : acc;
         (gU + (size_t)a * V)[p] = acc;
     }
+    if (census && threadIdx.x == 0) census[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
 
@@ -150,8 +155,10 @@ int launch_warp_grad(const float* Fcl, const float* Mcl, int C, int h, int w, in
                      const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s) {
     const int CP = (C + 3) / 4 * 4;
     const dim3 gv((unsigned)((cdiv(d, 16) * cdiv(w, 4) * cdiv(h, 4) + 7) / 8 * 8));     // multiple of the 8 XCDs
-    if (options().warp_flat) hipLaunchKernelGGL(k_warp_grad<false>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU);
-    else hipLaunchKernelGGL(k_warp_grad<true>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU);
+    unsigned long long* census = reinterpret_cast<unsigned long long*>(options().census_ptr);       // debugging aid: slots [8192, ..)
+    if (census) census += 8 * 1024;
+    if (options().warp_flat) hipLaunchKernelGGL(k_warp_grad<false>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census);
+    else hipLaunchKernelGGL(k_warp_grad<true>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census);
     return check_last("warp_grad");
 }
 
