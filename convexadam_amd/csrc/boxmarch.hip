@@ -35,6 +35,12 @@ struct BMGeomT {
     static constexpr int RS = 4 * QPR + 8;                                 // LDS row stride in floats
 };
 
+// Optional explicit work list (kernel argument, 2 KB): entry = z0 | zn << 12 | column << 20 for workgroup blockIdx.x, 0xffffffff =
+// no work.  Used for UNEVEN z chunks: with two workgroups per CU the one dispatched second shares an already busy CU and
+// advances ~25 % slower per step than the first one (tools/adam_census.py: 13.3 vs 16.9 us for equal chunks), so the
+// workgroups of the second dispatch round get shorter chunks and both rounds finish together.
+struct BMTable { int n; unsigned v[512]; };
+
 // per-workgroup constants shared by the three roles
 struct BMCtx {
     const float* ic;                       // input channel
@@ -260,7 +266,7 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(cons
                                                                 int w, int d, int zc, int nzc, int nyt, float* __restrict__ P,
                                                                 float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
                                                                 float* __restrict__ gsave, int vec_ok, int nxt, int tw,
-                                                                unsigned long long* __restrict__ census, int prio_mode) {
+                                                                unsigned long long* __restrict__ census, int prio_mode, BMTable tbl) {
     using G = BMGeomT<QPR, YT, CPT>;
     if (census && threadIdx.x == 0) {
         census[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -271,11 +277,22 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(cons
     __shared__ __attribute__((aligned(16))) float S1[2 * SLOT1];
     __shared__ __attribute__((aligned(16))) float S2[2 * SLOT2];
     __shared__ __attribute__((aligned(16))) float S3[ADAM ? 2 * G::ROWS3 * G::RS : 4];
-    // XCD-aware order: XCD q (workgroups q, q+8, ..) takes the q-th contiguous run of (channel, y tile, x tile, z chunk) tuples
-    const int nblk = 3 * nyt * nxt * nzc;
-    const int b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    if (b >= nblk) return;
-    const int zi = b % nzc, xi = (b / nzc) % nxt, yi = (b / (nzc * nxt)) % nyt, ch = b / (nzc * nxt * nyt);
+    int xi, yi, ch, z0w, znw;
+    if (tbl.n > 0) {                                   // explicit work list (uneven z chunks)
+        const unsigned e = tbl.v[blockIdx.x];
+        if (e == 0xffffffffu) return;
+        const int col = (int)(e >> 20);
+        z0w = (int)(e & 0xfffu); znw = (int)((e >> 12) & 0xffu);
+        xi = col % nxt; yi = (col / nxt) % nyt; ch = col / (nxt * nyt);
+    } else {
+        // XCD-aware order: XCD q (workgroups q, q+8, ..) takes the q-th contiguous run of (channel, y tile, x tile, z chunk) tuples
+        const int nblk = 3 * nyt * nxt * nzc;
+        const int b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+        if (b >= nblk) return;
+        const int zi = b % nzc;
+        xi = (b / nzc) % nxt; yi = (b / (nzc * nxt)) % nyt; ch = b / (nzc * nxt * nyt);
+        z0w = zi * zc; znw = min(zc, h - z0w);
+    }
     const size_t V = (size_t)h * w * d;
     BMCtx c;
     c.ic = in + (size_t)ch * V;
@@ -286,13 +303,13 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(cons
     c.gs = gsave ? gsave + (size_t)ch * V : nullptr;
     c.S0 = S0; c.S1 = S1; c.S2 = S2; c.S3 = S3;
     c.wd = (size_t)w * d;
-    c.h = h; c.w = w; c.d = d; c.z0 = zi * zc; c.y0 = yi * YT;
+    c.h = h; c.w = w; c.d = d; c.z0 = z0w; c.y0 = yi * YT;
     // x tiles (nxt > 1): tw columns each plus one quad of halo on either side, so that every 16-byte access stays aligned; the three
     // passes lose one column per side each, the tile's own columns are local 4 .. 4 + tw - 1
     c.xl0 = nxt > 1 ? xi * tw - 4 : 0;
     c.ox0 = nxt > 1 ? xi * tw : 0;
     c.ox1 = nxt > 1 ? min(d, (xi + 1) * tw) : d;
-    c.zn = min(zc, h - c.z0);
+    c.zn = znw;
     c.nsteps = c.zn + (ADAM ? 10 : 9);
     c.vec = vec_ok != 0;
     c.ac = ac;
@@ -343,6 +360,54 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(cons
 
 bool box3_march_supported(int d) { return d <= 126; }
 
+// Work list with uneven z chunks for a chip of 8 XCDs x 32 CUs (blockIdx.x % 8 = XCD, workgroups of an XCD are dealt to its CUs in
+// index order): `ncol` columns (channel x y tile x x tile) of h planes, k chunks each; XCD q owns a contiguous run of columns; its
+// first 32 workgroups (first dispatch round: alone on a CU, or the older of two) get the long chunks, the rest the short ones;
+// ratio_pct = long : short in percent.  Returns false when the shape does not give 33..64 workgroups per XCD (uniform chunks then).
+static bool bm_uneven_table(BMTable& T, unsigned& grid, int h, int ncol, long long ratio_pct) {
+    if (ratio_pct <= 100 || ncol < 8 || ncol > 256) return false;
+    const int k = 512 / ncol;
+    if (k < 2 || k > 64) return false;
+    int colq0[9];
+    for (int q = 0; q <= 8; ++q) colq0[q] = (int)((long long)q * ncol / 8);
+    int maxn = 0;
+    for (int q = 0; q < 8; ++q) {
+        const int nq = (colq0[q + 1] - colq0[q]) * k;
+        if (nq <= 32 || nq > 64) return false;
+        maxn = nq > maxn ? nq : maxn;
+    }
+    const double rho = (double)ratio_pct / 100.0;
+    for (int i = 0; i < 512; ++i) T.v[i] = 0xffffffffu;
+    for (int q = 0; q < 8; ++q) {
+        const int cols = colq0[q + 1] - colq0[q];
+        const int base = 32 / cols, rem = 32 % cols;                 // long chunks per column: 32 in this XCD
+        int jl = 0, js = 32;                                         // next long / short slot of this XCD
+        for (int ci = 0; ci < cols; ++ci) {
+            const int nL = base + (ci < rem ? 1 : 0), nS = k - nL;
+            if (nL > k) return false;
+            const double S = (double)h / (rho * nL + nS), Lg = rho * S;
+            if (S < 4.0 || Lg > 200.0) return false;
+            // alternate long / short as far as the counts allow, starting with the more numerous kind; boundaries by rounding the running sum
+            double acc = 0.0;
+            int z0 = 0, l = nL, sh = nS;
+            for (int c = 0; c < k; ++c) {
+                const bool lng = (l > sh) || (l == sh && (c & 1) == 0) ? l > 0 : !(sh > 0);
+                acc += lng ? Lg : S;
+                if (lng) --l; else --sh;
+                const int z1 = c == k - 1 ? h : (int)(acc + 0.5);
+                const int zn = z1 - z0;
+                if (zn < 1 || zn > 255) return false;
+                const int j = lng ? jl++ : js++;
+                T.v[j * 8 + q] = (unsigned)z0 | ((unsigned)zn << 12) | ((unsigned)(colq0[q] + ci) << 20);
+                z0 = z1;
+            }
+        }
+    }
+    T.n = 8 * maxn;
+    grid = (unsigned)T.n;
+    return true;
+}
+
 template <int QPR, int YT, int CPT = 4>
 static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt, int tw, bool backward, float* P, float* m, float* v,
                       AdamConsts ac, float* gsave, hipStream_t s) {
@@ -354,7 +419,10 @@ static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt,
     int zc = cdiv(h, nz_target);
     if (zc < 4) zc = 4;
     const int nzc = cdiv(h, zc);
-    const unsigned grid = (unsigned)((3 * nyt * nxt * nzc + 7) / 8 * 8);
+    unsigned grid = (unsigned)((3 * nyt * nxt * nzc + 7) / 8 * 8);
+    static thread_local BMTable tbl;                                          // (2 KB, passed by value)
+    tbl.n = 0;
+    if (options().box_wg_target <= 0 && nxt > 1 && h <= 4095) (void)bm_uneven_table(tbl, grid, h, 3 * nyt * nxt, options().box_uneven);
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec = (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave);
     // debugging aid (option census_ptr): forward kernel -> slots [0, 4096), adjoint kernel -> [4096, 8192)
@@ -362,8 +430,8 @@ static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt,
     if (census && backward) census += 4 * 1024;
 #define CVX_BM_LAUNCH(B, A)                                                                                                                        \
     do {                                                                                                                                           \
-        if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio); \
-        else hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio); \
+        if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        else hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
     } while (0)
     if (!backward) CVX_BM_LAUNCH(false, false);
     else if (!P) CVX_BM_LAUNCH(true, false);

@@ -22,6 +22,6 @@ def field_checks(g, name, out, exact):
     sub = out if ref.shape == out.shape else out[::2, ::2, ::2]
     if exact:
         assert np.array_equal(sub.astype(np.float32), ref), "%s: max |diff| %g" % (name, np.abs(sub - ref).max())
-        o = out.astype(np.float64)
+        o = np.ascontiguousarray(out, dtype=np.float64)            # (same summation order as the capture: numpy sums pairwise in memory order)
         assert np.allclose(o.sum((0, 1, 2)), g[name + "_sum"], rtol=1e-14, atol=0) and np.allclose((o * o).sum((0, 1, 2)), g[name + "_sumsq"], rtol=1e-14, atol=0)
     return float(np.sqrt(((sub.astype(np.float64) - ref.astype(np.float64)) ** 2).sum(-1)).mean())

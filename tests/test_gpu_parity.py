@@ -317,6 +317,34 @@ def test_adam_x_tiles_vs_oracle(U, orc, shape, xsplit):
     assert np.array_equal(sm, b)
 
 
+def test_adam_box_kernel_variants_with_two_workgroups_per_cu(U, orc):
+    """A control grid large enough for two marching workgroups per CU (80 x 64 x 112: 48 columns of 10 z chunks): the default work
+    list with UNEVEN z chunks (first dispatch round long, second short: option box_uneven = length ratio in percent), equal chunks,
+    extreme ratios, two columns per thread (box_cpt), 16-row tiles and the priority play (box_prio) all give the oracle's bits."""
+    from convexadam_amd import _lib
+    L = _lib.lib()
+    shape = (80, 64, 112)
+    rng = np.random.default_rng(80)
+    C = 4
+    F2 = rng.random((C,) + shape, dtype=np.float32)
+    M2 = rng.random((C,) + shape, dtype=np.float32)
+    P0 = (0.7 * rng.standard_normal((3,) + shape)).astype(np.float32)
+    r = orc.adam_run(F2, M2, P0, 1.25, 2, want_grad=True)
+    args = (dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.25, 2)
+    for opts in ({}, {"box_uneven": 100}, {"box_uneven": 130}, {"box_uneven": 400}, {"box_cpt": 2}, {"box_cpt": 2, "box_uneven": 100},
+                 {"box_yt": 16, "box_wg_target": 256}, {"box_prio": 1}, {"box_prio": 2, "box_uneven": 100}):
+        old = {k: L.cvx_get_option(k.encode()) for k in opts}
+        for k, v in opts.items():
+            assert L.cvx_set_option(k.encode(), v) == 0
+        try:
+            Ud, st = U.adam_run(*args, return_state=True)
+        finally:
+            for k, v in old.items():
+                L.cvx_set_option(k.encode(), v)
+        assert np.array_equal(host(Ud)[0], r["U"]) and np.array_equal(host(st["G"])[0], r["G"]), opts
+        assert np.array_equal(host(st["P"])[0], r["P"]) and np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"]), opts
+
+
 def test_adam_snapshots_and_resume(U, orc, golden):
     g = golden("adam")
     args = (dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]))
@@ -1018,7 +1046,7 @@ def test_full_size_sweep_extreme_settings(M):
 
 # ---- (9) every selectable kernel variant -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opt,val", [("mind_tiled", 1), ("mm_tx", 32), ("mm_tx", 64), ("mm_slots", 64), ("box_tiled", 1), ("no_prune", 1),
-                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0)])
+                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0), ("box_cpt", 2), ("box_uneven", 100), ("box_prio", 1)])
 def test_kernel_variants_agree(M, U, orc, golden, opt, val):
     """The library's run-time switches (cvx_set_option / CVX_* environment variables) select alternative kernels for the same
     operators; every one of them is bit-identical to the oracle: marching vs tiled MIND stencil and its tile shapes, marching vs tiled
