@@ -79,6 +79,7 @@ SIGNATURES = {
     "cvx_correlate_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "cvx_coupled_convex_workspace_bytes": (_sz, [_i] * 4),
     "cvx_coupled_convex_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "cvx_coupled_convex_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "cvx_inverse_consistency_workspace_bytes": (_sz, [_i] * 3),
     "cvx_inverse_consistency_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cvx_resize_trilinear_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
@@ -90,6 +91,8 @@ SIGNATURES = {
     "cvx_smooth_f32": (_i, [_vp, _i, _i, _i, _i, C.POINTER(Smoother), _i, _vp, _vp, _sz, _vp]),
     "cvx_adam_run_smoother_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                                        _vp, C.POINTER(Smoother), _vp, _sz, _vp]),
+    "cvx_adam_run_ex_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                 _vp, C.POINTER(Smoother), _i, _vp, _sz, _vp]),
     "cvx_register_pair_workspace_bytes": (_sz, [C.POINTER(PairParams)]),
     "cvx_register_pair_f32": (_i, [_vp, _vp, _vp, _vp, C.POINTER(PairParams), _vp, _vp, _vp, _sz, _vp]),
     "cvx_register_pair_snapshots_workspace_bytes": (_sz, [_vp, _i, _vp, _i]),

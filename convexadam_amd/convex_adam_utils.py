@@ -72,12 +72,14 @@ def avg_pool(features, g):
     return out if features.dtype == torch.float32 else out.to(features.dtype)
 
 
-def correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch=12, cost="ssd", n_box=2, mode="exact"):
+def correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch=12, cost="ssd", n_box=2, mode="exact", storage="fp32"):
     """SSD cost volume + argmin.  (convex_adam_utils.py:72-89)
     mind_fix/mind_mov (1,C,H',W',D') -> ssd (n^3,H',W',D') in the feature dtype, argmin (H',W',D') int64.
     Beyond the packaged operator: cost="sad" and n_box=1 are the variants of the challenge scripts
     (l2r_2021_convexAdam_task3_docker.py:54,56; task2:60); mode="fast" evaluates the same sums with fused multiply-adds and
-    separable box filters (last-bit differences, not bit-compatible with the reference; SSD with two boxes only)."""
+    separable box filters (last-bit differences, not bit-compatible with the reference; SSD with two boxes only);
+    storage="fp16" returns the cost volume as a torch.float16 tensor written by the kernel itself (float32 accumulation, one rounding
+    on the way out: the reference's GPU default dtype, convex_adam_MIND.py:79,89-91) and the argmin of the stored values."""
     mind_fix = require_device_tensor(mind_fix, "mind_fix")
     mind_mov = require_device_tensor(mind_mov, "mind_mov")
     H, W, D = int(shape[0]), int(shape[1]), int(shape[2])
@@ -87,17 +89,20 @@ def correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch=12, cost="ssd", n_
                          (tuple(mind_fix.shape), tuple(mind_mov.shape), ch, h, w, d))
     n = 2 * int(disp_hw) + 1
     f, m = f32c(mind_fix), f32c(mind_mov)
-    ssd = torch.empty((n ** 3, h, w, d), dtype=torch.float32, device=f.device)
+    if storage not in ("fp32", "fp16"):
+        raise ValueError("correlate: storage must be 'fp32' or 'fp16'")
+    half = storage == "fp16"
+    ssd = torch.empty((n ** 3, h, w, d), dtype=torch.float16 if half else torch.float32, device=f.device)
     am = torch.empty((h, w, d), dtype=torch.int64, device=f.device)
     nws = lib().cvx_correlate_workspace_bytes(ch, h, w, d, int(disp_hw))
     ws = workspace(nws, f.device)
     if cost not in ("ssd", "sad") or n_box not in (1, 2) or mode not in ("exact", "fast"):
         raise ValueError("correlate: cost must be 'ssd' or 'sad', n_box 1 or 2, mode 'exact' or 'fast'")
-    opts = CorrOpts(1 if cost == "sad" else 0, int(n_box), 1 if mode == "fast" else 0, 0)
+    opts = CorrOpts(1 if cost == "sad" else 0, int(n_box), 1 if mode == "fast" else 0, 2 if half else 0)
     with torch.cuda.device(f.device):
         check(lib().cvx_correlate_ex_f32(ptr(f), ptr(m), ch, h, w, d, int(disp_hw), C.byref(opts), ptr(ssd), ptr(am), ptr(ws), nws,
                                          stream_ptr(f.device)))
-    if mind_fix.dtype != torch.float32:
+    if mind_fix.dtype != torch.float32 and not half:
         ssd = ssd.to(mind_fix.dtype)
     return ssd, am
 
@@ -111,14 +116,16 @@ def coupled_convex(ssd, ssd_argmin, disp_mesh_t, grid_sp, shape):
     n = int(round(K ** (1.0 / 3.0)))
     if n ** 3 != K or tuple(ssd.shape[1:]) != (h, w, d):
         raise ValueError("coupled_convex: ssd shape %s does not match (n^3,%d,%d,%d)" % (tuple(ssd.shape), h, w, d))
-    s = f32c(ssd)
+    half = ssd.dtype == torch.float16                       # fp16 storage: the passes read the half-precision volume as it is
+    s = ssd.detach().contiguous() if half else f32c(ssd)
     am = ssd_argmin.to(device=s.device, dtype=torch.int64).contiguous()
     mesh = f32c(disp_mesh_t.to(s.device)).reshape(3, K)
     out = torch.empty((1, 3, h, w, d), dtype=torch.float32, device=s.device)
     nws = lib().cvx_coupled_convex_workspace_bytes(h, w, d, (n - 1) // 2)
     ws = workspace(nws, s.device)
     with torch.cuda.device(s.device):
-        check(lib().cvx_coupled_convex_f32(ptr(s), ptr(am), ptr(mesh), h, w, d, (n - 1) // 2, ptr(out), ptr(ws), nws, stream_ptr(s.device)))
+        fn = lib().cvx_coupled_convex_f16 if half else lib().cvx_coupled_convex_f32
+        check(fn(ptr(s), ptr(am), ptr(mesh), h, w, d, (n - 1) // 2, ptr(out), ptr(ws), nws, stream_ptr(s.device)))
     return out if disp_mesh_t.dtype == torch.float32 else out.to(disp_mesh_t.dtype)
 
 
@@ -187,11 +194,12 @@ def combineDeformation3d(disp_1st, disp_2nd, identity):
 
 
 def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snapshot_iters=(), return_state=False,
-             state=None, smoother=None):
+             state=None, smoother=None, storage="fp32"):
     """Adam instance optimisation of convex_adam_MIND.py:155-182 on pooled features (1,C,h,w,d) and an
     initial control grid P0 (1,3,h,w,d) in grid units.  Returns disp_sample of the last forward pass
     (1,3,h,w,d) [and optionally snapshots / optimiser state].  `smoother` = a GaussianSmoothing / kovesi_spline object of
-    convexadam_amd.convexAdam_hyper_util replaces the three 3^3 boxes (adam_run_withconfig_shiftSpline.py:217)."""
+    convexadam_amd.convexAdam_hyper_util replaces the three 3^3 boxes (adam_run_withconfig_shiftSpline.py:217).
+    storage="fp16": the loop keeps its copies of the features in half precision (rounded once; float32 arithmetic)."""
     F2 = f32c(require_device_tensor(feat_fix, "feat_fix"))
     M2 = f32c(require_device_tensor(feat_mov, "feat_mov"))
     _, Cn, h, w, d = [int(s) for s in F2.shape]
@@ -212,10 +220,11 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
     nws = lib().cvx_adam_workspace_bytes(Cn, h, w, d)
     ws = workspace(nws, dev)
     with torch.cuda.device(dev):
-        check(lib().cvx_adam_run_smoother_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
-                                              int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
-                                              C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf),
-                                              C.byref(smoother.spec) if smoother is not None else None, ptr(ws), nws, stream_ptr(dev)))
+        check(lib().cvx_adam_run_ex_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
+                                        int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
+                                        C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf),
+                                        C.byref(smoother.spec) if smoother is not None else None, 1 if storage == "fp16" else 0,
+                                        ptr(ws), nws, stream_ptr(dev)))
     if return_state:
         return U, dict(P=P, m=m, v=v, step=step0 + int(niter), G=G, snapshots=snap_buf)
     return U

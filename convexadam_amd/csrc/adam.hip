@@ -194,7 +194,17 @@ extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C
                                          const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
                                          void* workspace, size_t workspace_bytes, void* stream) {
     return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
-                              snapshot_iters_host, n_snap, snapshots, sm, true, workspace, workspace_bytes, stream);
+                              snapshot_iters_host, n_snap, snapshots, sm, true, false, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cvx_adam_run_ex_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
+                                   float lambda_weight, int niter, int step0, float cost_scale, const float* base_h,
+                                   const float* base_w, const float* base_d, float* U, float* grad_out,
+                                   const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
+                                   int feature_storage, void* workspace, size_t workspace_bytes, void* stream) {
+    CVX_REQUIRE(feature_storage == 0 || feature_storage == 1, "cvx_adam_run_ex_f32: feature_storage must be 0 (float32) or 1 (fp16)");
+    return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
+                              snapshot_iters_host, n_snap, snapshots, sm, true, feature_storage == 1, workspace, workspace_bytes, stream);
 }
 
 // keep_state = false (whole-pair pipeline): P, m, v are scratch there and the result is U of the LAST forward pass
@@ -202,7 +212,7 @@ extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C
 int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
                        float lambda_weight, int niter, int step0, float cost_scale, const float* base_h, const float* base_w,
                        const float* base_d, float* U, float* grad_out, const int* snapshot_iters_host, int n_snap,
-                       float* snapshots, const cvx_smoother* sm, bool keep_state, void* workspace, size_t workspace_bytes,
+                       float* snapshots, const cvx_smoother* sm, bool keep_state, bool f16_features, void* workspace, size_t workspace_bytes,
                        void* stream) {
     CVX_REQUIRE(F2 && M2 && P && m && v && U && base_h && base_w && base_d, "cvx_adam_run_f32: null pointer");
     CVX_REQUIRE(C > 0 && h > 1 && w > 1 && d > 1, "cvx_adam_run_f32: bad extent C=%d %dx%dx%d", C, h, w, d);
@@ -230,7 +240,7 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
     float* Mcl = cv.take<float>((size_t)CP * (V + 1));
     if (niter > 0) {
         int rc;
-        if ((rc = launch_to_chunked(F2, C, V, Fcl, s)) || (rc = launch_to_chunked(M2, C, V, Mcl, s))) return rc;
+        if ((rc = launch_to_chunked(F2, C, V, Fcl, f16_features, s)) || (rc = launch_to_chunked(M2, C, V, Mcl, f16_features, s))) return rc;
     }
 
     // MeanBackward of lambda*mean(diff^2): lambda / N_axis in float32                       (:167-169)
@@ -249,7 +259,7 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
         else if ((rc = launch_smoother(P, U, t1, 3, h, w, d, *sm, false, s))) return rc;
         const bool last = it == niter - 1;
         if (!(last && !keep_state && !grad_out)) {
-        if ((rc = launch_warp_grad(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, s))) return rc;
+        if ((rc = launch_warp_grad(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, f16_features, s))) return rc;
         float* gsave = (grad_out && it == niter - 1) ? grad_out : nullptr;
         if (fused) { if ((rc = launch_box3x3(gU, nullptr, h, w, d, true, P, m, v, ac, gsave, s))) return rc; }
         else {

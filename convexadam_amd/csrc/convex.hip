@@ -9,14 +9,31 @@
 // (cost bits << 32 | k) key -- ties resolve to the lowest k, like ATen's CPU argmin.
 // The coupled variant adds coef * sum_a (mesh[a,k] - u[a,x])^2 in the reference's evaluation order.
 // HBM-bound: K*v*4 bytes per pass, 1 + 6 passes per direction.
+#include <hip/hip_fp16.h>
 #include <stdlib.h>
 
 #include "cvx_common.h"
 
 namespace cvx {
 
-template <bool COUPLED>
-__global__ __launch_bounds__(256) void k_argmin(const float* __restrict__ ssd, const float* __restrict__ mesh,
+// Element type of the cost volume: float32, or half precision (fp16 STORAGE of the reference's GPU default, convex_adam_MIND.py:79,
+// SURVEY 8(f).4): values are widened to float32 on load -- exact -- and every comparison / sum runs in float32 as before.
+template <typename ST> struct SsdIO;
+template <> struct SsdIO<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+};
+template <> struct SsdIO<__half> {
+    static __device__ __forceinline__ float ld(const __half* p) { return __half2float(*p); }
+    static __device__ __forceinline__ float4 ld4(const __half* p) {                      // one 8-byte load
+        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+        const h16x4 r = *reinterpret_cast<const h16x4*>(p);
+        return make_float4((float)r.x, (float)r.y, (float)r.z, (float)r.w);
+    }
+};
+
+template <bool COUPLED, typename ST>
+__global__ __launch_bounds__(256) void k_argmin(const ST* __restrict__ ssd, const float* __restrict__ mesh,
                                                 const float* __restrict__ u, float coef, int K, size_t v, int kslice,
                                                 unsigned long long* __restrict__ keys) {
     const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -26,10 +43,10 @@ __global__ __launch_bounds__(256) void k_argmin(const float* __restrict__ ssd, c
     if (COUPLED) { u0 = u[x]; u1 = u[v + x]; u2 = u[2 * v + x]; }
     float best = 0.f;
     int bi = -1;
-    const float* p = ssd + (size_t)k0 * v + x;
+    const ST* p = ssd + (size_t)k0 * v + x;
 #pragma unroll 4
     for (int k = k0; k < k1; ++k, p += v) {
-        float cost = *p;
+        float cost = SsdIO<ST>::ld(p);
         if (COUPLED) {
             const float e0 = mesh[k] - u0, e1 = mesh[K + k] - u1, e2 = mesh[2 * K + k] - u2;
             float q = e0 * e0;          // (..).pow(2).sum(0): sequential over the 3 components
@@ -44,8 +61,8 @@ __global__ __launch_bounds__(256) void k_argmin(const float* __restrict__ ssd, c
 
 // Same pass with four consecutive voxels per thread (one 16-byte load per displacement plane, four loads in flight):
 // 4 KB per wavefront in flight instead of 1 KB -- the 4-byte version is latency-bound at ~4 TB/s.  Needs v % 4 == 0.
-template <bool COUPLED>
-__global__ __launch_bounds__(256) void k_argmin4(const float* __restrict__ ssd, const float* __restrict__ mesh,
+template <bool COUPLED, typename ST>
+__global__ __launch_bounds__(256) void k_argmin4(const ST* __restrict__ ssd, const float* __restrict__ mesh,
                                                  const float* __restrict__ u, float coef, int K, size_t v, int kslice,
                                                  unsigned long long* __restrict__ keys) {
     const size_t x = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -61,10 +78,10 @@ __global__ __launch_bounds__(256) void k_argmin4(const float* __restrict__ ssd, 
     }
     float best[4] = {0.f, 0.f, 0.f, 0.f};
     int bi[4] = {-1, -1, -1, -1};
-    const float* p = ssd + (size_t)k0 * v + x;
+    const ST* p = ssd + (size_t)k0 * v + x;
 #pragma unroll 4
     for (int k = k0; k < k1; ++k, p += v) {
-        const float4 q4 = *reinterpret_cast<const float4*>(p);
+        const float4 q4 = SsdIO<ST>::ld4(p);
         const float cst[4] = {q4.x, q4.y, q4.z, q4.w};
         float m0 = 0.f, m1 = 0.f, m2 = 0.f;
         if (COUPLED) { m0 = mesh[k]; m1 = mesh[K + k]; m2 = mesh[2 * K + k]; }
@@ -183,8 +200,8 @@ __device__ __forceinline__ T* shifted(T* p, ptrdiff_t bytes) {
 
 // (the kernel first evaluates u = box3(mesh[previous winners]) for its voxel -- the reference's smoothing step between two
 // passes -- and stores it for the wavefront kernel and as the running result)
-template <typename PrevT>
-__global__ __launch_bounds__(64) void k_argmin_voxel(const float* __restrict__ ssd, const float* __restrict__ mesh,
+template <typename PrevT, typename ST>
+__global__ __launch_bounds__(64) void k_argmin_voxel(const ST* __restrict__ ssd, const float* __restrict__ mesh,
                                                      float* __restrict__ u, float coef, int K, int n, int h, int w, int d,
                                                      const float* __restrict__ smin, const PrevT* __restrict__ kprev, int limit,
                                                      unsigned long long* __restrict__ list, int* __restrict__ list_count,
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const float* __restrict__ s
     if (x >= v) return;
     // the voxel's own previous winner, its cost and the per-voxel minimum do not depend on the smoothing: loads issued first
     const int kp = (int)(unsigned)kprev[x];                 // low 32 bits of a key = displacement index
-    const float ssd_kp = ssd[(size_t)kp * v + x];
+    const float ssd_kp = SsdIO<ST>::ld(ssd + (size_t)kp * v + x);
     const float sm_x = smin[x];
     float uc, ub, ua;
     smooth_winner(kprev, mesh, K, h, w, d, x, uc, ub, ua);
@@ -226,18 +243,19 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const float* __restrict__ s
                 const float pen = coef * q;                            // coeffs[j]*(...)                     (:104)
                 const float lower = c.sm + pen;                        // <= cost_k
                 if (lower > c.bound || (bi >= 0 && lower >= best)) continue;
-                const float cost = ssd[(size_t)k * v + x] + pen;       // ssd + coeffs[j]*(...)
+                const float cost = SsdIO<ST>::ld(ssd + (size_t)k * v + x) + pen;       // ssd + coeffs[j]*(...)
                 if (bi < 0 || cost < best) { best = cost; bi = k; }
             }
     if (bi < 0) { best = c.bound; bi = c.kp; }   // cannot happen (kp passes its own test); keeps the output defined
     keys[x] = pack_min_key(best, (unsigned)bi);
 }
 
-__device__ void argmin4_stream(const float* __restrict__ ssd, const float* __restrict__ mesh, const float* __restrict__ u, float coef, int K,
+template <typename ST>
+__device__ void argmin4_stream(const ST* __restrict__ ssd, const float* __restrict__ mesh, const float* __restrict__ u, float coef, int K,
                                size_t v, unsigned long long* __restrict__ keys, bool vec);
 
-template <typename PrevT>
-__global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ ssd, const float* __restrict__ mesh,
+template <typename PrevT, typename ST>
+__global__ __launch_bounds__(256) void k_argmin_wave(const ST* __restrict__ ssd, const float* __restrict__ mesh,
                                                      const float* __restrict__ u, float coef, int K, int n, size_t v,
                                                      const float* __restrict__ smin, const PrevT* __restrict__ kprev,
                                                      const unsigned long long* __restrict__ list, const int* __restrict__ list_count,
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ s
         const size_t x = (size_t)(item >> 8);
         const long long first = (long long)(item & 255) << 8;              // 256 displacements of the box: 4 per lane
         const int kp = (int)(unsigned)kprev[x];
-        const CandBox c = cand_box(mesh, u[x], u[v + x], u[2 * v + x], coef, K, n, kp, ssd[(size_t)kp * v + x], smin[x]);
+        const CandBox c = cand_box(mesh, u[x], u[v + x], u[2 * v + x], coef, K, n, kp, SsdIO<ST>::ld(ssd + (size_t)kp * v + x), smin[x]);
         const int nc = c.c_hi - c.c_lo + 1, nb = c.b_hi - c.b_lo + 1;
         int kk[4];
         float pen[4];
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ s
         }
         float val[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) val[j] = need[j] ? ssd[(size_t)kk[j] * v + x] : 0.0f;
+        for (int j = 0; j < 4; ++j) val[j] = need[j] ? SsdIO<ST>::ld(ssd + (size_t)kk[j] * v + x) : 0.0f;
         unsigned long long key = ~0ull;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -295,7 +313,8 @@ __global__ __launch_bounds__(256) void k_argmin_wave(const float* __restrict__ s
 // background, masked-out tissue -- keep their whole window), gathering them displacement by displacement would read far more
 // sectors than one coalesced scan of the volume, so the wavefront kernel then streams the whole pass like k_argmin4<true> (argmin4_stream below) instead of working through its list.  Voxels already settled by k_argmin_voxel receive the
 // same winner again through atomicMin.
-__device__ void argmin4_stream(const float* __restrict__ ssd, const float* __restrict__ mesh, const float* __restrict__ u, float coef, int K,
+template <typename ST>
+__device__ void argmin4_stream(const ST* __restrict__ ssd, const float* __restrict__ mesh, const float* __restrict__ u, float coef, int K,
                                size_t v, unsigned long long* __restrict__ keys, bool vec) {
     const int xb = (int)((((v + 3) >> 2) + 255) >> 8);                   // blocks of 256 threads x 4 voxels
     int nslices = (int)gridDim.x * 2 / xb;                                // about two tiles per workgroup
@@ -313,10 +332,10 @@ __device__ void argmin4_stream(const float* __restrict__ ssd, const float* __res
         for (int j = 0; j < 4; ++j) { const size_t x = x0 + (j < nv ? j : 0); u0[j] = u[x]; u1[j] = u[v + x]; u2[j] = u[2 * v + x]; }
         for (int k = k0; k < k1; ++k) {
             const float m0 = mesh[k], m1 = mesh[K + k], m2 = mesh[2 * K + k];
-            const float* p = ssd + (size_t)k * v + x0;
+            const ST* p = ssd + (size_t)k * v + x0;
             float c4[4];
-            if (vec) { const float4 q4 = *reinterpret_cast<const float4*>(p); c4[0] = q4.x; c4[1] = q4.y; c4[2] = q4.z; c4[3] = q4.w; }
-            else for (int j = 0; j < 4; ++j) c4[j] = j < nv ? p[j] : 0.0f;
+            if (vec) { const float4 q4 = SsdIO<ST>::ld4(p); c4[0] = q4.x; c4[1] = q4.y; c4[2] = q4.z; c4[3] = q4.w; }
+            else for (int j = 0; j < 4; ++j) c4[j] = j < nv ? SsdIO<ST>::ld(p + j) : 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j >= nv) continue;
@@ -355,11 +374,12 @@ __global__ __launch_bounds__(256) void k_keys_to_idx_min(const unsigned long lon
 }
 
 // smin[x] = ssd[argmin[x], x]: the exact minimum over the search window (argmin is the plain argmin of the same volume)
-__global__ __launch_bounds__(256) void k_gather_min(const float* __restrict__ ssd, const int* __restrict__ idx, size_t v,
+template <typename ST>
+__global__ __launch_bounds__(256) void k_gather_min(const ST* __restrict__ ssd, const int* __restrict__ idx, size_t v,
                                                     float* __restrict__ smin, Prob2 o) {
     if (blockIdx.y) { ssd = shifted(ssd, o.ssd); idx = shifted(idx, o.ws); smin = shifted(smin, o.ws); }
     const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x < v) smin[x] = ssd[(size_t)idx[x] * v + x];
+    if (x < v) smin[x] = SsdIO<ST>::ld(ssd + (size_t)idx[x] * v + x);
 }
 
 __global__ __launch_bounds__(256) void k_keys_to_index(const unsigned long long* __restrict__ keys, size_t v,
@@ -398,7 +418,8 @@ __global__ __launch_bounds__(256) void k_gather_box3(const IndexT* __restrict__ 
     out[2 * v + i] = o2;
 }
 
-static int argmin_pass(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
+template <typename ST>
+static int argmin_pass(const ST* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
                        unsigned long long* keys, bool arm, hipStream_t s) {
     if (arm && hipMemsetAsync(keys, 0xff, sizeof(unsigned long long) * v, s) != hipSuccess)
         return fail(CVX_ERR_LAUNCH, "argmin: memset failed");
@@ -413,41 +434,43 @@ static int argmin_pass(const float* ssd, const float* mesh, const float* u, floa
     nslices = cdiv(K, kslice);
     const dim3 grid(xb, nslices);
     if (vec4) {
-        if (coupled) hipLaunchKernelGGL(k_argmin4<true>, grid, dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, keys);
-        else hipLaunchKernelGGL(k_argmin4<false>, grid, dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, keys);
-    } else if (coupled) hipLaunchKernelGGL(k_argmin<true>, grid, dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, keys);
-    else hipLaunchKernelGGL(k_argmin<false>, grid, dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, keys);
+        if (coupled) hipLaunchKernelGGL((k_argmin4<true, ST>), grid, dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, keys);
+        else hipLaunchKernelGGL((k_argmin4<false, ST>), grid, dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, keys);
+    } else if (coupled) hipLaunchKernelGGL((k_argmin<true, ST>), grid, dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, keys);
+    else hipLaunchKernelGGL((k_argmin<false, ST>), grid, dim3(256), 0, s, ssd, mesh, u, coef, K, v, kslice, keys);
     return check_last("argmin");
 }
 
 // pruned coupled pass (smoothing step included): per-voxel candidate boxes, then one wavefront per 256-displacement chunk of the
 // large boxes; kprev = int32 indices (first pass) or the key buffer of the previous pass; *list_count must be zero on entry
 // (the previous pass's voxel kernel clears it through next_count; the two counters alternate)
-template <typename PrevT>
-static int argmin_pass_pruned(const float* ssd, const float* mesh, float* u, float coef, int K, int n, int h, int w, int d,
+template <typename PrevT, typename ST>
+static int argmin_pass_pruned(const ST* ssd, const float* mesh, float* u, float coef, int K, int n, int h, int w, int d,
                               const float* smin, const PrevT* kprev, unsigned long long* list, int* list_count, int* next_count,
                               unsigned long long* keys, const Prob2& o, int nprob, hipStream_t s) {
     const size_t v = (size_t)h * w * d;
-    hipLaunchKernelGGL((k_argmin_voxel<PrevT>), dim3((unsigned)cdiv64((int64_t)v, 64), nprob), dim3(64), 0, s, ssd, mesh, u, coef, K, n, h,
+    hipLaunchKernelGGL((k_argmin_voxel<PrevT, ST>), dim3((unsigned)cdiv64((int64_t)v, 64), nprob), dim3(64), 0, s, ssd, mesh, u, coef, K, n, h,
                        w, d, smin, kprev, 8, list, list_count, next_count, keys, o);
     // worst case bounded by one coalesced scan per pass: a chunk of 256 scattered reads moves about 8 KB, the scan K * v * 4 bytes
     const long long above = options().prune_stream_above >= 0 ? options().prune_stream_above : (long long)((double)K * (double)v / 2048.0);
     const int stream_above = (int)(above > 0x7fffffff ? 0x7fffffff : above);
     const int vec = (v % 4 == 0) && ((reinterpret_cast<uintptr_t>(ssd) | (uintptr_t)(o.ssd < 0 ? -o.ssd : o.ssd)) & 15) == 0;
     // voxels whose key the voxel kernel stored plainly keep it under the scan (it finds the same winner); listed voxels were armed to ~0
-    hipLaunchKernelGGL((k_argmin_wave<PrevT>), dim3(512, nprob), dim3(256), 0, s, ssd, mesh, u, coef, K, n, v, smin, kprev, list,
+    hipLaunchKernelGGL((k_argmin_wave<PrevT, ST>), dim3(512, nprob), dim3(256), 0, s, ssd, mesh, u, coef, K, n, v, smin, kprev, list,
                        list_count, keys, stream_above, vec, o);
     return check_last("argmin_pruned");
 }
 
 // plain argmin pass that leaves its (cost, index) keys in `keys` (first key buffer of a coupled-convex workspace)
-int launch_argmin_keys(const float* ssd, int K, size_t v, unsigned long long* keys, hipStream_t s) {
-    return argmin_pass(ssd, nullptr, nullptr, 0.0f, false, K, v, keys, true, s);
+int launch_argmin_keys(const void* ssd, bool f16, int K, size_t v, unsigned long long* keys, hipStream_t s) {
+    if (f16) return argmin_pass(static_cast<const __half*>(ssd), nullptr, nullptr, 0.0f, false, K, v, keys, true, s);
+    return argmin_pass(static_cast<const float*>(ssd), nullptr, nullptr, 0.0f, false, K, v, keys, true, s);
 }
 
-int launch_argmin(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
+int launch_argmin(const void* ssd, bool f16, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
                   unsigned long long* keys, int64_t* argmin_out, hipStream_t s) {
-    int rc = argmin_pass(ssd, mesh, u, coef, coupled, K, v, keys, true, s);
+    int rc = f16 ? argmin_pass(static_cast<const __half*>(ssd), mesh, u, coef, coupled, K, v, keys, true, s)
+                 : argmin_pass(static_cast<const float*>(ssd), mesh, u, coef, coupled, K, v, keys, true, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_keys_to_index, dim3((unsigned)cdiv64((int64_t)v, 256)), dim3(256), 0, s, keys, v, (int*)nullptr,
                        argmin_out);
@@ -492,13 +515,19 @@ extern "C" int cvx_coupled_convex_f32(const float* ssd, const int64_t* argmin, c
                                       int disp_hw, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     // the caller's `argmin` only seeds the first smoothing step (as in the reference); the lower bound of the pruned
     // passes is taken from the volume itself
-    return cvx::coupled_convex_impl(ssd, argmin, mesh, h, w, d, disp_hw, out, /*argmin_is_exact=*/false, workspace, workspace_bytes, stream);
+    return cvx::coupled_convex_impl(ssd, false, argmin, mesh, h, w, d, disp_hw, out, /*argmin_is_exact=*/false, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cvx_coupled_convex_f16(const void* ssd_half, const int64_t* argmin, const float* mesh, int h, int w, int d,
+                                      int disp_hw, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    return cvx::coupled_convex_impl(ssd_half, true, argmin, mesh, h, w, d, disp_hw, out, /*argmin_is_exact=*/false, workspace, workspace_bytes, stream);
 }
 
 // argmin_is_exact: `argmin` is the plain argmin of `ssd` (the whole-pair pipeline computes it itself), so ssd[argmin] is the
 // per-voxel minimum and the extra streaming pass that determines it can be skipped.
 // nprob = 2: a second, independent problem (displaced by `o`, see Prob2) is solved by the same launches.
-static int coupled_core(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
+template <typename ST>
+static int coupled_core(const ST* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
                         bool argmin_is_exact, void* workspace, size_t workspace_bytes, const Prob2& o, int nprob, void* stream) {
     // argmin == nullptr: the (cost, index) keys of the plain argmin pass sit in the first key buffer of the workspace
     const bool from_keys = argmin == nullptr;
@@ -531,7 +560,7 @@ static int coupled_core(const float* ssd, const int64_t* argmin, const float* me
             if (hipMemsetAsync(reinterpret_cast<char*>(counts) + (q ? o.ws : 0), 0, 2 * sizeof(int), s) != hipSuccess)
                 return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
         if (from_keys) hipLaunchKernelGGL(k_keys_to_idx_min, gv, dim3(256), 0, s, keys[0], v, idx, smin, o);
-        else if (argmin_is_exact) hipLaunchKernelGGL(k_gather_min, gv, dim3(256), 0, s, ssd, idx, v, smin, o);
+        else if (argmin_is_exact) hipLaunchKernelGGL(k_gather_min<ST>, gv, dim3(256), 0, s, ssd, idx, v, smin, o);
         else {
             int rc = argmin_pass(ssd, nullptr, nullptr, 0.0f, false, K, v, keys[0], true, s);   // per-voxel minimum of the volume
             if (rc) return rc;
@@ -542,8 +571,8 @@ static int coupled_core(const float* ssd, const int64_t* argmin, const float* me
             // smoothing of the previous winners + pruned argmin; keys[1], keys[2] alternate (keys[0] may hold the minimum pass)
             unsigned long long* kc = keys[1 + (it & 1)];
             int rc;
-            if (it == 0) rc = argmin_pass_pruned<int>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, idx, list, counts + (it & 1), counts + ((it + 1) & 1), kc, o, nprob, s);
-            else rc = argmin_pass_pruned<unsigned long long>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, keys[1 + ((it - 1) & 1)], list, counts + (it & 1), counts + ((it + 1) & 1), kc, o, nprob, s);
+            if (it == 0) rc = argmin_pass_pruned<int, ST>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, idx, list, counts + (it & 1), counts + ((it + 1) & 1), kc, o, nprob, s);
+            else rc = argmin_pass_pruned<unsigned long long, ST>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, keys[1 + ((it - 1) & 1)], list, counts + (it & 1), counts + ((it + 1) & 1), kc, o, nprob, s);
             if (rc) return rc;
         }
         hipLaunchKernelGGL(k_gather_box3<unsigned long long>, gv, dim3(256), 0, s, keys[1 + (5 & 1)], mesh, K, h, w, d, out, (unsigned long long*)nullptr, (int*)nullptr, o);
@@ -563,18 +592,20 @@ static int coupled_core(const float* ssd, const int64_t* argmin, const float* me
     return check_last("coupled_convex");
 }
 
-int cvx::coupled_convex_impl(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
+int cvx::coupled_convex_impl(const void* ssd, bool f16, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
                              bool argmin_is_exact, void* workspace, size_t workspace_bytes, void* stream) {
-    return coupled_core(ssd, argmin, mesh, h, w, d, disp_hw, out, argmin_is_exact, workspace, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);
+    if (f16) return coupled_core(static_cast<const __half*>(ssd), argmin, mesh, h, w, d, disp_hw, out, argmin_is_exact, workspace, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);
+    return coupled_core(static_cast<const float*>(ssd), argmin, mesh, h, w, d, disp_hw, out, argmin_is_exact, workspace, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);
 }
 
 // Forward and reverse direction of a pair in the same launches (the per-pass kernels are latency-bound at 30 000 voxels, so two
 // problems cost about as much as one).  Both argmins must be the plain argmins of their volumes; both workspaces have the size
 // cvx_coupled_convex_workspace_bytes.  Falls back to two sequential solves when pruning is switched off.  argminA == argminB ==
 // nullptr: the plain argmin passes left their (cost, index) keys at the start of the respective workspace (launch_argmin_keys).
-int cvx::coupled_convex_dual_impl(const float* ssdA, const int64_t* argminA, float* outA, void* wsA, const float* ssdB,
-                                  const int64_t* argminB, float* outB, void* wsB, const float* mesh, int h, int w, int d, int disp_hw,
-                                  size_t workspace_bytes, void* stream) {
+template <typename ST>
+static int coupled_dual_t(const ST* ssdA, const int64_t* argminA, float* outA, void* wsA, const ST* ssdB,
+                          const int64_t* argminB, float* outB, void* wsB, const float* mesh, int h, int w, int d, int disp_hw,
+                          size_t workspace_bytes, void* stream) {
     const bool no_prune = options().no_prune != 0;
     if (no_prune || !ssdB || !outB || !wsB) {
         int rc = coupled_core(ssdA, argminA, mesh, h, w, d, disp_hw, outA, true, wsA, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);
@@ -587,6 +618,12 @@ int cvx::coupled_convex_dual_impl(const float* ssdA, const int64_t* argminA, flo
         return fail(CVX_ERR_INVALID_ARG, "coupled_convex_dual: workspaces must share their alignment modulo 256");
     const Prob2 o{diff(ssdB, ssdA), diff(argminB, argminA), diff(outB, outA), diff(wsB, wsA)};
     return coupled_core(ssdA, argminA, mesh, h, w, d, disp_hw, outA, true, wsA, workspace_bytes, o, 2, stream);
+}
+int cvx::coupled_convex_dual_impl(const void* ssdA, const int64_t* argminA, float* outA, void* wsA, const void* ssdB, bool f16,
+                                  const int64_t* argminB, float* outB, void* wsB, const float* mesh, int h, int w, int d, int disp_hw,
+                                  size_t workspace_bytes, void* stream) {
+    if (f16) return coupled_dual_t(static_cast<const __half*>(ssdA), argminA, outA, wsA, static_cast<const __half*>(ssdB), argminB, outB, wsB, mesh, h, w, d, disp_hw, workspace_bytes, stream);
+    return coupled_dual_t(static_cast<const float*>(ssdA), argminA, outA, wsA, static_cast<const float*>(ssdB), argminB, outB, wsB, mesh, h, w, d, disp_hw, workspace_bytes, stream);
 }
 
 extern "C" size_t cvx_inverse_consistency_workspace_bytes(int h, int w, int d) {

@@ -261,7 +261,9 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
 extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, int h, int w, int d, int disp_hw, const cvx_corr_opts* opts,
                                     float* ssd, int64_t* argmin, void* workspace, size_t workspace_bytes, void* stream) {
     const int cost = opts ? opts->cost : 0, n_box = opts ? opts->n_box : 2, fast = opts ? opts->fast : 0, f16 = opts ? opts->f16 : 0;
-    CVX_REQUIRE((cost == 0 || cost == 1) && (n_box == 1 || n_box == 2) && (fast == 0 || fast == 1), "cvx_correlate_ex_f32: bad options");
+    CVX_REQUIRE((cost == 0 || cost == 1) && (n_box == 1 || n_box == 2) && (fast == 0 || fast == 1) && f16 >= 0 && f16 <= 2, "cvx_correlate_ex_f32: bad options");
+    CVX_REQUIRE(!(f16 && (cost != 0 || n_box != 2)), "cvx_correlate_ex_f32: fp16 storage exists for the SSD cost with two boxes only");
+    CVX_REQUIRE(!(fast && (cost != 0 || n_box != 2)), "cvx_correlate_ex_f32: the fast mode exists for the SSD cost with two boxes only");
     CVX_REQUIRE(fix && mov && ssd && workspace, "cvx_correlate_f32: null pointer");
     CVX_REQUIRE(C > 0 && C < 256 && h > 0 && w > 0 && d > 0, "cvx_correlate_f32: bad extent C=%d %dx%dx%d", C, h, w, d);
     CVX_REQUIRE(disp_hw >= 0, "cvx_correlate_f32: negative disp_hw");
@@ -277,7 +279,7 @@ extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, i
         if (rc) return rc;
         if (argmin) {
             unsigned long long* keys = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + align_up(fws, 256));
-            return launch_argmin(ssd, nullptr, nullptr, 0.0f, false, (int)K, (size_t)h * w * d, keys, argmin, s);
+            return launch_argmin(ssd, f16 == 2, nullptr, nullptr, 0.0f, false, (int)K, (size_t)h * w * d, keys, argmin, s);
         }
         return CVX_OK;
     }
@@ -312,6 +314,6 @@ extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, i
 
     int rc = launch_corr_box2(raw, (int)K, h, w, d, g.px, ssd, s);
     if (rc) return rc;
-    if (argmin) return launch_argmin(ssd, nullptr, nullptr, 0.0f, false, (int)K, (size_t)h * w * d, keys, argmin, s);
+    if (argmin) return launch_argmin(ssd, false, nullptr, nullptr, 0.0f, false, (int)K, (size_t)h * w * d, keys, argmin, s);
     return CVX_OK;
 }

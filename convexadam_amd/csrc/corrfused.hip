@@ -27,6 +27,8 @@
 // through a small side buffer.  C >= 16 (cascade sum) and planes of more than 320 quads keep the unfused path.
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "cvx_common.h"
 
 namespace cvx {
@@ -240,8 +242,11 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
 
 // ---- box stages: FIRST = reads the raw planes (else the box-1 planes), LAST = writes the cost volume (else the box-1 planes);
 // FIRST && LAST is the single-box variant of the challenge scripts (l2r_2021_convexAdam_task2_docker.py:60) ------------------------
-template <int G, bool FIRST, bool LAST, bool FAST, bool ONEBOX, bool F16>
-__device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const float* Sin, float* S1, const float* zero, float* __restrict__ ssd) {
+typedef _Float16 h16x4u __attribute__((ext_vector_type(4), aligned(2)));   // four half-precision values at 2-byte alignment
+
+// OT = element type of the cost volume: float, or __half (fp16 STORAGE: half the bytes written here and read by the argmin passes)
+template <int G, bool FIRST, bool LAST, bool FAST, bool ONEBOX, bool F16, typename OT>
+__device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const float* Sin, float* S1, const float* zero, OT* __restrict__ ssd) {
     constexpr int R = G + 2, NSUB = (G + 1) / 2;
     const int n = g.n, nn = n * n, y = it.y, q = it.q, RS = g.RS, PF = g.PF;
     float mid[G][4], pre[G][4];
@@ -255,8 +260,8 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
     const unsigned doff1 = (unsigned)((y + 1) * RS + 4 * q);
     const int c0 = FIRST ? 4 * q : 4 * q - 3;                                          // first column of the four outputs
     const unsigned vol = (unsigned)(g.h * g.w * g.d), plane = (unsigned)(g.w * g.d);
-    const unsigned ooff = 4u * (unsigned)(y * g.d + 4 * q);                            // bytes, relative to (plane base + c0 - 4q)
-    float* ssd_item = ssd + ((size_t)((4 * it.grp) * n + it.iW) * n + it.iH) * vol - (FIRST ? 0 : 3);   // uniform
+    const unsigned ooff = (unsigned)sizeof(OT) * (unsigned)(y * g.d + 4 * q);          // bytes, relative to (plane base + c0 - 4q)
+    OT* ssd_item = ssd + ((size_t)((4 * it.grp) * n + it.iW) * n + it.iH) * vol - (FIRST ? 0 : 3);   // uniform
     const size_t kstride = (size_t)nn * vol;                                           // next D-shift
     const bool full = c0 >= 0 && c0 + 3 < g.d;
     const int jlo = c0 < 0 ? -c0 : 0, jhi = min(4, g.d - c0);                          // valid columns of a partial quad
@@ -308,7 +313,16 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
                                         if (4 * q + j >= g.d) ol[j] = 0.0f;
                             } else {
                                 char* ob = reinterpret_cast<char*>(ssd_item + (size_t)k * kstride + (size_t)(m - 1) * plane);   // uniform
-                                if (full) *reinterpret_cast<f32x4u*>(ob + ooff) = f32x4u{o[0], o[1], o[2], o[3]};   // (a non-temporal store changed nothing: 393 vs 385 MB of traffic)
+                                if (sizeof(OT) == 2) {
+                                    if (full) *reinterpret_cast<h16x4u*>(ob + ooff) = h16x4u{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                                    else {
+                                        _Float16* oe = reinterpret_cast<_Float16*>(ob + ooff);
+                                        if (jlo <= 0 && jhi > 0) oe[0] = (_Float16)o[0];
+                                        if (jlo <= 1 && jhi > 1) oe[1] = (_Float16)o[1];
+                                        if (jlo <= 2 && jhi > 2) oe[2] = (_Float16)o[2];
+                                        if (jlo <= 3 && jhi > 3) oe[3] = (_Float16)o[3];
+                                    }
+                                } else if (full) *reinterpret_cast<f32x4u*>(ob + ooff) = f32x4u{o[0], o[1], o[2], o[3]};   // (a non-temporal store changed nothing: 393 vs 385 MB of traffic)
                                 else {
                                     float* oe = reinterpret_cast<float*>(ob + ooff);
                                     if (jlo <= 0 && jhi > 0) oe[0] = o[0];
@@ -328,22 +342,25 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
     }
 }
 
-// MODE bits: 1 = FAST (FMA + separable sums, not bit-compatible), 2 = SAD cost, 4 = single box, 8 = cost volume rounded to fp16
+// MODE bits: 1 = FAST (FMA + separable sums, not bit-compatible), 2 = SAD cost, 4 = single box, 8 = cost volume rounded to fp16 (values in a
+// float32 buffer), 16 = cost volume STORED as fp16 (the buffer holds __half: same values as 8, half the bytes)
 template <int G, int MODE>
 __device__ __forceinline__ void cf_roles(int role, const float* Fp, const float* Mp, const float* tail, const CFGeom& g, const CFItem& it,
-                                         float* lds, float* S0, float* S1, float* ssd) {
-    constexpr bool FAST = (MODE & 1) != 0, SAD = (MODE & 2) != 0, ONEBOX = (MODE & 4) != 0, F16 = (MODE & 8) != 0;
+                                         float* lds, float* S0, float* S1, void* ssd_any) {
+    constexpr bool FAST = (MODE & 1) != 0, SAD = (MODE & 2) != 0, ONEBOX = (MODE & 4) != 0, F16 = (MODE & 8) != 0, HALF = (MODE & 16) != 0;
+    using OT = typename std::conditional<HALF, __half, float>::type;
+    OT* ssd = static_cast<OT*>(ssd_any);
     if (role == 0) {
         if (g.C == 12) cf_raw<G, 12, FAST, SAD>(Fp, Mp, tail, g, it, S0, ONEBOX ? g.h + 2 : g.h + 4);
         else cf_raw<G, 0, FAST, SAD>(Fp, Mp, tail, g, it, S0, ONEBOX ? g.h + 2 : g.h + 4);
-    } else if (ONEBOX) cf_box<G, true, true, FAST, true, F16>(g, it, S0, S1, lds, ssd);
-    else if (role == 1) cf_box<G, true, false, FAST, false, F16>(g, it, S0, S1, lds, ssd);
-    else cf_box<G, false, true, FAST, false, F16>(g, it, S1, S1, lds, ssd);
+    } else if (ONEBOX) cf_box<G, true, true, FAST, true, F16, OT>(g, it, S0, S1, lds, ssd);
+    else if (role == 1) cf_box<G, true, false, FAST, false, F16, OT>(g, it, S0, S1, lds, ssd);
+    else cf_box<G, false, true, FAST, false, F16, OT>(g, it, S1, S1, lds, ssd);
 }
 
 template <int GMAX, int MODE>
 __global__ __launch_bounds__(1024, 8) void k_corr_fused(const float* __restrict__ Fp, const float* __restrict__ Mp,
-                                                        const float* __restrict__ tail, CFGeom g, float* __restrict__ ssd) {
+                                                        const float* __restrict__ tail, CFGeom g, void* __restrict__ ssd) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int n = g.n, nn = n * n;
@@ -423,7 +440,7 @@ void launch_corr_prep_generic(const float* fix, const float* mov, int C, int h, 
 void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int sad, float* tail, hipStream_t s);
 
 template <int MODE>
-static void cf_launch(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, float* ssd, hipStream_t s) {
+static void cf_launch(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, void* ssd, hipStream_t s) {
     constexpr bool ONEBOX = (MODE & 4) != 0;
     const size_t lds = sizeof(float) * (16 + (ONEBOX ? 1 : 2) * (size_t)(CF_GMAX + 2) * gl.PF);
     static size_t granted = 0;
@@ -433,11 +450,15 @@ static void cf_launch(const CFGeom& gl, const float* Fp, const float* Mp, const 
 }
 
 // opts: cost 0 = SSD / 1 = SAD, n_box 2 / 1, fast 0 / 1 (fast: SSD with two boxes only)
+// f16: 0 float32 cost volume; 1 values rounded to half precision, float32 buffer; 2 the buffer holds __half (fp16 storage)
 int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
-                      float* ssd, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                      void* ssd, void* workspace, size_t workspace_bytes, hipStream_t s) {
     const CFGeom g = cf_geom(C, h, w, d, hw);
+    // every argument check comes before the first launch: a refused call leaves nothing on the stream
     if (workspace_bytes < corr_fused_workspace_bytes(C, h, w, d, hw)) return fail(CVX_ERR_WORKSPACE, "correlate (fused): workspace too small");
     if (fast && (cost != 0 || n_box != 2)) return fail(CVX_ERR_UNSUPPORTED, "correlate: the fast mode exists for the SSD cost with two boxes only");
+    if (f16 && (cost != 0 || n_box != 2)) return fail(CVX_ERR_UNSUPPORTED, "correlate: fp16 storage exists for the SSD cost with two boxes only");
+    if (f16 < 0 || f16 > 2) return fail(CVX_ERR_INVALID_ARG, "correlate: f16 must be 0, 1 or 2");
     Carver cv(workspace, workspace_bytes);
     float* Fp = cv.take<float>((size_t)C * h * w * g.RS);
     float* Mp = cv.take<float>((size_t)C * g.hq * g.wq * g.dq + 8);
@@ -447,9 +468,10 @@ int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, i
     if (g.ntail > 0 && !fast) launch_corr_tail_compact(fix, mov, C, h, w, d, hw, cost, tail, s);
     CFGeom gl = g;
     gl.dbg = options().cf_census ? census_buf : nullptr;      // debugging aid: per-workgroup start / end / placement in the workspace
-    if (f16 && (cost != 0 || n_box != 2)) return fail(CVX_ERR_UNSUPPORTED, "correlate: fp16 storage exists for the SSD cost with two boxes only");
-    if (fast && f16) cf_launch<9>(gl, Fp, Mp, tail, ssd, s);
+    if (fast && f16 == 2) cf_launch<1 + 8 + 16>(gl, Fp, Mp, tail, ssd, s);
+    else if (fast && f16) cf_launch<9>(gl, Fp, Mp, tail, ssd, s);
     else if (fast) cf_launch<1>(gl, Fp, Mp, tail, ssd, s);
+    else if (f16 == 2) cf_launch<8 + 16>(gl, Fp, Mp, tail, ssd, s);
     else if (f16) cf_launch<8>(gl, Fp, Mp, tail, ssd, s);
     else if (cost == 0 && n_box == 2) cf_launch<0>(gl, Fp, Mp, tail, ssd, s);
     else if (cost == 0) cf_launch<4>(gl, Fp, Mp, tail, ssd, s);

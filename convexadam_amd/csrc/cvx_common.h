@@ -294,8 +294,9 @@ __device__ __forceinline__ float tri_sample(const Tri& t, const float* __restric
 int launch_box_zero(const float* in, float* out, int C, int H, int W, int D, int k, bool backward, hipStream_t s);
 int launch_smoother(const float* in, float* out, float* tmp, int C, int H, int W, int D, const cvx_smoother& sm, bool backward,
                     hipStream_t s);
-int launch_argmin_keys(const float* ssd, int K, size_t v, unsigned long long* keys, hipStream_t s);
-int launch_argmin(const float* ssd, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
+// (ssd: float32 cost volume, or half precision when f16 -- fp16 storage)
+int launch_argmin_keys(const void* ssd, bool f16, int K, size_t v, unsigned long long* keys, hipStream_t s);
+int launch_argmin(const void* ssd, bool f16, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
                   unsigned long long* keys, int64_t* argmin_out, hipStream_t s);
 // out = interp(in * pre_mul) / post_div   (pre_mul, post_div = 1 -> plain F.interpolate)
 int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D, float pre_mul,
@@ -334,11 +335,11 @@ __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& 
 int adam_run_impl(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v, float lambda_weight,
                   int niter, int step0, float cost_scale, const float* base_h, const float* base_w, const float* base_d, float* U,
                   float* grad_out, const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
-                  bool keep_state, void* workspace, size_t workspace_bytes, void* stream);
+                  bool keep_state, bool f16_features, void* workspace, size_t workspace_bytes, void* stream);
 // convex.hip: coupled convex regularisation behind cvx_coupled_convex_f32 (argmin_is_exact: see there)
-int coupled_convex_impl(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
+int coupled_convex_impl(const void* ssd, bool f16, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
                         bool argmin_is_exact, void* workspace, size_t workspace_bytes, void* stream);
-int coupled_convex_dual_impl(const float* ssdA, const int64_t* argminA, float* outA, void* wsA, const float* ssdB, const int64_t* argminB,
+int coupled_convex_dual_impl(const void* ssdA, const int64_t* argminA, float* outA, void* wsA, const void* ssdB, bool f16, const int64_t* argminB,
                              float* outB, void* wsB, const float* mesh, int h, int w, int d, int disp_hw, size_t workspace_bytes,
                              void* stream);
 // mind.hip: MIND-SSC delivered only through its stride poolings (pipeline path, no full-resolution descriptor)
@@ -352,14 +353,15 @@ int launch_corr_box2(const float* raw, int K, int h, int w, int d, int px, float
 bool corr_fused_supported(int C, int h, int w, int d, int hw);
 size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw);
 int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
-                      float* ssd, void* workspace, size_t workspace_bytes, hipStream_t s);
+                      void* ssd, void* workspace, size_t workspace_bytes, hipStream_t s);
 // boxmarch.hip: three chained 3^3 boxes (forward / adjoint / adjoint + Adam) for rows of at most 126 voxels
 bool box3_march_supported(int d);
 int launch_box3_march(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
                       AdamConsts ac, float* gsave, hipStream_t s);
 // warp.hip: [C][V] -> [CP/4][V][4] feature copies and the warp + data-term gradient of one Adam iteration
-int launch_to_chunked(const float* in, int C, size_t V, float* out, hipStream_t s);
+// (half: records of four half-precision values -- fp16 storage of the pooled features -- instead of four floats)
+int launch_to_chunked(const float* in, int C, size_t V, float* out, bool half, hipStream_t s);
 int launch_warp_grad(const float* Fcl, const float* Mcl, int C, int h, int w, int d, const float* U, const float* bh,
-                     const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s);
+                     const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, bool half, hipStream_t s);
 
 }  // namespace cvx

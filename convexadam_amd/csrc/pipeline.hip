@@ -89,7 +89,9 @@ static PairLayout pair_layout(const cvx_pair_params& p, int n_snap = 0, int max_
     L.fs = take(u, f * L.C * L.v);
     L.ms = take(u, f * L.C * L.v);
     L.corr_ws = take(u, cvx_correlate_workspace_bytes(L.C, L.h, L.w, L.d, p.disp_hw));
-    L.ssd = take(u, f * (size_t)L.K * L.v);
+    // fp16 storage: the cost volumes hold __half (half the bytes written by the correlation kernel and read by every argmin pass)
+    const size_t ssd_elem = p.fp16_storage ? 2 : f;
+    L.ssd = take(u, ssd_elem * (size_t)L.K * L.v);
     L.argmin = take(u, sizeof(int64_t) * L.v);
     L.mesh = take(u, f * 3 * (size_t)L.K);
     L.conv_ws = take(u, cvx_coupled_convex_workspace_bytes(L.h, L.w, L.d, p.disp_hw));
@@ -97,7 +99,7 @@ static PairLayout pair_layout(const cvx_pair_params& p, int n_snap = 0, int max_
     L.bh = take(u, f * L.h); L.bw = take(u, f * L.w); L.bd = take(u, f * L.d);
     if (p.ic) {
         // the reverse direction keeps its own cost volume: both coupled-convex solves share their launches
-        L.ssd2 = take(u, f * (size_t)L.K * L.v);
+        L.ssd2 = take(u, ssd_elem * (size_t)L.K * L.v);
         L.argmin2 = take(u, sizeof(int64_t) * L.v);
         L.conv_ws2 = take(u, cvx_coupled_convex_workspace_bytes(L.h, L.w, L.d, p.disp_hw));
         L.soft2 = take(u, f * 3 * L.v);
@@ -292,7 +294,8 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     int64_t* am = reinterpret_cast<int64_t*>(ws + L.argmin);
     // first key buffer of the coupled-convex workspace (carved exactly as coupled_core does): the plain argmin leaves its keys there
     unsigned long long* keys = Carver(ws + L.conv_ws, vws).take<unsigned long long>(L.v);
-    const cvx_corr_opts copt = {p->cost, p->n_box == 1 ? 1 : 2, p->corr_fast, p->fp16_storage};
+    const bool f16 = p->fp16_storage != 0;
+    const cvx_corr_opts copt = {p->cost, p->n_box == 1 ? 1 : 2, p->corr_fast, f16 ? 2 : 0};
     const bool variant = copt.cost || copt.n_box == 1 || copt.fast || copt.f16;
     if (p->fp16_storage) {                      // features are stored in half precision by the reference's GPU default (MIND:79)
         if ((rc = cvx_round_f16_f32(F(L.fs), (int64_t)L.C * L.v, stream)) || (rc = cvx_round_f16_f32(F(L.ms), (int64_t)L.C * L.v, stream))) return rc;
@@ -300,8 +303,8 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     if ((rc = cvx_correlate_ex_f32(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, variant ? &copt : nullptr, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
     mark("correlate", s);
     const bool no_prune = options().no_prune != 0;        // streaming coupled passes need int64 winners
-    if (no_prune) rc = launch_argmin(F(L.ssd), nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s);
-    else rc = launch_argmin_keys(F(L.ssd), L.K, L.v, keys, s);            // keys stay in the coupled workspace's first buffer
+    if (no_prune) rc = launch_argmin(F(L.ssd), f16, nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s);
+    else rc = launch_argmin_keys(F(L.ssd), f16, L.K, L.v, keys, s);            // keys stay in the coupled workspace's first buffer
     if (rc) return rc;
     mark("argmin", s);
     int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
@@ -309,13 +312,13 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
         unsigned long long* keys2 = Carver(ws + L.conv_ws2, vws).take<unsigned long long>(L.v);
         if ((rc = cvx_correlate_ex_f32(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, variant ? &copt : nullptr, F(L.ssd2), nullptr, ws + L.corr_ws, cws, stream))) return rc;
         mark("correlate_rev", s);
-        if (no_prune) rc = launch_argmin(F(L.ssd2), nullptr, nullptr, 0.0f, false, L.K, L.v, keys2, am2, s);
-        else rc = launch_argmin_keys(F(L.ssd2), L.K, L.v, keys2, s);
+        if (no_prune) rc = launch_argmin(F(L.ssd2), f16, nullptr, nullptr, 0.0f, false, L.K, L.v, keys2, am2, s);
+        else rc = launch_argmin_keys(F(L.ssd2), f16, L.K, L.v, keys2, s);
         if (rc) return rc;
         mark("argmin_rev", s);
     }
     // both coupled-convex solves in the same launches (ic) or the forward one alone
-    if ((rc = coupled_convex_dual_impl(F(L.ssd), no_prune ? am : nullptr, F(L.soft), ws + L.conv_ws, p->ic ? F(L.ssd2) : nullptr, no_prune ? am2 : nullptr,
+    if ((rc = coupled_convex_dual_impl(F(L.ssd), no_prune ? am : nullptr, F(L.soft), ws + L.conv_ws, p->ic ? F(L.ssd2) : nullptr, f16, no_prune ? am2 : nullptr,
                                        p->ic ? F(L.soft2) : nullptr, p->ic ? ws + L.conv_ws2 : nullptr, F(L.mesh), L.h, L.w, L.d,
                                        p->disp_hw, vws, stream))) return rc;
     mark("coupled_convex", s);
@@ -352,14 +355,12 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
         } else if ((rc = launch_resize(disp_hr, 3, hh, hw_, hd, F(L.P), L.h2, L.w2, L.d2, 1.0f, (float)p->grid_sp_adam, s))) return rc;
         (void)hipMemsetAsync(F(L.m), 0, sizeof(float) * 3 * L.V2, s);
         (void)hipMemsetAsync(F(L.v_), 0, sizeof(float) * 3 * L.V2, s);
-        if (p->fp16_storage) {
-            if ((rc = cvx_round_f16_f32(F(L.F2), (int64_t)L.C * L.V2, stream)) || (rc = cvx_round_f16_f32(F(L.M2), (int64_t)L.C * L.V2, stream))) return rc;
-        }
+        // (fp16 storage: the Adam loop keeps its feature records in half precision -- rounded when the records are built)
         mark("adam_setup", s);
         const cvx_smoother two_pools = {0, 2, {3, 3, 0, 0}, {0.f, 0.f, 0.f, 0.f, 0.f}};            // task3_docker.py:191
         if ((rc = adam_run_impl(F(L.F2), F(L.M2), L.C, L.h2, L.w2, L.d2, F(L.P), F(L.m), F(L.v_), p->lambda_weight,
                                 p->selected_niter, 0, p->cost_scale, F(L.bh2), F(L.bw2), F(L.bd2), F(L.U), nullptr, snap_iters_host, n_snap,
-                                n_snap ? F(L.snaps) : nullptr, p->n_spline_pools == 2 ? &two_pools : nullptr, /*keep_state=*/false, ws + L.adam_ws,
+                                n_snap ? F(L.snaps) : nullptr, p->n_spline_pools == 2 ? &two_pools : nullptr, /*keep_state=*/false, f16, ws + L.adam_ws,
                                 cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2), stream))) return rc;
         mark("adam", s);
         // disp_hr = interpolate(fitted_grid * grid_sp_adam, (H,W,D))                            (:182)

@@ -27,7 +27,32 @@ __global__ __launch_bounds__(256) void k_to_chunked(const float* __restrict__ in
     reinterpret_cast<float4*>(out)[(size_t)blockIdx.y * (V + 1) + p] = r;
 }
 
-template <bool BUF>
+// fp16 STORAGE of the pooled features (the reference's GPU default dtype, convex_adam_MIND.py:79): the same records with four
+// half-precision values (8 bytes, rounded to nearest even here); the warp kernel widens them to float32 -- exact -- on load.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_to_chunked_h(const float* __restrict__ in, int C, size_t V, uint2* __restrict__ out) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > V) return;
+    const int c0 = 4 * (int)blockIdx.y;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < V) {
+        const float* src = in + (size_t)c0 * V + p;
+        r.x = src[0];
+        if (c0 + 1 < C) r.y = src[V];
+        if (c0 + 2 < C) r.z = src[2 * V];
+        if (c0 + 3 < C) r.w = src[3 * V];
+    }
+    const h16x4 o = {(_Float16)r.x, (_Float16)r.y, (_Float16)r.z, (_Float16)r.w};          // round to nearest even
+    out[(size_t)blockIdx.y * (V + 1) + p] = __builtin_bit_cast(uint2, o);
+}
+// (plain _Float16 vectors: a __builtin_bit_cast to hip_fp16.h's __half2 made the compiler drop the second dword of the load)
+__device__ __forceinline__ float4 buffer_load8h(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, unsigned uni_off) {
+    const h16x4 v = __builtin_bit_cast(h16x4, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)uni_off, 0));
+    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+
+// HALF: records of four half-precision values (k_to_chunked_h) instead of four floats; buffer loads only
+template <bool BUF, bool HALF = false>
 __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2, const float* __restrict__ M2, int C, int CP,
                                                    int h, int w, int d, const float* __restrict__ U,
                                                    const float* __restrict__ bh, const float* __restrict__ bw,
@@ -62,12 +87,13 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
     const bool zin0 = (unsigned)z0 < (unsigned)h, zin1 = (unsigned)z1 < (unsigned)h, yin0 = (unsigned)y0 < (unsigned)w,
                yin1 = (unsigned)y1 < (unsigned)w, xin0 = (unsigned)x0 < (unsigned)d, xin1 = (unsigned)x1 < (unsigned)d;
     const int r00 = (z0 * w + y0) * d, r01 = (z0 * w + y1) * d, r10 = (z1 * w + y0) * d, r11 = (z1 * w + y1) * d;
-    const unsigned zero_rec = (unsigned)V * 16u;
+    constexpr unsigned REC = HALF ? 8u : 16u;                             // bytes per record
+    const unsigned zero_rec = (unsigned)V * REC;
     unsigned off[8];
-    off[0] = (zin0 && yin0 && xin0) ? (unsigned)(r00 + x0) * 16u : zero_rec; off[1] = (zin0 && yin0 && xin1) ? (unsigned)(r00 + x1) * 16u : zero_rec;
-    off[2] = (zin0 && yin1 && xin0) ? (unsigned)(r01 + x0) * 16u : zero_rec; off[3] = (zin0 && yin1 && xin1) ? (unsigned)(r01 + x1) * 16u : zero_rec;
-    off[4] = (zin1 && yin0 && xin0) ? (unsigned)(r10 + x0) * 16u : zero_rec; off[5] = (zin1 && yin0 && xin1) ? (unsigned)(r10 + x1) * 16u : zero_rec;
-    off[6] = (zin1 && yin1 && xin0) ? (unsigned)(r11 + x0) * 16u : zero_rec; off[7] = (zin1 && yin1 && xin1) ? (unsigned)(r11 + x1) * 16u : zero_rec;
+    off[0] = (zin0 && yin0 && xin0) ? (unsigned)(r00 + x0) * REC : zero_rec; off[1] = (zin0 && yin0 && xin1) ? (unsigned)(r00 + x1) * REC : zero_rec;
+    off[2] = (zin0 && yin1 && xin0) ? (unsigned)(r01 + x0) * REC : zero_rec; off[3] = (zin0 && yin1 && xin1) ? (unsigned)(r01 + x1) * REC : zero_rec;
+    off[4] = (zin1 && yin0 && xin0) ? (unsigned)(r10 + x0) * REC : zero_rec; off[5] = (zin1 && yin0 && xin1) ? (unsigned)(r10 + x1) * REC : zero_rec;
+    off[6] = (zin1 && yin1 && xin0) ? (unsigned)(r11 + x0) * REC : zero_rec; off[7] = (zin1 && yin1 && xin1) ? (unsigned)(r11 + x1) * REC : zero_rec;
     // forward weights in ATen's corner order and the backward factor pairs per corner (GridSampler.cpp)
     const float wgt[8] = {t.tnw, t.tne, t.tsw, t.tse, t.bnw, t.bne, t.bsw, t.bse};
     const float ax[8] = {fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0, fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0};
@@ -75,8 +101,8 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
     const float ay[8] = {fx1 - t.ix, t.ix - fx0, fx1 - t.ix, t.ix - fx0, fx1 - t.ix, t.ix - fx0, fx1 - t.ix, t.ix - fx0};
     const float bz[8] = {fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0, fy1 - t.iy, fy1 - t.iy, t.iy - fy0, t.iy - fy0};
     float gix = 0.f, giy = 0.f, giz = 0.f;
-    const unsigned foff = p * 16u;
-    const unsigned chunk_bytes = (unsigned)(V + 1) * 16u;
+    const unsigned foff = p * REC;
+    const unsigned chunk_bytes = (unsigned)(V + 1) * REC;
     // buffer descriptors: per-lane 32-bit offsets + the chunk offset in a scalar register (9 address registers instead of 18, no
     // 64-bit vector adds in the loop); the launcher guarantees CP/4 * (V + 1) * 16 < 2^32
     const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M2), 0, (int)(chunk_bytes * (unsigned)(CP / 4)), 0x00020000);
@@ -86,10 +112,10 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
         float vv[8][4], fv[4];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float4 q = BUF ? buffer_load16(mr, off[k], coff) : *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(M2) + (size_t)c0 * chunk_bytes + off[k]);
+            const float4 q = HALF ? buffer_load8h(mr, off[k], coff) : BUF ? buffer_load16(mr, off[k], coff) : *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(M2) + (size_t)c0 * chunk_bytes + off[k]);
             vv[k][0] = q.x; vv[k][1] = q.y; vv[k][2] = q.z; vv[k][3] = q.w;
         }
-        const float4 fq = BUF ? buffer_load16(fr, foff, coff) : *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(F2) + (size_t)c0 * chunk_bytes + foff);
+        const float4 fq = HALF ? buffer_load8h(fr, foff, coff) : BUF ? buffer_load16(fr, foff, coff) : *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(F2) + (size_t)c0 * chunk_bytes + foff);
         fv[0] = fq.x; fv[1] = fq.y; fv[2] = fq.z; fv[3] = fq.w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -144,20 +170,22 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
 }
 
 
-int launch_to_chunked(const float* in, int C, size_t V, float* out, hipStream_t s) {
+int launch_to_chunked(const float* in, int C, size_t V, float* out, bool half, hipStream_t s) {
     const int CP = (C + 3) / 4 * 4;
     if ((size_t)(CP / 4) * (V + 1) * 16 >= ((size_t)1 << 31)) return fail(CVX_ERR_UNSUPPORTED, "adam_run: control grid too large (%zu voxels x %d channels)", V, C);
-    hipLaunchKernelGGL(k_to_chunked, dim3((unsigned)cdiv64((int64_t)(V + 1), 256), CP / 4), dim3(256), 0, s, in, C, V, out);
+    if (half) hipLaunchKernelGGL(k_to_chunked_h, dim3((unsigned)cdiv64((int64_t)(V + 1), 256), CP / 4), dim3(256), 0, s, in, C, V, reinterpret_cast<uint2*>(out));
+    else hipLaunchKernelGGL(k_to_chunked, dim3((unsigned)cdiv64((int64_t)(V + 1), 256), CP / 4), dim3(256), 0, s, in, C, V, out);
     return check_last("to_chunked");
 }
 
 int launch_warp_grad(const float* Fcl, const float* Mcl, int C, int h, int w, int d, const float* U, const float* bh,
-                     const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s) {
+                     const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, bool half, hipStream_t s) {
     const int CP = (C + 3) / 4 * 4;
     const dim3 gv((unsigned)((cdiv(d, 16) * cdiv(w, 4) * cdiv(h, 4) + 7) / 8 * 8));     // multiple of the 8 XCDs
     unsigned long long* census = reinterpret_cast<unsigned long long*>(options().census_ptr);       // debugging aid: slots [8192, ..)
     if (census) census += 8 * 1024;
-    if (options().warp_flat) hipLaunchKernelGGL(k_warp_grad<false>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census);
+    if (half) hipLaunchKernelGGL((k_warp_grad<true, true>), gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census);
+    else if (options().warp_flat) hipLaunchKernelGGL(k_warp_grad<false>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census);
     else hipLaunchKernelGGL(k_warp_grad<true>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census);
     return check_last("warp_grad");
 }

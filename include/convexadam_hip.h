@@ -144,8 +144,11 @@ int cvx_correlate_f32(const float* fix, const float* mov, int C, int h, int w, i
  *   n_box 2: two avg_pool3d       convex_adam_utils.py:84            1: one             l2r_2021_convexAdam_task2_docker.py:60, task3:56
  *   fast  0: ATen's evaluation order, bit-identical to the CPU oracle
  *         1: fused multiply-adds and separable box sums (same real-arithmetic result, last-bit differences; cost 0, n_box 2 only)
- *   f16   1: the cost volume is rounded to half precision on its way out (fp16 storage of the reference's GPU default,
- *            convex_adam_MIND.py:79; values only -- the buffer stays float32) */
+ *   f16   fp16 STORAGE of the cost volume (the reference's GPU default dtype, convex_adam_MIND.py:79,89-91; float32 accumulation, one
+ *         rounding to nearest even on the way out; SSD with two boxes only):
+ *         2: `ssd` points to a HALF-PRECISION buffer [n^3][h][w][d] (2-byte elements) -- half the bytes written here and read by
+ *            cvx_coupled_convex_f16; `argmin` is the first minimum of the stored values
+ *         1: the same values in a float32 buffer (no byte saved; kept for comparisons) */
 typedef struct cvx_corr_opts { int cost, n_box, fast, f16; } cvx_corr_opts;
 int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, int h, int w, int d, int disp_hw, const cvx_corr_opts* opts,
                          float* ssd, int64_t* argmin, void* workspace, size_t workspace_bytes, void* stream);
@@ -155,6 +158,10 @@ int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, int h, int w
  *   mesh [3][n^3] (device); out [3][h][w][d] in coarse-voxel units */
 size_t cvx_coupled_convex_workspace_bytes(int h, int w, int d, int disp_hw);
 int cvx_coupled_convex_f32(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d,
+                           int disp_hw, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* the same solve on a half-precision cost volume (cvx_corr_opts.f16 = 2): values are widened to float32 on load (exact) */
+int cvx_coupled_convex_f16(const void* ssd_half, const int64_t* argmin, const float* mesh, int h, int w, int d,
                            int disp_hw, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* inverse consistency -------------------------------------------------------------------------------
@@ -239,6 +246,15 @@ int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C, int h, in
                               const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* the same loop with an explicit storage format for the loop's own feature copies: feature_storage 0 = float32 records,
+ * 1 = half-precision records (fp16 storage, convex_adam_MIND.py:79: rounded once when the records are built, widened on every load;
+ * halves the bytes gathered per iteration); sm as above */
+int cvx_adam_run_ex_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m,
+                        float* v, float lambda_weight, int niter, int step0, float cost_scale,
+                        const float* base_h, const float* base_w, const float* base_d, float* U, float* grad_out,
+                        const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
+                        int feature_storage, void* workspace, size_t workspace_bytes, void* stream);
+
 /* whole pair ---------------------------------------------------------------------------------------
  * replaces convex_adam_pt(...)                                       convex_adam_MIND.py:64-202
  * (use_mask=False path; features are MIND-SSC of the two images, or caller-supplied feature
@@ -258,8 +274,10 @@ typedef struct cvx_pair_params {
     int n_box;           /* 0 or 2: two box filters on the cost volume, 1: one     task2_docker.py:60 */
     int n_spline_pools;  /* 0 or 3: three 3^3 boxes in the Adam loop, 2: two       task3_docker.py:191 */
     int corr_fast;       /* 1: fast correlation mode (see cvx_corr_opts) */
-    int fp16_storage;    /* 1: pooled features and cost volume rounded to half precision, float32 accumulation
-                            (the reference's GPU default dtype, convex_adam_MIND.py:79; graded by end-point error) */
+    int fp16_storage;    /* 1: half-precision STORAGE with float32 accumulation (the reference's GPU default dtype, convex_adam_MIND.py:79):
+                            both cost volumes and the Adam loop's feature records are __half buffers (half the bytes written and
+                            re-read), the coarse pooled features (2 x C x h x w x d values) are rounded to half precision in their
+                            float32 working copies; graded by end-point error against the float32 field */
     const cvx_context* ctx;  /* switches + tables for this call; NULL: the context bound to the calling thread (else the default one) */
 } cvx_pair_params;
 
