@@ -198,7 +198,7 @@ __global__ void k_corr_tail_compact(const float* __restrict__ fix, const float* 
     const int mz = z + iH - g.hw, my = y + iW - g.hw, mx = x + iD - g.hw;
     const bool inb = mz >= 0 && mz < g.h && my >= 0 && my < g.w && mx >= 0 && mx < g.d;
     const size_t v = (size_t)g.h * g.w * g.d;
-    float sq[16];
+    float sq[256];
     for (int c = 0; c < g.C; ++c) {
         const float f = fix[(size_t)c * v + ((size_t)z * g.w + y) * g.d + x];
         const float m = inb ? mov[(size_t)c * v + ((size_t)mz * g.w + my) * g.d + mx] : 0.0f;
@@ -207,7 +207,7 @@ __global__ void k_corr_tail_compact(const float* __restrict__ fix, const float* 
     }
     const int n4 = g.C / 4;
     float p[4];
-    for (int k = 0; k < 4; ++k) { p[k] = 0.f; for (int i = 0; i < n4; ++i) p[k] += sq[4 * i + k]; }   // C < 16: one cascade level
+    for (int k = 0; k < 4; ++k) p[k] = sum_cascade_strided(sq + k, 4, n4);       // (one cascade level below 64 channels)
     for (int i = n4 * 4; i < g.C; ++i) p[0] += sq[i];
     p[0] += p[1]; p[0] += p[2]; p[0] += p[3];
     tail[iH * 32 + (t % ntail)] = p[0];
@@ -240,9 +240,21 @@ static void corr_raw_dispatch(const float* Fp, const float* Mp, const CorrGeom& 
 
 using namespace cvx;
 
+// Which path the packaged operator takes.  The fused kernel covers every shape (C up to 255 through the cascade sum, tall planes through
+// y tiles); for C >= 16 its raw stage -- one third of the wavefronts -- carries most of the work and the round-1 kernels (all wavefronts
+// on the raw SSD, then the box pipeline) are faster when their raw intermediate is affordable (tools/time_corr.py: C = 32 at 26x32x37,
+// hw 6: 0.40 vs 0.63 ms), so they stay the default there; option corr_fused_all = 1 selects the fused kernel for every C.
+static bool corr_use_unfused(int C, int h, int w, int d, int hw, bool variant) {
+    if (!corr_fused_supported(C, h, w, d, hw)) return true;
+    if (variant || options().corr_fused_all != 0 || C < 16) return false;
+    const CorrGeom g = corr_geom(C, h, w, d, hw);
+    return corr_box2_supported(h, w, d, g.px) && (size_t)g.n * g.n * g.n * h * w * g.px * sizeof(float) <= ((size_t)2 << 30);
+}
+
 extern "C" size_t cvx_correlate_workspace_bytes(int C, int h, int w, int d, int disp_hw) {
-    if (corr_fused_supported(C, h, w, d, disp_hw))       // fused kernel: no raw intermediate
-        return carve_size(corr_fused_workspace_bytes(C, h, w, d, disp_hw), sizeof(unsigned long long) * (size_t)h * w * d) + 256;
+    const size_t fused = corr_fused_supported(C, h, w, d, disp_hw)
+                             ? carve_size(corr_fused_workspace_bytes(C, h, w, d, disp_hw), sizeof(unsigned long long) * (size_t)h * w * d) + 256 : 0;
+    if (fused && !corr_use_unfused(C, h, w, d, disp_hw, false)) return fused;         // fused kernel: no raw intermediate
     const CorrGeom g = corr_geom(C, h, w, d, disp_hw);
     const size_t K = (size_t)g.n * g.n * g.n;
     size_t used = 0;
@@ -250,7 +262,7 @@ extern "C" size_t cvx_correlate_workspace_bytes(int C, int h, int w, int d, int 
     used = carve_size(used, sizeof(float) * (size_t)C * g.hq * g.wq * g.dq);      // Mp
     used = carve_size(used, sizeof(float) * K * h * w * g.px);                    // raw
     used = carve_size(used, sizeof(unsigned long long) * (size_t)h * w * d);      // argmin keys
-    return used + 256;
+    return (used + 256 > fused ? used + 256 : fused);                             // (the variants of cvx_correlate_ex_f32 take the fused kernel)
 }
 
 extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int h, int w, int d, int disp_hw, float* ssd,
@@ -273,7 +285,8 @@ extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, i
     hipStream_t s = as_stream(stream);
     const CorrGeom g = corr_geom(C, h, w, d, disp_hw);
     const size_t K = (size_t)g.n * g.n * g.n;
-    if (corr_fused_supported(C, h, w, d, disp_hw)) {
+    const bool variant = cost != 0 || n_box != 2 || fast || f16;
+    if (!corr_use_unfused(C, h, w, d, disp_hw, variant)) {
         const size_t fws = corr_fused_workspace_bytes(C, h, w, d, disp_hw);
         int rc = launch_corr_fused(fix, mov, C, h, w, d, disp_hw, cost, n_box, fast, f16, ssd, workspace, fws, s);
         if (rc) return rc;
@@ -283,8 +296,8 @@ extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, i
         }
         return CVX_OK;
     }
-    if (cost != 0 || n_box != 2 || fast || f16)
-        return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_ex_f32: cost / n_box / fast variants need the fused kernel (C < 16, planes of at most 320 quads)");
+    if (variant)
+        return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_ex_f32: cost / n_box / fast / fp16 variants need the fused kernel (option corr_unfused is set, or rows of more than 1270 voxels)");
     if (!corr_box2_supported(h, w, d, g.px))
         return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
     Carver cv(workspace, workspace_bytes);

@@ -43,6 +43,8 @@ struct CFGeom {
     int lpr, RS;            // quads per row; row pitch of LDS planes and of Fp (floats) = 4 * lpr
     int dq, hq, wq;         // Mp row pitch, plane extents (h + 2hw, w + 2hw); element x at index x + 1 + hw
     int ng;                 // D-shift groups per (dH, dW)
+    int tiled, T, nyt;      // planes taller than one role can hold (5 wavefronts x 64 quads) are cut into y tiles of T output rows; the
+                            // raw stage then evaluates rows y0-2 .. y0+T+1 and the first box y0-1 .. y0+T (halo rows are recomputed)
     int wpr;                // wavefronts per role
     int PF;                 // floats per LDS plane: 4 + (w + 2) * RS + 4
     int64_t tail_from;      // first flat index (h, n^2, w, d order) of ATen's interleaved-order tail; ntail = ncols - tail_from
@@ -118,7 +120,8 @@ __device__ __forceinline__ void cf_box_item_fast(const float* src, int rs, float
 
 // what every role needs to know about its work item
 struct CFItem {
-    int iH, iW, grp, y, q;
+    int iH, iW, grp, y, q;  // y = row index of the thread inside its role's row range
+    int y0;                 // first output row of the y tile (0 without tiling)
     bool active;
 };
 
@@ -126,34 +129,41 @@ __device__ __forceinline__ float4 cf_ld16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 
 // ---- raw stage: G x 4 channel sums per thread and step ---------------------------------------------------------------------
 // CT = compile-time channel count (12: fully unrolled software pipeline, every register static) or 0 (run-time count, rolled loop)
-template <int G, int CT, bool FAST, bool SAD>
+// CASC: ATen's cascade order of `.sum(0)` for C >= 16 (blocks of 16 channels are folded into a second accumulator, cvx_common.h cascade_seq)
+template <int G, int CT, bool FAST, bool SAD, bool CASC, bool TILED>
 __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float* __restrict__ Mp, const float* __restrict__ tail,
                                        const CFGeom& g, const CFItem& it, float* S0, int nsteps) {
     constexpr int R = G + 2, NSUB = (G + 1) / 2;
-    const int n = g.n, nn = n * n, y = it.y, q = it.q, RS = g.RS, PF = g.PF;
+    const int n = g.n, nn = n * n, q = it.q, RS = g.RS, PF = g.PF;
     const int C = CT ? CT : g.C;
+    static_assert(!CASC || CT == 0, "the cascade sum uses the rolled channel loop");
     // the raw stage is the longest instruction stream of every sub-interval: its wavefronts win the issue arbitration
-    static_assert(true, "");
     if (CF_RAW_PRIO) __builtin_amdgcn_s_setprio(CF_RAW_PRIO);
+    // tiled: local row it.y stands for the global row y0 - 2 + it.y, rows outside the volume are written as zeros (the boxes zero-pad)
+    const int y = TILED ? it.y0 - 2 + it.y : it.y;
+    const bool rowok = !TILED || (y >= 0 && y < g.w);
+    const int yc = !TILED ? y : (y < 0 ? 0 : (y >= g.w ? g.w - 1 : y));
     // per-thread byte offsets; everything else of an address is wave-uniform and travels in the scalar offset
-    const unsigned foff = 4u * (unsigned)(y * RS + 4 * q);
-    const unsigned moff = 4u * (unsigned)((y + it.iW) * g.dq + 4 * q + 4 * it.grp);
-    const unsigned doff = (unsigned)((y + 1) * RS + 4 * q);
+    const unsigned foff = 4u * (unsigned)(yc * RS + 4 * q);
+    const unsigned moff = 4u * (unsigned)((yc + it.iW) * g.dq + 4 * q + 4 * it.grp);
+    const unsigned doff = (unsigned)((TILED ? it.y : it.y + 1) * RS + 4 * q);
     const unsigned fstride = 4u * (unsigned)(g.h * g.w * RS), mstride = 4u * (unsigned)(g.hq * g.wq * g.dq);     // bytes per channel
     const unsigned fplane = 4u * (unsigned)(g.w * RS), mplane = 4u * (unsigned)(g.wq * g.dq);                    // bytes per plane
     const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Fp), 0, (int)(fstride * (unsigned)g.C), 0x00020000);
     const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Mp), 0, (int)(mstride * (unsigned)g.C + 32u), 0x00020000);
     // does this item hold elements of ATen's interleaved-order tail (the last < 32 elements of the (h, n^2, w, d) tensor)?
-    const int64_t item_last = (((int64_t)(g.h - 1) * nn + it.iW * n + 4 * it.grp + G - 1) * g.w + (g.w - 1)) * g.d + g.d - 1;
+    const int ylast = TILED ? min(g.w - 1, it.y0 + g.T + 1) : g.w - 1;              // last row this workgroup evaluates
+    const int64_t item_last = (((int64_t)(g.h - 1) * nn + it.iW * n + 4 * it.grp + G - 1) * g.w + ylast) * g.d + g.d - 1;
     const bool tail_item = !FAST && g.ntail > 0 && item_last >= g.tail_from;
     int base = 0;                                          // (s * G) mod R
     for (int s = 0; s < nsteps; ++s) {
         const bool live = s < g.h;
         float acc[G][4];
+        float acc1[CASC ? G : 1][4];
 #pragma unroll
         for (int k = 0; k < G; ++k)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[k][j] = 0.0f;
+            for (int j = 0; j < 4; ++j) { acc[k][j] = 0.0f; if (CASC) acc1[k][j] = 0.0f; }
         const unsigned fz = (unsigned)s * fplane, mz = (unsigned)(s + it.iH) * mplane;     // uniform
         auto consume = [&](const float4& f4, const float4& m0, const float4& m1) {
             const float f[4] = {f4.x, f4.y, f4.z, f4.w};
@@ -190,23 +200,45 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
                 if (part < NSUB - 1) cvx_barrier();
             }
         } else {
+            // run-time channel count: rolled loop, software-pipelined by hand -- channel c + 1 is requested before channel c is consumed
+            // (the loop is unrolled by two so that the two register sets alternate without copies)
             int c = 0;
+            float4 fn, mn0, mn1;
+            if (live) { fn = cf_ld16(fr, foff, fz); mn0 = cf_ld16(mr, moff, mz); mn1 = cf_ld16(mr, moff + 16, mz); }
 #pragma unroll
             for (int part = 0; part < NSUB; ++part) {
                 const int cend = part_end(part);
                 if (live) {
-#pragma unroll 1
+#pragma unroll 2
                     for (; c < cend; ++c) {
-                        const unsigned fo = fz + (unsigned)c * fstride, mo = mz + (unsigned)c * mstride;
-                        consume(cf_ld16(fr, foff, fo), cf_ld16(mr, moff, mo), cf_ld16(mr, moff + 16, mo));
+                        const float4 f4 = fn, m0 = mn0, m1 = mn1;
+                        if (c + 1 < C) {
+                            const unsigned fo = fz + (unsigned)(c + 1) * fstride, mo = mz + (unsigned)(c + 1) * mstride;
+                            fn = cf_ld16(fr, foff, fo); mn0 = cf_ld16(mr, moff, mo); mn1 = cf_ld16(mr, moff + 16, mo);
+                        }
+                        consume(f4, m0, m1);
+                        if (CASC && (c & 15) == 15) {                      // a block of 16 channels is complete
+#pragma unroll
+                            for (int k = 0; k < G; ++k)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { acc1[k][j] += acc[k][j]; acc[k][j] = 0.0f; }
+                        }
                     }
                 }
                 if (part < NSUB - 1) cvx_barrier();
             }
         }
+        if (CASC) {
+#pragma unroll
+            for (int k = 0; k < G; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[k][j] += acc1[k][j];       // partial block + folded blocks (0 + a1 when C % 16 == 0)
+        }
         if (live && it.active) {
             // all planes of the step go to the ring in the last sub-interval (their slots were consumed earlier in the step)
-            if (tail_item && s == g.h - 1) {           // rare: replace the channel sums of the tail elements
+            // rare: replace the channel sums of the tail elements (the last < 32 elements of the (h, n^2, w, d) tensor; on tiny volumes
+            // they span more than one plane)
+            if (tail_item && rowok && (int64_t)(s + 1) * nn * g.w * g.d > g.tail_from) {
 #pragma unroll 1
                 for (int k = 0; k < G; ++k)
 #pragma unroll 1
@@ -227,7 +259,8 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
             for (int k = 0; k < G; ++k) {
                 int slot = base + k; slot = slot >= R ? slot - R : slot;
                 float* o = S0 + doff + slot * PF;
-                lds_store4(o, f32x4{acc[k][0], acc[k][1], acc[k][2], acc[k][3]});
+                if (rowok) lds_store4(o, f32x4{acc[k][0], acc[k][1], acc[k][2], acc[k][3]});
+                else lds_store4(o, f32x4{0.f, 0.f, 0.f, 0.f});   // (tiled) row outside the volume
                 if (q == 0) o[0] = 0.0f;                         // x = -1
                 if (4 * q + 3 > g.d)                             // x >= d: the boxes zero-pad
 #pragma unroll
@@ -245,10 +278,16 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
 typedef _Float16 h16x4u __attribute__((ext_vector_type(4), aligned(2)));   // four half-precision values at 2-byte alignment
 
 // OT = element type of the cost volume: float, or __half (fp16 STORAGE: half the bytes written here and read by the argmin passes)
-template <int G, bool FIRST, bool LAST, bool FAST, bool ONEBOX, bool F16, typename OT>
+template <int G, bool FIRST, bool LAST, bool FAST, bool ONEBOX, bool F16, typename OT, bool TILED>
 __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const float* Sin, float* S1, const float* zero, OT* __restrict__ ssd) {
     constexpr int R = G + 2, NSUB = (G + 1) / 2;
-    const int n = g.n, nn = n * n, y = it.y, q = it.q, RS = g.RS, PF = g.PF;
+    const int n = g.n, nn = n * n, q = it.q, RS = g.RS, PF = g.PF;
+    // local row it.y of this role: y = global output row, rin = first of the three input rows in a ring plane, rout = output row in a
+    // box-1 plane.  Untiled planes carry a zero row above and below (ring row = y + 1); tiled planes hold exactly the rows of the tile.
+    const int y = !TILED ? it.y : (FIRST && !LAST ? it.y0 - 1 + it.y : it.y0 + it.y);
+    const int rin = TILED && FIRST && LAST ? it.y + 1 : it.y;
+    const int rout = TILED ? it.y : it.y + 1;
+    const bool rowok = !TILED || (y >= 0 && y < g.w);
     float mid[G][4], pre[G][4];
 #pragma unroll
     for (int k = 0; k < G; ++k)
@@ -256,8 +295,8 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
         for (int j = 0; j < 4; ++j) { mid[k][j] = 0.0f; pre[k][j] = 0.0f; }
     // window origin in a ring plane: rows y-1 .. y+1 = ring rows y .. y+2; a FIRST stage reads raw columns 4q-1 .. 4q+4 (index x + 1)
     // and produces columns 4q .. 4q+3, the second stage reads box-1 columns 4q-4 .. 4q+1 (index x) and produces 4q-3 .. 4q
-    const float* srcbase = Sin + y * RS + 4 * q - (FIRST ? 0 : 4);
-    const unsigned doff1 = (unsigned)((y + 1) * RS + 4 * q);
+    const float* srcbase = Sin + rin * RS + 4 * q - (FIRST ? 0 : 4);
+    const unsigned doff1 = (unsigned)(rout * RS + 4 * q);
     const int c0 = FIRST ? 4 * q : 4 * q - 3;                                          // first column of the four outputs
     const unsigned vol = (unsigned)(g.h * g.w * g.d), plane = (unsigned)(g.w * g.d);
     const unsigned ooff = (unsigned)sizeof(OT) * (unsigned)(y * g.d + 4 * q);          // bytes, relative to (plane base + c0 - 4q)
@@ -302,11 +341,12 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
 #pragma unroll
                             for (int j = 0; j < 4; ++j) o[j] = __half2float(__float2half_rn(o[j]));
                         }
-                        if (emit && it.active) {
+                        if (emit && it.active && (rowok || !LAST)) {
                             if (!LAST) {
                                 int sn = base + k; sn = sn >= R ? sn - R : sn;
                                 float* ol = S1 + doff1 + sn * PF;
-                                lds_store4(ol, f32x4{o[0], o[1], o[2], o[3]});
+                                if (rowok) lds_store4(ol, f32x4{o[0], o[1], o[2], o[3]});
+                                else lds_store4(ol, f32x4{0.f, 0.f, 0.f, 0.f});      // (tiled) the second box zero-pads outside the volume
                                 if (4 * q + 3 >= g.d)
 #pragma unroll
                                     for (int j = 0; j < 4; ++j)
@@ -344,31 +384,34 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
 
 // MODE bits: 1 = FAST (FMA + separable sums, not bit-compatible), 2 = SAD cost, 4 = single box, 8 = cost volume rounded to fp16 (values in a
 // float32 buffer), 16 = cost volume STORED as fp16 (the buffer holds __half: same values as 8, half the bytes)
-template <int G, int MODE>
+template <int G, int MODE, bool CASC, bool TILED>
 __device__ __forceinline__ void cf_roles(int role, const float* Fp, const float* Mp, const float* tail, const CFGeom& g, const CFItem& it,
                                          float* lds, float* S0, float* S1, void* ssd_any) {
     constexpr bool FAST = (MODE & 1) != 0, SAD = (MODE & 2) != 0, ONEBOX = (MODE & 4) != 0, F16 = (MODE & 8) != 0, HALF = (MODE & 16) != 0;
     using OT = typename std::conditional<HALF, __half, float>::type;
     OT* ssd = static_cast<OT*>(ssd_any);
     if (role == 0) {
-        if (g.C == 12) cf_raw<G, 12, FAST, SAD>(Fp, Mp, tail, g, it, S0, ONEBOX ? g.h + 2 : g.h + 4);
-        else cf_raw<G, 0, FAST, SAD>(Fp, Mp, tail, g, it, S0, ONEBOX ? g.h + 2 : g.h + 4);
-    } else if (ONEBOX) cf_box<G, true, true, FAST, true, F16, OT>(g, it, S0, S1, lds, ssd);
-    else if (role == 1) cf_box<G, true, false, FAST, false, F16, OT>(g, it, S0, S1, lds, ssd);
-    else cf_box<G, false, true, FAST, false, F16, OT>(g, it, S1, S1, lds, ssd);
+        if (CASC) cf_raw<G, 0, FAST, SAD, true, TILED>(Fp, Mp, tail, g, it, S0, ONEBOX ? g.h + 2 : g.h + 4);
+        else if (g.C == 12) cf_raw<G, 12, FAST, SAD, false, TILED>(Fp, Mp, tail, g, it, S0, ONEBOX ? g.h + 2 : g.h + 4);
+        else cf_raw<G, 0, FAST, SAD, false, TILED>(Fp, Mp, tail, g, it, S0, ONEBOX ? g.h + 2 : g.h + 4);
+    } else if (ONEBOX) cf_box<G, true, true, FAST, true, F16, OT, TILED>(g, it, S0, S1, lds, ssd);
+    else if (role == 1) cf_box<G, true, false, FAST, false, F16, OT, TILED>(g, it, S0, S1, lds, ssd);
+    else cf_box<G, false, true, FAST, false, F16, OT, TILED>(g, it, S1, S1, lds, ssd);
 }
 
-template <int GMAX, int MODE>
-__global__ __launch_bounds__(1024, 8) void k_corr_fused(const float* __restrict__ Fp, const float* __restrict__ Mp,
+template <int GMAX, int MODE, bool CASC, bool TILED>
+__global__ __launch_bounds__(1024, (CASC ? 4 : 8)) void k_corr_fused(const float* __restrict__ Fp, const float* __restrict__ Mp,
                                                         const float* __restrict__ tail, CFGeom g, void* __restrict__ ssd) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int n = g.n, nn = n * n;
     CFItem it;
-    // items: the large last groups first (they take longest), then the groups of four
+    // items: the large last groups first (they take longest), then the groups of four; y tiles innermost
     int pair;
-    if ((int)blockIdx.x < nn) { it.grp = g.ng - 1; pair = blockIdx.x; }
-    else { const int b = blockIdx.x - nn; it.grp = b / nn; pair = b - it.grp * nn; }
+    const int bi = TILED ? (int)blockIdx.x / g.nyt : (int)blockIdx.x;
+    it.y0 = TILED ? ((int)blockIdx.x - bi * g.nyt) * g.T : 0;
+    if (bi < nn) { it.grp = g.ng - 1; pair = bi; }
+    else { const int b = bi - nn; it.grp = b / nn; pair = b - it.grp * nn; }
     it.iH = pair % n; it.iW = pair / n;
     const int G = cf_group_size(n, g.ng, it.grp);
     if (g.dbg && tid == 0) {
@@ -384,16 +427,20 @@ __global__ __launch_bounds__(1024, 8) void k_corr_fused(const float* __restrict_
 
     const int role = __builtin_amdgcn_readfirstlane(tid / (64 * g.wpr));
     const int tr = tid - role * 64 * g.wpr;
-    it.active = tr < g.w * g.lpr;
-    const int trc = it.active ? tr : g.w * g.lpr - 1;
+    // rows of this role: whole planes, or (tiled) T + 4 raw rows, T + 2 rows of the first box (T for a single box), T output rows
+    const bool onebox = (MODE & 4) != 0;
+    int rows = !TILED ? g.w : (role == 0 ? g.T + 4 : (role == 1 && !onebox ? g.T + 2 : g.T));
+    if (TILED && role > 0 && (role == 2 || onebox)) rows = min(rows, g.w - it.y0);        // last tile: output rows inside the volume only
+    it.active = tr < rows * g.lpr;
+    const int trc = it.active ? tr : rows * g.lpr - 1;
     it.y = trc / g.lpr; it.q = trc - it.y * g.lpr;
     // the group size is a compile-time constant inside the roles (ring arithmetic, register arrays, no idle accumulators)
     switch (G) {
-        case 5: cf_roles<5, MODE>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
-        case 4: cf_roles<4, MODE>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
-        case 3: cf_roles<3, MODE>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
-        case 2: cf_roles<2, MODE>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
-        default: cf_roles<1, MODE>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 5: cf_roles<5, MODE, CASC, TILED>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 4: cf_roles<4, MODE, CASC, TILED>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 3: cf_roles<3, MODE, CASC, TILED>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        case 2: cf_roles<2, MODE, CASC, TILED>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
+        default: cf_roles<1, MODE, CASC, TILED>(role, Fp, Mp, tail, g, it, lds, S0, S1, ssd); break;
     }
     if (g.dbg && tid == 0) g.dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
 }
@@ -408,8 +455,18 @@ static CFGeom cf_geom(int C, int h, int w, int d, int hw) {
     g.ng = (n >= 4 && n % 4 <= 1) ? n / 4 : (n + 3) / 4;
     g.dq = g.RS + 4 * g.ng + 4;
     g.hq = h + 2 * hw; g.wq = w + 2 * hw;
-    g.wpr = cdiv(w * g.lpr, 64);
-    g.PF = (w + 2) * g.RS + 8;
+    // a role has at most 5 wavefronts (3 roles = 15 of the 16 a workgroup may hold): planes of up to 320 quads go through whole, taller
+    // ones in y tiles whose halo rows (2 + 2 for the raw stage, 1 + 1 for the first box) are recomputed by the neighbouring tile
+    const int max_rows = 320 / g.lpr;
+    if (w <= max_rows) { g.tiled = 0; g.T = w; g.nyt = 1; g.wpr = cdiv(w * g.lpr, 64); g.PF = (w + 2) * g.RS + 8; }
+    else {
+        g.tiled = 1;
+        g.T = max_rows - 4 > 0 ? max_rows - 4 : 0;
+        g.nyt = g.T > 0 ? cdiv(w, g.T) : 0;
+        if (g.T > 0) g.T = cdiv(w, g.nyt);                                          // balanced tiles
+        g.wpr = cdiv((g.T + 4) * g.lpr, 64);
+        g.PF = (g.T + 4) * g.RS + 8;
+    }
     const int64_t ncols = (int64_t)h * n * n * w * d;
     g.tail_from = (ncols / 32) * 32;
     g.ntail = (int)(ncols - g.tail_from);
@@ -419,9 +476,11 @@ static size_t cf_lds_bytes(const CFGeom& g) { return sizeof(float) * (16 + 2 * (
 
 bool corr_fused_supported(int C, int h, int w, int d, int hw) {
     const bool off = options().corr_unfused != 0;
-    if (off || C >= 16 || hw < 0 || hw > 8) return false;
+    if (off || C < 1 || C > 255 || hw < 0 || hw > 8 || h < 1 || w < 1 || d < 1) return false;
     const CFGeom g = cf_geom(C, h, w, d, hw);
-    return 3 * g.wpr <= 16 && cf_lds_bytes(g) <= 160 * 1024 && (size_t)g.n * g.n * g.n * h * w * d * 4 < ((size_t)1 << 32);
+    if (g.T < 1 || g.wpr < 1 || 3 * g.wpr > 16 || cf_lds_bytes(g) > 160 * 1024) return false;
+    // 32-bit byte offsets inside a feature copy and inside one displacement plane of the cost volume
+    return (size_t)C * g.hq * g.wq * g.dq * 4 + 64 < ((size_t)1 << 31) && (size_t)h * w * d * 4 < ((size_t)1 << 31);
 }
 
 size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw) {
@@ -430,7 +489,7 @@ size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw) {
     used = carve_size(used, sizeof(float) * (size_t)C * h * w * g.RS);            // Fp
     used = carve_size(used, sizeof(float) * ((size_t)C * g.hq * g.wq * g.dq + 8));  // Mp
     used = carve_size(used, sizeof(float) * 32 * g.n);                             // tail values
-    used = carve_size(used, 32 * (size_t)g.n * g.n * g.ng);                         // residency census (CVX_CF_CENSUS)
+    used = carve_size(used, 32 * (size_t)g.n * g.n * g.ng * (g.nyt > 0 ? g.nyt : 1));  // residency census (CVX_CF_CENSUS)
     return used + 256;
 }
 
@@ -439,14 +498,22 @@ void launch_corr_prep_generic(const float* fix, const float* mov, int C, int h, 
                               float* Mp, hipStream_t s);
 void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int sad, float* tail, hipStream_t s);
 
-template <int MODE>
-static void cf_launch(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, void* ssd, hipStream_t s) {
+template <int MODE, bool CASC, bool TILED>
+static void cf_launch_c(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, void* ssd, hipStream_t s) {
     constexpr bool ONEBOX = (MODE & 4) != 0;
     const size_t lds = sizeof(float) * (16 + (ONEBOX ? 1 : 2) * (size_t)(CF_GMAX + 2) * gl.PF);
     static size_t granted = 0;
-    ensure_dynamic_lds(&k_corr_fused<CF_GMAX, MODE>, lds, granted);
-    const int items = gl.n * gl.n * gl.ng;
-    hipLaunchKernelGGL((k_corr_fused<CF_GMAX, MODE>), dim3(items), dim3((ONEBOX ? 2 : 3) * 64 * gl.wpr), lds, s, Fp, Mp, tail, gl, ssd);
+    ensure_dynamic_lds(&k_corr_fused<CF_GMAX, MODE, CASC, TILED>, lds, granted);
+    const int items = gl.n * gl.n * gl.ng * gl.nyt;
+    hipLaunchKernelGGL((k_corr_fused<CF_GMAX, MODE, CASC, TILED>), dim3(items), dim3((ONEBOX ? 2 : 3) * 64 * gl.wpr), lds, s, Fp, Mp, tail, gl, ssd);
+}
+template <int MODE>
+static void cf_launch(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, void* ssd, hipStream_t s) {
+    // C >= 16: ATen's cascade channel sum; tiled: planes taller than one role holds (both are separate instantiations so that the
+    // packaged configuration keeps its 64-register budget)
+    if (gl.C >= 16) { if (gl.tiled) cf_launch_c<MODE, true, true>(gl, Fp, Mp, tail, ssd, s); else cf_launch_c<MODE, true, false>(gl, Fp, Mp, tail, ssd, s); }
+    else if (gl.tiled) cf_launch_c<MODE, false, true>(gl, Fp, Mp, tail, ssd, s);
+    else cf_launch_c<MODE, false, false>(gl, Fp, Mp, tail, ssd, s);
 }
 
 // opts: cost 0 = SSD / 1 = SAD, n_box 2 / 1, fast 0 / 1 (fast: SSD with two boxes only)
@@ -463,7 +530,7 @@ int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, i
     float* Fp = cv.take<float>((size_t)C * h * w * g.RS);
     float* Mp = cv.take<float>((size_t)C * g.hq * g.wq * g.dq + 8);
     float* tail = cv.take<float>((size_t)32 * g.n);
-    unsigned long long* census_buf = cv.take<unsigned long long>((size_t)4 * g.n * g.n * g.ng);
+    unsigned long long* census_buf = cv.take<unsigned long long>((size_t)4 * g.n * g.n * g.ng * g.nyt);
     launch_corr_prep_generic(fix, mov, C, h, w, d, hw, g.RS, hw, g.dq, Fp, Mp, s);
     if (g.ntail > 0 && !fast) launch_corr_tail_compact(fix, mov, C, h, w, d, hw, cost, tail, s);
     CFGeom gl = g;

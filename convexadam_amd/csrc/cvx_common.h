@@ -68,6 +68,7 @@ struct Options {
     long long box_tiled;           // 1: tiled three-box kernels of the Adam loop instead of the z-marching ones
     long long no_prune;            // 1: streaming coupled-convex passes instead of branch and bound
     long long corr_unfused;        // 1: k_corr_raw + k_corr_box2 instead of the fused correlation kernel
+    long long corr_fused_all;      // 1: the fused correlation kernel also for C >= 16 (default there: the round-1 kernels, which are faster)
     long long prune_stream_above;  // pruned pass falls back to a coalesced scan above this many 256-displacement chunks (-1 = K*v/2048)
     long long cf_census;           // 1: the fused correlation kernel records per-workgroup residency in its workspace
     long long warp_flat;           // 1: flat 64-bit gathers in k_warp_grad instead of buffer loads

@@ -60,6 +60,8 @@ int cvx_device_count(void);            /* number of visible HIP devices (0 on a 
  *   no_prune            1: streaming coupled-convex passes instead of branch and bound
  *   prune_stream_above  chunk budget above which a pruned pass scans the volume (-1 = automatic)
  *   corr_unfused        1: separate raw-SSD and box kernels instead of the fused correlation kernel
+ *   corr_fused_all      1: the fused correlation kernel also for C >= 16 (it covers them -- cascade channel sum -- but the separate
+ *                       kernels are faster there and stay the default)
  *   cf_census           1: the fused correlation kernel records per-workgroup residency in its workspace
  *   mind_mean_threads   0: exactly rounded global mean in MINDSSC; T > 0: torch's float32 sum with T threads
  * Workspace sizes (cvx_*_workspace_bytes) depend on some switches: query them with the same context / options the call will use.

@@ -90,9 +90,20 @@ def test_workspace_queries(L):
     assert n < 3 * 1024 ** 3
     bad = PairParams(160, 192, 224, 1, 2, 1.25, 6, 6, 0, 0, 2, 1, 0, 12.0)       # niter 0 with lambda > 0
     assert L.cvx_register_pair_workspace_bytes(C.byref(bad)) == 0
-    # fused correlation kernel (C < 16): padded feature copies only, no raw SSD intermediate; C >= 16 keeps the unfused path
+    # fused correlation kernel: padded feature copies only, no raw SSD intermediate -- also for C >= 16 (cascade channel sum) and for the
+    # tall planes of the sweep's fine grids (y tiles); the round-1 kernels with their raw intermediate remain behind `corr_unfused`
     assert L.cvx_correlate_workspace_bytes(12, 26, 32, 37, 6) < 16 * 1024 ** 2
+    assert L.cvx_correlate_workspace_bytes(32, 26, 32, 37, 6) >= 4 * K * 26 * 32 * 40       # C >= 16: the faster round-1 kernels by default
+    L.cvx_set_option(b"corr_fused_all", 1)
+    assert L.cvx_correlate_workspace_bytes(32, 26, 32, 37, 6) < 32 * 1024 ** 2
+    L.cvx_set_option(b"corr_fused_all", 0)
+    for gs in (2, 3, 4, 5):                                        # every stage-1 grid of the sweep at 160 x 192 x 224
+        h, w, d = 160 // gs, 192 // gs, 224 // gs
+        assert L.cvx_correlate_workspace_bytes(12, h, w, d, 5) < 2 * 12 * (h + 10) * (w + 10) * (d + 32) * 4 + 8 * h * w * d + (1 << 20), gs
+    old = L.cvx_get_option(b"corr_unfused")
+    L.cvx_set_option(b"corr_unfused", 1)
     assert L.cvx_correlate_workspace_bytes(20, 26, 32, 37, 6) >= 4 * K * 26 * 32 * 40
+    L.cvx_set_option(b"corr_unfused", old)
 
 
 def test_no_cpu_fallback():

@@ -107,21 +107,39 @@ def test_correlate_tiled_rows_vs_oracle(U, orc, C, shape, hw):
                                         # every search width of the pipeline at realistic coarse shapes (BASELINE configs 1-3: rows of 37)
                                         (12, (9, 8, 37), 5), (12, (9, 8, 37), 6), (12, (9, 8, 37), 7), (12, (9, 8, 37), 8),
                                         (12, (13, 16, 20), 6), (12, (13, 16, 20), 8), (32, (13, 16, 20), 5), (32, (9, 8, 37), 7),
-                                        (14, (26, 32, 37), 6), (5, (11, 12, 13), 8)])
+                                        (14, (26, 32, 37), 6), (5, (11, 12, 13), 8),
+                                        # planes taller than one role of the fused kernel holds -> y tiles with recomputed halo rows (the coarse
+                                        # grids of the sweep's grid_sp 2..5 at 160 x 192 x 224 have 38 .. 96 rows of 44 .. 112 voxels)
+                                        (12, (6, 40, 37), 3), (12, (5, 23, 74), 2), (7, (4, 38, 44), 4), (12, (3, 96, 112), 1), (12, (9, 33, 37), 6),
+                                        (32, (5, 48, 56), 2), (18, (6, 40, 37), 3), (64, (4, 9, 10), 2), (67, (3, 5, 6), 1),
+                                        # the interleaved-order tail (last ncols mod 32 elements) spans several planes on tiny grids
+                                        (12, (3, 3, 3), 0), (12, (5, 2, 3), 1), (20, (7, 1, 3), 0)])
 def test_correlate_vs_oracle(U, orc, C, shape, hw):
     """Includes C >= 16 (ATen cascade sum), ragged inner sizes (interleaved tail rule), D not a multiple of 4,
-    search windows larger than the volume, and the degenerate hw = 0."""
+    search windows larger than the volume, the degenerate hw = 0, y-tiled planes and multi-plane tails: all through the fused kernel."""
+    from convexadam_amd import _lib
+    L = _lib.lib()
     rng = np.random.default_rng(C * 100 + hw)
     f = rng.random((C,) + shape, dtype=np.float32)
     m = rng.random((C,) + shape, dtype=np.float32)
-    ssd, am = U.correlate(dev(f)[None], dev(m)[None], hw, 1, shape, C)
     rs, ra = orc.correlate(f, m, hw)
-    assert np.array_equal(host(ssd), rs), "max |diff| %g" % np.abs(host(ssd) - rs).max()
-    assert np.array_equal(host(am), ra)
+    # default path (C >= 16: the round-1 kernels, faster there) and the fused kernel forced for every C
+    for fused_all in ((0, 1) if C >= 16 else (0,)):
+        L.cvx_set_option(b"corr_fused_all", fused_all)
+        try:
+            if fused_all or C < 16:
+                assert L.cvx_correlate_workspace_bytes(C, *shape, hw) < 4 * (2 * hw + 1) ** 3 * shape[0] * shape[1] * shape[2] + (1 << 22), \
+                    "the fused kernel (no raw-SSD intermediate in the workspace) must cover this shape"
+            ssd, am = U.correlate(dev(f)[None], dev(m)[None], hw, 1, shape, C)
+        finally:
+            L.cvx_set_option(b"corr_fused_all", 0)
+        assert np.array_equal(host(ssd), rs), "max |diff| %g" % np.abs(host(ssd) - rs).max()
+        assert np.array_equal(host(am), ra)
 
 
 @pytest.mark.parametrize("cost,n_box", [("sad", 1), ("ssd", 1), ("sad", 2)])
-@pytest.mark.parametrize("C,shape,hw", [(12, (9, 8, 37), 6), (12, (7, 9, 11), 3), (5, (6, 7, 9), 1), (12, (13, 16, 20), 4), (12, (5, 6, 41), 2)])
+@pytest.mark.parametrize("C,shape,hw", [(12, (9, 8, 37), 6), (12, (7, 9, 11), 3), (5, (6, 7, 9), 1), (12, (13, 16, 20), 4), (12, (5, 6, 41), 2),
+                                        (12, (5, 40, 37), 2), (20, (4, 23, 74), 1)])
 def test_correlate_variants_vs_oracle(U, orc, cost, n_box, C, shape, hw):
     """the SAD cost (l2r_2021 task 3 :54) and the single box filter (task 2 :60) in the fused kernel, bit-identical
     to the oracle (which is pinned to the reference scripts' own functions, tests/golden/variants.npz)."""
@@ -962,7 +980,7 @@ def test_pipeline_variants_vs_oracle_bit_exact(M, orc, golden, var):
     assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), ref), "EPE %g" % epe(np.moveaxis(out, 0, -1), ref)
 
 
-@pytest.mark.parametrize("shape,hw,C", [((9, 8, 37), 3, 12), ((13, 16, 20), 4, 12), ((6, 7, 9), 2, 5)])
+@pytest.mark.parametrize("shape,hw,C", [((9, 8, 37), 3, 12), ((13, 16, 20), 4, 12), ((6, 7, 9), 2, 5), ((5, 40, 37), 2, 12), ((4, 23, 74), 1, 18)])
 def test_fp16_storage_operators_vs_oracle(U, orc, shape, hw, C):
     """Real half-precision storage (convex_adam_MIND.py:79,89-91): `correlate(storage="fp16")` writes a torch.float16
     cost volume (float32 accumulation, one rounding) = the oracle's volume rounded to half, its argmin is the first minimum of the
