@@ -51,7 +51,7 @@ struct cvx_context {
 };
 namespace cvx {
 static Options env_options() {
-    return {env_ll("CVX_MIND_TILED", 0),   env_ll("CVX_MM_TX", 0),        env_ll("CVX_MM_SLOTS", 512),          env_ll("CVX_BOX_TILED", 0),
+    return {env_ll("CVX_MIND_TILED", 0),   env_ll("CVX_MIND_OVERLAP", 0),  env_ll("CVX_MM_TX", 0),        env_ll("CVX_MM_SLOTS", 512),          env_ll("CVX_BOX_TILED", 0),
             env_ll("CVX_NO_PRUNE", 0),     env_ll("CVX_CORR_UNFUSED", 0), env_ll("CVX_CORR_FUSED_ALL", 0), env_ll("CVX_PRUNE_STREAM_ABOVE", -1), env_ll("CVX_CF_CENSUS", 0),
             env_ll("CVX_WARP_FLAT", 0),    env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 0),
             env_ll("CVX_BOX_XSPLIT", -1),  env_ll("CVX_BOX_CPT", 4),      env_ll("CVX_BOX_UNEVEN", 200), env_ll("CVX_BOX_PRIO", 0),     0,                             env_ll("CVX_MIND_MEAN_THREADS", 0)};
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_expf(const float* __restrict__ x, float
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = cvx_expf(x[i]);
 }
 struct OptName { const char* name; long long Options::*field; };
-static const OptName kOptNames[] = {{"mind_tiled", &Options::mind_tiled},     {"mm_tx", &Options::mm_tx},
+static const OptName kOptNames[] = {{"mind_tiled", &Options::mind_tiled},     {"mind_overlap", &Options::mind_overlap},   {"mm_tx", &Options::mm_tx},
                                     {"mm_slots", &Options::mm_slots},         {"box_tiled", &Options::box_tiled},
                                     {"no_prune", &Options::no_prune},         {"corr_unfused", &Options::corr_unfused}, {"corr_fused_all", &Options::corr_fused_all},
                                     {"prune_stream_above", &Options::prune_stream_above}, {"cf_census", &Options::cf_census},

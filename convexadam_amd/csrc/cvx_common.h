@@ -63,6 +63,7 @@ static inline size_t carve_size(size_t used, size_t bytes) { return align_up(use
 // switches exist for A/B timing and so that the test-suite can run every variant (tests/test_gpu_parity.py::test_kernel_variants_agree).
 struct Options {
     long long mind_tiled;          // 1: tiled MIND stencil instead of the z-marching one
+    long long mind_overlap;        // 1: the whole-pair pipeline runs the moving image's descriptor pass on a side stream beside the fixed one's (measured: no gain)
     long long mm_tx;               // 32 / 64: tile width of the marching MIND stencil (0 = automatic)
     long long mm_slots;            // workgroup budget of the marching MIND stencil (512)
     long long box_tiled;           // 1: tiled three-box kernels of the Adam loop instead of the z-marching ones

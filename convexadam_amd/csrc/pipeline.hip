@@ -60,7 +60,7 @@ struct PairLayout {
     int H, W, D, h, w, d, h2, w2, d2, C, K;
     size_t V, v, V2;
     // byte offsets into the workspace (0 = not used)
-    size_t featF, featM, mind_ws, fs, ms, corr_ws, ssd, argmin, mesh, conv_ws, ssd2, argmin2, conv_ws2, soft, soft2, in1, in2, ic1, ic2, ic_ws,
+    size_t featF, featM, mind_ws, mind_ws2, fs, ms, corr_ws, ssd, argmin, mesh, conv_ws, ssd2, argmin2, conv_ws2, soft, soft2, in1, in2, ic1, ic2, ic_ws,
         upin, disp_hr, F2, M2, P, m, v_, U, adam_ws, smooth_ws, snaps, bh, bw, bd, bh2, bw2, bd2, total;
 };
 
@@ -85,6 +85,7 @@ static PairLayout pair_layout(const cvx_pair_params& p, int n_snap = 0, int max_
         L.featF = take(u, f * 12 * L.V);
         L.featM = take(u, f * 12 * L.V);
         L.mind_ws = take(u, cvx_mindssc_workspace_bytes(p.H, p.W, p.D, p.mind_r, p.mind_d));
+        L.mind_ws2 = take(u, cvx_mindssc_workspace_bytes(p.H, p.W, p.D, p.mind_r, p.mind_d));      // the moving image's pass runs beside the fixed one's
     }
     L.fs = take(u, f * L.C * L.v);
     L.ms = take(u, f * L.C * L.v);
@@ -139,6 +140,31 @@ static void mark(const char* name, hipStream_t s) {
     hipEvent_t e = g_pool[g_pool_used++];
     (void)hipEventRecord(e, s);
     g_marks.push_back({name, e});
+}
+
+// ---- side stream for the independent half of a stage (the two images' descriptors) ---------------------------------------
+// One per (thread, slot): slot = the internal stream index of cvx_register_pairs_f32 (0 for a single pair), so that concurrent pairs do
+// not share a side stream.  Forks from / joins into the pair's stream with events; created once per thread and device.
+struct SidePool {
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> fork, join;
+    int device = -1;
+};
+static thread_local SidePool g_side;
+static thread_local int g_side_slot = 0;
+static bool side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    SidePool& P = g_side;
+    if (P.device != dev) { P.streams.clear(); P.fork.clear(); P.join.clear(); P.device = dev; }        // leaked on device switch (rare)
+    while ((int)P.streams.size() <= g_side_slot) {
+        hipStream_t st; hipEvent_t a, b;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+        P.streams.push_back(st); P.fork.push_back(a); P.join.push_back(b);
+    }
+    *side = P.streams[g_side_slot]; *fork = P.fork[g_side_slot]; *join = P.join[g_side_slot];
+    return true;
 }
 
 static int validate(const cvx_pair_params* p) {
@@ -264,10 +290,20 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
         const size_t mws = cvx_mindssc_workspace_bytes(p->H, p->W, p->D, p->mind_r, p->mind_d);
         if (pooled_mind) {
             const int g2 = adam ? p->grid_sp_adam : 0;
+            // The two images are independent until `correlate`.  Option mind_overlap = 1 runs the moving image's pass on a side stream (one
+            // image's VALU-bound stencil beside the other's memory-bound normalise + pool pass); measured on the benchmark pair: 0.52 vs
+            // 0.53 ms for the stage and a SLOWER pair (7.92 vs 7.76 ms) -- every one of these kernels fills the chip on its own -- so the
+            // default keeps them in order.
+            hipStream_t side = s; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+            const bool overlap = options().mind_overlap != 0 && side_stream(&side, &ev_fork, &ev_join);
+            if (overlap) { (void)hipEventRecord(ev_fork, s); (void)hipStreamWaitEvent(side, ev_fork, 0); }
+            else side = s;
             if ((rc = launch_mind_pooled(img_fixed, p->H, p->W, p->D, p->mind_r, p->mind_d, p->grid_sp, F(L.fs), g2, adam ? F(L.F2) : nullptr,
                                          F(L.featF), ws + L.mind_ws, mws, s))) return rc;
-            if ((rc = launch_mind_pooled(img_moving, p->H, p->W, p->D, p->mind_r, p->mind_d, p->grid_sp, F(L.ms), g2, adam ? F(L.M2) : nullptr,
-                                         F(L.featM), ws + L.mind_ws, mws, s))) return rc;
+            rc = launch_mind_pooled(img_moving, p->H, p->W, p->D, p->mind_r, p->mind_d, p->grid_sp, F(L.ms), g2, adam ? F(L.M2) : nullptr,
+                                    F(L.featM), ws + (overlap ? L.mind_ws2 : L.mind_ws), mws, side);
+            if (overlap) { (void)hipEventRecord(ev_join, side); (void)hipStreamWaitEvent(s, ev_join, 0); }      // (joined even after an error)
+            if (rc) return rc;
         } else {
             if ((rc = cvx_mindssc_f32(img_fixed, p->H, p->W, p->D, p->mind_r, p->mind_d, F(L.featF), ws + L.mind_ws, mws, stream))) return rc;
             if ((rc = cvx_mindssc_f32(img_moving, p->H, p->W, p->D, p->mind_r, p->mind_d, F(L.featM), ws + L.mind_ws, mws, stream))) return rc;
@@ -449,6 +485,7 @@ extern "C" int cvx_register_pairs_f32(int n_pairs, const float* const* img_fixed
     for (int s = 0; s < n_streams; ++s) (void)hipStreamWaitEvent(P.streams[s], P.fork, 0);
     for (int i = 0; i < n_pairs && rc == CVX_OK; ++i) {
         const int s = i % n_streams;
+        g_side_slot = s;
         rc = cvx_register_pair_f32(img_fixed ? img_fixed[i] : nullptr, img_moving ? img_moving[i] : nullptr,
                                    feat_fixed ? feat_fixed[i] : nullptr, feat_moving ? feat_moving[i] : nullptr, p, out_fields[i],
                                    out_dims_host, static_cast<char*>(workspace) + per_al * (size_t)s, per, P.streams[s]);
@@ -458,5 +495,6 @@ extern "C" int cvx_register_pairs_f32(int n_pairs, const float* const* img_fixed
         (void)hipStreamWaitEvent(user, P.done[s], 0);
     }
     g_profiling = saved_prof;
+    g_side_slot = 0;
     return rc;
 }

@@ -197,13 +197,19 @@ class WorkQueue:
 
 
 class ResultLog:
-    """Append-only results of one rank (`<out>.rank<r>.jsonl`), keyed by (stage, setting, pair); `--resume` reads every rank's file."""
+    """Append-only results of one rank (`<out>.rank<r>.jsonl`), keyed by (stage, setting, pair); `--resume` reads every rank's file.
+    Every file starts with a header record describing the run (`run`: shape, pairs, setting counts, mode); on resume, files whose header
+    differs from this run's are ignored (their records belong to another sweep), and a fresh start removes EVERY rank file of the
+    output name -- also those of an earlier run with more ranks (rank 0 does it; the caller puts a barrier after construction)."""
 
-    def __init__(self, out, rank, resume):
+    def __init__(self, out, rank, resume, run=None):
         self.path = "%s.rank%d.jsonl" % (out, rank) if out else None
         self.done = {}
+        self.run = run
+        self.ignored_files = []
         if out and resume:
-            for f in glob.glob(out + ".rank*.jsonl"):
+            for f in sorted(glob.glob(out + ".rank*.jsonl")):
+                recs, header = [], None
                 for line in open(f):
                     line = line.strip()
                     if line:
@@ -211,9 +217,32 @@ class ResultLog:
                             r = json.loads(line)
                         except ValueError:
                             continue                                        # a line cut off by the kill
-                        self.done[(r["stage"], r["setting"], r["pair"])] = r
-        elif self.path and os.path.exists(self.path):
-            os.remove(self.path)
+                        if "header" in r:
+                            header = r["header"]
+                        else:
+                            recs.append(r)
+                if run is not None and header != run:
+                    self.ignored_files.append(f)                            # another sweep's records (or a file without header)
+                    continue
+                for r in recs:
+                    self.done[(r["stage"], r["setting"], r["pair"])] = r
+            if self.path and (not os.path.exists(self.path) or self.path in self.ignored_files):
+                self._write_header("w")
+        elif out:
+            if rank == 0:
+                for f in glob.glob(out + ".rank*.jsonl"):
+                    os.remove(f)
+
+    def start(self):
+        """Fresh run: called after the barrier that follows rank 0's clean-up."""
+        if self.path and not os.path.exists(self.path):
+            self._write_header("w")
+
+    def _write_header(self, mode):
+        with open(self.path, mode) as f:
+            f.write(json.dumps(dict(header=self.run)) + "\n")
+            f.flush()
+            os.fsync(f.fileno())
 
     def add(self, rec):
         self.done[(rec["stage"], rec["setting"], rec["pair"])] = rec
@@ -325,7 +354,12 @@ def main(argv=None):
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     two_stage = a.stage1 > 0
     queue = WorkQueue(rank, world)
-    log = ResultLog(a.out, rank, a.resume)
+    run_id = dict(shape=list(a.shape), pairs=a.pairs, stage1=a.stage1, stage2=a.stage2, settings=a.settings, niter=a.niter, evaluate=bool(a.evaluate),
+                  dry_run=bool(a.dry_run))
+    log = ResultLog(a.out, rank, a.resume, run_id)
+    if world > 1:
+        dist.barrier()                                                      # rank 0 has removed the files of an earlier run
+    log.start()
     data = PairData(a.shape, device)
     shape = tuple(a.shape)
 
@@ -349,11 +383,28 @@ def main(argv=None):
                 mine.append(dict(log.done[(phase, s, p)], item=i))
                 continue
             rec = dict(stage=phase, setting=s, pair=p, rank=rank, item=i)
-            rec.update(worker(settings[s], p))
+            try:
+                if os.environ.get("CVX_SWEEP_FAIL_ITEM") == str(i):
+                    raise RuntimeError("injected failure (test hook CVX_SWEEP_FAIL_ITEM)")
+                rec.update(worker(settings[s], p))
+            except Exception as e:                                          # keep drawing: the other ranks wait in the gather that follows
+                failures.append(dict(stage=phase, setting=s, pair=p, rank=rank, item=i, error="%s: %s" % (type(e).__name__, e)))
+                continue
             log.add(rec)
             mine.append(rec)
             fresh += 1
         return mine, fresh
+
+    failures = []
+
+    def check_failures():
+        """After a phase's gather: every rank learns about every failed item and the run stops with one message."""
+        allf = gather_records(failures, world)
+        if allf:
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            raise RuntimeError("sweep: %d item(s) failed, e.g. %s" % (len(allf), json.dumps(allf[0])))
 
     if world > 1:
         dist.barrier()
@@ -367,6 +418,7 @@ def main(argv=None):
             w1 = lambda cfg, p: run_stage1_item(cfg, p, data)                                                                          # noqa: E731
         mine1, fresh1 = run_phase("convex", s1, w1)
         all1 = gather_records(mine1, world)
+        check_failures()
         seen = {}
         for r in all1:
             seen[(r["setting"], r["pair"])] = r
@@ -384,6 +436,7 @@ def main(argv=None):
                 w2 = lambda cfg, p: dict(evals=run_stage2_item(best1, cfg, p, data, smoothers))                                     # noqa: E731
             mine2, fresh2 = run_phase("adam", s2, w2)
             all2 = gather_records(mine2, world)
+            check_failures()
             flat, seen2 = [], set()
             for r in all2:
                 if (r["setting"], r["pair"]) in seen2:
@@ -417,6 +470,7 @@ def main(argv=None):
 
         mine, _ = run_phase("pipeline", settings, w0)
         allres = sorted(gather_records(mine, world), key=lambda r: r["item"])
+        check_failures()
         summary.update(n_items=len(settings) * a.pairs, items_done=sorted(r["item"] for r in allres),
                        per_rank={str(r): sorted(x["item"] for x in allres if x["rank"] == r) for r in range(world)}, results=allres)
         if a.evaluate and not a.dry_run:

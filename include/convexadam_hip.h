@@ -51,6 +51,7 @@ int cvx_device_count(void);            /* number of visible HIP devices (0 on a 
 /* Run-time switches between kernel variants (A/B timing, variant coverage in the tests).  Every variant is bit-identical except
  * "mind_mean_threads", which changes MINDSSC's clamp bounds by ulps (reference-bits mode).  Names:
  *   mind_tiled          1: tiled MIND stencil instead of the z-marching one
+ *   mind_overlap        1: the whole-pair pipeline computes the two images' descriptors side by side on two streams (default: in order)
  *   mm_tx, mm_slots     tile width (32 / 64, 0 = automatic) and workgroup budget (512) of the marching MIND stencil
  *   box_tiled           1: tiled three-box kernels in the Adam loop instead of the z-marching ones
  *   box_yt              rows per tile of the marching three-box kernels: 8 (default) or 4

@@ -127,6 +127,8 @@ def test_two_stage_sweep_queue_and_resume_gloo(tmp_path):
     logs = sorted(str(p) for p in tmp_path.glob("res.json.rank*.jsonl"))
     assert len(logs) == 2
     recs = [json.loads(l) for f in logs for l in open(f)]
+    assert sum("header" in r for r in recs) == 2 and all("header" in json.loads(open(f).readline()) for f in logs)   # every log names its run
+    recs = [r for r in recs if "header" not in r]
     assert len(recs) == 30
     # kill simulation: drop the last 5 lines of rank 0's log (one of them cut in the middle), then resume
     lines = open(logs[0]).read().splitlines()
@@ -136,6 +138,40 @@ def test_two_stage_sweep_queue_and_resume_gloo(tmp_path):
     assert res2["stage1"]["n_items"] == 18 and res2["stage2"]["n_items"] == 12
     assert res2["stage1"]["fresh_items"] + res2["stage2"]["fresh_items"] == 5
     assert res2["stage1"]["best_setting"] == res["stage1"]["best_setting"] and res2["stage2"]["best_setting"] == res["stage2"]["best_setting"]
+
+
+def test_result_log_header_and_stale_files(tmp_path):
+    """Per-rank logs carry a header naming the run: --resume ignores files of another sweep (other shape / pair count / setting counts)
+    and files without a header; a fresh start removes every rank file of the output name, also those of an earlier run with more ranks."""
+    from convexadam_amd.sweep import ResultLog
+    out = str(tmp_path / "r.json")
+    run_a, run_b = dict(shape=[8, 8, 8], pairs=2), dict(shape=[8, 8, 8], pairs=3)
+    for rank in range(3):                                                   # an earlier run with three ranks
+        lg = ResultLog(out, rank, False, run_a)
+        lg.start()
+        lg.add(dict(stage="convex", setting=rank, pair=0, v=rank))
+    assert len(list(tmp_path.glob("r.json.rank*.jsonl"))) == 3
+    r0 = ResultLog(out, 0, True, run_a)                                    # resume of the same run: all three files count
+    assert sorted(k[1] for k in r0.done) == [0, 1, 2] and not r0.ignored_files
+    rb = ResultLog(out, 0, True, run_b)                                    # another sweep: nothing is reused, this rank's file starts over
+    assert not rb.done and len(rb.ignored_files) == 3
+    assert "header" in open(out + ".rank0.jsonl").readline()
+    rb.add(dict(stage="convex", setting=5, pair=1, v=9))
+    rc = ResultLog(out, 1, True, run_b)
+    assert list(rc.done) == [("convex", 5, 1)] and len(rc.ignored_files) == 2
+    fresh = ResultLog(out, 0, False, run_b)                                # fresh start with fewer ranks: rank 0 removes every old file
+    fresh.start()
+    assert [p.name for p in tmp_path.glob("r.json.rank*.jsonl")] == ["r.json.rank0.jsonl"]
+
+
+def test_sweep_worker_failure_is_reported(tmp_path):
+    """An exception inside a worker does not leave the other ranks waiting in the gather: the failing item is recorded, every rank
+    finishes its phase, and the run ends with one error message (world size 2, gloo, dry run with an injected failure)."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), CVX_SWEEP_FAIL_ITEM="3")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29623",
+           os.path.join(ROOT, "convexadam_amd", "sweep.py"), "--dry-run", "--pairs", "4", "--settings", "2", "--out", str(tmp_path / "f.json")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode != 0 and "sweep: 1 item(s) failed" in r.stdout and "injected failure" in r.stdout, r.stdout[-2000:]
 
 
 def test_sweep_settings_tables():
