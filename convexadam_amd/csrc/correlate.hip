@@ -246,7 +246,7 @@ using namespace cvx;
 // hw 6: 0.40 vs 0.63 ms), so they stay the default there; option corr_fused_all = 1 selects the fused kernel for every C.
 static bool corr_use_unfused(int C, int h, int w, int d, int hw, bool variant) {
     if (!corr_fused_supported(C, h, w, d, hw)) return true;
-    if (variant || options().corr_fused_all != 0 || C < 16) return false;
+    if (variant || options().corr_fused_all != 0 || C < 16 || hw > 8) return false;      // (the round-1 raw kernel is instantiated for hw <= 8)
     const CorrGeom g = corr_geom(C, h, w, d, hw);
     return corr_box2_supported(h, w, d, g.px) && (size_t)g.n * g.n * g.n * h * w * g.px * sizeof(float) <= ((size_t)2 << 30);
 }
@@ -279,7 +279,7 @@ extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, i
     CVX_REQUIRE(fix && mov && ssd && workspace, "cvx_correlate_f32: null pointer");
     CVX_REQUIRE(C > 0 && C < 256 && h > 0 && w > 0 && d > 0, "cvx_correlate_f32: bad extent C=%d %dx%dx%d", C, h, w, d);
     CVX_REQUIRE(disp_hw >= 0, "cvx_correlate_f32: negative disp_hw");
-    if (disp_hw > 8) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: disp_hw %d > 8 not built", disp_hw);
+    if (disp_hw > CVX_MAX_DISP_HW) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: disp_hw %d > %d not built", disp_hw, CVX_MAX_DISP_HW);
     if (workspace_bytes < cvx_correlate_workspace_bytes(C, h, w, d, disp_hw))
         return fail(CVX_ERR_WORKSPACE, "cvx_correlate_f32: workspace too small");
     hipStream_t s = as_stream(stream);
@@ -298,6 +298,7 @@ extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, i
     }
     if (variant)
         return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_ex_f32: cost / n_box / fast / fp16 variants need the fused kernel (option corr_unfused is set, or rows of more than 1270 voxels)");
+    if (disp_hw > 8) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: disp_hw %d > 8 needs the fused kernel (option corr_unfused is set, or rows of more than 1270 voxels)", disp_hw);
     if (!corr_box2_supported(h, w, d, g.px))
         return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
     Carver cv(workspace, workspace_bytes);

@@ -476,7 +476,7 @@ static size_t cf_lds_bytes(const CFGeom& g) { return sizeof(float) * (16 + 2 * (
 
 bool corr_fused_supported(int C, int h, int w, int d, int hw) {
     const bool off = options().corr_unfused != 0;
-    if (off || C < 1 || C > 255 || hw < 0 || hw > 8 || h < 1 || w < 1 || d < 1) return false;
+    if (off || C < 1 || C > 255 || hw < 0 || hw > CVX_MAX_DISP_HW || h < 1 || w < 1 || d < 1) return false;
     const CFGeom g = cf_geom(C, h, w, d, hw);
     if (g.T < 1 || g.wpr < 1 || 3 * g.wpr > 16 || cf_lds_bytes(g) > 160 * 1024) return false;
     // 32-bit byte offsets inside a feature copy and inside one displacement plane of the cost volume

@@ -173,7 +173,7 @@ static int validate(const cvx_pair_params* p) {
     CVX_REQUIRE(p->grid_sp >= 1 && p->grid_sp_adam >= 1, "cvx_register_pair: grid spacing must be >= 1");
     CVX_REQUIRE(p->H / p->grid_sp >= 2 && p->W / p->grid_sp >= 2 && p->D / p->grid_sp >= 2,
                 "cvx_register_pair: volume too small for grid_sp %d", p->grid_sp);
-    CVX_REQUIRE(p->disp_hw >= 0 && p->disp_hw <= 8, "cvx_register_pair: disp_hw %d not in 0..8", p->disp_hw);
+    CVX_REQUIRE(p->disp_hw >= 0 && p->disp_hw <= CVX_MAX_DISP_HW, "cvx_register_pair: disp_hw %d not in 0..%d", p->disp_hw, CVX_MAX_DISP_HW);
     CVX_REQUIRE(p->n_feat >= 0 && p->n_feat < 256, "cvx_register_pair: n_feat out of range");
     CVX_REQUIRE(p->selected_smooth == 0 || (p->selected_smooth & 1), "cvx_register_pair: selected_smooth must be odd "
                 "(an even kernel changes the volume size in the reference, convex_adam_MIND.py:185-191)");

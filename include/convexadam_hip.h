@@ -42,6 +42,7 @@ extern "C" {
 #define CVX_ERR_WORKSPACE (-2)
 #define CVX_ERR_LAUNCH (-3)
 #define CVX_ERR_UNSUPPORTED (-4)
+#define CVX_MAX_DISP_HW 15     /* largest search half-width (n = 31, 29 791 displacements); the reference itself has no limit */
 
 /* library / device ------------------------------------------------------------------------------ */
 int cvx_version(void);                 /* 1000*major + minor */

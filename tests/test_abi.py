@@ -57,7 +57,7 @@ def test_argument_validation_without_gpu(L):
     assert b"null" in L.cvx_last_error()
     assert L.cvx_correlate_f32(None, None, 12, 4, 4, 4, 2, None, None, None, 0, None) == -1
     dummy = C.c_void_p(256)
-    assert L.cvx_correlate_f32(dummy, dummy, 12, 4, 4, 4, 9, dummy, None, dummy, 1 << 40, None) == -4   # hw > 8 unsupported
+    assert L.cvx_correlate_f32(dummy, dummy, 12, 4, 4, 4, 16, dummy, None, dummy, 1 << 40, None) == -4  # hw > 15 unsupported
     assert L.cvx_correlate_f32(dummy, dummy, 12, 4, 4, 4, 2, dummy, None, dummy, 16, None) == -2         # workspace too small
     assert L.cvx_box_smooth_f32(dummy, 3, 4, 4, 4, 4, 1, C.c_void_p(512), None, 0, None) == -1           # even kernel
     assert b"odd" in L.cvx_last_error()

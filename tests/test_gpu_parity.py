@@ -113,7 +113,9 @@ def test_correlate_tiled_rows_vs_oracle(U, orc, C, shape, hw):
                                         (12, (6, 40, 37), 3), (12, (5, 23, 74), 2), (7, (4, 38, 44), 4), (12, (3, 96, 112), 1), (12, (9, 33, 37), 6),
                                         (32, (5, 48, 56), 2), (18, (6, 40, 37), 3), (64, (4, 9, 10), 2), (67, (3, 5, 6), 1),
                                         # the interleaved-order tail (last ncols mod 32 elements) spans several planes on tiny grids
-                                        (12, (3, 3, 3), 0), (12, (5, 2, 3), 1), (20, (7, 1, 3), 0)])
+                                        (12, (3, 3, 3), 0), (12, (5, 2, 3), 1), (20, (7, 1, 3), 0),
+                                        # search half-widths beyond the reference's usual range (no limit there; 15 here)
+                                        (12, (5, 6, 9), 9), (6, (4, 5, 13), 11), (20, (3, 4, 5), 10), (12, (4, 3, 6), 15)])
 def test_correlate_vs_oracle(U, orc, C, shape, hw):
     """Includes C >= 16 (ATen cascade sum), ragged inner sizes (interleaved tail rule), D not a multiple of 4,
     search windows larger than the volume, the degenerate hw = 0, y-tiled planes and multi-plane tails: all through the fused kernel."""
@@ -383,6 +385,19 @@ def test_pipeline_vs_oracle_bit_exact(M, orc, golden, kw):
     ref = orc.convex_adam_pipeline(g["fix"], g["mov"], **base, **kw)
     assert out.shape == ref.shape and out.dtype == np.float64
     assert np.array_equal(out, ref), "EPE %g" % epe(out, ref)
+
+
+@pytest.mark.parametrize("hw,gs", [(9, 4), (12, 4), (15, 6)])
+def test_pipeline_with_search_widths_beyond_8(M, orc, hw, gs):
+    """The reference puts no limit on disp_hw; since round 3 the fused correlation kernel, the coupled-convex passes and the search mesh
+    take half-widths up to 15 (n = 31, 29 791 displacements; windows larger than the coarse grid): whole pipeline, bit for bit."""
+    from convexadam_amd.phantom import phantom
+    shape = (40, 36, 44)
+    fix = phantom(shape, 1, 10)
+    mov = torch.roll(phantom(shape, 1, 11), (3, -2, 1), (0, 1, 2))
+    kw = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=gs, disp_hw=hw, selected_niter=3, grid_sp_adam=2, ic=True)
+    out = M.convex_adam_pt(fix, mov, dtype=torch.float32, device=torch.device(DEV), **kw)
+    assert np.array_equal(out, orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), **kw))
 
 
 def test_batched_pairs_on_internal_streams_match_single_calls(M, golden):

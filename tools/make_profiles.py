@@ -66,6 +66,15 @@ def main(src, tag):
     buf.write("%-44s %6s %14s %14s %18s\n" % ("kernel", "calls", "FETCH_KiB/call", "WRITE_KiB/call", "corrected_MB/call"))
     for k, n, fe, wr, mb in rows:
         buf.write("%-44s %6d %14.1f %14.1f %18.1f\n" % (k[-44:], n, fe, wr, mb))
+    # calibration of the FETCH_SIZE factor on kernels whose read volume is known exactly (benchmark configuration): the guide's x2 holds for
+    # accesses that fetch whole 128-byte lines (tallied at 64 B); kernels that read shorter contiguous pieces are counted 1:1
+    V, v, K = 160 * 192 * 224, 26 * 32 * 37, 2197
+    known = {"k_argmin4": K * v * 4, "k_mind_finish_pool": 12 * V * 4, "k_to_chunked": 12 * (V // 8) * 4, "k_resize<3>": None}
+    buf.write("# FETCH_SIZE calibration (known read bytes / counted bytes; x2 is applied to every kernel above, i.e. an UPPER bound where the factor is 1):\n")
+    for k, n, fe, wr, mb in rows:
+        for name, nbytes in known.items():
+            if nbytes and name in k:
+                buf.write("#   %-40s reads %7.1f MB, FETCH_SIZE %7.1f MB -> factor %.2f\n" % (k[-40:], nbytes / 1e6, fe * 1024 / 1e6, nbytes / (fe * 1024)))
     open(os.path.join(prof, tag + "_pmc_hbm_traffic.txt"), "w").write(buf.getvalue())
     stage = [(r[0], r[1], r[2], r[3], r[4]) for r in rows if any(s in r[0] for s in ("k_corr_prep", "k_corr_raw", "k_corr_tail", "k_corr_box", "k_corr_fused"))]
     total = sum(r[4] for r in stage) * 1e6
