@@ -23,6 +23,8 @@ device (csrc/metrics.hip, edt.hip).  torch.distributed is used for the phase bar
 `--settings N --evaluate` keeps the round-1 behaviour (the build's own 256-point grid, whole pipeline per item).
 """
 import argparse
+import contextlib
+import threading
 import glob
 import itertools
 import json
@@ -182,17 +184,19 @@ class WorkQueue:
 
     def __init__(self, rank, world):
         self.rank, self.world, self.store = rank, world, None
+        self.lock = threading.Lock()
         if world > 1:
             port = int(os.environ.get("MASTER_PORT", "29500")) + 17
             self.store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, is_master=(rank == 0), wait_for_workers=True)
         self.local = {}
 
     def next(self, phase, order):
-        if self.store is not None:
-            i = self.store.add("q_" + phase, 1) - 1
-        else:
-            i = self.local.get(phase, 0)
-            self.local[phase] = i + 1
+        with self.lock:                                                     # (several worker threads of one rank may draw)
+            if self.store is not None:
+                i = self.store.add("q_" + phase, 1) - 1
+            else:
+                i = self.local.get(phase, 0)
+                self.local[phase] = i + 1
         return order[i] if i < len(order) else None
 
 
@@ -267,25 +271,32 @@ class PairData:
 
     def __init__(self, shape, device):
         self.shape, self.device, self.pairs, self.labels, self.coarse = tuple(shape), device, {}, {}, {}
+        self.lock = threading.Lock()
 
     def pair(self, p):
-        if p not in self.pairs:
-            self.pairs[p] = _make_pair(self.shape, p, self.device)
-        return self.pairs[p]
+        with self.lock:
+            if p not in self.pairs:
+                self.pairs[p] = _make_pair(self.shape, p, self.device)
+                if self.device.type == "cuda":
+                    torch.cuda.current_stream(self.device).synchronize()       # made on this worker's stream, used on every worker's
+            return self.pairs[p]
 
     def label(self, p):
-        if p not in self.labels:
-            self.labels[p] = _make_labels(self.shape, p, self.device)
-        return self.labels[p]
+        with self.lock:
+            if p not in self.labels:
+                self.labels[p] = _make_labels(self.shape, p, self.device)
+                if self.device.type == "cuda":
+                    torch.cuda.current_stream(self.device).synchronize()
+            return self.labels[p]
 
 
 def run_stage1_item(cfg, p, data):
     from convexadam_amd.convex_adam_MIND import register_pair_device
     fix, mov = data.pair(p)
-    torch.cuda.synchronize(data.device)
+    torch.cuda.current_stream(data.device).synchronize()
     t = time.time()
     disp = register_pair_device(fix, mov, lambda_weight=0, ic=True, **cfg)                  # convex stage + inverse consistency (:100-128)
-    torch.cuda.synchronize(data.device)
+    torch.cuda.current_stream(data.device).synchronize()
     rec = dict(ms=(time.time() - t) * 1e3)
     rec.update(evaluate_item(disp, *data.label(p)))
     return rec
@@ -298,11 +309,13 @@ def run_stage2_item(best1, cfg2, p, data, smoothers):
     fix, mov = data.pair(p)
     H, W, D = data.shape
     key = (p, tuple(sorted(best1.items())))
-    if key not in data.coarse:                                                              # the convex stage runs once per pair (:100-126)
-        data.coarse[key] = register_pair_device(fix, mov, lambda_weight=0, ic=True, **best1)
-    disp_hr = data.coarse[key]
+    with data.lock:                                                                         # the convex stage runs once per pair (:100-126)
+        if key not in data.coarse:
+            data.coarse[key] = register_pair_device(fix, mov, lambda_weight=0, ic=True, **best1)
+            torch.cuda.current_stream(data.device).synchronize()                           # (read on other workers' streams)
+        disp_hr = data.coarse[key]
     gsa, lam = cfg2["grid_sp_adam"], cfg2["lambda_weight"]
-    torch.cuda.synchronize(data.device)
+    torch.cuda.current_stream(data.device).synchronize()
     t = time.time()
     ff = U.MINDSSC(fix[None, None], best1["mind_r"], best1["mind_d"], device=data.device)
     fm = U.MINDSSC(mov[None, None], best1["mind_r"], best1["mind_d"], device=data.device)
@@ -313,7 +326,7 @@ def run_stage2_item(best1, cfg2, p, data, smoothers):
     n_ch = int(F2.shape[1])
     _, st = U.adam_run(F2, M2, P0, lam, ADAM_ITERS, smoother=smoothers[cfg2["avg_n"]], cost_scale=float(n_ch), snapshot_iters=SNAP_ITERS,
                        return_state=True)
-    torch.cuda.synchronize(data.device)
+    torch.cuda.current_stream(data.device).synchronize()
     ms = (time.time() - t) * 1e3
     recs = []
     lab = data.label(p)
@@ -341,6 +354,8 @@ def main(argv=None):
     ap.add_argument("--static", action="store_true", help="round-robin assignment instead of the shared queue")
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercises queue, logs, resume and gather only (CPU/gloo)")
     ap.add_argument("--evaluate", action="store_true", help="round-1 mode: score every item on the device and rank the settings")
+    ap.add_argument("--workers", type=int, default=0, help="items in flight per rank, each on its own thread and HIP stream (0 = automatic: 2 on a GPU -- "
+                    "a second registration fills the issue slots one leaves idle, DESIGN.md section 9 -- 1 otherwise)")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", 0))
@@ -353,6 +368,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     two_stage = a.stage1 > 0
+    n_workers = a.workers if a.workers > 0 else (2 if use_gpu else 1)
     queue = WorkQueue(rank, world)
     run_id = dict(shape=list(a.shape), pairs=a.pairs, stage1=a.stage1, stage2=a.stage2, settings=a.settings, niter=a.niter, evaluate=bool(a.evaluate),
                   dry_run=bool(a.dry_run))
@@ -367,33 +383,57 @@ def main(argv=None):
         """Hands out (setting, pair) items of one phase; returns this rank's records (resumed ones included)."""
         items = [(s, p) for s in range(len(settings)) for p in range(a.pairs)]
         order = sorted(range(len(items)), key=lambda i: -item_cost(settings[items[i][0]], shape))
-        mine, fresh = [], 0
+        mine, fresh = [], [0]
         static = shard_items(order, rank, world) if a.static else None
-        k = 0
-        while True:
-            if static is not None:
-                i = static[k] if k < len(static) else None
-                k += 1
-            else:
-                i = queue.next(phase, order)
-            if i is None:
-                break
-            s, p = items[i]
-            if (phase, s, p) in log.done:                                   # --resume: already on disk; reported by whoever draws it
-                mine.append(dict(log.done[(phase, s, p)], item=i))
-                continue
-            rec = dict(stage=phase, setting=s, pair=p, rank=rank, item=i)
-            try:
-                if os.environ.get("CVX_SWEEP_FAIL_ITEM") == str(i):
-                    raise RuntimeError("injected failure (test hook CVX_SWEEP_FAIL_ITEM)")
-                rec.update(worker(settings[s], p))
-            except Exception as e:                                          # keep drawing: the other ranks wait in the gather that follows
-                failures.append(dict(stage=phase, setting=s, pair=p, rank=rank, item=i, error="%s: %s" % (type(e).__name__, e)))
-                continue
-            log.add(rec)
-            mine.append(rec)
-            fresh += 1
-        return mine, fresh
+        static_pos = [0]
+        lock = threading.Lock()
+
+        def draw():
+            if static is None:
+                return queue.next(phase, order)
+            with lock:
+                k = static_pos[0]
+                static_pos[0] = k + 1
+            return static[k] if k < len(static) else None
+
+        def loop(widx):
+            stream = torch.cuda.Stream(device) if use_gpu and n_workers > 1 else None
+            ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+            with ctx:
+                while True:
+                    i = draw()
+                    if i is None:
+                        break
+                    s, p = items[i]
+                    if (phase, s, p) in log.done:                           # --resume: already on disk; reported by whoever draws it
+                        with lock:
+                            mine.append(dict(log.done[(phase, s, p)], item=i))
+                        continue
+                    rec = dict(stage=phase, setting=s, pair=p, rank=rank, item=i, worker=widx)
+                    try:
+                        if os.environ.get("CVX_SWEEP_FAIL_ITEM") == str(i):
+                            raise RuntimeError("injected failure (test hook CVX_SWEEP_FAIL_ITEM)")
+                        rec.update(worker(settings[s], p))
+                    except Exception as e:                                  # keep drawing: the other ranks wait in the gather that follows
+                        with lock:
+                            failures.append(dict(stage=phase, setting=s, pair=p, rank=rank, item=i, error="%s: %s" % (type(e).__name__, e)))
+                        continue
+                    with lock:
+                        log.add(rec)
+                        mine.append(rec)
+                        fresh[0] += 1
+                if stream is not None:
+                    stream.synchronize()
+
+        if n_workers > 1:
+            ths = [threading.Thread(target=loop, args=(k,)) for k in range(n_workers)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        else:
+            loop(0)
+        return mine, fresh[0]
 
     failures = []
 
@@ -406,10 +446,15 @@ def main(argv=None):
                 dist.destroy_process_group()
             raise RuntimeError("sweep: %d item(s) failed, e.g. %s" % (len(allf), json.dumps(allf[0])))
 
+    if use_gpu:                                                             # the validation pairs are resident before the clock starts
+        for p in range(a.pairs):
+            data.pair(p)
+            data.label(p)
+        torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     t0 = time.time()
-    summary = dict(world_size=world, shape=list(shape), pairs=a.pairs)
+    summary = dict(world_size=world, shape=list(shape), pairs=a.pairs, workers_per_rank=n_workers)
     if two_stage:
         s1 = stage1_settings(a.stage1)
         if a.dry_run:
@@ -459,10 +504,10 @@ def main(argv=None):
                 return dict(ms=0.0, mean_abs_disp=0.0)
             from convexadam_amd.convex_adam_MIND import register_pair_device
             fix, mov = data.pair(p)
-            torch.cuda.synchronize(device)
+            torch.cuda.current_stream(device).synchronize()
             t1 = time.time()
             disp = register_pair_device(fix, mov, **cfg)
-            torch.cuda.synchronize(device)
+            torch.cuda.current_stream(device).synchronize()
             res = dict(ms=(time.time() - t1) * 1e3, mean_abs_disp=float(disp.abs().mean()))
             if a.evaluate:
                 res.update(evaluate_item(disp, *data.label(p)))

@@ -110,6 +110,10 @@ def test_sharded_driver_gloo_world_size_2(tmp_path):
     assert sorted(sum(parts, [])) == list(range(15))                       # every item exactly once, whoever drew it
     res, _ = _run_sweep(tmp_path, 29615, ["--pairs", "5", "--settings", "3", "--static"])
     assert sorted(len(v) for v in res["per_rank"].values()) == [7, 8]
+    # two worker threads per rank (two registrations in flight per GPU): still every item exactly once
+    res, _ = _run_sweep(tmp_path, 29621, ["--pairs", "5", "--settings", "3", "--workers", "2"])
+    assert res["workers_per_rank"] == 2 and sorted(res["items_done"]) == list(range(15))
+    assert sorted(sum(res["per_rank"].values(), [])) == list(range(15))
 
 
 @pytest.mark.timeout(300)
