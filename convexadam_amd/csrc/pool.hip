@@ -7,6 +7,8 @@
 // All of them are HBM/L2-bound gathers; arithmetic follows the ATen CPU kernels (raster-order sums,
 // one division; FMA exactly where the ATen build fuses).
 #include <hip/hip_fp16.h>
+#include <math.h>
+#include <string.h>
 
 #include "cvx_common.h"
 
@@ -510,18 +512,119 @@ extern "C" int cvx_label_histogram_i64(const float* lab, int64_t V, int max_labe
 }
 
 // weight = 1/((n_fix + n_mov) + eps).float().pow(.3); weight /= weight.mean()   (convex_adam_nnUNet.py:32-33)
+// ---- host-side restatement of torch.pow(float32 tensor, scalar) and torch.sum for the label weights ----------------------------------
+// (the same arithmetic as oracle/cvx_oracle.c sp_sleef_powf / torch_inner_sum, whose header explains how it was pinned: ATen evaluates
+// the leading blocks of 32 elements with Sleef's powf -- double-float log and exp, fused multiply-adds -- and the trailing n mod 32
+// elements with the scalar std::pow(float, double exponent))
+namespace {
+typedef struct { float x, y; } lw_f2;
+static inline float lw_i2f(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int32_t lw_f2i(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+static inline lw_f2 lw_mk(float x, float y) { lw_f2 r = {x, y}; return r; }
+static inline lw_f2 lw_dfadd2_f_f(float x, float y) { lw_f2 r; r.x = x + y; float v = r.x - x; r.y = (x - (r.x - v)) + (y - v); return r; }
+static inline lw_f2 lw_dfadd2_f2_f(lw_f2 x, float y) { lw_f2 r; r.x = x.x + y; float v = r.x - x.x; r.y = (x.x - (r.x - v)) + (y - v); r.y = r.y + x.y; return r; }
+static inline lw_f2 lw_dfadd2_f2_f2(lw_f2 x, lw_f2 y) { lw_f2 r; r.x = x.x + y.x; float v = r.x - x.x; r.y = (x.x - (r.x - v)) + (y.x - v); r.y = r.y + (x.y + y.y); return r; }
+static inline lw_f2 lw_dfadd_f2_f2(lw_f2 x, lw_f2 y) { lw_f2 r; r.x = x.x + y.x; r.y = x.x - r.x + y.x + x.y + y.y; return r; }
+static inline lw_f2 lw_dfadd_f_f2(float x, lw_f2 y) { lw_f2 r; r.x = x + y.x; r.y = x - r.x + y.x + y.y; return r; }
+static inline lw_f2 lw_dfmul_f2_f(lw_f2 x, float y) { lw_f2 r; r.x = x.x * y; r.y = fmaf(x.y, y, fmaf(x.x, y, -r.x)); return r; }
+static inline lw_f2 lw_dfmul_f2_f2(lw_f2 x, lw_f2 y) { lw_f2 r; r.x = x.x * y.x; r.y = fmaf(x.x, y.y, fmaf(x.y, y.x, fmaf(x.x, y.x, -r.x))); return r; }
+static inline lw_f2 lw_dfsqu(lw_f2 x) { lw_f2 r; r.x = x.x * x.x; r.y = fmaf(x.x + x.x, x.y, fmaf(x.x, x.x, -r.x)); return r; }
+static inline lw_f2 lw_dfdiv(lw_f2 n, lw_f2 d) {
+    float t = 1.0f / d.x; lw_f2 q; q.x = n.x * t;
+    float u = fmaf(t, n.x, -q.x);
+    q.y = fmaf(-d.y, t, fmaf(-d.x, t, 1.0f));
+    q.y = fmaf(q.x, q.y, fmaf(n.y, t, u));
+    return q;
+}
+static inline lw_f2 lw_dfscale(lw_f2 d, float s) { return lw_mk(d.x * s, d.y * s); }
+static inline lw_f2 lw_dfnormalize(lw_f2 t) { lw_f2 s; s.x = t.x + t.y; s.y = t.x - s.x + t.y; return s; }
+static lw_f2 lw_logkf(float d) {
+    int o = d < 1.17549435e-38f;
+    if (o) d = d * (float)(1LL << 32) * (float)(1LL << 32);
+    int e = ((lw_f2i(d * (1.0f / 0.75f)) >> 23) & 0xff) - 0x7f;
+    float m = lw_i2f(lw_f2i(d) + ((-e) << 23));
+    if (o) e -= 64;
+    lw_f2 x = lw_dfdiv(lw_dfadd2_f_f(-1.0f, m), lw_dfadd2_f_f(1.0f, m));
+    lw_f2 x2 = lw_dfsqu(x);
+    float t = 0.240320354700088500976562f;
+    t = fmaf(t, x2.x, 0.285112679004669189453125f);
+    t = fmaf(t, x2.x, 0.400007992982864379882812f);
+    lw_f2 c = lw_mk(0.66666662693023681640625f, 3.69183861259614332084311e-09f);
+    lw_f2 s = lw_dfmul_f2_f(lw_mk(0.69314718246459960938f, -1.904654323148236017e-09f), (float)e);
+    s = lw_dfadd_f2_f2(s, lw_dfscale(x, 2.0f));
+    s = lw_dfadd_f2_f2(s, lw_dfmul_f2_f2(lw_dfmul_f2_f2(x2, x), lw_dfadd2_f2_f2(lw_dfmul_f2_f(x2, t), c)));
+    return s;
+}
+static float lw_ldexpkf(float x, int q) {
+    int m = q >> 31;
+    m = (((m + q) >> 6) - m) << 4;
+    q = q - (m << 2);
+    m += 127; m = m < 0 ? 0 : m; m = m > 255 ? 255 : m;
+    float u = lw_i2f(m << 23);
+    x = x * u * u * u * u;
+    u = lw_i2f((q + 0x7f) << 23);
+    return x * u;
+}
+static float lw_expkf(lw_f2 d) {
+    float u = (d.x + d.y) * 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    int q = (int)rintf(u);
+    lw_f2 s = lw_dfadd2_f2_f(d, (float)q * -0.693145751953125f);
+    s = lw_dfadd2_f2_f(s, (float)q * -1.428606765330187045e-06f);
+    s = lw_dfnormalize(s);
+    float t = 0.00136324646882712841033936f;
+    t = fmaf(t, s.x, 0.00836596917361021041870117f);
+    t = fmaf(t, s.x, 0.0416710823774337768554688f);
+    t = fmaf(t, s.x, 0.166665524244308471679688f);
+    t = fmaf(t, s.x, 0.499999850988388061523438f);
+    lw_f2 tt = lw_dfadd_f2_f2(s, lw_dfmul_f2_f(lw_dfsqu(s), t));
+    tt = lw_dfadd_f_f2(1.0f, tt);
+    u = tt.x + tt.y;
+    u = lw_ldexpkf(u, q);
+    if (d.x < -104.0f) u = 0.0f;
+    return u;
+}
+static float lw_sleef_powf(float x, float y) {          // x > 0 only
+    return lw_expkf(lw_dfmul_f2_f(lw_logkf(fabsf(x)), y));
+}
+// torch.sum of n <= 255 contiguous floats on one thread (ATen SumKernel, 8-float vectors): the scalar tail first, then per lane four
+// interleaved partial sums of the vectors (vector i -> partial i mod 4, leftover vectors -> partial 0, ((p0 + p1) + p2) + p3), lanes in
+// order; fewer than 8 elements: the same scheme on scalars (the cascade levels start at 16 values per partial: never reached here).
+static float torch_sum_small(const float* x, int n) {
+    auto strided = [](const float* v, int stride, int size) { float a = 0.0f; for (int i = 0; i < size; ++i) a += v[i * stride]; return a; };
+    if (n < 8) {
+        const int n4 = n / 4;
+        float p[4];
+        for (int k = 0; k < 4; ++k) p[k] = strided(x + k, 4, n4);
+        for (int i = n4 * 4; i < n; ++i) p[0] += x[i];
+        for (int k = 1; k < 4; ++k) p[0] += p[k];
+        return 0.0f + p[0];
+    }
+    const int nv = n / 8, nv4 = nv / 4;
+    float fin = 0.0f;
+    for (int k = nv * 8; k < n; ++k) fin += x[k];
+    for (int lane = 0; lane < 8; ++lane) {
+        float p[4];
+        for (int k = 0; k < 4; ++k) p[k] = strided(x + k * 8 + lane, 32, nv4);
+        for (int i = nv4 * 4; i < nv; ++i) p[0] += x[i * 8 + lane];
+        for (int k = 1; k < 4; ++k) p[0] += p[k];
+        fin += p[0];
+    }
+    return 0.0f + fin;
+}
+}  // namespace
+
 extern "C" int cvx_label_weights_host(const int64_t* hist_fix_host, const int64_t* hist_mov_host, int max_label,
                                       int* present_host, float* weights_host) {
     int C = 0;
     for (int l = 0; l <= max_label; ++l)
         if (hist_fix_host[l] + hist_mov_host[l] > 0) present_host[C++] = l;
-    float sum = 0.f;
+    // weight = 1 / (n_fix + n_mov + eps).float().pow(.3) ; weight /= weight.mean()          (convex_adam_nnUNet.py:31-32)
     for (int c = 0; c < C; ++c) {
         const float cnt = (float)(hist_fix_host[present_host[c]] + hist_mov_host[present_host[c]]) + 1e-32f;
-        weights_host[c] = 1.0f / powf(cnt, 0.3f);
-        sum += weights_host[c];
+        const float pw = c < (C / 32) * 32 ? lw_sleef_powf(cnt, 0.3f) : (float)pow((double)cnt, 0.3);
+        weights_host[c] = 1.0f / pw;
     }
-    const float mean = sum / (float)C;
+    const float mean = torch_sum_small(weights_host, C) / (float)C;
     for (int c = 0; c < C; ++c) weights_host[c] = weights_host[c] / mean;
     return C;
 }

@@ -885,6 +885,90 @@ ORC_API void orc_adam_run_smoother(const float* F2, const float* M2, int C, int 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * torch.pow(float32 tensor, python scalar) on the CPU, as the reference evaluates `(...).float().pow(.3)` in its label weights
+ * (src/convexAdam/convex_adam_nnUNet.py:31).  Black-box finding (inputs fed, outputs compared; tests/test_oracle_vs_reference_live.py):
+ * ATen's vectorised loop handles the leading blocks of 32 elements with Sleef's powf (1.0-ULP variant, FMA build, exponent rounded to
+ * float32) and the trailing `n mod 32` elements with the scalar lambda std::pow(float, double exponent), i.e. (float)pow((double)x, y).
+ * The Sleef routine is restated from its published algorithm (sleefsimdsp.c: xpowf = sp_expkf(sp_logkf(|x|) * y) in double-float arithmetic,
+ * dd.h / df.h with fused multiply-adds); it agrees with torch.pow on every one of the 16 777 184 block elements of arange(1, 2^24).
+ * Positive bases only (voxel counts).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float x, y; } sp_f2;
+static inline float sp_i2f(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int32_t sp_f2i(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+static inline sp_f2 sp_mk(float x, float y) { sp_f2 r = {x, y}; return r; }
+static inline sp_f2 sp_dfadd2_f_f(float x, float y) { sp_f2 r; r.x = x + y; float v = r.x - x; r.y = (x - (r.x - v)) + (y - v); return r; }
+static inline sp_f2 sp_dfadd2_f2_f(sp_f2 x, float y) { sp_f2 r; r.x = x.x + y; float v = r.x - x.x; r.y = (x.x - (r.x - v)) + (y - v); r.y = r.y + x.y; return r; }
+static inline sp_f2 sp_dfadd2_f2_f2(sp_f2 x, sp_f2 y) { sp_f2 r; r.x = x.x + y.x; float v = r.x - x.x; r.y = (x.x - (r.x - v)) + (y.x - v); r.y = r.y + (x.y + y.y); return r; }
+static inline sp_f2 sp_dfadd_f2_f2(sp_f2 x, sp_f2 y) { sp_f2 r; r.x = x.x + y.x; r.y = x.x - r.x + y.x + x.y + y.y; return r; }
+static inline sp_f2 sp_dfadd_f_f2(float x, sp_f2 y) { sp_f2 r; r.x = x + y.x; r.y = x - r.x + y.x + y.y; return r; }
+static inline sp_f2 sp_dfmul_f2_f(sp_f2 x, float y) { sp_f2 r; r.x = x.x * y; r.y = fmaf(x.y, y, fmaf(x.x, y, -r.x)); return r; }
+static inline sp_f2 sp_dfmul_f2_f2(sp_f2 x, sp_f2 y) { sp_f2 r; r.x = x.x * y.x; r.y = fmaf(x.x, y.y, fmaf(x.y, y.x, fmaf(x.x, y.x, -r.x))); return r; }
+static inline sp_f2 sp_dfsqu(sp_f2 x) { sp_f2 r; r.x = x.x * x.x; r.y = fmaf(x.x + x.x, x.y, fmaf(x.x, x.x, -r.x)); return r; }
+static inline sp_f2 sp_dfdiv(sp_f2 n, sp_f2 d) {
+    float t = 1.0f / d.x; sp_f2 q; q.x = n.x * t;
+    float u = fmaf(t, n.x, -q.x);
+    q.y = fmaf(-d.y, t, fmaf(-d.x, t, 1.0f));
+    q.y = fmaf(q.x, q.y, fmaf(n.y, t, u));
+    return q;
+}
+static inline sp_f2 sp_dfscale(sp_f2 d, float s) { return sp_mk(d.x * s, d.y * s); }
+static inline sp_f2 sp_dfnormalize(sp_f2 t) { sp_f2 s; s.x = t.x + t.y; s.y = t.x - s.x + t.y; return s; }
+static sp_f2 sp_logkf(float d) {
+    int o = d < 1.17549435e-38f;
+    if (o) d = d * (float)(1LL << 32) * (float)(1LL << 32);
+    int e = ((sp_f2i(d * (1.0f / 0.75f)) >> 23) & 0xff) - 0x7f;
+    float m = sp_i2f(sp_f2i(d) + ((-e) << 23));
+    if (o) e -= 64;
+    sp_f2 x = sp_dfdiv(sp_dfadd2_f_f(-1.0f, m), sp_dfadd2_f_f(1.0f, m));
+    sp_f2 x2 = sp_dfsqu(x);
+    float t = 0.240320354700088500976562f;
+    t = fmaf(t, x2.x, 0.285112679004669189453125f);
+    t = fmaf(t, x2.x, 0.400007992982864379882812f);
+    sp_f2 c = sp_mk(0.66666662693023681640625f, 3.69183861259614332084311e-09f);
+    sp_f2 s = sp_dfmul_f2_f(sp_mk(0.69314718246459960938f, -1.904654323148236017e-09f), (float)e);
+    s = sp_dfadd_f2_f2(s, sp_dfscale(x, 2.0f));
+    s = sp_dfadd_f2_f2(s, sp_dfmul_f2_f2(sp_dfmul_f2_f2(x2, x), sp_dfadd2_f2_f2(sp_dfmul_f2_f(x2, t), c)));
+    return s;
+}
+static float sp_ldexpkf(float x, int q) {
+    int m = q >> 31;
+    m = (((m + q) >> 6) - m) << 4;
+    q = q - (m << 2);
+    m += 127; m = m < 0 ? 0 : m; m = m > 255 ? 255 : m;
+    float u = sp_i2f(m << 23);
+    x = x * u * u * u * u;
+    u = sp_i2f((q + 0x7f) << 23);
+    return x * u;
+}
+static float sp_expkf(sp_f2 d) {
+    float u = (d.x + d.y) * 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    int q = (int)rintf(u);
+    sp_f2 s = sp_dfadd2_f2_f(d, (float)q * -0.693145751953125f);
+    s = sp_dfadd2_f2_f(s, (float)q * -1.428606765330187045e-06f);
+    s = sp_dfnormalize(s);
+    float t = 0.00136324646882712841033936f;
+    t = fmaf(t, s.x, 0.00836596917361021041870117f);
+    t = fmaf(t, s.x, 0.0416710823774337768554688f);
+    t = fmaf(t, s.x, 0.166665524244308471679688f);
+    t = fmaf(t, s.x, 0.499999850988388061523438f);
+    sp_f2 tt = sp_dfadd_f2_f2(s, sp_dfmul_f2_f(sp_dfsqu(s), t));
+    tt = sp_dfadd_f_f2(1.0f, tt);
+    u = tt.x + tt.y;
+    u = sp_ldexpkf(u, q);
+    if (d.x < -104.0f) u = 0.0f;
+    return u;
+}
+static float sp_sleef_powf(float x, float y) {          /* x > 0 only */
+    return sp_expkf(sp_dfmul_f2_f(sp_logkf(fabsf(x)), y));
+}
+/* element i of an n-element tensor */
+static float sp_torch_pow_at(float x, double y, int64_t i, int64_t n) {
+    return i < (n / 32) * 32 ? sp_sleef_powf(x, (float)y) : (float)pow((double)x, y);
+}
+ORC_API float orc_torch_pow_at(float x, double y, int64_t i, int64_t n) { return sp_torch_pow_at(x, y, i, n); }
+
+/* ------------------------------------------------------------------------------------------------
  * nnUNet label features, convex_adam_nnUNet.py:19-38 (fp32 restatement; the reference stores fp16).
  * labels are float-valued integer maps; present = labels occurring in either image (ascending).
  * Returns C (number of channels); feat_* = [C][V] = 10 * w_c * onehot.
@@ -898,9 +982,8 @@ ORC_API int orc_label_features(const float* lab_fix, const float* lab_mov, int64
     for (int l = 0; l <= max_label; ++l) if (cf[l] + cm[l] > 0) present[C++] = l;
     float* wt = (float*)malloc(sizeof(float) * C);
     /* weight = 1/((n_fix+n_mov)+eps).float().pow(.3) ; weight /= weight.mean() */
-    for (int c = 0; c < C; ++c) wt[c] = 1.0f / powf((float)(cf[present[c]] + cm[present[c]]) + 1e-32f, 0.3f);
-    float s = 0.f; for (int c = 0; c < C; ++c) s += wt[c];
-    const float mean = s / (float)C;
+    for (int c = 0; c < C; ++c) wt[c] = 1.0f / sp_torch_pow_at((float)(cf[present[c]] + cm[present[c]]) + 1e-32f, 0.3, c, C);
+    const float mean = orc_torch_sum(wt, C, 1, 8) / (float)C;                   /* weight.mean(): ATen's sum (one chunk), then / C */
     for (int c = 0; c < C; ++c) wt[c] = wt[c] / mean;
     if (feat_fix && feat_mov)
         for (int c = 0; c < C; ++c)

@@ -178,6 +178,37 @@ def test_sweep_worker_failure_is_reported(tmp_path):
     assert r.returncode != 0 and "sweep: 1 item(s) failed" in r.stdout and "injected failure" in r.stdout, r.stdout[-2000:]
 
 
+def test_torch_pow_restatement():
+    """The label weights of the multi-channel path use `(...).float().pow(.3)` (convex_adam_nnUNet.py:31): torch evaluates the leading
+    blocks of 32 elements with Sleef's powf and the trailing n mod 32 with the scalar double pow.  The oracle's restatement
+    (orc_torch_pow_at) and the library's host helper (cvx_label_weights_host, which also restates weight.mean()) against torch itself."""
+    import ctypes as C
+    from oracle import oracle
+    from convexadam_amd import _lib
+    oracle.build()
+    lo = oracle.lib()
+    lo.orc_torch_pow_at.restype = C.c_float
+    lo.orc_torch_pow_at.argtypes = [C.c_float, C.c_double, C.c_int64, C.c_int64]
+    rng = np.random.default_rng(3)
+    for n in (1, 5, 31, 32, 33, 64, 95, 200, 4096 + 7):
+        x = torch.from_numpy(rng.integers(1, 1 << 24, n).astype(np.float32))
+        for y in (0.3, 1.7, 0.123):                                  # (0.5, 2, 3, -1 ... are special-cased by torch: sqrt, x*x, ...)
+            ref = torch.pow(x, y).numpy()
+            got = np.array([lo.orc_torch_pow_at(float(v), y, i, n) for i, v in enumerate(x.numpy())], np.float32)
+            assert np.array_equal(got, ref), (n, y)
+    L = _lib.lib()
+    for n in (1, 3, 8, 13, 18, 32, 33, 100, 255):
+        hf = rng.integers(0, 3000000, n).astype(np.int64)
+        hm = rng.integers(0, 3000000, n).astype(np.int64)
+        hf[hf + hm == 0] = 1
+        w = 1 / ((torch.from_numpy(hf) + torch.from_numpy(hm)) + 1e-32).float().pow(.3)          # the reference's expression (:31-32)
+        w /= w.mean()
+        pres, wt = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        assert L.cvx_label_weights_host(hf.ctypes.data_as(C.c_void_p), hm.ctypes.data_as(C.c_void_p), n - 1, pres.ctypes.data_as(C.c_void_p),
+                                        wt.ctypes.data_as(C.c_void_p)) == n
+        assert np.array_equal(wt, w.numpy()), n
+
+
 def test_sweep_settings_tables():
     from convexadam_amd.sweep import item_cost, stage1_settings, stage2_settings
     s1, s2 = stage1_settings(100), stage2_settings(75)
