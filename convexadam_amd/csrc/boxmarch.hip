@@ -141,7 +141,7 @@ __device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int
 // The whole march of one role.  Every role executes exactly nsteps barriers.  Lanes beyond the role's last row
 // compute on a clamped row and only their stores are masked, so that the window registers never pass through a
 // divergent merge (no register copies).
-template <int K, int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC>
+template <int K, int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC, bool PK>
 __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int lane) {
     using G = BMGeomT<QPR, YT, CPT>;
     constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
@@ -170,9 +170,13 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     // ((0 + taps(z-1)) + taps(z)) + taps(z+1); when input plane n arrives the thread finishes plane n-1 from `mid` (= prefix of
     // planes n-2, n-1), advances `mid` from `pre` (= taps of plane n-1 added to +0.0) and restarts `pre`: every tap is read once
     // and only the newest plane's 3 x WIN window is live.
-    float mid[CPT], pre[CPT];
+    // (mid, pre) travel as ONE register pair per column: the two running sums receive the same taps, so after the first tap of a
+    // plane (which also restarts `pre` from +0.0) every tap costs one scalar add for the finishing sum and one v_pk_add_f32 with a
+    // broadcast operand for the pair -- 19 instead of 27 issue slots per column and plane, the same additions in the same order
+    // (packed fp32 adds run at half rate, so the VALU time is unchanged; what shrinks is the serial issue of one wavefront).
+    f32x2 mp[CPT];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) { mid[j] = 0.f; pre[j] = 0.f; }
+    for (int j = 0; j < CPT; ++j) mp[j] = f32x2{0.f, 0.f};
     // one step; n = t - (3K-2) counts the input planes of this role; EMIT: n >= 2, an output plane is due
     auto step = [&](auto emit, int t) {
         constexpr bool EMIT = decltype(emit)::value;
@@ -182,9 +186,6 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
         }
         bm_load_step<SLOT0, BACKWARD, VEC>(c, L, t);
         const float* sp = src + ((t - 1) & 1) * SRC_SLOT;
-        float f[CPT], m[CPT], p[CPT];
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) { f[j] = mid[j]; m[j] = pre[j]; p[j] = 0.0f; }       // (+0.0 + tap: a -0.0 tap must not survive, like ATen's sum)
         float win[3][WIN];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {                 // all three rows in flight: one LDS round trip per step
@@ -198,18 +199,43 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
                 win[i][0] = a.x; win[i][1] = a.y; win[i][WIN - 2] = b.x; win[i][WIN - 1] = b.y;
             }
         }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float (&w)[WIN] = win[i];
+        float f[CPT];
+        if (PK) {
 #pragma unroll
             for (int j = 0; j < CPT; ++j) {
-                f[j] += w[j]; m[j] += w[j]; p[j] += w[j];
-                f[j] += w[j + 1]; m[j] += w[j + 1]; p[j] += w[j + 1];
-                f[j] += w[j + 2]; m[j] += w[j + 2]; p[j] += w[j + 2];
-            }
-        }
+                // first tap: f = mid + w, mid' = pre + w, pre' = +0.0 + w (a -0.0 tap must not survive, like ATen's sum)
+                const float w0 = win[0][j];
+                f[j] = mp[j].x + w0;
+                f32x2 n;
+                n.x = mp[j].y + w0;
+                n.y = 0.0f + w0;
+                f[j] += win[0][j + 1]; n += win[0][j + 1];
+                f[j] += win[0][j + 2]; n += win[0][j + 2];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) { mid[j] = m[j]; pre[j] = p[j]; }
+                for (int i = 1; i < 3; ++i) {
+                    f[j] += win[i][j]; n += win[i][j];
+                    f[j] += win[i][j + 1]; n += win[i][j + 1];
+                    f[j] += win[i][j + 2]; n += win[i][j + 2];
+                }
+                mp[j] = n;
+            }
+        } else {                                      // three scalar adds per tap
+            float m[CPT], p[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) { f[j] = mp[j].x; m[j] = mp[j].y; p[j] = 0.0f; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float (&w)[WIN] = win[i];
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    f[j] += w[j]; m[j] += w[j]; p[j] += w[j];
+                    f[j] += w[j + 1]; m[j] += w[j + 1]; p[j] += w[j + 1];
+                    f[j] += w[j + 2]; m[j] += w[j + 2]; p[j] += w[j + 2];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) mp[j] = f32x2{m[j], p[j]};
+        }
         const float (&s)[CPT] = f;
         if (EMIT) {
             const int gz = c.z0 - (2 * K + 3) + t;
@@ -261,7 +287,7 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     }
 }
 
-template <int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC>
+template <int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC, bool PK>
 __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
                                                                 int w, int d, int zc, int nzc, int nyt, float* __restrict__ P,
                                                                 float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
@@ -352,9 +378,9 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(cons
 
     // role of this wavefront (wave-uniform, kept in a scalar register)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    if (wave < G::NW1) bm_run<1, QPR, YT, CPT, BACKWARD, ADAM, VEC>(c, L, wave, lane);
-    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, CPT, BACKWARD, ADAM, VEC>(c, L, wave - G::NW1, lane);
-    else bm_run<3, QPR, YT, CPT, BACKWARD, ADAM, VEC>(c, L, wave - G::NW1 - G::NW2, lane);
+    if (wave < G::NW1) bm_run<1, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK>(c, L, wave, lane);
+    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK>(c, L, wave - G::NW1, lane);
+    else bm_run<3, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK>(c, L, wave - G::NW1 - G::NW2, lane);
     if (census && threadIdx.x == 0) census[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -425,13 +451,15 @@ static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt,
     if (options().box_wg_target <= 0 && nxt > 1 && h <= 4095) (void)bm_uneven_table(tbl, grid, h, 3 * nyt * nxt, options().box_uneven);
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec = (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave);
+    const bool pk = options().box_pk != 0;                                     // packed (mid, pre) pair: v_pk_add_f32 with a broadcast tap
     // debugging aid (option census_ptr): forward kernel -> slots [0, 4096), adjoint kernel -> [4096, 8192)
     unsigned long long* census = reinterpret_cast<unsigned long long*>(options().census_ptr);
     if (census && backward) census += 4 * 1024;
 #define CVX_BM_LAUNCH(B, A)                                                                                                                        \
     do {                                                                                                                                           \
-        if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
-        else hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        if (vec && pk) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        else if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        else hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
     } while (0)
     if (!backward) CVX_BM_LAUNCH(false, false);
     else if (!P) CVX_BM_LAUNCH(true, false);
