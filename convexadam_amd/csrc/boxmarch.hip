@@ -23,7 +23,11 @@ namespace cvx {
 
 // QPR = quads (16-byte slots) per LDS row, YT = output rows per tile, CPT = output columns per thread (4, or 2: twice the wavefronts
 // with half the per-step instruction stream each -- a step is bound by the serial issue of ONE wavefront)
-template <int QPR, int YT, int CPT = 4>
+// DPP (QPR = 16, CPT = 4 only): every stage keeps column c at index c; a thread reads ONE aligned 16-byte piece per window row and takes
+// the two halo columns from its neighbour lanes (v_mov_b32_dpp row_shr / row_shl: a row of 16 lanes IS a tile row; the lanes at the row
+// ends receive 0, which only reaches the tile's discarded halo columns or stands for the zero padding of the volume): 3 LDS reads
+// instead of 6 per step, no misaligned loader stores, no bank conflicts.
+template <int QPR, int YT, int CPT = 4, bool DPP = false>
 struct BMGeomT {
     static constexpr int TPR = QPR * 4 / CPT;                              // threads per row
     static constexpr int RPW = 64 / TPR;                                   // rows per wavefront
@@ -32,7 +36,8 @@ struct BMGeomT {
     static constexpr int ROWS0 = YT + 6, ROWS1 = YT + 4, ROWS2 = YT + 2, ROWS3 = YT;
     static constexpr int NW1 = (ROWS1 + RPW - 1) / RPW, NW2 = (ROWS2 + RPW - 1) / RPW, NW3 = (ROWS3 + RPW - 1) / RPW;
     static constexpr int NT = 64 * (NW1 + NW2 + NW3);
-    static constexpr int RS = 4 * QPR + 8;                                 // LDS row stride in floats
+    static constexpr int RS = DPP ? 4 * QPR : 4 * QPR + 8;                 // LDS row stride in floats
+    static_assert(!DPP || (QPR == 16 && CPT == 4), "the DPP halo needs rows of exactly 16 lanes");
 };
 
 // Optional explicit work list (kernel argument, 2 KB): entry = z0 | zn << 12 | column << 20 for workgroup blockIdx.x, 0xffffffff =
@@ -85,8 +90,17 @@ __device__ __forceinline__ void bm_issue(const BMCtx& c, BMLoader& L, int gz) {
 }
 
 // loader part of step t: publish the plane fetched during the previous step, start fetching the next one
-template <int SLOT0, bool BACKWARD, bool VEC>
+template <int SLOT0, bool BACKWARD, bool VEC, bool DPP>
 __device__ __forceinline__ void bm_load_step(const BMCtx& c, BMLoader& L, int t) {
+    if (DPP) {
+        if (L.ldr && t <= c.zn + 5) {
+            float mx = L.reg.x, my = L.reg.y, mz = L.reg.z, mw = L.reg.w;
+            if (BACKWARD) { mx = div27_signed(mx); my = div27_signed(my); mz = div27_signed(mz); mw = div27_signed(mw); }
+            lds_store4(L.lds0 + (t & 1) * SLOT0, f32x4{mx, my, mz, mw});      // aligned: index 4lq
+            if (t + 1 <= c.zn + 5) bm_issue<BACKWARD, VEC>(c, L, c.z0 - 3 + t + 1);
+        }
+        return;
+    }
     if (L.ldr && t <= c.zn + 5) {
         float* p = L.lds0 + (t & 1) * SLOT0;                         // indices 4lq+7 .. 4lq+10: b32 + b64 + b32
         // the 8-byte store needs an even-aligned register pair, the middle of a 16-byte load is an odd one: without the barrier below
@@ -111,9 +125,9 @@ __device__ __forceinline__ void bm_load_step(const BMCtx& c, BMLoader& L, int t)
 // not on the critical path of the step barrier.
 struct BMAdamPre { float p[2], m[2], v[2]; };
 
-template <int QPR, int YT, int CPT>
+template <int QPR, int YT, int CPT, bool DPP>
 __device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int t) {
-    using G = BMGeomT<QPR, YT, CPT>;
+    using G = BMGeomT<QPR, YT, CPT, DPP>;
     constexpr int SLOT3 = G::ROWS3 * G::RS;
     if (t >= 10 && t <= c.zn + 9) {
         const size_t po = (size_t)(c.z0 + t - 10) * c.wd;             // uniform plane offset
@@ -141,9 +155,9 @@ __device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int
 // The whole march of one role.  Every role executes exactly nsteps barriers.  Lanes beyond the role's last row
 // compute on a clamped row and only their stores are masked, so that the window registers never pass through a
 // divergent merge (no register copies).
-template <int K, int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC, bool PK>
+template <int K, int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC, bool PK, bool DPP>
 __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int lane) {
-    using G = BMGeomT<QPR, YT, CPT>;
+    using G = BMGeomT<QPR, YT, CPT, DPP>;
     constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
     constexpr int ROWS = YT + 6 - 2 * K;
     constexpr int SRC_SLOT = K == 1 ? SLOT0 : (K == 2 ? SLOT1 : SLOT2), DST_SLOT = K == 1 ? SLOT1 : SLOT2;
@@ -151,15 +165,15 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     const int r_raw = wk * G::RPW + lane / G::TPR, q = lane % G::TPR;
     const bool active = r_raw < ROWS;
     const int r = active ? r_raw : ROWS - 1;
-    const int c0 = CPT * q - 3 + K;                                      // first output column (local)
+    const int c0 = DPP ? CPT * q : CPT * q - 3 + K;                      // first output column (local)
     const int gy = c.y0 - 3 + K + r;
     const bool rowok = active && gy >= 0 && gy < c.w;
     bool ok[CPT];
 #pragma unroll
     for (int j = 0; j < CPT; ++j) ok[j] = rowok && c.xl0 + c0 + j >= 0 && c.xl0 + c0 + j < c.d;
     // window of pass K = columns c0-1 .. c0+CPT of stage K-1 = indices CPT*q+4 .. (stage shifts 7, 6, 5); outputs at CPT*q+4 .. of stage K
-    const float* src = (K == 1 ? c.S0 : (K == 2 ? c.S1 : c.S2)) + r * G::RS + CPT * q + 4;
-    float* dst = (K == 1 ? c.S1 : c.S2) + r * G::RS + CPT * q + 4;
+    const float* src = (K == 1 ? c.S0 : (K == 2 ? c.S1 : c.S2)) + r * G::RS + CPT * q + (DPP ? 0 : 4);
+    float* dst = (K == 1 ? c.S1 : c.S2) + r * G::RS + CPT * q + (DPP ? 0 : 4);
     const int gx = c.xl0 + CPT * q;                                      // pass 3: first global column of this thread
     const int ncol = gx >= c.ox0 ? c.ox1 - gx : 0;                       //         and how many of its columns this workgroup owns
     const unsigned rowbase = (unsigned)((gy < 0 ? 0 : gy) * c.d + (gx < 0 ? 0 : gx));
@@ -184,12 +198,18 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
             if ((t + c.prio_par) & 1) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(0);
         }
-        bm_load_step<SLOT0, BACKWARD, VEC>(c, L, t);
+        bm_load_step<SLOT0, BACKWARD, VEC, DPP>(c, L, t);
         const float* sp = src + ((t - 1) & 1) * SRC_SLOT;
         float win[3][WIN];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {                 // all three rows in flight: one LDS round trip per step
-            if (CPT == 4) {
+            if constexpr (DPP) {
+                const f32x4 a = lds_load4(sp + i * G::RS);
+                win[i][1] = a.x; win[i][2] = a.y; win[i][3] = a.z; win[i][4] = a.w;
+                // column 4q-1 = the last value of the left neighbour, column 4q+4 = the first value of the right one; 0 at the row ends
+                win[i][0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.w), 0x111, 0xf, 0xf, true));       // row_shr:1
+                win[i][5] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.x), 0x101, 0xf, 0xf, true));       // row_shl:1
+            } else if (CPT == 4) {
                 const f32x4 a = lds_load4(sp + i * G::RS);
                 const f32x2 b = lds_load2(sp + i * G::RS + 4);
                 win[i][0] = a.x; win[i][1] = a.y; win[i][2] = a.z; win[i][3] = a.w; win[i][WIN - 2] = b.x; win[i][WIN - 1] = b.y;
@@ -250,7 +270,7 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
                 }
             } else if (ADAM) {
                 // plain adjoint sums of this plane -> S3 (index = column + 4); consumed by bm_adam_step of the next step
-                float* o3 = c.S3 + (t & 1) * (G::ROWS3 * G::RS) + r * G::RS + CPT * q + 4;
+                float* o3 = c.S3 + (t & 1) * (G::ROWS3 * G::RS) + r * G::RS + CPT * q + (DPP ? 0 : 4);
                 if (active) {
                     if (CPT == 4) lds_store4(o3, f32x4{s[0], s[1], s[CPT - 2], s[CPT - 1]});
                     else lds_store2(o3, f32x2{s[0], s[1]});
@@ -269,31 +289,31 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
                 }
             }
         }
-        if (ADAM) bm_adam_step<QPR, YT, CPT>(c, apre, t);
+        if (ADAM) bm_adam_step<QPR, YT, CPT, DPP>(c, apre, t);
         cvx_barrier();
     };
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
     int t = 0;
-    for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD, VEC>(c, L, t); cvx_barrier(); }                    // (Adam starts at t = 10)
+    for (; t < 3 * K - 2; ++t) { bm_load_step<SLOT0, BACKWARD, VEC, DPP>(c, L, t); cvx_barrier(); }                    // (Adam starts at t = 10)
     step(No{}, t); ++t;                                 // t = 3K-2: input plane 0
     step(No{}, t); ++t;                                 // t = 3K-1: input plane 1
 #pragma unroll 1
     for (; t <= tlast; ++t) step(Yes{}, t);             // t = 3K ..: output planes
     for (; t < c.nsteps; ++t) {
-        bm_load_step<SLOT0, BACKWARD, VEC>(c, L, t);
-        if (ADAM) bm_adam_step<QPR, YT, CPT>(c, apre, t);
+        bm_load_step<SLOT0, BACKWARD, VEC, DPP>(c, L, t);
+        if (ADAM) bm_adam_step<QPR, YT, CPT, DPP>(c, apre, t);
         cvx_barrier();
     }
 }
 
-template <int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC, bool PK>
-__global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
+template <int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC, bool PK, bool DPP>
+__global__ __launch_bounds__((BMGeomT<QPR, YT, CPT, DPP>::NT)) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
                                                                 int w, int d, int zc, int nzc, int nyt, float* __restrict__ P,
                                                                 float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
                                                                 float* __restrict__ gsave, int vec_ok, int nxt, int tw,
                                                                 unsigned long long* __restrict__ census, int prio_mode, BMTable tbl) {
-    using G = BMGeomT<QPR, YT, CPT>;
+    using G = BMGeomT<QPR, YT, CPT, DPP>;
     if (census && threadIdx.x == 0) {
         census[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         census[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
@@ -356,7 +376,7 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(cons
             const int row = e / ow, col = e - row * ow;
             const bool have = row < YT && c.y0 + row < w;
             c.e_off[k] = (unsigned)((c.y0 + row) * d + c.ox0 + col);
-            c.e_lds[k] = have ? (unsigned)(row * G::RS + (c.ox0 - c.xl0) + col + 4) : 0xffffffffu;
+            c.e_lds[k] = have ? (unsigned)(row * G::RS + (c.ox0 - c.xl0) + col + (DPP ? 0 : 4)) : 0xffffffffu;
         }
     }
     BMLoader L;
@@ -367,7 +387,7 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(cons
     const int lgx = c.xl0 + 4 * L.lq;
     L.lrow = L.ldr && lgy >= 0 && lgy < w && lgx >= 0 && lgx < d;
     L.loff = (unsigned)((lgy < 0 ? 0 : lgy) * d + (lgx < 0 ? 0 : lgx));
-    L.lds0 = S0 + lr * G::RS + 4 * L.lq + 7;
+    L.lds0 = S0 + lr * G::RS + 4 * L.lq + (DPP ? 0 : 7);
     bm_issue<BACKWARD, VEC>(c, L, c.z0 - 3);
     cvx_barrier();
     if (census) {                                        // arrival of the first input plane
@@ -378,9 +398,9 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT>::NT)) void k_box3_march(cons
 
     // role of this wavefront (wave-uniform, kept in a scalar register)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    if (wave < G::NW1) bm_run<1, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK>(c, L, wave, lane);
-    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK>(c, L, wave - G::NW1, lane);
-    else bm_run<3, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK>(c, L, wave - G::NW1 - G::NW2, lane);
+    if (wave < G::NW1) bm_run<1, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK, DPP>(c, L, wave, lane);
+    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK, DPP>(c, L, wave - G::NW1, lane);
+    else bm_run<3, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK, DPP>(c, L, wave - G::NW1 - G::NW2, lane);
     if (census && threadIdx.x == 0) census[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -434,10 +454,10 @@ static bool bm_uneven_table(BMTable& T, unsigned& grid, int h, int ncol, long lo
     return true;
 }
 
-template <int QPR, int YT, int CPT = 4>
+template <int QPR, int YT, int CPT = 4, bool DPP = false>
 static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt, int tw, bool backward, float* P, float* m, float* v,
                       AdamConsts ac, float* gsave, hipStream_t s) {
-    using G = BMGeomT<QPR, YT, CPT>;
+    using G = BMGeomT<QPR, YT, CPT, DPP>;
     const int nyt = cdiv(w, YT);
     long long wg_target = options().box_wg_target;                            // workgroups to aim for (z chunks follow from it);
     if (wg_target <= 0) wg_target = nxt > 1 ? 512 : 256;                      // 0 = automatic: two x-tile workgroups share a CU
@@ -457,9 +477,9 @@ static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt,
     if (census && backward) census += 4 * 1024;
 #define CVX_BM_LAUNCH(B, A)                                                                                                                        \
     do {                                                                                                                                           \
-        if (vec && pk) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, true>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
-        else if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
-        else hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        if (vec && pk) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, true, DPP>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        else if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, false, DPP>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        else hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, false, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
     } while (0)
     if (!backward) CVX_BM_LAUNCH(false, false);
     else if (!P) CVX_BM_LAUNCH(true, false);
@@ -486,6 +506,7 @@ int launch_box3_march(const float* in, float* out, int h, int w, int d, bool bac
         if (options().box_yt == 4) return launch_qpr<16, 4>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);
         if (cpt2) return launch_qpr<16, 8, 2>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);
         if (options().box_yt == 16) return launch_qpr<16, 16>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);
+        if (options().box_dpp != 0) return launch_qpr<16, 8, 4, true>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);     // (nxt > 1 implies 16-byte aligned rows)
         return launch_qpr<16, 8>(in, out, h, w, d, nxt, tw, backward, P, m, v, ac, gsave, s);
     }
     if (options().box_yt == 4) {              // 4-row tiles: 9-wave workgroups, three per CU
