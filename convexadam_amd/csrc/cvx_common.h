@@ -232,11 +232,12 @@ __device__ __forceinline__ float outer_sum_ilp(const float (&v)[N]) {
     return p[0];
 }
 
-// order-preserving key for non-negative floats (+NaN sorts last): packs (value, index) so that a
-// 64-bit atomicMin returns the smallest value and, among equals, the smallest index.
+// order-preserving key for floats: packs (value, index) so that a 64-bit atomicMin returns the smallest value and, among equals, the
+// smallest index.  A NaN sorts BEFORE everything (value part 0), like torch.argmin, whose scan stops at the first NaN (round 3).
 __device__ __forceinline__ unsigned long long pack_min_key(float v, unsigned idx) {
     unsigned b = __float_as_uint(v);
     b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // total order for any sign
+    if (v != v) b = 0u;
     return ((unsigned long long)b << 32) | idx;
 }
 
@@ -325,6 +326,8 @@ __device__ __forceinline__ float adam_sqrt(float x, const unsigned* __restrict__
     }
     return r;
 }
+// torch.argmin's comparison inside a sequential scan: a candidate replaces the running best when it is smaller, or when it is the first NaN
+__device__ __forceinline__ bool argmin_better(float cost, float best) { return cost < best || (cost != cost && best == best); }
 __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& v, const AdamConsts& ac) {
     const float mm = __builtin_fmaf(ac.w1, g - m, m);            // exp_avg.lerp_(grad, 1-beta1)
     float vv = v * ac.b2;                                         // exp_avg_sq.mul_(beta2)

@@ -505,7 +505,8 @@ ORC_API void orc_correlate_ex(const float* fix, const float* mov, int C, int h, 
 #pragma omp parallel for schedule(static)
         for (size_t x = 0; x < v; ++x) {
             float best = ssd[x]; int64_t bi = 0;
-            for (int64_t k = 1; k < K; ++k) { const float s = ssd[(size_t)k * v + x]; if (s < best) { best = s; bi = k; } }
+            /* torch.argmin: the first minimum, and a NaN counts as smaller than everything (the first NaN wins and ends the scan) */
+            for (int64_t k = 1; k < K && best == best; ++k) { const float s = ssd[(size_t)k * v + x]; if (s < best || s != s) { best = s; bi = k; } }
             argmin[x] = bi;
         }
     }
@@ -540,7 +541,7 @@ ORC_API void orc_coupled_convex(const float* ssd, const int64_t* argmin, const f
                 const float e0 = mesh[k] - u0, e1 = mesh[K + k] - u1, e2 = mesh[2 * K + k] - u2;
                 float q = 0.0f; q += e0 * e0; q += e1 * e1; q += e2 * e2;     /* .pow(2).sum(0) */
                 const float cost = ssd[(size_t)k * v + x] + coef * q;           /* :104 */
-                if (k == 0 || cost < best) { best = cost; bi = k; }
+                if (k == 0 || (best == best && (cost < best || cost != cost))) { best = cost; bi = k; }      /* first minimum; the first NaN wins */
             }
             am[x] = bi;
         }

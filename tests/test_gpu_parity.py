@@ -139,6 +139,45 @@ def test_correlate_vs_oracle(U, orc, C, shape, hw):
         assert np.array_equal(host(am), ra)
 
 
+@pytest.mark.parametrize("case", [0, 3, 4])
+def test_nan_in_the_cost_volume(U, orc, case):
+    """Nulls in the features: NaNs propagate through the raw SSD and both boxes exactly as in the oracle (which equals the reference
+    there, tests/test_oracle_vs_reference_live.py), and argmin follows torch: the FIRST NaN of a column wins -- plain argmin, the
+    pruned coupled-convex passes (a voxel with a NaN keeps its winner) and the streaming ones (option no_prune).  (+-Inf voxels are
+    outside the contract: the 3-instruction exact division of the box filters turns Inf / 27 into NaN; INTEGRATION.md.)"""
+    from convexadam_amd import _lib
+    rng = np.random.default_rng(case)
+    shape, hw = (5, 6, 7), 2
+    f = rng.random((12,) + shape, dtype=np.float32)
+    m = rng.random((12,) + shape, dtype=np.float32)
+    if case == 0:
+        m[3, 2, 3, 4] = np.nan                                            # some displacements of the neighbouring voxels see the NaN
+    elif case == 3:
+        f[:, 2, 2, 2] = np.nan                                            # every displacement of the neighbourhood is NaN
+    else:
+        m[0, 0, 0, 0] = np.nan
+        m[5, 4, 5, 6] = np.nan
+        f[2, 1, 4, 3] = np.nan
+    rs, ra = orc.correlate(f, m, hw)
+    mesh = orc.disp_mesh(hw)
+    want = orc.coupled_convex(rs, ra, mesh, hw)
+    ssd, am = U.correlate(dev(f)[None], dev(m)[None], hw, 1, shape, 12)
+    assert np.array_equal(host(ssd), rs, equal_nan=True) and np.array_equal(host(am), ra)
+    for no_prune in (0, 1):
+        _lib.lib().cvx_set_option(b"no_prune", no_prune)
+        try:
+            soft = U.coupled_convex(ssd, am, dev(mesh)[:, :, None], 1, shape)
+        finally:
+            _lib.lib().cvx_set_option(b"no_prune", 0)
+        assert np.array_equal(host(soft)[0], want, equal_nan=True), no_prune
+    ssd16, am16 = U.correlate(dev(f)[None], dev(m)[None], hw, 1, shape, 12, storage="fp16")       # half-precision volume: same rule
+    ref16 = rs.astype(np.float16)
+    assert np.array_equal(host(ssd16), ref16, equal_nan=True)
+    col = ref16.astype(np.float32).reshape(ref16.shape[0], -1)
+    first = np.where(np.isnan(col).any(0), np.isnan(col).argmax(0), np.nanargmin(np.where(np.isnan(col), np.inf, col), 0))
+    assert np.array_equal(host(am16).reshape(-1), first)
+
+
 @pytest.mark.parametrize("cost,n_box", [("sad", 1), ("ssd", 1), ("sad", 2)])
 @pytest.mark.parametrize("C,shape,hw", [(12, (9, 8, 37), 6), (12, (7, 9, 11), 3), (5, (6, 7, 9), 1), (12, (13, 16, 20), 4), (12, (5, 6, 41), 2),
                                         (12, (5, 40, 37), 2), (20, (4, 23, 74), 1)])

@@ -90,3 +90,30 @@ def test_whole_pipeline_bit_identical_in_reference_bits_mode_on_fresh_pairs(ref,
         orc.set_exp_table(None)
         orc.set_sqrt_table(None)
         orc.set_mean_threads(0)
+
+
+def test_nan_and_inf_in_the_cost_volume(ref, orc):
+    """Nulls: torch.argmin returns the FIRST NaN of a column (a NaN counts as smaller than everything) and otherwise the first minimum;
+    the oracle follows that in the plain argmin and in the six coupled passes (round 3; before, NaN entries were skipped)."""
+    utils, _ = ref
+    rng = np.random.default_rng(0)
+    shape, hw = (5, 6, 7), 2
+    mesh = orc.disp_mesh(hw)
+    for case in range(4):
+        f = rng.random((12,) + shape, dtype=np.float32)
+        m = rng.random((12,) + shape, dtype=np.float32)
+        if case == 0:
+            m[3, 2, 3, 4] = np.nan                                        # some displacements of the neighbouring voxels see the NaN
+        elif case == 1:
+            m[0, 0, 0, 0] = np.nan
+            f[5, 4, 5, 6] = np.inf
+        elif case == 2:
+            m[7, 1, 1, 1] = np.inf
+            m[2, 3, 3, 3] = -np.inf
+        else:
+            f[:, 2, 2, 2] = np.nan                                        # every displacement of the neighbourhood is NaN
+        ssd, am = utils.correlate(torch.from_numpy(f)[None], torch.from_numpy(m)[None], hw, 1, shape, 12)
+        rs, ra = orc.correlate(f, m, hw)
+        assert np.array_equal(ssd.numpy(), rs, equal_nan=True) and np.array_equal(am.numpy(), ra), case
+        cs = utils.coupled_convex(ssd, am, torch.from_numpy(mesh)[:, :, None], 1, shape)
+        assert np.array_equal(cs.numpy()[0], orc.coupled_convex(rs, ra, mesh, hw), equal_nan=True), case
