@@ -36,6 +36,8 @@ struct BMGeomT {
     static constexpr int ROWS0 = YT + 6, ROWS1 = YT + 4, ROWS2 = YT + 2, ROWS3 = YT;
     static constexpr int NW1 = (ROWS1 + RPW - 1) / RPW, NW2 = (ROWS2 + RPW - 1) / RPW, NW3 = (ROWS3 + RPW - 1) / RPW;
     static constexpr int NT = 64 * (NW1 + NW2 + NW3);
+    static constexpr int NWA = 2;                                          // wavefronts of the Adam role (variant AROLE of the adjoint kernel)
+    static constexpr int NTA = NT + 64 * NWA;
     static constexpr int RS = DPP ? 4 * QPR : 4 * QPR + 8;                 // LDS row stride in floats
     static_assert(!DPP || (QPR == 16 && CPT == 4), "the DPP halo needs rows of exactly 16 lanes");
 };
@@ -57,6 +59,7 @@ struct BMCtx {
     size_t wd;                              // plane stride w*d
     unsigned e_off[2];                      // Adam variant: offset (y0+row)*d + col inside a plane of the <= 2 elements this thread updates
     unsigned e_lds[2];                      //               and their index in an S3 slot; 0xffffffff = none
+    unsigned long long* phases;             // (experiment build only) per-wave phase clocks
     int prio_par;                           // -1: no priority play; 0 / 1: this workgroup issues at raised priority on even / odd steps
     bool vec;
     AdamConsts ac;
@@ -152,10 +155,58 @@ __device__ __forceinline__ void bm_adam_step(const BMCtx& c, BMAdamPre& pre, int
     }
 }
 
+// AROLE variant: the Adam update as a FOURTH role (two extra wavefronts) instead of a share of every wavefront's step.  The per-phase
+// clocks of the spread version (tools/box_phases.py) show ~1 000 of the ~2 700 clocks of an adjoint step inside the update (two IEEE
+// divisions, a square root, the wait for P, m, v and four stores) on EVERY wavefront, while the pass-3 wavefronts idle 1 300 clocks at
+// the barrier; as its own role the update runs beside the three passes and the step shrinks to the passes' own length.
+// EPT elements per thread: the tile's YT x (ox1 - ox0) outputs over 128 threads.
+template <int QPR, int YT, int CPT, bool DPP, int EPT>
+__device__ __forceinline__ void bm_adam_role(const BMCtx& c, int atid) {
+    using G = BMGeomT<QPR, YT, CPT, DPP>;
+    constexpr int SLOT3 = G::ROWS3 * G::RS, NA = 64 * G::NWA;
+    unsigned e_off[EPT], e_lds[EPT];
+    const int ow = c.ox1 - c.ox0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = atid + k * NA;
+        const int row = e / ow, col = e - row * ow;
+        const bool have = row < YT && c.y0 + row < c.w;
+        e_off[k] = (unsigned)((c.y0 + (have ? row : 0)) * c.d + c.ox0 + (have ? col : 0));
+        e_lds[k] = have ? (unsigned)(row * G::RS + (c.ox0 - c.xl0) + col + (DPP ? 0 : 4)) : 0xffffffffu;
+    }
+    float pp[EPT], pm[EPT], pv[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) { pp[k] = 0.f; pm[k] = 0.f; pv[k] = 0.f; }
+    for (int t = 0; t < c.nsteps; ++t) {
+        if (t >= 10 && t <= c.zn + 9) {
+            const size_t po = (size_t)(c.z0 + t - 10) * c.wd;             // uniform plane offset
+            float *Pz = c.Pc + po, *mz = c.mc + po, *vz = c.vc + po;
+            const float* sp = c.S3 + ((t - 1) & 1) * SLOT3;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (e_lds[k] != 0xffffffffu) {
+                    const float g = sp[e_lds[k]];
+                    float p = pp[k], m = pm[k], v = pv[k];
+                    adam_update(g, p, m, v, c.ac);
+                    Pz[e_off[k]] = p; mz[e_off[k]] = m; vz[e_off[k]] = v;
+                    if (c.gs) (c.gs + po)[e_off[k]] = g;
+                }
+        }
+        if (t + 1 >= 10 && t + 1 <= c.zn + 9) {                          // P, m, v of the next plane: requested a step ahead
+            const size_t po = (size_t)(c.z0 + t + 1 - 10) * c.wd;
+            const float *Pz = c.Pc + po, *mz = c.mc + po, *vz = c.vc + po;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (e_lds[k] != 0xffffffffu) { pp[k] = Pz[e_off[k]]; pm[k] = mz[e_off[k]]; pv[k] = vz[e_off[k]]; }
+        }
+        cvx_barrier();
+    }
+}
+
 // The whole march of one role.  Every role executes exactly nsteps barriers.  Lanes beyond the role's last row
 // compute on a clamped row and only their stores are masked, so that the window registers never pass through a
 // divergent merge (no register copies).
-template <int K, int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC, bool PK, bool DPP>
+template <int K, int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC, bool PK, bool DPP, bool AROLE>
 __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int lane) {
     using G = BMGeomT<QPR, YT, CPT, DPP>;
     constexpr int SLOT0 = G::ROWS0 * G::RS, SLOT1 = G::ROWS1 * G::RS, SLOT2 = G::ROWS2 * G::RS;
@@ -192,8 +243,22 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
 #pragma unroll
     for (int j = 0; j < CPT; ++j) mp[j] = f32x2{0.f, 0.f};
     // one step; n = t - (3K-2) counts the input planes of this role; EMIT: n >= 2, an output plane is due
+#ifdef CVX_BM_PHASES        // experiment build (tools/box_phases.sh): where does a step's time go?  shader clocks per phase, summed over the emit steps
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tprev = 0;
+#define CVX_PH(i)                                                                  \
+    do {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();              \
+        if (EMIT && tprev) ph[i] += now_ - tprev;                                  \
+        tprev = now_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    } while (0)
+#else
+#define CVX_PH(i) do {} while (0)
+#endif
     auto step = [&](auto emit, int t) {
         constexpr bool EMIT = decltype(emit)::value;
+        CVX_PH(4);                                     // (time since the previous stamp = the barrier wait)
         if (c.prio_par >= 0) {                         // (wave-uniform) the two workgroups of a CU take turns at the issue arbitration
             if ((t + c.prio_par) & 1) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(0);
@@ -219,6 +284,10 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
                 win[i][0] = a.x; win[i][1] = a.y; win[i][WIN - 2] = b.x; win[i][WIN - 1] = b.y;
             }
         }
+#ifdef CVX_BM_PHASES
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        CVX_PH(0);                                     // loader part + LDS window reads
         float f[CPT];
         if (PK) {
 #pragma unroll
@@ -256,6 +325,11 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
 #pragma unroll
             for (int j = 0; j < CPT; ++j) mp[j] = f32x2{m[j], p[j]};
         }
+#ifdef CVX_BM_PHASES
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) asm volatile("" ::"v"(f[j]), "v"(mp[j].x), "v"(mp[j].y));
+#endif
+        CVX_PH(1);                                     // the 27-tap sums
         const float (&s)[CPT] = f;
         if (EMIT) {
             const int gz = c.z0 - (2 * K + 3) + t;
@@ -289,7 +363,9 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
                 }
             }
         }
-        if (ADAM) bm_adam_step<QPR, YT, CPT, DPP>(c, apre, t);
+        CVX_PH(2);                                     // division + stage store (LDS or global)
+        if (ADAM && !AROLE) bm_adam_step<QPR, YT, CPT, DPP>(c, apre, t);
+        CVX_PH(3);                                     // Adam update of this thread's elements
         cvx_barrier();
     };
     using Yes = std::integral_constant<bool, true>;
@@ -302,18 +378,28 @@ __device__ __forceinline__ void bm_run(const BMCtx& c, BMLoader& L, int wk, int 
     for (; t <= tlast; ++t) step(Yes{}, t);             // t = 3K ..: output planes
     for (; t < c.nsteps; ++t) {
         bm_load_step<SLOT0, BACKWARD, VEC, DPP>(c, L, t);
-        if (ADAM) bm_adam_step<QPR, YT, CPT, DPP>(c, apre, t);
+        if (ADAM && !AROLE) bm_adam_step<QPR, YT, CPT, DPP>(c, apre, t);
         cvx_barrier();
     }
+#ifdef CVX_BM_PHASES
+    if (c.phases && lane == 0) {                       // slot = (workgroup, role K, wave of the role): 8 values
+        unsigned long long* o = c.phases + ((size_t)blockIdx.x * 16 + (K - 1) * 4 + wk) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = ph[i];
+        o[5] = (unsigned long long)(tlast - 3 * K + 1);           // emit steps
+    }
+#endif
+#undef CVX_PH
 }
 
-template <int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC, bool PK, bool DPP>
-__global__ __launch_bounds__((BMGeomT<QPR, YT, CPT, DPP>::NT)) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
+template <int QPR, int YT, int CPT, bool BACKWARD, bool ADAM, bool VEC, bool PK, bool DPP, bool AROLE>
+__global__ __launch_bounds__((AROLE ? BMGeomT<QPR, YT, CPT, DPP>::NTA : BMGeomT<QPR, YT, CPT, DPP>::NT)) void k_box3_march(const float* __restrict__ in, float* __restrict__ out, int h,
                                                                 int w, int d, int zc, int nzc, int nyt, float* __restrict__ P,
                                                                 float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
                                                                 float* __restrict__ gsave, int vec_ok, int nxt, int tw,
                                                                 unsigned long long* __restrict__ census, int prio_mode, BMTable tbl) {
     using G = BMGeomT<QPR, YT, CPT, DPP>;
+    constexpr int NTK = AROLE ? G::NTA : G::NT;                       // threads of this launch
+    static_assert(!AROLE || ADAM, "the Adam role exists in the adjoint + Adam kernel only");
     if (census && threadIdx.x == 0) {
         census[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         census[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
@@ -359,16 +445,18 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT, DPP>::NT)) void k_box3_march
     c.nsteps = c.zn + (ADAM ? 10 : 9);
     c.vec = vec_ok != 0;
     c.ac = ac;
+    // (experiment build) behind the census slots of all three kernels: forward kernel first, adjoint kernel 1024 x 16 x 8 entries later
+    c.phases = census ? (BACKWARD ? census - 4 * 1024 : census) + 4 * (8192 + 4096) + (BACKWARD ? 1024 * 16 * 8 : 0) : nullptr;
     // prio_mode 1: alternate by step, phase from the workgroup's slot id on its CU (HW_ID.TG_ID); 2: the same from the block index
     c.prio_par = prio_mode == 1 ? (int)((__builtin_amdgcn_s_getreg((4 << 0) | (16 << 6) | (3 << 11))) & 1u)
                : prio_mode == 2 ? (int)((blockIdx.x >> 8) & 1u) : -1;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * SLOT0; i += G::NT) S0[i] = 0.0f;
-    for (int i = tid; i < 2 * SLOT1; i += G::NT) S1[i] = 0.0f;
-    for (int i = tid; i < 2 * SLOT2; i += G::NT) S2[i] = 0.0f;
-    if (ADAM) for (int i = tid; i < 2 * G::ROWS3 * G::RS; i += G::NT) S3[i] = 0.0f;
+    for (int i = tid; i < 2 * SLOT0; i += NTK) S0[i] = 0.0f;
+    for (int i = tid; i < 2 * SLOT1; i += NTK) S1[i] = 0.0f;
+    for (int i = tid; i < 2 * SLOT2; i += NTK) S2[i] = 0.0f;
+    if (ADAM) for (int i = tid; i < 2 * G::ROWS3 * G::RS; i += NTK) S3[i] = 0.0f;
 
-    if (ADAM) {
+    if (ADAM && !AROLE) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int e = tid + k * G::NT;                           // 8 rows x (<= 126) columns <= 1008 elements <= 2 per thread
@@ -398,9 +486,10 @@ __global__ __launch_bounds__((BMGeomT<QPR, YT, CPT, DPP>::NT)) void k_box3_march
 
     // role of this wavefront (wave-uniform, kept in a scalar register)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    if (wave < G::NW1) bm_run<1, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK, DPP>(c, L, wave, lane);
-    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK, DPP>(c, L, wave - G::NW1, lane);
-    else bm_run<3, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK, DPP>(c, L, wave - G::NW1 - G::NW2, lane);
+    if (wave < G::NW1) bm_run<1, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK, DPP, AROLE>(c, L, wave, lane);
+    else if (wave < G::NW1 + G::NW2) bm_run<2, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK, DPP, AROLE>(c, L, wave - G::NW1, lane);
+    else if (!AROLE || wave < G::NW1 + G::NW2 + G::NW3) bm_run<3, QPR, YT, CPT, BACKWARD, ADAM, VEC, PK, DPP, AROLE>(c, L, wave - G::NW1 - G::NW2, lane);
+    else bm_adam_role<QPR, YT, CPT, DPP, (YT * (4 * QPR - 2) + 127) / 128>(c, tid - G::NT);          // rows of at most 4 * QPR - 2 outputs
     if (census && threadIdx.x == 0) census[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -471,15 +560,17 @@ static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt,
     if (options().box_wg_target <= 0 && nxt > 1 && h <= 4095) (void)bm_uneven_table(tbl, grid, h, 3 * nyt * nxt, options().box_uneven);
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec = (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave);
+    const bool arole = options().box_adam_role != 0 && G::NTA <= 1024;          // Adam update as a role of its own (two extra wavefronts)
     const bool pk = options().box_pk != 0;                                     // packed (mid, pre) pair: v_pk_add_f32 with a broadcast tap
     // debugging aid (option census_ptr): forward kernel -> slots [0, 4096), adjoint kernel -> [4096, 8192)
     unsigned long long* census = reinterpret_cast<unsigned long long*>(options().census_ptr);
     if (census && backward) census += 4 * 1024;
 #define CVX_BM_LAUNCH(B, A)                                                                                                                        \
     do {                                                                                                                                           \
-        if (vec && pk) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, true, DPP>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
-        else if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, false, DPP>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
-        else hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, false, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        if (vec && A && arole) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, false, DPP, A>), dim3(grid), dim3(G::NTA), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        else if (vec && pk) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, true, DPP, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        else if (vec) hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, true, false, DPP, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
+        else hipLaunchKernelGGL((k_box3_march<QPR, YT, CPT, B, A, false, false, false, false>), dim3(grid), dim3(G::NT), 0, s, in, out, h, w, d, zc, nzc, nyt, P, m, v, ac, gsave, vec, nxt, tw, census, (int)options().box_prio, tbl); \
     } while (0)
     if (!backward) CVX_BM_LAUNCH(false, false);
     else if (!P) CVX_BM_LAUNCH(true, false);

@@ -79,6 +79,7 @@ struct Options {
     long long box_cpt;             // output columns per thread of the marching three-box kernels: 4, or 2 (x tiles / rows <= 62 columns only)
     long long box_uneven;          // marching three-box kernels with two workgroups per CU: length ratio (percent) of the z chunks given to the first and
                                    //    to the second dispatch round (boxmarch.hip, BMTable); <= 100: equal chunks
+    long long box_adam_role;       // adjoint + Adam kernel: 1 = the Adam update runs as a fourth role (two extra wavefronts) instead of inside every wavefront's step
     long long box_dpp;             // marching three-box kernels, x-tile path: 1 = halo columns through DPP lane shifts instead of a second LDS read per row
     long long box_pk;              // marching three-box kernels: 1 = the two running sums of a column as one register pair (v_pk_add_f32 with a broadcast tap)
     long long box_prio;            // marching three-box kernels: 1 / 2 = the workgroups sharing a CU alternate their issue priority step by step

@@ -58,7 +58,7 @@ int cvx_device_count(void);            /* number of visible HIP devices (0 on a 
  *   box_yt              rows per tile of the marching three-box kernels: 8 (default) or 4
  *   box_wg_target       workgroups the marching three-box kernels aim for (z-chunk length follows); 0 = automatic
  *   box_cpt, box_pk, box_dpp, box_prio, box_uneven   measured variants of the marching three-box kernels (2 columns per thread; packed
- *                       running sums; halo columns through DPP lane shifts; alternating issue priority; z-chunk length ratio between the two dispatch rounds, default 200)
+ *                       running sums; halo columns through DPP lane shifts; box_adam_role: the Adam update as a role of its own; alternating issue priority; z-chunk length ratio between the two dispatch rounds, default 200)
  *   box_xsplit          x tiles of the marching three-box kernels: -1 automatic, 0 off, 2..32 that many (ignored when a tile would be empty)
  *   warp_flat           1: flat 64-bit gathers in the warp kernel instead of buffer loads
  *   no_prune            1: streaming coupled-convex passes instead of branch and bound

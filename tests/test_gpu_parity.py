@@ -391,7 +391,7 @@ def test_adam_box_kernel_variants_with_two_workgroups_per_cu(U, orc):
     r = orc.adam_run(F2, M2, P0, 1.25, 2, want_grad=True)
     args = (dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.25, 2)
     for opts in ({}, {"box_uneven": 100}, {"box_uneven": 130}, {"box_uneven": 400}, {"box_cpt": 2}, {"box_cpt": 2, "box_uneven": 100},
-                 {"box_yt": 16, "box_wg_target": 256}, {"box_prio": 1}, {"box_prio": 2, "box_uneven": 100}, {"box_pk": 1}, {"box_pk": 1, "box_cpt": 2}, {"box_dpp": 1}, {"box_dpp": 1, "box_pk": 1, "box_uneven": 100}):
+                 {"box_yt": 16, "box_wg_target": 256}, {"box_prio": 1}, {"box_prio": 2, "box_uneven": 100}, {"box_pk": 1}, {"box_pk": 1, "box_cpt": 2}, {"box_dpp": 1}, {"box_dpp": 1, "box_pk": 1, "box_uneven": 100}, {"box_adam_role": 1}, {"box_adam_role": 1, "box_dpp": 1}):
         old = {k: L.cvx_get_option(k.encode()) for k in opts}
         for k, v in opts.items():
             assert L.cvx_set_option(k.encode(), v) == 0
