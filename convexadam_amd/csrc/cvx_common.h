@@ -83,6 +83,7 @@ struct Options {
     long long box_dpp;             // marching three-box kernels, x-tile path: 1 = halo columns through DPP lane shifts instead of a second LDS read per row
     long long box_pk;              // marching three-box kernels: 1 = the two running sums of a column as one register pair (v_pk_add_f32 with a broadcast tap)
     long long box_prio;            // marching three-box kernels: 1 / 2 = the workgroups sharing a CU alternate their issue priority step by step
+    long long label_pow_block;     // cvx_label_weights_host: elements per vectorised block of the reference host's torch.pow (32: AVX-512 build, the golden host; 16: AVX2)
     long long census_ptr;          // debugging aid: device address of a uint64 buffer; the Adam-loop kernels record per workgroup
                                    //    {start, first data, end} in 100 MHz ticks (s_memrealtime) + placement there (0 = off)
     long long mind_mean_threads;   // 0: exactly rounded global mean in MINDSSC (default); T > 0: torch's own float sum with T threads

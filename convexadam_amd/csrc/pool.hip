@@ -621,7 +621,8 @@ extern "C" int cvx_label_weights_host(const int64_t* hist_fix_host, const int64_
     // weight = 1 / (n_fix + n_mov + eps).float().pow(.3) ; weight /= weight.mean()          (convex_adam_nnUNet.py:31-32)
     for (int c = 0; c < C; ++c) {
         const float cnt = (float)(hist_fix_host[present_host[c]] + hist_mov_host[present_host[c]]) + 1e-32f;
-        const float pw = c < (C / 32) * 32 ? lw_sleef_powf(cnt, 0.3f) : (float)pow((double)cnt, 0.3);
+        const int blk = options().label_pow_block > 0 ? (int)options().label_pow_block : 32;      // 2 x the vector width of the reference host's ATen build
+        const float pw = c < (C / blk) * blk ? lw_sleef_powf(cnt, 0.3f) : (float)pow((double)cnt, 0.3);
         weights_host[c] = 1.0f / pw;
     }
     const float mean = torch_sum_small(weights_host, C) / (float)C;

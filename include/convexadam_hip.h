@@ -67,6 +67,7 @@ int cvx_device_count(void);            /* number of visible HIP devices (0 on a 
  *   corr_fused_all      1: the fused correlation kernel also for C >= 16 (it covers them -- cascade channel sum -- but the separate
  *                       kernels are faster there and stay the default)
  *   cf_census           1: the fused correlation kernel records per-workgroup residency in its workspace
+ *   label_pow_block     cvx_label_weights_host: elements per vectorised block of the reference host's torch.pow (32 = AVX-512 build, 16 = AVX2)
  *   mind_mean_threads   0: exactly rounded global mean in MINDSSC; T > 0: torch's float32 sum with T threads
  * Workspace sizes (cvx_*_workspace_bytes) depend on some switches: query them with the same context / options the call will use.
  *

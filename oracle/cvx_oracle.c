@@ -963,9 +963,12 @@ static float sp_expkf(sp_f2 d) {
 static float sp_sleef_powf(float x, float y) {          /* x > 0 only */
     return sp_expkf(sp_dfmul_f2_f(sp_logkf(fabsf(x)), y));
 }
-/* element i of an n-element tensor */
+/* element i of an n-element tensor; the vectorised loop covers blocks of 2 x (vector width of the host's ATen build) elements:
+ * 32 on an AVX-512 host (the host that produced tests/golden), 16 on an AVX2 host -- like the MKL tables, a property of the reference HOST */
+static int g_pow_block = 32;
+ORC_API void orc_set_pow_block(int b) { g_pow_block = b > 0 ? b : 32; }
 static float sp_torch_pow_at(float x, double y, int64_t i, int64_t n) {
-    return i < (n / 32) * 32 ? sp_sleef_powf(x, (float)y) : (float)pow((double)x, y);
+    return i < (n / g_pow_block) * g_pow_block ? sp_sleef_powf(x, (float)y) : (float)pow((double)x, y);
 }
 ORC_API float orc_torch_pow_at(float x, double y, int64_t i, int64_t n) { return sp_torch_pow_at(x, y, i, n); }
 

@@ -168,3 +168,19 @@ def test_contexts_are_per_caller(L):
     assert L.cvx_context_set_adam_sqrt_table(ctx.handle, None, None) == 0
     assert L.cvx_context_set_mind_exp_table(ctx.handle, None, 0, 0, None) == 0
     ctx.close()
+
+
+def test_every_option_has_its_environment_variable():
+    """The default context reads CVX_<NAME> for every switch (positional initialiser in api.hip): each name must map to its own field."""
+    import subprocess
+    import sys
+    names = ["mind_tiled", "mind_overlap", "mm_tx", "mm_slots", "box_tiled", "no_prune", "corr_unfused", "corr_fused_all", "prune_stream_above",
+             "cf_census", "warp_flat", "box_yt", "box_wg_target", "box_xsplit", "box_cpt", "box_uneven", "box_adam_role", "box_dpp", "box_pk",
+             "box_prio", "label_pow_block", "mind_mean_threads"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for i, n in enumerate(names):
+        env["CVX_" + n.upper()] = str(11 + i)
+    code = ("from convexadam_amd import _lib; L = _lib.lib(); import sys; names = sys.argv[1].split(',');"
+            "print(','.join(str(L.cvx_get_option(n.encode())) for n in names + ['census_ptr']))")
+    out = subprocess.run([sys.executable, "-c", code, ",".join(names)], env=env, stdout=subprocess.PIPE, text=True, check=True).stdout.strip()
+    assert out == ",".join(str(11 + i) for i in range(len(names))) + ",0", out

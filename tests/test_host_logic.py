@@ -189,6 +189,10 @@ def test_torch_pow_restatement():
     lo = oracle.lib()
     lo.orc_torch_pow_at.restype = C.c_float
     lo.orc_torch_pow_at.argtypes = [C.c_float, C.c_double, C.c_int64, C.c_int64]
+    # the vectorised loop covers blocks of 2 x the vector width of THIS host's ATen build (the goldens come from an AVX-512 host: 32)
+    block = 32 if "512" in torch.backends.cpu.get_cpu_capability() else 16
+    lo.orc_set_pow_block(block)
+    _lib.lib().cvx_set_option(b"label_pow_block", block)
     rng = np.random.default_rng(3)
     for n in (1, 5, 31, 32, 33, 64, 95, 200, 4096 + 7):
         x = torch.from_numpy(rng.integers(1, 1 << 24, n).astype(np.float32))
@@ -207,6 +211,8 @@ def test_torch_pow_restatement():
         assert L.cvx_label_weights_host(hf.ctypes.data_as(C.c_void_p), hm.ctypes.data_as(C.c_void_p), n - 1, pres.ctypes.data_as(C.c_void_p),
                                         wt.ctypes.data_as(C.c_void_p)) == n
         assert np.array_equal(wt, w.numpy()), n
+    lo.orc_set_pow_block(32)
+    L.cvx_set_option(b"label_pow_block", 32)
 
 
 def test_sweep_settings_tables():
