@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_argmin(const ST* __restrict__ ssd, cons
             q += e2 * e2;
             cost = cost + coef * q;     // ssd + coeffs[j]*(...)                       (:104)
         }
-        if (bi < 0 || argmin_better(cost, best)) { best = cost; bi = k; }
+        if ((bi < 0) | argmin_better(cost, best)) { best = cost; bi = k; }
     }
     if (bi >= 0) atomicMin(&keys[x], pack_min_key(best, (unsigned)bi));
 }
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_argmin4(const ST* __restrict__ ssd, con
                 q += e2 * e2;
                 cost = cost + coef * q; // ssd + coeffs[j]*(...)                       (:104)
             }
-            if (bi[j] < 0 || argmin_better(cost, best[j])) { best[j] = cost; bi[j] = k; }
+            if ((bi[j] < 0) | argmin_better(cost, best[j])) { best[j] = cost; bi[j] = k; }
         }
     }
 #pragma unroll
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const ST* __restrict__ ssd,
                 const float lower = c.sm + pen;                        // <= cost_k
                 if (lower > c.bound || (bi >= 0 && lower >= best)) continue;
                 const float cost = SsdIO<ST>::ld(ssd + (size_t)k * v + x) + pen;       // ssd + coeffs[j]*(...)
-                if (bi < 0 || argmin_better(cost, best)) { best = cost; bi = k; }
+                if ((bi < 0) | argmin_better(cost, best)) { best = cost; bi = k; }
             }
     if (bi < 0) { best = c.bound; bi = c.kp; }   // cannot happen (kp passes its own test); keeps the output defined
     keys[x] = pack_min_key(best, (unsigned)bi);
@@ -347,7 +347,7 @@ __device__ void argmin4_stream(const ST* __restrict__ ssd, const float* __restri
                 q += e1 * e1;
                 q += e2 * e2;
                 const float cost = c4[j] + coef * q;    // ssd + coeffs[j]*(...)                       (:104)
-                if (bi[j] < 0 || argmin_better(cost, best[j])) { best[j] = cost; bi[j] = k; }
+                if ((bi[j] < 0) | argmin_better(cost, best[j])) { best[j] = cost; bi[j] = k; }
             }
         }
 #pragma unroll

@@ -329,7 +329,8 @@ __device__ __forceinline__ float adam_sqrt(float x, const unsigned* __restrict__
     return r;
 }
 // torch.argmin's comparison inside a sequential scan: a candidate replaces the running best when it is smaller, or when it is the first NaN
-__device__ __forceinline__ bool argmin_better(float cost, float best) { return cost < best || (cost != cost && best == best); }
+// (bitwise operators: no short-circuit branches inside the unrolled streaming loops)
+__device__ __forceinline__ bool argmin_better(float cost, float best) { return (cost < best) | ((cost != cost) & (best == best)); }
 __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& v, const AdamConsts& ac) {
     const float mm = __builtin_fmaf(ac.w1, g - m, m);            // exp_avg.lerp_(grad, 1-beta1)
     float vv = v * ac.b2;                                         // exp_avg_sq.mul_(beta2)
