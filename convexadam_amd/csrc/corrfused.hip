@@ -34,9 +34,6 @@
 namespace cvx {
 
 constexpr int CF_GMAX = 5;
-#ifndef CF_RAW_PRIO
-#define CF_RAW_PRIO 2
-#endif
 
 struct CFGeom {
     int C, h, w, d, hw, n;
@@ -49,6 +46,7 @@ struct CFGeom {
     int PF;                 // floats per LDS plane: 4 + (w + 2) * RS + 4
     int64_t tail_from;      // first flat index (h, n^2, w, d order) of ATen's interleaved-order tail; ntail = ncols - tail_from
     int ntail;
+    int prio;               // issue priorities (option cf_prio): base-4 digits first-round raw / box, second-round raw / box
     unsigned long long* dbg;   // optional residency census (CVX_CF_CENSUS): per workgroup {start, end, HW_ID, XCC_ID}
 };
 
@@ -137,8 +135,6 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
     const int n = g.n, nn = n * n, q = it.q, RS = g.RS, PF = g.PF;
     const int C = CT ? CT : g.C;
     static_assert(!CASC || CT == 0, "the cascade sum uses the rolled channel loop");
-    // the raw stage is the longest instruction stream of every sub-interval: its wavefronts win the issue arbitration
-    if (CF_RAW_PRIO) __builtin_amdgcn_s_setprio(CF_RAW_PRIO);
     // tiled: local row it.y stands for the global row y0 - 2 + it.y, rows outside the volume are written as zeros (the boxes zero-pad)
     const int y = TILED ? it.y0 - 2 + it.y : it.y;
     const bool rowok = !TILED || (y >= 0 && y < g.w);
@@ -432,6 +428,15 @@ __global__ __launch_bounds__(1024, (CASC ? 4 : 8)) void k_corr_fused(const float
     int rows = !TILED ? g.w : (role == 0 ? g.T + 4 : (role == 1 && !onebox ? g.T + 2 : g.T));
     if (TILED && role > 0 && (role == 2 || onebox)) rows = min(rows, g.w - it.y0);        // last tile: output rows inside the volume only
     it.active = tr < rows * g.lpr;
+    {
+        // issue priority of this wavefront: the raw stage is the longest instruction stream of every sub-interval and runs above the
+        // boxes; with two workgroups on a CU (one launch round of 257..512 items) the one dispatched second may be given its own pair
+        const bool second = gridDim.x > 256 && gridDim.x <= 512 && blockIdx.x >= 256;
+        const int pr = (g.prio >> ((second ? 0 : 4) + (role == 0 ? 2 : 0))) & 3;
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
     const int trc = it.active ? tr : rows * g.lpr - 1;
     it.y = trc / g.lpr; it.q = trc - it.y * g.lpr;
     // the group size is a compile-time constant inside the roles (ring arithmetic, register arrays, no idle accumulators)
@@ -534,6 +539,7 @@ int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, i
     launch_corr_prep_generic(fix, mov, C, h, w, d, hw, g.RS, hw, g.dq, Fp, Mp, s);
     if (g.ntail > 0 && !fast) launch_corr_tail_compact(fix, mov, C, h, w, d, hw, cost, tail, s);
     CFGeom gl = g;
+    gl.prio = (int)options().cf_prio;
     gl.dbg = options().cf_census ? census_buf : nullptr;      // debugging aid: per-workgroup start / end / placement in the workspace
     if (fast && f16 == 2) cf_launch<1 + 8 + 16>(gl, Fp, Mp, tail, ssd, s);
     else if (fast && f16) cf_launch<9>(gl, Fp, Mp, tail, ssd, s);

@@ -72,6 +72,8 @@ struct Options {
     long long corr_fused_all;      // 1: the fused correlation kernel also for C >= 16 (default there: the round-1 kernels, which are faster)
     long long prune_stream_above;  // pruned pass falls back to a coalesced scan above this many 256-displacement chunks (-1 = K*v/2048)
     long long cf_census;           // 1: the fused correlation kernel records per-workgroup residency in its workspace
+    long long cf_prio;             // fused correlation kernel: issue priorities (s_setprio, 0..3) as four base-4 digits -- first-round workgroup raw / box,
+                                   //    second-round workgroup raw / box (two workgroups share a CU; 136 = 2,0,2,0: the raw stage above the boxes)
     long long warp_flat;           // 1: flat 64-bit gathers in k_warp_grad instead of buffer loads
     long long box_yt;              // rows per tile of the marching three-box kernels: 8 (default) or 4
     long long box_wg_target;       // workgroups the z-marching three-box kernels of the Adam loop aim for (z-chunk length follows); 0 = automatic

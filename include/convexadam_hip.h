@@ -64,6 +64,8 @@ int cvx_device_count(void);            /* number of visible HIP devices (0 on a 
  *   no_prune            1: streaming coupled-convex passes instead of branch and bound
  *   prune_stream_above  chunk budget above which a pruned pass scans the volume (-1 = automatic)
  *   corr_unfused        1: separate raw-SSD and box kernels instead of the fused correlation kernel
+ *   cf_prio             issue priorities of the fused correlation kernel (s_setprio 0..3), four base-4 digits: first-round workgroup raw / box,
+ *                       second-round workgroup raw / box; 136 = 2,0,2,0 (default; the other settings measured equal or slower)
  *   corr_fused_all      1: the fused correlation kernel also for C >= 16 (it covers them -- cascade channel sum -- but the separate
  *                       kernels are faster there and stay the default)
  *   cf_census           1: the fused correlation kernel records per-workgroup residency in its workspace

@@ -175,7 +175,7 @@ def test_every_option_has_its_environment_variable():
     import subprocess
     import sys
     names = ["mind_tiled", "mind_overlap", "mm_tx", "mm_slots", "box_tiled", "no_prune", "corr_unfused", "corr_fused_all", "prune_stream_above",
-             "cf_census", "warp_flat", "box_yt", "box_wg_target", "box_xsplit", "box_cpt", "box_uneven", "box_adam_role", "box_dpp", "box_pk",
+             "cf_census", "cf_prio", "warp_flat", "box_yt", "box_wg_target", "box_xsplit", "box_cpt", "box_uneven", "box_adam_role", "box_dpp", "box_pk",
              "box_prio", "label_pow_block", "mind_mean_threads"]
     env = dict(os.environ, PYTHONPATH=ROOT)
     for i, n in enumerate(names):
