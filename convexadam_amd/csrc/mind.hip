@@ -7,7 +7,7 @@
 // Two passes (the global mean mu is a grid-wide dependency), after a min/max pre-pass that sizes the exact accumulation:
 //   stencil pass  : the 12 patch-SSDs D_c(x) -> out (raw), per-voxel variance -> order-independent exact sum (three
 //                   power-of-two split grids, double atomics)   [reads V*4, writes 12*V*4 B]
-//                   k_mind_march (mindmarch.hip) for radius 1 / dilation 2 / rows of 4k voxels, the tiled k_mind<R> below otherwise
+//                   k_mind_march (mindmarch.hip) for radius 1 / dilation 2 / rows of 4k voxels, the tiled k_mind<R, TX> below otherwise
 //   k_mind_finish : streaming, in place -- min, mean, clamp, exp per voxel        [reads + writes 12*V*4 B]
 //   k_mind_finish_pool : the pipeline's variant of the second pass -- normalisation and both stride poolings in one go
 // (recomputing the stencil in the second pass instead costs 2.2 x the time of streaming the 12 channels once)
@@ -21,7 +21,7 @@
 
 namespace cvx {
 
-constexpr int TZ = 4, TY = 8, TX = 64, RUN = 4, NT = 512;
+constexpr int TZ = 4, TY = 8, RUN = 4;
 
 // ---- min / max of the image (bound for the exact accumulation) -----------------------------------
 __global__ __launch_bounds__(256) void k_minmax_partial(const float* __restrict__ img, size_t V, float* part) {
@@ -89,10 +89,11 @@ __device__ __forceinline__ void mind_bounds(const MindStats* __restrict__ st, do
 }
 
 // ---- the tiled stencil ---------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(NT) void k_mind(const float* __restrict__ img, int H, int W, int D, int dil, int nbuf,
+// TX = tile width (64, or 32 when radius + dilation is too large for the 160 KB of LDS), NT = TX / RUN * TY * TZ threads
+template <int R, int TX>
+__global__ __launch_bounds__(TX / RUN * TY * TZ) void k_mind(const float* __restrict__ img, int H, int W, int D, int dil, int nbuf,
                                               MindStats* __restrict__ st, float* __restrict__ out) {
-    constexpr int K = 2 * R + 1;
+    constexpr int K = 2 * R + 1, NT = TX / RUN * TY * TZ;
     constexpr int SZ = TZ + 2 * R, SY = TY + 2 * R, SX = TX + 2 * R;
     constexpr int SXP = (SX + 3) / 4 * 4 + 2;        // row pitch = 2 (mod 4) floats: the 8-byte reads of lanes 16 B apart in
                                                      // adjacent rows land on disjoint banks
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restr
     }
 }
 
-static size_t mind_lds_bytes(int R, int dil, int nbuf) {
+static size_t mind_lds_bytes(int R, int dil, int nbuf, int TX) {
     const int halo = R + dil;
     const int IZ = TZ + 2 * halo, IY = TY + 2 * halo, IX = TX + 2 * halo;
     const int SZ = TZ + 2 * R, SY = TY + 2 * R, SX = TX + 2 * R, SXP = (SX + 3) / 4 * 4 + 2;
@@ -572,12 +573,21 @@ static int mind_launch_r(const float* img, int H, int W, int D, int dil, MindSta
         launch_mind_march(img, H, W, D, st, out, s);
         return check_last("mindssc");
     }
-    const dim3 grid(cdiv(D, TX), cdiv(W, TY), cdiv(H, TZ));
-    const int nbuf = mind_lds_bytes(R, dil, 2) <= 160 * 1024 ? 2 : 1;
-    const size_t lds = mind_lds_bytes(R, dil, nbuf);
-    static size_t granted0 = 0;
-    ensure_dynamic_lds(&k_mind<R>, lds, granted0);
-    hipLaunchKernelGGL((k_mind<R>), grid, dim3(NT), lds, s, img, H, W, D, dil, nbuf, st, out);
+    if (mind_lds_bytes(R, dil, 1, 64) <= 160 * 1024) {
+        const dim3 grid(cdiv(D, 64), cdiv(W, TY), cdiv(H, TZ));
+        const int nbuf = mind_lds_bytes(R, dil, 2, 64) <= 160 * 1024 ? 2 : 1;
+        const size_t lds = mind_lds_bytes(R, dil, nbuf, 64);
+        static size_t granted0 = 0;
+        ensure_dynamic_lds(&k_mind<R, 64>, lds, granted0);
+        hipLaunchKernelGGL((k_mind<R, 64>), grid, dim3(64 / RUN * TY * TZ), lds, s, img, H, W, D, dil, nbuf, st, out);
+    } else {                                        // radius 3 with dilation 4: tiles of 32 columns
+        const dim3 grid(cdiv(D, 32), cdiv(W, TY), cdiv(H, TZ));
+        const int nbuf = mind_lds_bytes(R, dil, 2, 32) <= 160 * 1024 ? 2 : 1;
+        const size_t lds = mind_lds_bytes(R, dil, nbuf, 32);
+        static size_t granted1 = 0;
+        ensure_dynamic_lds(&k_mind<R, 32>, lds, granted1);
+        hipLaunchKernelGGL((k_mind<R, 32>), grid, dim3(32 / RUN * TY * TZ), lds, s, img, H, W, D, dil, nbuf, st, out);
+    }
     return check_last("mindssc");
 }
 
@@ -637,7 +647,7 @@ static int mind_check(const float* img, const float* out, const void* workspace,
     CVX_REQUIRE(dilation >= 1 && dilation <= 4, "cvx_mindssc_f32: dilation %d not in 1..4", dilation);
     if (workspace_bytes < cvx_mindssc_workspace_bytes(H, W, D, radius, dilation))
         return fail(CVX_ERR_WORKSPACE, "cvx_mindssc_f32: workspace too small");
-    if (mind_lds_bytes(radius, dilation, 1) > 160 * 1024)
+    if (mind_lds_bytes(radius, dilation, 1, 32) > 160 * 1024)
         return fail(CVX_ERR_UNSUPPORTED, "cvx_mindssc_f32: radius %d dilation %d exceeds the LDS tile", radius, dilation);
     return CVX_OK;
 }

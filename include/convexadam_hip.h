@@ -102,7 +102,8 @@ void cvx_disp_mesh_host(int disp_hw, float* out_host);
 
 /* MIND-SSC descriptors ---------------------------------------------------------------------------
  * replaces MINDSSC(img, radius, dilation, device)          convex_adam_utils.py:24-68
- *   img [H][W][D] -> out [12][H][W][D] (reference channel order after the permutation at :66) */
+ *   img [H][W][D] -> out [12][H][W][D] (reference channel order after the permutation at :66)
+ *   radius 1..3, dilation 1..4 (CVX_ERR_INVALID_ARG outside; the reference's sweeps draw both from 1..3) */
 size_t cvx_mindssc_workspace_bytes(int H, int W, int D, int radius, int dilation);
 int cvx_mindssc_f32(const float* img, int H, int W, int D, int radius, int dilation, float* out,
                     void* workspace, size_t workspace_bytes, void* stream);

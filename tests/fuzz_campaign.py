@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Long randomised parity campaign on the GPU box (not collected by pytest; the suite's own fuzz test is the short version):
+    python tests/fuzz_campaign.py [--minutes 10] [--seed 1]
+Random pairs through the whole pipeline (extents up to ~100 voxels, MIND radius / dilation, both grid spacings, search half-widths up
+to 10, the challenge-script variants and fp16 storage, masked pairs, label-map pairs) and random Adam control grids, each compared
+with the CPU oracle bit for bit.  Prints one line per failure with the configuration that reproduces it, and a summary."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from convexadam_amd import convex_adam_MIND as M           # noqa: E402
+from convexadam_amd import convex_adam_utils as U          # noqa: E402
+from convexadam_amd.phantom import ellipsoid_mask, phantom  # noqa: E402
+from oracle import oracle as orc                           # noqa: E402  (the checker)
+
+DEV = "cuda"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def field(t):
+    return np.moveaxis(host(t), 0, -1).astype(np.float64)
+
+
+def trial_pipeline(rng, t):
+    gs, gsa, hw = int(rng.choice([2, 3, 4, 5, 6, 7])), int(rng.choice([1, 2, 3, 4])), int(rng.integers(1, 11))
+    big = rng.random() < 0.3
+    shape = tuple(int(max(2 * gs, 2 * gsa, 8) + rng.integers(0, 90 if big else 36)) for _ in range(3))
+    coarse = np.prod([s // gs for s in shape])
+    while (2 * hw + 1) ** 3 * coarse > 6e7:                 # keep the oracle's cost volume below ~240 MB
+        hw -= 1
+    kw = dict(mind_r=int(rng.choice([1, 2, 3])), mind_d=int(rng.choice([1, 2, 3, 4])), grid_sp=gs, disp_hw=hw, grid_sp_adam=gsa,
+              lambda_weight=float(rng.choice([0.0, 0.7, 1.25])), selected_niter=int(rng.integers(1, 6)), ic=bool(rng.integers(0, 2)),
+              selected_smooth=int(rng.choice([0, 0, 3, 5])))
+    var = {}
+    if rng.random() < 0.4:
+        var = [dict(cost="sad"), dict(n_box=1), dict(n_spline_pools=2), dict(cost="sad", n_box=1, n_spline_pools=2), dict(storage="fp16"),
+               dict(storage="fp16", n_spline_pools=2)][int(rng.integers(0, 6))]
+    fix = phantom(shape, 1000 + t, 2000 + t)
+    mov = torch.roll(phantom(shape, 1000 + t, 3000 + t), (1, -1, 2), (0, 1, 2))
+    out = field(M.register_pair_device(fix.to(DEV), mov.to(DEV), **kw, **var))
+    ref = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), **kw, **var)
+    return np.array_equal(out, ref), ("pipeline", shape, kw, var)
+
+
+def trial_masked(rng, t):
+    gs, hw = int(rng.choice([3, 4, 6])), int(rng.integers(1, 6))
+    shape = tuple(int(2 * (max(gs, 6) + rng.integers(0, 24))) for _ in range(3))
+    kw = dict(mind_r=1, mind_d=int(rng.choice([1, 2])), grid_sp=gs, disp_hw=hw, grid_sp_adam=2, lambda_weight=1.25,
+              selected_niter=int(rng.integers(1, 4)), ic=True, selected_smooth=0)
+    fix = phantom(shape, 4000 + t, 5000 + t)
+    mov = torch.roll(phantom(shape, 4000 + t, 6000 + t), (1, 0, -1), (0, 1, 2))
+    mf = ellipsoid_mask(shape, float(rng.uniform(0.25, 0.45))).float()
+    mm = torch.roll(mf, (1, 0, -1), (0, 1, 2))
+    gf, gm = M.extract_features(fix, mov, kw["mind_r"], kw["mind_d"], True, mf, mm, device=torch.device(DEV), dtype=torch.float32)
+    rest = {k: v for k, v in kw.items() if k not in ("mind_r", "mind_d")}
+    out = field(M.register_pair_device(feat_fixed=gf[0], feat_moving=gm[0], **rest))
+    ff, _ = orc.replicate_fill(fix.numpy(), mf.numpy())
+    fm, _ = orc.replicate_fill(mov.numpy(), mm.numpy())
+    ref = orc.convex_adam_pipeline(ff, fm, **kw)
+    return np.array_equal(out, ref), ("masked", shape, kw)
+
+
+def trial_labels(rng, t):
+    from convexadam_amd import convex_adam_nnUNet as N
+    gs, hw = int(rng.choice([2, 3, 4])), int(rng.integers(1, 5))
+    shape = tuple(int(max(2 * gs, 8) + rng.integers(0, 30)) for _ in range(3))
+    nlab = int(rng.choice([3, 9, 15, 16, 17, 33, 40]))
+    blocks = rng.integers(0, nlab, [max(1, s // 5) for s in shape])
+    lab = np.kron(blocks, np.ones((5, 5, 5), np.int64))
+    lab = np.pad(lab, [(0, max(0, s - l)) for s, l in zip(shape, lab.shape)], mode="edge")[:shape[0], :shape[1], :shape[2]].astype(np.float32)
+    lab2 = np.roll(lab, (1, -1, 1), (0, 1, 2))
+    kw = dict(lambda_weight=1.25, grid_sp=gs, disp_hw=hw, selected_niter=int(rng.integers(1, 4)), selected_smooth=int(rng.choice([0, 3, 5])),
+              grid_sp_adam=int(rng.choice([1, 2])), ic=bool(rng.integers(0, 2)))
+    ff, fm = N.extract_features(torch.from_numpy(lab), torch.from_numpy(lab2), device=DEV)
+    of, om, _ = orc.label_features(lab, lab2)
+    ok = np.array_equal(host(ff)[0], of) and np.array_equal(host(fm)[0], om)
+    out = field(M.register_pair_device(feat_fixed=ff[0], feat_moving=fm[0], cost_scale=12.0, **kw))
+    ref = orc.convex_adam_pipeline(None, None, features=(of, om), **kw)
+    return ok and np.array_equal(out, ref), ("labels", shape, nlab, kw)
+
+
+def trial_adam(rng, t):
+    from convexadam_amd import convexAdam_hyper_util as HU
+    shape = tuple(int(rng.integers(3, 60)) for _ in range(2)) + (int(rng.integers(3, 150)),)
+    C = int(rng.choice([1, 3, 4, 5, 12, 13, 16, 24, 33]))
+    F2 = rng.random((C,) + shape, dtype=np.float32)
+    M2 = rng.random((C,) + shape, dtype=np.float32)
+    P0 = (float(rng.choice([0.3, 1.0, 3.0])) * rng.standard_normal((3,) + shape)).astype(np.float32)
+    lam, nit = float(rng.choice([0.5, 1.0, 1.25])), int(rng.integers(1, 5))
+    mod, sm, storage = None, None, "fp32"
+    r = rng.random()
+    if r < 0.2:
+        mod, sm = HU.GaussianSmoothing(0.7), None
+        sm = orc.make_smoother(gauss_w=np.array(list(mod.spec.gauss_w), np.float32))
+    elif r < 0.4:
+        mod = HU.kovesi_spline(float(rng.choice([1.6, 1.9, 2.8])), 4)
+        sm = orc.make_smoother(mod.sizes)
+    elif r < 0.55:
+        storage = "fp16"
+    Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], lam, nit, return_state=True, smoother=mod, storage=storage)
+    h = (lambda a: a.astype(np.float16).astype(np.float32)) if storage == "fp16" else (lambda a: a)
+    ref = orc.adam_run(h(F2), h(M2), P0, lam, nit, want_grad=True, smoother=sm)
+    ok = all(np.array_equal(host(st[k])[0], ref[k]) for k in ("P", "m", "v")) and np.array_equal(host(Ud)[0], ref["U"])
+    return ok, ("adam", shape, C, lam, nit, storage, None if mod is None else type(mod).__name__)
+
+
+def trial_mind(rng, t):
+    shape = tuple(int(rng.integers(4, 50)) for _ in range(2)) + (int(rng.choice([5, 31, 32, 33, 64, 70, 96, 100, 130])),)
+    r, d = int(rng.choice([1, 2, 3])), int(rng.choice([1, 2, 3, 4]))
+    img = phantom(shape, 7000 + t, 8000 + t)
+    got = host(U.MINDSSC(img.to(DEV)[None, None], r, d, device=torch.device(DEV)))[0]
+    return np.array_equal(got, orc.mindssc(img.numpy(), r, d)), ("mind", shape, r, d)
+
+
+def trial_convex_ops(rng, t):
+    hw = int(rng.integers(1, 9))
+    shape = tuple(int(rng.integers(2, 30)) for _ in range(2)) + (int(rng.integers(2, 60)),)
+    C = int(rng.choice([1, 5, 12, 16, 20, 33]))
+    while (2 * hw + 1) ** 3 * np.prod(shape) > 4e7:
+        hw -= 1
+    f = rng.random((C,) + shape, dtype=np.float32)
+    m = rng.random((C,) + shape, dtype=np.float32)
+    if rng.random() < 0.3:                                   # nulls: torch.argmin returns the first NaN of a column
+        f.flat[rng.integers(0, f.size, 3)] = np.nan
+    cost, n_box = str(rng.choice(["ssd", "ssd", "sad"])), int(rng.choice([2, 2, 1]))
+    ssd, am = U.correlate(dev(f)[None], dev(m)[None], hw, 1, shape, C, cost=cost, n_box=n_box)
+    rs, ra = orc.correlate(f, m, hw, cost=cost, n_box=n_box)
+    ok = np.array_equal(host(ssd), rs, equal_nan=True) and np.array_equal(host(am), ra)
+    mesh = orc.disp_mesh(hw)
+    soft = U.coupled_convex(ssd, am, dev(mesh)[:, :, None], 1, shape)
+    ok = ok and np.array_equal(host(soft)[0], orc.coupled_convex(rs, ra, mesh, hw), equal_nan=True)
+    return ok, ("convex_ops", shape, C, hw, cost, n_box)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=10.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    orc.build()
+    rng = np.random.default_rng(a.seed)
+    kinds = [trial_pipeline, trial_pipeline, trial_masked, trial_labels, trial_adam, trial_adam, trial_convex_ops, trial_mind]
+    if a.only:
+        kinds = [k for k in kinds if a.only in k.__name__]
+    t0, n, bad, count = time.time(), 0, [], {}
+    while time.time() - t0 < a.minutes * 60:
+        k = kinds[n % len(kinds)]
+        try:
+            ok, what = k(rng, n)
+        except Exception as e:                               # an explicit error for a supported configuration is a finding too
+            ok, what = False, (k.__name__, "EXCEPTION", repr(e)[:300])
+        count[k.__name__] = count.get(k.__name__, 0) + 1
+        if not ok:
+            bad.append(what)
+            print("MISMATCH seed=%d trial=%d: %r" % (a.seed, n, what), flush=True)
+        n += 1
+    kindsum = {}
+    for w in bad:
+        key = (w[0], w[1]) if w[1] == "EXCEPTION" else (w[0],)
+        kindsum[key + ((w[2][:120],) if w[1] == "EXCEPTION" else ())] = kindsum.get(key + ((w[2][:120],) if w[1] == "EXCEPTION" else ()), 0) + 1
+    for k, v in kindsum.items():
+        print("  %4d x %r" % (v, k), flush=True)
+    print("fuzz campaign: %d trials in %.1f min (%s), %d mismatches" % (n, (time.time() - t0) / 60, count, len(bad)), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -47,8 +47,10 @@ def test_library_sees_the_gpu():
 
 # ---- (1) HIP vs oracle, bit-exact --------------------------------------------------------------------
 @pytest.mark.parametrize("shape,r,d", [((20, 18, 23), 1, 2), ((33, 40, 70), 1, 2), ((20, 18, 23), 2, 2), ((17, 9, 66), 1, 1),
-                                       ((12, 13, 14), 3, 3), ((9, 70, 8), 2, 1)])
+                                       ((12, 13, 14), 3, 3), ((9, 70, 8), 2, 1), ((10, 11, 70), 3, 4), ((6, 20, 33), 1, 4)])
 def test_mindssc_vs_oracle(U, orc, shape, r, d):
+    """(radius 3 with dilation 4 needs the 32-column tile of the tiled stencil: its image tile with a 7-voxel halo does not fit
+    the LDS at 64 columns)"""
     from convexadam_amd.phantom import phantom
     img = phantom(shape, 3, 30)
     out = host(U.MINDSSC(img[None, None].to(DEV), r, d, device=DEV))[0]
