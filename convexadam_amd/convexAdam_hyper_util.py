@@ -126,7 +126,9 @@ def jacobian_determinant_3d(dense_flow, convert1=True):
     B, ch, H, W, D = [int(v) for v in x.shape]
     if B != 1 or ch != 3:
         raise ValueError("jacobian_determinant_3d: expected a (1,3,H,W,D) field")
-    out = torch.empty((H - 4, W - 4, D - 4), dtype=torch.float32, device=x.device)
+    out = torch.empty((max(H - 4, 0), max(W - 4, 0), max(D - 4, 0)), dtype=torch.float32, device=x.device)
+    if out.numel() == 0:                         # an extent of at most 4 voxels: the slice [2:-2] of the reference (:103) is empty
+        return out
     with torch.cuda.device(x.device):
         check(lib().cvx_jacobian_det_f32(ptr(x), H, W, D, 1 if convert1 else 0, ptr(out), stream_ptr(x.device)))
     return out

@@ -145,6 +145,58 @@ def trial_convex_ops(rng, t):
     return ok, ("convex_ops", shape, C, hw, cost, n_box)
 
 
+def trial_operators(rng, t):
+    """inverse consistency, trilinear resize, grid_sample, box smoothing, stride pooling, feature transform"""
+    from scipy.ndimage import distance_transform_edt as edt
+    sh = tuple(int(rng.integers(2, 28)) for _ in range(3))
+    a = (0.3 * rng.standard_normal((3,) + sh)).astype(np.float32)
+    b = (0.3 * rng.standard_normal((3,) + sh)).astype(np.float32)
+    it = int(rng.choice([1, 3, 15]))
+    o1, o2 = U.inverse_consistency(dev(a)[None], dev(b)[None], iter=it)
+    r1, r2 = orc.inverse_consistency(a, b, it)
+    ok = np.array_equal(host(o1)[0], r1) and np.array_equal(host(o2)[0], r2)
+    C = int(rng.choice([1, 2, 3, 5]))
+    dst = tuple(int(rng.integers(1, 60)) for _ in range(2)) + (int(rng.integers(1, 200)),)
+    x = rng.standard_normal((C,) + sh).astype(np.float32)
+    ok = ok and np.array_equal(host(U.resize_trilinear(dev(x)[None], dst))[0], orc.resize_trilinear(x, dst))
+    grid = (rng.random(dst[:2] + (min(dst[2], 40), 3), dtype=np.float32) * 2.8 - 1.4).astype(np.float32)
+    ok = ok and np.array_equal(host(U.grid_sample(dev(x)[None], dev(grid)[None]))[0], orc.grid_sample(x, grid))
+    k, passes = int(rng.choice([3, 5, 7])), int(rng.integers(1, 4))
+    r = x
+    for _ in range(passes):
+        r = orc.box_zero(r, k)
+    ok = ok and np.array_equal(host(U.box_smooth(dev(x)[None], k, passes))[0], r)
+    g = int(rng.integers(1, 7))
+    big = rng.standard_normal((C,) + tuple(s + g for s in sh)).astype(np.float32)
+    ok = ok and np.array_equal(host(U.avg_pool(dev(big)[None], g))[0], orc.avgpool_stride(big, g))
+    m = rng.random(sh) < float(rng.choice([0.3, 0.8, 0.98]))
+    if m.any() and not m.all():
+        got = host(M.feature_transform(dev((~m).astype(np.float32))))
+        ok = ok and np.array_equal(got, edt(~m, return_indices=True)[1])
+    return ok, ("operators", sh, C, dst, it, k, passes, g)
+
+
+def trial_metrics(rng, t):
+    from convexadam_amd import convexAdam_hyper_util as HU
+    from oracle import metrics_oracle as morc
+    from scipy.ndimage import distance_transform_edt as edt
+    sh = tuple(int(rng.integers(3, 36)) for _ in range(3))
+    conv = bool(rng.integers(0, 2))
+    flow = (rng.standard_normal((3,) + sh) * (0.1 if conv else 2.0)).astype(np.float32)
+    ok = np.array_equal(host(HU.jacobian_determinant_3d(dev(flow)[None], conv)), morc.jacobian_determinant_3d(flow, conv))
+    nl = int(rng.integers(2, 12))
+    seg = rng.integers(0, nl, sh).astype(np.float32)
+    seg2 = np.roll(seg, (1, 0, -1), (0, 1, 2))
+    disp = (rng.standard_normal((3,) + sh) * 2.5).astype(np.float32)
+    w = HU.warp_labels_nearest(dev(seg), dev(disp)[None])
+    ok = ok and np.array_equal(host(w), morc.warp_labels_nearest(seg, disp))
+    ok = ok and np.array_equal(HU.dice_coeff(dev(seg2), w, nl).numpy(), morc.dice_coeff(seg2, host(w), nl))
+    m = (rng.random(sh) < float(rng.choice([0.5, 0.9, 0.99]))).astype(np.float32)
+    if (m == 0).any():
+        ok = ok and np.array_equal(host(HU.edt_squared(dev(m))).astype(np.int64), np.rint(edt(m) ** 2).astype(np.int64))
+    return ok, ("metrics", sh, conv, nl)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=10.0)
@@ -153,7 +205,7 @@ def main():
     a = ap.parse_args()
     orc.build()
     rng = np.random.default_rng(a.seed)
-    kinds = [trial_pipeline, trial_pipeline, trial_masked, trial_labels, trial_adam, trial_adam, trial_convex_ops, trial_mind]
+    kinds = [trial_pipeline, trial_pipeline, trial_masked, trial_labels, trial_adam, trial_adam, trial_convex_ops, trial_mind, trial_operators, trial_metrics]
     if a.only:
         kinds = [k for k in kinds if a.only in k.__name__]
     t0, n, bad, count = time.time(), 0, [], {}

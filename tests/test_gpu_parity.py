@@ -732,7 +732,8 @@ def morc():
     return metrics_oracle
 
 
-@pytest.mark.parametrize("shape,convert1", [((9, 10, 11), False), ((9, 10, 11), True), ((5, 6, 37), False), ((40, 33, 29), True)])
+@pytest.mark.parametrize("shape,convert1", [((9, 10, 11), False), ((9, 10, 11), True), ((5, 6, 37), False), ((40, 33, 29), True),
+                                            ((4, 9, 10), False), ((3, 5, 6), True)])      # extents <= 4: empty, like the reference's slice
 def test_jacobian_determinant_vs_oracle(HU, morc, shape, convert1):
     rng = np.random.default_rng(sum(shape))
     flow = (rng.standard_normal((3,) + shape) * (0.1 if convert1 else 2.0)).astype(np.float32)
