@@ -52,6 +52,18 @@ for name, lo, hi in (("forward boxes", 0, 1024), ("adjoint boxes + Adam", 1024, 
     for k in sorted(set(cnt.tolist())):
         sel = cnt[inv] == k
         print("      CUs holding %d workgroups: life median %.2f max %.2f us, end median %.2f max %.2f" % (k, np.median(life[sel]), life[sel].max(), np.median(en[sel]), en[sel].max()))
+    if "warp" in name:                           # occupancy over time: resident workgroups per microsecond, starts per microsecond
+        T = int(np.ceil(en.max())) + 1
+        occ = np.zeros(T); sts = np.zeros(T)
+        for a, b_ in zip(st, en):
+            occ[int(a):int(np.ceil(b_))] += 1
+            sts[int(a)] += 1
+        print("    resident workgroups at each us (of %d slots at 6 per CU):" % (6 * 256), " ".join("%d" % v for v in occ))
+        print("    workgroups started in each us:", " ".join("%d" % v for v in sts))
+        order_ = np.argsort(st)
+        third = len(st) // 3
+        for nm, sel in (("first third by start", order_[:third]), ("middle third", order_[third:2 * third]), ("last third", order_[2 * third:])):
+            print("    life of the %s: median %.2f p10 %.2f p90 %.2f" % (nm, np.median(life[sel]), np.percentile(life[sel], 10), np.percentile(life[sel], 90)))
     if "boxes" in name:                          # which tiles are slow?  (launch_qpr: b = (blk & 7) * (grid >> 3) + (blk >> 3); zi fastest, then xi, yi, channel)
         grid = len(r)
         blk = np.arange(grid)
