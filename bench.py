@@ -157,11 +157,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # test hooks (tests/test_gpu_parity.py runs the N > 1 path on a one-GPU box): BENCH_SHARE_DEVICE=1 puts every rank on device 0,
+    # BENCH_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks on one device; the driver's runs set neither
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")          # where the max-over-ranks reduction of the clock lives
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from convexadam_amd.convex_adam_MIND import last_profile, register_pair_device, register_pairs_device, set_profiling
 
@@ -189,7 +198,7 @@ def main():
         stage_ms.setdefault(name, []).append(ms)
     set_profiling(0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -209,7 +218,7 @@ def main():
             dist.barrier()
         eb = time.perf_counter() - tb
         if world > 1:
-            t = torch.tensor([eb], dtype=torch.float64, device=dev)
+            t = torch.tensor([eb], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             eb = float(t.item())
         batched = {"pairs_per_call": 2, "n_streams": 2, "value": world * a.steps * 2 / eb, "unit": "pairs/s",

@@ -891,6 +891,32 @@ def test_sweep_driver_scores_items_on_the_device(tmp_path):
         assert r["dice"] > r["dice_before"] + 0.1 and r["tre"] < 0.5 * r["tre_before"] and r["folding"] == 0.0
 
 
+def test_bench_line_with_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path (one process per rank under torch.distributed.run, barrier + max over ranks, rank 0 prints): two ranks share
+    this box's GPU through the test hooks (gloo instead of RCCL, which refuses two ranks on one device).  Checks the contract of the line,
+    not a speed: whole-job value = 2 pairs per step over the slower rank's clock."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-batched"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # exactly one JSON line, from rank 0
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["steps"] == 3 and b["warmup"] == 1 and b["scaling"] == "weak" and b["unit"] == "pairs/s"
+    assert abs(b["value"] - 2 * 3 / (b["ms_per_step"] * 3e-3)) < 1e-6 * b["value"]
+    assert "cpu_baseline" not in b and b["roofline"]["frac"] > 0 and b["vs_baseline"] is None
+
+
 # ---- (5) Euclidean feature transform of the masked path (SURVEY 8(f).2) ------------------------------------------------
 def test_feature_transform_vs_scipy_and_oracle(M, orc):
     """Device EDT indices == scipy.ndimage.distance_transform_edt(return_indices=True) (the call of convex_adam_MIND.py:44),
