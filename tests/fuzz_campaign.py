@@ -14,6 +14,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from convexadam_amd import convex_adam_MIND as M           # noqa: E402
 from convexadam_amd import convex_adam_utils as U          # noqa: E402
 from convexadam_amd.phantom import ellipsoid_mask, phantom  # noqa: E402
@@ -202,15 +203,29 @@ def main():
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", default="")
+    ap.add_argument("--reference-bits", action="store_true",
+                    help="library AND oracle in reference-bits mode: the golden host's MKL exp / sqrt tables, torch's thread-count dependent mean")
     a = ap.parse_args()
     orc.build()
+    if a.reference_bits:
+        import mkl_tables
+        from convexadam_amd import reference_bits as rb
+        t = mkl_tables.golden_tables()
+        rb.set_mind_exp_table(t["exp"], t["exp_first"], t["exp_count"], device=DEV)
+        rb.set_adam_sqrt_table(t["sqrt"], device=DEV)
+        orc.set_exp_table(t["exp"], t["exp_first"], t["exp_count"])
+        orc.set_sqrt_table(t["sqrt"])
     rng = np.random.default_rng(a.seed)
     kinds = [trial_pipeline, trial_pipeline, trial_masked, trial_labels, trial_adam, trial_adam, trial_convex_ops, trial_mind, trial_operators, trial_metrics]
     if a.only:
-        kinds = [k for k in kinds if a.only in k.__name__]
+        kinds = [k for k in kinds if any(tok in k.__name__ for tok in a.only.replace(',', ' ').split())]
     t0, n, bad, count = time.time(), 0, [], {}
     while time.time() - t0 < a.minutes * 60:
         k = kinds[n % len(kinds)]
+        if a.reference_bits:                                 # the mean of MINDSSC as torch computes it with T threads
+            T = int(rng.choice([1, 2, 3, 8, 16]))
+            rb.set_mean_threads(T)
+            orc.set_mean_threads(T)
         try:
             ok, what = k(rng, n)
         except Exception as e:                               # an explicit error for a supported configuration is a finding too
