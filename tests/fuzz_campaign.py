@@ -35,12 +35,19 @@ def field(t):
     return np.moveaxis(host(t), 0, -1).astype(np.float64)
 
 
+LARGE = False          # --large: extents of 96 .. 224 voxels (x tiles, uneven z chunks, y-tiled correlation, streaming fallbacks)
+
+
 def trial_pipeline(rng, t):
     gs, gsa, hw = int(rng.choice([2, 3, 4, 5, 6, 7])), int(rng.choice([1, 2, 3, 4])), int(rng.integers(1, 11))
     big = rng.random() < 0.3
-    shape = tuple(int(max(2 * gs, 2 * gsa, 8) + rng.integers(0, 90 if big else 36)) for _ in range(3))
+    if LARGE:
+        gs, gsa = int(rng.choice([3, 4, 5, 6, 8])), int(rng.choice([2, 2, 3, 4]))
+        shape = tuple(int(rng.integers(96, 225)) for _ in range(3))
+    else:
+        shape = tuple(int(max(2 * gs, 2 * gsa, 8) + rng.integers(0, 90 if big else 36)) for _ in range(3))
     coarse = np.prod([s // gs for s in shape])
-    while (2 * hw + 1) ** 3 * coarse > 6e7:                 # keep the oracle's cost volume below ~240 MB
+    while (2 * hw + 1) ** 3 * coarse > (4e8 if LARGE else 6e7):     # keep the oracle's cost volume below ~240 MB (1.6 GB with --large)
         hw -= 1
     kw = dict(mind_r=int(rng.choice([1, 2, 3])), mind_d=int(rng.choice([1, 2, 3, 4])), grid_sp=gs, disp_hw=hw, grid_sp_adam=gsa,
               lambda_weight=float(rng.choice([0.0, 0.7, 1.25])), selected_niter=int(rng.integers(1, 6)), ic=bool(rng.integers(0, 2)),
@@ -203,9 +210,12 @@ def main():
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", default="")
+    ap.add_argument("--large", action="store_true", help="pipeline trials on extents of 96 .. 224 voxels")
     ap.add_argument("--reference-bits", action="store_true",
                     help="library AND oracle in reference-bits mode: the golden host's MKL exp / sqrt tables, torch's thread-count dependent mean")
     a = ap.parse_args()
+    global LARGE
+    LARGE = a.large
     orc.build()
     if a.reference_bits:
         import mkl_tables
