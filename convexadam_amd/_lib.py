@@ -13,6 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CONVEXADAM_HIP_LIB") or os.path.join(_HERE, "csrc", "libconvexadam_hip.so")     # (override: race-stress build)
 
+ABI_VERSION = 2          # CVX_ABI_VERSION of include/convexadam_hip.h this binding was written against
 CVX_OK, CVX_ERR_INVALID_ARG, CVX_ERR_WORKSPACE, CVX_ERR_LAUNCH, CVX_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 
 
@@ -38,7 +39,7 @@ class PairParams(C.Structure):
                 ("lambda_weight", C.c_float), ("grid_sp", C.c_int), ("disp_hw", C.c_int), ("selected_niter", C.c_int),
                 ("selected_smooth", C.c_int), ("grid_sp_adam", C.c_int), ("ic", C.c_int), ("n_feat", C.c_int),
                 ("cost_scale", C.c_float), ("cost", C.c_int), ("n_box", C.c_int), ("n_spline_pools", C.c_int), ("corr_fast", C.c_int),
-                ("fp16_storage", C.c_int), ("ctx", C.c_void_p)]
+                ("fp16_storage", C.c_int), ("ctx", C.c_void_p), ("adam_fast", C.c_int), ("reserved_", C.c_int * 3)]
 
 
 _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -93,6 +94,9 @@ SIGNATURES = {
                                        _vp, C.POINTER(Smoother), _vp, _sz, _vp]),
     "cvx_adam_run_ex_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                                  _vp, C.POINTER(Smoother), _i, _vp, _sz, _vp]),
+    "cvx_adam_run_fast_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                   _vp, _vp, _sz, _vp]),
+    "cvx_box3_fast_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "cvx_register_pair_workspace_bytes": (_sz, [C.POINTER(PairParams)]),
     "cvx_register_pair_f32": (_i, [_vp, _vp, _vp, _vp, C.POINTER(PairParams), _vp, _vp, _vp, _sz, _vp]),
     "cvx_register_pair_snapshots_workspace_bytes": (_sz, [_vp, _i, _vp, _i]),
@@ -135,6 +139,9 @@ def lib():
                     fn = getattr(L, name)
                     fn.restype = res
                     fn.argtypes = args
+                if L.cvx_version() != ABI_VERSION:
+                    raise RuntimeError("%s reports ABI version %d, this binding needs %d (struct layouts differ): rebuild with "
+                                       "`python -m convexadam_amd.csrc.build`" % (LIB_PATH, L.cvx_version(), ABI_VERSION))
                 _lib = L
     return _lib
 

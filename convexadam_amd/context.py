@@ -9,6 +9,8 @@ Threads that enter different contexts (and launch on different streams) are inde
 it enqueues its kernels.  Outside any `with` block a thread uses the process default context (cvx_set_option, reference_bits.enable).
 The library copies tables into memory the context owns, so nothing has to be kept alive on the Python side.
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -20,7 +22,7 @@ class Context:
         self._h = lib().cvx_context_create()
         if not self._h:
             raise MemoryError("cvx_context_create failed")
-        self._prev = []
+        self._tls = threading.local()
         for k, v in options.items():
             self.set_option(k, v)
 
@@ -61,11 +63,16 @@ class Context:
         return self._h
 
     def __enter__(self):
-        self._prev.append(lib().cvx_context_bind(self._h))
+        # the saved bindings are PER THREAD (one Context object -- e.g. the 80 MB reference-bits tables -- may be entered by several
+        # worker threads at once; the library's binding is thread-local too)
+        stack = getattr(self._tls, "prev", None)
+        if stack is None:
+            stack = self._tls.prev = []
+        stack.append(lib().cvx_context_bind(self._h))
         return self
 
     def __exit__(self, *exc):
-        lib().cvx_context_bind(self._prev.pop())
+        lib().cvx_context_bind(self._tls.prev.pop())
         return False
 
     def close(self):

@@ -107,13 +107,14 @@ def extract_features(img_fixed: torch.Tensor, img_moving: torch.Tensor, mind_r: 
 def register_pair_device(img_fixed=None, img_moving=None, feat_fixed=None, feat_moving=None, mind_r=1, mind_d=2,
                          lambda_weight=1.25, grid_sp=6, disp_hw=4, selected_niter=80, selected_smooth=0, grid_sp_adam=2,
                          ic=True, cost_scale=12.0, out=None, profile=None, cost="ssd", n_box=2, n_spline_pools=3, corr_mode="exact",
-                         storage="fp32"):
+                         storage="fp32", adam_mode="exact"):
     """One registration, device in / device out: returns the displacement field as a (3,H',W',D') float32
     device tensor (full resolution, or the coarse grid for the reference's ic=False & lambda_weight<=0 case).
     Either two (H,W,D) images (MIND-SSC features are computed) or two (C,H,W,D) feature volumes.
     Variants of the challenge scripts: cost="sad" (l2r_2021 task 3 :54), n_box=1 (task 2 :60), n_spline_pools=2
     (task 3 :191); corr_mode="fast" = FMA / separable correlation sums; storage="fp16" = pooled features and cost volume rounded to
-    half precision with float32 accumulation (the reference's GPU default dtype, convex_adam_MIND.py:79)."""
+    half precision with float32 accumulation (the reference's GPU default dtype, convex_adam_MIND.py:79); adam_mode="fast" = the
+    Adam loop in throughput arithmetic (cvx_adam_run_fast_f32; same mathematics, graded by end-point error, not by bits)."""
     if feat_fixed is not None:
         ff, fm = f32c(feat_fixed), f32c(feat_moving)
         n_feat = int(ff.shape[0])
@@ -133,11 +134,12 @@ def register_pair_device(img_fixed=None, img_moving=None, feat_fixed=None, feat_
         # the reference reads `disp_sample` after a loop that never ran (:181)
         raise UnboundLocalError("local variable 'disp_sample' referenced before assignment "
                                 "(selected_niter=0 with lambda_weight>0, convex_adam_MIND.py:181)")
-    if cost not in ("ssd", "sad") or corr_mode not in ("exact", "fast") or storage not in ("fp32", "fp16"):
-        raise ValueError("cost must be 'ssd' or 'sad', corr_mode 'exact' or 'fast', storage 'fp32' or 'fp16'")
+    if cost not in ("ssd", "sad") or corr_mode not in ("exact", "fast") or storage not in ("fp32", "fp16") or adam_mode not in ("exact", "fast"):
+        raise ValueError("cost must be 'ssd' or 'sad', corr_mode / adam_mode 'exact' or 'fast', storage 'fp32' or 'fp16'")
     p = PairParams(H, W, D, int(mind_r), int(mind_d), float(lambda_weight), int(grid_sp), int(disp_hw), int(selected_niter),
                    int(selected_smooth), int(grid_sp_adam), 1 if ic else 0, n_feat, float(cost_scale), 1 if cost == "sad" else 0,
                    int(n_box), int(n_spline_pools), 1 if corr_mode == "fast" else 0, 1 if storage == "fp16" else 0)
+    p.adam_fast = 1 if adam_mode == "fast" else 0
     L = lib()
     nws = L.cvx_register_pair_workspace_bytes(C.byref(p))
     if nws == 0:
@@ -190,7 +192,7 @@ def register_pair_snapshots_device(img_fixed=None, img_moving=None, feat_fixed=N
 
 
 def register_pairs_device(imgs_fixed, imgs_moving, outs=None, n_streams=2, mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6,
-                          disp_hw=4, selected_niter=80, selected_smooth=0, grid_sp_adam=2, ic=True, cost_scale=12.0):
+                          disp_hw=4, selected_niter=80, selected_smooth=0, grid_sp_adam=2, ic=True, cost_scale=12.0, adam_mode="exact"):
     """Several independent pairs (lists of (H,W,D) device tensors, equal shapes) in one call: the library deals them
     onto `n_streams` internal HIP streams so that independent pairs fill each other's idle issue slots
     (cvx_register_pairs_f32).  Returns the list of (3,H,W,D) fields."""
@@ -204,6 +206,7 @@ def register_pairs_device(imgs_fixed, imgs_moving, outs=None, n_streams=2, mind_
         raise UnboundLocalError("local variable 'disp_sample' referenced before assignment (convex_adam_MIND.py:181)")
     p = PairParams(H, W, D, int(mind_r), int(mind_d), float(lambda_weight), int(grid_sp), int(disp_hw), int(selected_niter),
                    int(selected_smooth), int(grid_sp_adam), 1 if ic else 0, 0, float(cost_scale))
+    p.adam_fast = 1 if adam_mode == "fast" else 0
     L = lib()
     per = L.cvx_register_pair_workspace_bytes(C.byref(p))
     if per == 0:

@@ -188,18 +188,39 @@ def box_smooth(x, k, passes=1):
     return out if x.dtype == torch.float32 else out.to(x.dtype)
 
 
+def box3_fast(x):
+    """The separable restatement of box3(box3(box3(x))) (zero padding per stage) that adam_mode "fast" uses for the adjoint:
+    x (1,3,h,w,d) or (3,h,w,d) device tensor -> same shape (cvx_box3_fast_f32)."""
+    t = f32c(require_device_tensor(x, "x"))
+    h, w, d = [int(s) for s in t.shape[-3:]]
+    if t.numel() != 3 * h * w * d:
+        raise ValueError("box3_fast expects three channels")
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        check(lib().cvx_box3_fast_f32(ptr(t), h, w, d, ptr(out), stream_ptr(t.device)))
+    return out
+
+
 def combineDeformation3d(disp_1st, disp_2nd, identity):
     """disp_2nd + grid_sample(disp_1st, disp_2nd.permute(0,2,3,4,1) + identity).  (convex_adam_utils.py:133-135)"""
     return disp_2nd + grid_sample(disp_1st, disp_2nd.permute(0, 2, 3, 4, 1) + identity)
 
 
 def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snapshot_iters=(), return_state=False,
-             state=None, smoother=None, storage="fp32"):
+             state=None, smoother=None, storage="fp32", mode="exact"):
     """Adam instance optimisation of convex_adam_MIND.py:155-182 on pooled features (1,C,h,w,d) and an
     initial control grid P0 (1,3,h,w,d) in grid units.  Returns disp_sample of the last forward pass
     (1,3,h,w,d) [and optionally snapshots / optimiser state].  `smoother` = a GaussianSmoothing / kovesi_spline object of
     convexadam_amd.convexAdam_hyper_util replaces the three 3^3 boxes (adam_run_withconfig_shiftSpline.py:217).
-    storage="fp16": the loop keeps its copies of the features in half precision (rounded once; float32 arithmetic)."""
+    storage="fp16": the loop keeps its copies of the features in half precision (rounded once; float32 arithmetic).
+    mode="fast": throughput arithmetic (cvx_adam_run_fast_f32: FMA / factored warp gradient, separable adjoint boxes, one division in
+    the update; forward boxes in ATen's order) -- same mathematics, graded by end-point error; packaged smoother, float32 only."""
+    if storage not in ("fp32", "fp16"):
+        raise ValueError("storage must be 'fp32' or 'fp16', got %r" % (storage,))
+    if mode not in ("exact", "fast"):
+        raise ValueError("mode must be 'exact' or 'fast', got %r" % (mode,))
+    if mode == "fast" and (smoother is not None or storage != "fp32"):
+        raise ValueError("mode='fast' supports the packaged three 3^3 boxes and float32 storage only")
     F2 = f32c(require_device_tensor(feat_fix, "feat_fix"))
     M2 = f32c(require_device_tensor(feat_mov, "feat_mov"))
     _, Cn, h, w, d = [int(s) for s in F2.shape]
@@ -220,11 +241,17 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
     nws = lib().cvx_adam_workspace_bytes(Cn, h, w, d)
     ws = workspace(nws, dev)
     with torch.cuda.device(dev):
-        check(lib().cvx_adam_run_ex_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
-                                        int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
-                                        C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf),
-                                        C.byref(smoother.spec) if smoother is not None else None, 1 if storage == "fp16" else 0,
-                                        ptr(ws), nws, stream_ptr(dev)))
+        if mode == "fast":
+            check(lib().cvx_adam_run_fast_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
+                                              int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
+                                              C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf),
+                                              ptr(ws), nws, stream_ptr(dev)))
+        else:
+            check(lib().cvx_adam_run_ex_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
+                                            int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
+                                            C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf),
+                                            C.byref(smoother.spec) if smoother is not None else None, 1 if storage == "fp16" else 0,
+                                            ptr(ws), nws, stream_ptr(dev)))
     if return_state:
         return U, dict(P=P, m=m, v=v, step=step0 + int(niter), G=G, snapshots=snap_buf)
     return U

@@ -194,7 +194,21 @@ extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C
                                          const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
                                          void* workspace, size_t workspace_bytes, void* stream) {
     return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
-                              snapshot_iters_host, n_snap, snapshots, sm, true, false, workspace, workspace_bytes, stream);
+                              snapshot_iters_host, n_snap, snapshots, sm, true, false, false, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cvx_adam_run_fast_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
+                                     float lambda_weight, int niter, int step0, float cost_scale, const float* base_h,
+                                     const float* base_w, const float* base_d, float* U, float* grad_out,
+                                     const int* snapshot_iters_host, int n_snap, float* snapshots, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
+                              snapshot_iters_host, n_snap, snapshots, nullptr, true, false, true, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cvx_box3_fast_f32(const float* in, int h, int w, int d, float* out, void* stream) {
+    CVX_REQUIRE(in && out && in != out && h > 0 && w > 0 && d > 0, "cvx_box3_fast_f32: bad arguments");
+    return cvx::launch_box3_fast(in, out, h, w, d, nullptr, nullptr, nullptr, 1.0, 1.0, nullptr, as_stream(stream));
 }
 
 extern "C" int cvx_adam_run_ex_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
@@ -204,7 +218,7 @@ extern "C" int cvx_adam_run_ex_f32(const float* F2, const float* M2, int C, int 
                                    int feature_storage, void* workspace, size_t workspace_bytes, void* stream) {
     CVX_REQUIRE(feature_storage == 0 || feature_storage == 1, "cvx_adam_run_ex_f32: feature_storage must be 0 (float32) or 1 (fp16)");
     return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
-                              snapshot_iters_host, n_snap, snapshots, sm, true, feature_storage == 1, workspace, workspace_bytes, stream);
+                              snapshot_iters_host, n_snap, snapshots, sm, true, feature_storage == 1, false, workspace, workspace_bytes, stream);
 }
 
 // keep_state = false (whole-pair pipeline): P, m, v are scratch there and the result is U of the LAST forward pass
@@ -212,8 +226,8 @@ extern "C" int cvx_adam_run_ex_f32(const float* F2, const float* M2, int C, int 
 int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
                        float lambda_weight, int niter, int step0, float cost_scale, const float* base_h, const float* base_w,
                        const float* base_d, float* U, float* grad_out, const int* snapshot_iters_host, int n_snap,
-                       float* snapshots, const cvx_smoother* sm, bool keep_state, bool f16_features, void* workspace, size_t workspace_bytes,
-                       void* stream) {
+                       float* snapshots, const cvx_smoother* sm, bool keep_state, bool f16_features, bool fast, void* workspace,
+                       size_t workspace_bytes, void* stream) {
     CVX_REQUIRE(F2 && M2 && P && m && v && U && base_h && base_w && base_d, "cvx_adam_run_f32: null pointer");
     CVX_REQUIRE(C > 0 && h > 1 && w > 1 && d > 1, "cvx_adam_run_f32: bad extent C=%d %dx%dx%d", C, h, w, d);
     CVX_REQUIRE(niter >= 0 && step0 >= 0, "cvx_adam_run_f32: negative iteration count");
@@ -235,6 +249,8 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
             for (int i = 0; i < sm->n_boxes; ++i) CVX_REQUIRE(sm->box_k[i] >= 1 && (sm->box_k[i] & 1), "cvx_adam_run_smoother_f32: box size must be odd");
         }
     }
+    if (fast && (!fused || f16_features))
+        return fail(CVX_ERR_UNSUPPORTED, "adam_mode fast: only the packaged three 3^3 boxes with float32 feature records");
     const int CP = (C + 3) / 4 * 4;
     float* Fcl = cv.take<float>((size_t)CP * (V + 1));
     float* Mcl = cv.take<float>((size_t)CP * (V + 1));
@@ -259,13 +275,18 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
         else if ((rc = launch_smoother(P, U, t1, 3, h, w, d, *sm, false, s))) return rc;
         const bool last = it == niter - 1;
         if (!(last && !keep_state && !grad_out)) {
-        if ((rc = launch_warp_grad(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, f16_features, s))) return rc;
         float* gsave = (grad_out && it == niter - 1) ? grad_out : nullptr;
+        if (fast) {
+            if ((rc = launch_warp_grad_fast(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, s))) return rc;
+            if ((rc = launch_box3_fast(gU, nullptr, h, w, d, P, m, v, bc1, bc2, gsave, s))) return rc;
+        } else {
+        if ((rc = launch_warp_grad(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, f16_features, s))) return rc;
         if (fused) { if ((rc = launch_box3x3(gU, nullptr, h, w, d, true, P, m, v, ac, gsave, s))) return rc; }
         else {
             if ((rc = launch_smoother(gU, t2, t1, 3, h, w, d, *sm, true, s))) return rc;
             hipLaunchKernelGGL(k_adam_update, dim3((unsigned)cdiv64((int64_t)(3 * V), 256)), dim3(256), 0, s, t2, P, m, v, 3 * V, ac);
             if (gsave) (void)hipMemcpyAsync(gsave, t2, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice, s);
+        }
         }
         }
         while (snap < n_snap && snapshot_iters_host[snap] == it + 1) {

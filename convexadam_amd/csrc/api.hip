@@ -54,7 +54,8 @@ static Options env_options() {
     return {env_ll("CVX_MIND_TILED", 0),   env_ll("CVX_MIND_OVERLAP", 0),  env_ll("CVX_MM_TX", 0),        env_ll("CVX_MM_SLOTS", 512),          env_ll("CVX_BOX_TILED", 0),
             env_ll("CVX_NO_PRUNE", 0),     env_ll("CVX_CORR_UNFUSED", 0), env_ll("CVX_CORR_FUSED_ALL", 0), env_ll("CVX_PRUNE_STREAM_ABOVE", -1), env_ll("CVX_CF_CENSUS", 0), env_ll("CVX_CF_PRIO", 136),
             env_ll("CVX_WARP_FLAT", 0),    env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 0),
-            env_ll("CVX_BOX_XSPLIT", -1),  env_ll("CVX_BOX_CPT", 4),      env_ll("CVX_BOX_UNEVEN", 200), env_ll("CVX_BOX_ADAM_ROLE", 0), env_ll("CVX_BOX_DPP", 0),      env_ll("CVX_BOX_PK", 0),       env_ll("CVX_BOX_PRIO", 0),     env_ll("CVX_LABEL_POW_BLOCK", 32), 0,                             env_ll("CVX_MIND_MEAN_THREADS", 0)};
+            env_ll("CVX_BOX_XSPLIT", -1),  env_ll("CVX_BOX_CPT", 4),      env_ll("CVX_BOX_UNEVEN", 200), env_ll("CVX_BOX_ADAM_ROLE", 0), env_ll("CVX_BOX_DPP", 0),      env_ll("CVX_BOX_PK", 0),       env_ll("CVX_BOX_PRIO", 0),     env_ll("CVX_LABEL_POW_BLOCK", 32), 0,                             env_ll("CVX_MIND_MEAN_THREADS", 0),
+            env_ll("CVX_FBOX_TILE", 0)};
 }
 static cvx_context& default_context() {
     static cvx_context c = [] { cvx_context d; d.opt = env_options(); return d; }();
@@ -87,12 +88,13 @@ static void drop_table(cvx_context& c, void** slot) {
     *slot = nullptr;
 }
 // device copy of `bytes` bytes at `src` (device memory of the current device) owned by the context
+// (the new copy is allocated and filled BEFORE the old table is released: a failed setter leaves the installed table in place)
 static int adopt_table(cvx_context& c, const void* src, size_t bytes, void** slot, hipStream_t s, const char* what) {
-    drop_table(c, slot);
-    if (!src) return CVX_OK;
+    if (!src) { drop_table(c, slot); return CVX_OK; }
     int cur = 0;
     (void)hipGetDevice(&cur);
-    if (c.tbl_device >= 0 && c.tbl_device != cur && (c.sqrt_tbl || c.exp_tbl))
+    const bool other_table = (slot == reinterpret_cast<void**>(&c.sqrt_tbl)) ? c.exp_tbl != nullptr : c.sqrt_tbl != nullptr;
+    if (c.tbl_device >= 0 && c.tbl_device != cur && other_table)
         return fail(CVX_ERR_INVALID_ARG, "%s: the context already holds a table on device %d (current device %d)", what, c.tbl_device, cur);
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(CVX_ERR_LAUNCH, "%s: cannot allocate %zu bytes for the table copy", what, bytes); }
@@ -100,6 +102,7 @@ static int adopt_table(cvx_context& c, const void* src, size_t bytes, void** slo
         (void)hipGetLastError(); (void)hipFree(p);
         return fail(CVX_ERR_LAUNCH, "%s: table copy failed", what);
     }
+    drop_table(c, slot);                       // waits for enqueued work that still reads the old table
     c.tbl_device = cur;
     *slot = p;
     return CVX_OK;
@@ -115,7 +118,8 @@ static const OptName kOptNames[] = {{"mind_tiled", &Options::mind_tiled},     {"
                                     {"no_prune", &Options::no_prune},         {"corr_unfused", &Options::corr_unfused}, {"corr_fused_all", &Options::corr_fused_all},
                                     {"prune_stream_above", &Options::prune_stream_above}, {"cf_census", &Options::cf_census}, {"cf_prio", &Options::cf_prio},
                                     {"warp_flat", &Options::warp_flat},       {"box_yt", &Options::box_yt},             {"box_wg_target", &Options::box_wg_target},
-                                    {"box_xsplit", &Options::box_xsplit},     {"box_cpt", &Options::box_cpt},           {"box_uneven", &Options::box_uneven},     {"box_adam_role", &Options::box_adam_role}, {"box_dpp", &Options::box_dpp},           {"box_pk", &Options::box_pk},             {"box_prio", &Options::box_prio},         {"label_pow_block", &Options::label_pow_block}, {"census_ptr", &Options::census_ptr},     {"mind_mean_threads", &Options::mind_mean_threads}};
+                                    {"box_xsplit", &Options::box_xsplit},     {"box_cpt", &Options::box_cpt},           {"box_uneven", &Options::box_uneven},     {"box_adam_role", &Options::box_adam_role}, {"box_dpp", &Options::box_dpp},           {"box_pk", &Options::box_pk},             {"box_prio", &Options::box_prio},         {"label_pow_block", &Options::label_pow_block}, {"census_ptr", &Options::census_ptr},     {"mind_mean_threads", &Options::mind_mean_threads},
+                                    {"fbox_tile", &Options::fbox_tile}};
 
 }  // namespace cvx
 
@@ -186,7 +190,9 @@ extern "C" int cvx_expf_f32(const float* x, float* out, size_t n, void* stream) 
     return cvx::check_last("expf");
 }
 
-extern "C" int cvx_version(void) { return 1000 * 0 + 1; }
+// 2: cvx_pair_params grew (ctx in round 3, adam_fast / corr_verify / struct_size in round 4) -- bindings compiled against an older header
+// must not call the whole-pair entry points; they can assert on this number
+extern "C" int cvx_version(void) { return CVX_ABI_VERSION; }
 extern "C" const char* cvx_last_error(void) { return cvx::g_err; }
 extern "C" int cvx_device_count(void) {
     int n = 0;

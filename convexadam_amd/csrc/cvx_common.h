@@ -90,6 +90,8 @@ struct Options {
                                    //    {start, first data, end} in 100 MHz ticks (s_memrealtime) + placement there (0 = off)
     long long mind_mean_threads;   // 0: exactly rounded global mean in MINDSSC (default); T > 0: torch's own float sum with T threads
                                    //    (reference-bits mode; NOT a bit-identical variant -- it changes the clamp bounds by ulps)
+    long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
+                                   //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };
 // All three read the context bound to the calling thread (cvx_context_bind / cvx_pair_params.ctx), else the process default context;
 // launchers copy what they need into kernel arguments at enqueue time (api.hip).
@@ -347,7 +349,7 @@ __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& 
 int adam_run_impl(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v, float lambda_weight,
                   int niter, int step0, float cost_scale, const float* base_h, const float* base_w, const float* base_d, float* U,
                   float* grad_out, const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
-                  bool keep_state, bool f16_features, void* workspace, size_t workspace_bytes, void* stream);
+                  bool keep_state, bool f16_features, bool fast, void* workspace, size_t workspace_bytes, void* stream);
 // convex.hip: coupled convex regularisation behind cvx_coupled_convex_f32 (argmin_is_exact: see there)
 int coupled_convex_impl(const void* ssd, bool f16, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
                         bool argmin_is_exact, void* workspace, size_t workspace_bytes, void* stream);
@@ -375,5 +377,12 @@ int launch_box3_march(const float* in, float* out, int h, int w, int d, bool bac
 int launch_to_chunked(const float* in, int C, size_t V, float* out, bool half, hipStream_t s);
 int launch_warp_grad(const float* Fcl, const float* Mcl, int C, int h, int w, int d, const float* U, const float* bh,
                      const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, bool half, hipStream_t s);
+// adamfast.hip: adam_mode "fast" -- FMA / factored warp + gradient (float32 records) and the separable adjoint boxes with the Adam
+// update in the epilogue (P != nullptr: in-place update of P, m, v with G = box(in); P == nullptr: out = box(in)); bc1, bc2 = the bias
+// corrections 1 - beta^step of this iteration
+int launch_warp_grad_fast(const float* Fcl, const float* Mcl, int C, int h, int w, int d, const float* U, const float* bh,
+                          const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s);
+int launch_box3_fast(const float* in, float* out, int h, int w, int d, float* P, float* m, float* v, double bc1, double bc2,
+                     float* gsave, hipStream_t s);
 
 }  // namespace cvx

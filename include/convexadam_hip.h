@@ -45,7 +45,11 @@ extern "C" {
 #define CVX_MAX_DISP_HW 15     /* largest search half-width (n = 31, 29 791 displacements); the reference itself has no limit */
 
 /* library / device ------------------------------------------------------------------------------ */
-int cvx_version(void);                 /* 1000*major + minor */
+/* ABI version of THIS header.  cvx_version() returns the number the loaded library was built with; a binding must check
+ * cvx_version() == CVX_ABI_VERSION before it calls an entry point that takes a struct (cvx_pair_params grew in versions 1 -> 2:
+ * a struct laid out by an older header is shorter than what the library reads). */
+#define CVX_ABI_VERSION 2
+int cvx_version(void);
 const char* cvx_last_error(void);      /* message of the last failing call on this thread */
 int cvx_device_count(void);            /* number of visible HIP devices (0 on a CPU-only host) */
 
@@ -80,7 +84,10 @@ int cvx_device_count(void);            /* number of visible HIP devices (0 on a 
  * environment variables; cvx_set_option / cvx_get_option and the legacy table setters address that default context (set them while no
  * other thread is inside the library).  cvx_get_option returns -1 for an unknown name.
  *   cvx_context_create     new context; switches start as a copy of the default context's, no tables
- *   cvx_context_destroy    waits for the device, frees the context and the table copies it owns
+ *   cvx_context_destroy    waits for the device, frees the context and the table copies it owns.  LIFETIME: the caller must unbind the
+ *                          context on EVERY thread that bound it (cvx_context_bind(NULL) there) and must not have a call in flight whose
+ *                          cvx_pair_params.ctx names it; only the calling thread's own binding is cleared here.  A table setter that
+ *                          fails leaves the previously installed table in place
  *   cvx_context_bind       binds ctx (NULL = default) to the calling thread, returns the previously bound one
  *   cvx_context_set_*      ctx == NULL addresses the default context */
 typedef struct cvx_context cvx_context;
@@ -265,6 +272,19 @@ int cvx_adam_run_ex_f32(const float* F2, const float* M2, int C, int h, int w, i
                         const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
                         int feature_storage, void* workspace, size_t workspace_bytes, void* stream);
 
+/* adam_mode "fast": the same loop (packaged three 3^3 boxes, float32 feature records) in throughput arithmetic -- replaces the body of
+ * the reference's loop, convex_adam_MIND.py:163-179, to within rounding: the forward boxes keep ATen's order (the regulariser
+ * differentiates U twice, so U's rounding pattern decides how long the trajectory stays next to the reference's), the warp / data-term
+ * gradient uses FMA chains and eight corner accumulators, the adjoint boxes are separable sums with one final scale, the update has
+ * one IEEE division.  Deterministic; bit-identical to oracle/cvx_oracle.c::orc_adam_run_fast.  Arguments as cvx_adam_run_f32. */
+int cvx_adam_run_fast_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m,
+                          float* v, float lambda_weight, int niter, int step0, float cost_scale,
+                          const float* base_h, const float* base_w, const float* base_d, float* U, float* grad_out,
+                          const int* snapshot_iters_host, int n_snap, float* snapshots,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* out = fastbox(in): the separable restatement of box3(box3(box3(.))) used for the adjoint in adam_mode "fast"; [C][h][w][d], C = 3 */
+int cvx_box3_fast_f32(const float* in, int h, int w, int d, float* out, void* stream);
+
 /* whole pair ---------------------------------------------------------------------------------------
  * replaces convex_adam_pt(...)                                       convex_adam_MIND.py:64-202
  * (use_mask=False path; features are MIND-SSC of the two images, or caller-supplied feature
@@ -289,6 +309,11 @@ typedef struct cvx_pair_params {
                             re-read), the coarse pooled features (2 x C x h x w x d values) are rounded to half precision in their
                             float32 working copies; graded by end-point error against the float32 field */
     const cvx_context* ctx;  /* switches + tables for this call; NULL: the context bound to the calling thread (else the default one) */
+    /* ---- ABI version 2 (appended; zero = the behaviour of version 1) ---- */
+    int adam_fast;       /* 1: adam_mode "fast" -- throughput arithmetic of the Adam loop (cvx_adam_run_fast_f32): same mathematics as
+                            convex_adam_MIND.py:163-179, graded by end-point error against the reference's field instead of by bits.
+                            Needs the packaged smoother (n_spline_pools 0 / 3) and float32 storage */
+    int reserved_[3];    /* must be zero */
 } cvx_pair_params;
 
 size_t cvx_register_pair_workspace_bytes(const cvx_pair_params* p);

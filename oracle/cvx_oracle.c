@@ -886,6 +886,154 @@ ORC_API void orc_adam_run_smoother(const float* F2, const float* M2, int C, int 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * FAST (throughput) mode of the Adam instance optimisation -- opt-in, graded by end-point error against the reference's field,
+ * NOT a restatement of ATen's evaluation order.  Same mathematics as orc_adam_run (convex_adam_MIND.py:163-179), cheaper arithmetic:
+ *   (1) the ADJOINT of the three chained zero-padded 3^3 boxes (a symmetric operator) as separable sums -- per axis (H, then W,
+ *       then D) three chained 1-D stages  t[i] = (t[i-1] + t[i]) + t[i+1]  with zeros outside the volume after every stage (each
+ *       avg_pool3d zero-pads its own input), then ONE multiplication by (float)(1/19683).  The FORWARD boxes keep ATen's order
+ *       (orc_smooth): the diffusion regulariser differentiates U twice, so U's rounding pattern decides how long the trajectory
+ *       stays next to the reference's -- measured on the full-size benchmark pair against the reference's own capture
+ *       (tests/golden/fullsize.npz, mean EPE after 20 / 40 / 80 iterations): exact mode 5.5e-6 / 5.2e-5 / 1.23e-3, this mode
+ *       8.5e-6 / 3.9e-5 / 1.28e-3, the same with separable FORWARD boxes 7.2e-5 / 1.8e-4 / 2.29e-3;
+ *   (2) the warp / data-term gradient with the per-voxel set-up (coordinates, floor, the eight corner weights) exactly as
+ *       ATen's, but per channel an FMA chain for the warped value and eight corner accumulators  A_k += df * v_k ; the three
+ *       gradient components are combined from the A_k once per voxel;
+ *   (3) the Adam update with one IEEE division:  den = fma(sqrt(v), 1/sqrt(bc2), eps) ; P += (neg_step * m) / den.
+ * Every operation is a correctly rounded IEEE operation in a FIXED order, which the HIP kernels of adam_mode = "fast"
+ * (convexadam_amd/csrc/adamfast.hip) follow step by step: HIP-fast == oracle-fast bit for bit (tests/test_gpu_parity.py).
+ * ---------------------------------------------------------------------------------------------- */
+ORC_API void orc_fast_box3x3(const float* in, float* out, int C, int h, int w, int d) {
+    const size_t V = (size_t)h * w * d;
+    const int dims[3] = {h, w, d};
+    const size_t strides[3] = {(size_t)w * d, (size_t)d, 1};
+    if (out != in) memcpy(out, in, sizeof(float) * (size_t)C * V);
+    for (int axis = 0; axis < 3; ++axis) {
+        const int n = dims[axis];
+        const size_t st = strides[axis];
+        const size_t nlines = (size_t)C * V / (size_t)n;
+#pragma omp parallel
+        {
+            float* a = (float*)malloc(sizeof(float) * (size_t)(n + 2));
+            float* b = (float*)malloc(sizeof(float) * (size_t)(n + 2));
+#pragma omp for schedule(static)
+            for (size_t l = 0; l < nlines; ++l) {
+                /* line l: all index combinations of the other two axes (and the channel) */
+                size_t base;
+                if (axis == 0) base = (l / ((size_t)w * d)) * V + l % ((size_t)w * d);
+                else if (axis == 1) base = (l / d) * ((size_t)w * d) + l % d;
+                else base = l * (size_t)d;
+                a[0] = a[n + 1] = b[0] = b[n + 1] = 0.0f;
+                for (int i = 0; i < n; ++i) a[i + 1] = out[base + (size_t)i * st];
+                for (int s = 0; s < 3; ++s) {
+                    for (int i = 1; i <= n; ++i) b[i] = (a[i - 1] + a[i]) + a[i + 1];
+                    float* t = a; a = b; b = t;
+                }
+                for (int i = 0; i < n; ++i) out[base + (size_t)i * st] = a[i + 1];
+            }
+            free(a); free(b);
+        }
+    }
+    const float r = (float)(1.0 / 19683.0);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < (size_t)C * V; ++i) out[i] = out[i] * r;
+}
+
+ORC_API void orc_adam_run_fast(const float* F2, const float* M2, int C, int h, int w, int d, float* P,
+                               float* m, float* v, float lambda_weight, int niter, int step0, float cost_scale,
+                               float* U, float* G, int keep_last_step) {
+    const size_t V = (size_t)h * w * d;
+    float* t1 = (float*)malloc(sizeof(float) * 3 * V);
+    float* gU = (float*)malloc(sizeof(float) * 3 * V);
+    float* bh = (float*)malloc(sizeof(float) * h); float* bw = (float*)malloc(sizeof(float) * w);
+    float* bd = (float*)malloc(sizeof(float) * d);
+    orc_affine_base(h, bh); orc_affine_base(w, bw); orc_affine_base(d, bd);
+    const float sc[3] = {(float)((h - 1) / 2.0), (float)((w - 1) / 2.0), (float)((d - 1) / 2.0)};
+    const float nH = (float)((int64_t)3 * (h - 1) * w * d), nW = (float)((int64_t)3 * h * (w - 1) * d),
+                nD = (float)((int64_t)3 * h * w * (d - 1));
+    const float cH = lambda_weight / nH, cW = lambda_weight / nW, cD = lambda_weight / nD;
+    const float m2H = -2.0f * cH, m2W = -2.0f * cW, m2D = -2.0f * cD;          /* exact doublings */
+    const float gsc = ((1.0f / (float)V) * cost_scale) / (float)C;
+    const float gsc2 = 2.0f * gsc;
+    const float gmx = (float)d / 2.0f, gmy = (float)w / 2.0f, gmz = (float)h / 2.0f;
+    const orc_smoother boxes3 = {0, 3, {3, 3, 3, 0}, {0, 0, 0, 0, 0}};
+    for (int it = 0; it < niter; ++it) {
+        orc_smooth(P, U, 3, h, w, d, &boxes3, 0);           /* forward boxes: ATen's order, as in orc_adam_run */
+        if (it == niter - 1 && !keep_last_step) break;      /* the pipeline never observes the last gradient / update */
+#pragma omp parallel for schedule(static)
+        for (size_t p = 0; p < V; ++p) {
+            const int z = (int)(p / ((size_t)w * d)), y = (int)((p / d) % w), x = (int)(p % d);
+            const float uH = U[p], uW = U[V + p], uD = U[2 * V + p];
+            orc_tri_t t;
+            tri_setup(&t, bd[x] + uD / sc[2], bw[y] + uW / sc[1], bh[z] + uH / sc[0], h, w, d);
+            const int x0 = t.x0, y0 = t.y0, z0 = t.z0, x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+            const float fx0 = (float)x0, fy0 = (float)y0, fz0 = (float)z0, fx1 = (float)x1, fy1 = (float)y1, fz1 = (float)z1;
+            const float wx[2] = {fx1 - t.ix, t.ix - fx0}, wy[2] = {fy1 - t.iy, t.iy - fy0}, wz[2] = {fz1 - t.iz, t.iz - fz0};
+            const float wgt[8] = {t.tnw, t.tne, t.tsw, t.tse, t.bnw, t.bne, t.bsw, t.bse};
+            size_t off[8]; int inb[8];
+            for (int k = 0; k < 8; ++k) {
+                const int zz = (k & 4) ? z1 : z0, yy = (k & 2) ? y1 : y0, xx = (k & 1) ? x1 : x0;
+                inb[k] = inb3(zz, yy, xx, h, w, d);
+                off[k] = inb[k] ? ((size_t)zz * w + yy) * d + xx : 0;
+            }
+            float A[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < C; ++c) {
+                const float* mv = M2 + (size_t)c * V;
+                float vk[8];
+                for (int k = 0; k < 8; ++k) vk[k] = inb[k] ? mv[off[k]] : 0.0f;     /* corners outside the volume read zero */
+                float wv = vk[0] * wgt[0];
+                for (int k = 1; k < 8; ++k) wv = fmaf(vk[k], wgt[k], wv);
+                const float df = wv - F2[(size_t)c * V + p];
+                for (int k = 0; k < 8; ++k) A[k] = fmaf(df, vk[k], A[k]);
+            }
+            /* d warp / d ix = sum_k (+-) wy wz v_k etc. (corner k: bit 0 = x1, bit 1 = y1, bit 2 = z1) */
+            float gix = 0.f, giy = 0.f, giz = 0.f;
+            for (int k = 0; k < 8; ++k) {
+                const int kx = k & 1, ky = (k >> 1) & 1, kz = (k >> 2) & 1;
+                const float cx = wy[ky] * wz[kz], cy = wx[kx] * wz[kz], cz = wx[kx] * wy[ky];
+                gix = fmaf(kx ? cx : -cx, A[k], gix);
+                giy = fmaf(ky ? cy : -cy, A[k], giy);
+                giz = fmaf(kz ? cz : -cz, A[k], giz);
+            }
+            gix = gix * gsc2; giy = giy * gsc2; giz = giz * gsc2;
+            float g[3];
+            g[0] = (gmz * giz) / sc[0]; g[1] = (gmy * giy) / sc[1]; g[2] = (gmx * gix) / sc[2];
+            /* diffusion regulariser: d/dU of lam * mean(diff^2) along the three axes, order D+, D-, H+, H-, W+, W- */
+            for (int a = 0; a < 3; ++a) {
+                const float* Ua = U + (size_t)a * V;
+                const float uc = Ua[p];
+                float acc = g[a];
+                if (x < d - 1) acc = fmaf(m2D, Ua[p + 1] - uc, acc);
+                if (x > 0)     acc = fmaf(m2D, Ua[p - 1] - uc, acc);
+                if (z < h - 1) acc = fmaf(m2H, Ua[p + (size_t)w * d] - uc, acc);
+                if (z > 0)     acc = fmaf(m2H, Ua[p - (size_t)w * d] - uc, acc);
+                if (y < w - 1) acc = fmaf(m2W, Ua[p + d] - uc, acc);
+                if (y > 0)     acc = fmaf(m2W, Ua[p - d] - uc, acc);
+                gU[(size_t)a * V + p] = acc;
+            }
+        }
+        orc_fast_box3x3(gU, t1, 3, h, w, d);
+        if (G) memcpy(G, t1, sizeof(float) * 3 * V);
+        const int step = step0 + it + 1;
+        const double beta1 = 0.9, beta2 = 0.999;
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2);
+        const float inv_bc2s = (float)(1.0 / sqrt(bc2));
+        const float neg_step = (float)(-(1.0 / bc1));
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < 3 * V; ++i) {
+            const float g = t1[i];
+            const float mm = fmaf(w1, g - m[i], m[i]);
+            float vv = v[i] * b2;
+            vv = fmaf(omb2 * g, g, vv);
+            const float den = fmaf(sqrtf(vv), inv_bc2s, 1e-8f);
+            P[i] = P[i] + (neg_step * mm) / den;
+            m[i] = mm; v[i] = vv;
+        }
+    }
+    free(t1); free(gU); free(bh); free(bw); free(bd);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * torch.pow(float32 tensor, python scalar) on the CPU, as the reference evaluates `(...).float().pow(.3)` in its label weights
  * (src/convexAdam/convex_adam_nnUNet.py:31).  Black-box finding (inputs fed, outputs compared; tests/test_oracle_vs_reference_live.py):
  * ATen's vectorised loop handles the leading blocks of 32 elements with Sleef's powf (1.0-ULP variant, FMA build, exponent rounded to

@@ -72,6 +72,9 @@ def lib():
         L.orc_smooth.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [C.POINTER(Smoother), C.c_int]
         L.orc_adam_run_smoother.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [_f32p, _f32p, _f32p, C.c_float, C.c_int,
                                                                             C.c_int, C.c_float, _f32p, C.c_void_p, C.c_void_p, C.POINTER(Smoother)]
+        L.orc_fast_box3x3.argtypes = [_f32p, _f32p] + [C.c_int] * 4
+        L.orc_adam_run_fast.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [_f32p, _f32p, _f32p, C.c_float, C.c_int,
+                                                                        C.c_int, C.c_float, _f32p, C.c_void_p, C.c_int]
         L.orc_label_features.argtypes = [_f32p, _f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_label_features.restype = C.c_int
         L.orc_feature_transform.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -263,11 +266,27 @@ def smooth(x, smoother, backward=False):
     return out
 
 
-def adam_run(F2, M2, P, lambda_weight, niter, m=None, v=None, step0=0, cost_scale=12.0, want_grad=False, smoother=None):
-    """Runs `niter` Adam iterations in place on copies; returns dict(P, m, v, U, G, loss)."""
+def fast_box3x3(x):
+    """Fast-mode restatement of box3(box3(box3(x))) (zero padding per stage): separable chained sums, one final scale."""
+    x = _f(x); c, h, w, d = x.shape
+    out = np.empty_like(x); lib().orc_fast_box3x3(x.reshape(-1), out.reshape(-1), c, h, w, d); return out
+
+
+def adam_run(F2, M2, P, lambda_weight, niter, m=None, v=None, step0=0, cost_scale=12.0, want_grad=False, smoother=None, mode="exact",
+             keep_last_step=True):
+    """Runs `niter` Adam iterations in place on copies; returns dict(P, m, v, U, G, loss).
+    mode="fast": the tolerance-graded throughput arithmetic (orc_adam_run_fast; three 3^3 boxes only); keep_last_step=False skips the
+    gradient + update of the final iteration like the whole-pair pipeline does (U is the same either way)."""
     F2 = _f(F2); M2 = _f(M2); c, h, w, d = F2.shape
     P = _f(P).copy(); m = np.zeros_like(P) if m is None else _f(m).copy(); v = np.zeros_like(P) if v is None else _f(v).copy()
     U = np.zeros_like(P); G = np.zeros_like(P) if want_grad else None; loss = np.zeros(max(niter, 1), np.float32)
+    if mode == "fast":
+        assert smoother is None, "fast mode: the packaged three 3^3 boxes only"
+        lib().orc_adam_run_fast(F2.reshape(-1), M2.reshape(-1), c, h, w, d, P.reshape(-1), m.reshape(-1), v.reshape(-1),
+                                float(lambda_weight), int(niter), int(step0), float(cost_scale), U.reshape(-1),
+                                G.ctypes.data_as(C.c_void_p) if G is not None else None, 1 if keep_last_step else 0)
+        return dict(P=P, m=m, v=v, U=U, G=G, loss=None)
+    assert mode == "exact", mode
     lib().orc_adam_run_smoother(F2.reshape(-1), M2.reshape(-1), c, h, w, d, P.reshape(-1), m.reshape(-1), v.reshape(-1),
                                 float(lambda_weight), int(niter), int(step0), float(cost_scale), U.reshape(-1),
                                 G.ctypes.data_as(C.c_void_p) if G is not None else None, loss.ctypes.data_as(C.c_void_p),
@@ -293,7 +312,7 @@ def _h(x):
 
 def convex_adam_pipeline(img_fixed, img_moving, mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6, disp_hw=4,
                          selected_niter=80, selected_smooth=0, grid_sp_adam=2, ic=True, features=None,
-                         return_stages=False, cost="ssd", n_box=2, n_spline_pools=3, storage="fp32"):
+                         return_stages=False, cost="ssd", n_box=2, n_spline_pools=3, storage="fp32", adam_mode="exact"):
     """float32 restatement of convex_adam_pt(); returns (H,W,D,3) float64 like the reference.
     cost / n_box / n_spline_pools: the operator variants of the challenge scripts (l2r_2021_convexAdam_task3_docker.py:54,56,191;
     task2:60); storage="fp16": pooled features and cost volume rounded to half precision (float32 accumulation)."""
@@ -334,8 +353,9 @@ def convex_adam_pipeline(img_fixed, img_moving, mind_r=1, mind_d=2, lambda_weigh
         F2 = q(avgpool_stride(ffix, g)); M2 = q(avgpool_stride(fmov, g))
         disp_lr = resize_trilinear(disp_hr, (H // g, W // g, D // g))
         P0 = disp_lr / np.float32(g)
-        r = adam_run(F2, M2, P0, lambda_weight, selected_niter, smoother=make_smoother([3, 3]) if n_spline_pools == 2 else None)
-        st.update(P0=P0, U=r["U"])
+        r = adam_run(F2, M2, P0, lambda_weight, selected_niter, smoother=make_smoother([3, 3]) if n_spline_pools == 2 else None,
+                     mode=adam_mode)
+        st.update(P0=P0, U=r["U"], F2=F2, M2=M2)
         disp_hr = resize_trilinear(r["U"] * np.float32(g), (H, W, D))
         if selected_smooth > 0:
             for _ in range(3):

@@ -43,6 +43,38 @@ def test_library_exports_every_declared_symbol(L):
     assert sorted(_lib.SIGNATURES) == header_functions()
 
 
+def test_pair_params_layout_matches_the_header_and_the_version_is_checked(L):
+    """cvx_pair_params grew twice (ctx in round 3, adam_fast + reserved in round 4): the ctypes mirror must have the header's fields in
+    the header's order, the library must report the header's CVX_ABI_VERSION, and the reserved tail must be refused when non-zero
+    (what a struct laid out by an older header would look like to the library)."""
+    import ctypes as C
+    from convexadam_amd import _lib
+    from convexadam_amd._lib import PairParams
+    hdr = open(HEADER).read()
+    ver = int(re.search(r"#define\s+CVX_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert L.cvx_version() == ver == _lib.ABI_VERSION
+    body = re.search(r"typedef struct cvx_pair_params \{(.*?)\} cvx_pair_params;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for piece in decl.split(","):
+            names.append(re.sub(r"\[.*\]", "", piece.strip().split()[-1].lstrip("*")))
+    assert names == [f[0] for f in PairParams._fields_], (names, [f[0] for f in PairParams._fields_])
+    assert C.sizeof(PairParams) == 19 * 4 + 4 + 8 + 4 * 4          # 19 ints/floats, padding, ctx pointer, adam_fast + reserved_[3]
+    p = PairParams(64, 64, 64, 1, 2, 1.25, 4, 3, 5, 0, 2, 1, 0, 12.0)
+    assert L.cvx_register_pair_workspace_bytes(C.byref(p)) > 0
+    p.reserved_[1] = 7
+    assert L.cvx_register_pair_workspace_bytes(C.byref(p)) == 0 and b"older header" in L.cvx_last_error()
+    p.reserved_[1] = 0
+    p.adam_fast = 1
+    assert L.cvx_register_pair_workspace_bytes(C.byref(p)) > 0
+    p.n_spline_pools = 2
+    assert L.cvx_register_pair_workspace_bytes(C.byref(p)) == 0            # fast mode: packaged smoother only
+
+
 def test_version_and_device_count(L):
     assert L.cvx_version() >= 1
     n = L.cvx_device_count()

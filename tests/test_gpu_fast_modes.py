@@ -1,0 +1,181 @@
+"""GPU tests of the tolerance-graded THROUGHPUT modes (round 4): adam_mode="fast" and the verified-fast correlation.
+
+Two bars, both asserted here:
+  (1) HIP-fast == oracle-fast BIT FOR BIT: the fast arithmetic is a fixed sequence of correctly rounded IEEE operations that
+      oracle/cvx_oracle.c restates (orc_adam_run_fast, orc_fast_box3x3), so np.array_equal still applies;
+  (2) the pre-registered acceptance criteria of SURVEY section 7 / VERDICT round 3 against the field captured from the reference
+      itself (tests/golden/fullsize.npz): convex stage bit-identical, mean EPE 0 at 1 iteration, < 1e-3 at 20 and 40, and at 80
+      <= the reference's own 1-ulp self-perturbation EPE and <= 1.15 x the exact mode's.
+The exact mode's bit-parity tests live in tests/test_gpu_parity.py and are untouched."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def epe(a, b):
+    return float(np.sqrt(((a.astype(np.float64) - b.astype(np.float64)) ** 2).sum(-1)).mean())
+
+
+@pytest.fixture(scope="module")
+def U():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from convexadam_amd import convex_adam_utils
+    return convex_adam_utils
+
+
+@pytest.fixture(scope="module")
+def M():
+    from convexadam_amd import convex_adam_MIND
+    return convex_adam_MIND
+
+
+BOX_SHAPES = [(6, 9, 30), (5, 10, 28), (7, 9, 61), (16, 17, 60), (5, 9, 124), (4, 8, 130), (14, 8, 12), (3, 3, 5), (2, 2, 2), (9, 21, 25), (40, 48, 56)]
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", BOX_SHAPES)
+def test_box3_fast_vs_oracle(U, orc, shape, tile):
+    """The separable adjoint-box operator, every tile shape of the kernel, ragged extents, rows that are / are not multiples of four
+    voxels, grids smaller than one tile."""
+    from convexadam_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(sum(shape) + tile)
+    x = rng.standard_normal((3,) + shape).astype(np.float32)
+    old = L.cvx_get_option(b"fbox_tile")
+    assert L.cvx_set_option(b"fbox_tile", tile) == 0
+    try:
+        got = host(U.box3_fast(dev(x)))
+    finally:
+        L.cvx_set_option(b"fbox_tile", old)
+    assert np.array_equal(got, orc.fast_box3x3(x))
+    # and it IS the three chained zero-padded boxes, to rounding
+    ref = orc.box_zero(orc.box_zero(orc.box_zero(x, 3), 3), 3)
+    assert np.abs(got - ref).max() <= 4e-6 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("niter", [1, 3, 10])
+def test_adam_fast_vs_oracle(U, orc, golden, niter):
+    g = golden("adam")
+    Ud, st = U.adam_run(dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]), niter, return_state=True, mode="fast")
+    r = orc.adam_run(g["F2"], g["M2"], g["P0"], float(g["lam"]), niter, want_grad=True, mode="fast")
+    assert np.array_equal(host(Ud)[0], r["U"])
+    assert np.array_equal(host(st["G"])[0], r["G"])
+    assert np.array_equal(host(st["P"])[0], r["P"])
+    assert np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
+    # same mathematics as the exact mode: one iteration moves P by the same step to within rounding
+    if niter == 1:
+        e = orc.adam_run(g["F2"], g["M2"], g["P0"], float(g["lam"]), 1, want_grad=True)
+        assert np.abs(r["G"] - e["G"]).max() <= 1e-5 * np.abs(e["G"]).max()
+
+
+@pytest.mark.parametrize("shape", [(6, 9, 30), (5, 10, 28), (7, 9, 61), (6, 17, 60), (5, 9, 124), (4, 8, 130), (14, 8, 12), (3, 3, 5), (2, 2, 2)])
+@pytest.mark.parametrize("C", [5, 12])
+def test_adam_fast_grid_shapes_vs_oracle(U, orc, shape, C):
+    """Ragged control grids, zero-padded feature chunks (C = 5), displacements that leave the volume (zero-record corners)."""
+    rng = np.random.default_rng(sum(shape) + C)
+    F2 = rng.random((C,) + shape, dtype=np.float32)
+    M2 = rng.random((C,) + shape, dtype=np.float32)
+    P0 = (1.5 * rng.standard_normal((3,) + shape)).astype(np.float32)
+    Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.25, 3, return_state=True, mode="fast")
+    r = orc.adam_run(F2, M2, P0, 1.25, 3, want_grad=True, mode="fast")
+    assert np.array_equal(host(Ud)[0], r["U"])
+    assert np.array_equal(host(st["G"])[0], r["G"])
+    assert np.array_equal(host(st["P"])[0], r["P"])
+    assert np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
+
+
+def test_adam_fast_resume_and_snapshots(U, orc, golden):
+    """4 + 3 iterations through the optimiser state equal 7 in one call; snapshots are the U of the listed iterations."""
+    g = golden("adam")
+    a = (dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]))
+    U7, s7 = U.adam_run(*a, 7, return_state=True, mode="fast", snapshot_iters=(2, 7))
+    U4, s4 = U.adam_run(*a, 4, return_state=True, mode="fast")
+    U3, s3 = U.adam_run(*a, 3, return_state=True, state=s4, mode="fast")
+    assert torch.equal(U3, U7) and torch.equal(s3["P"], s7["P"]) and torch.equal(s3["v"], s7["v"])
+    assert torch.equal(s7["snapshots"][1], U7[0])
+    assert torch.equal(s7["snapshots"][0], U.adam_run(*a, 2, mode="fast")[0])
+
+
+def test_adam_fast_rejects_what_it_does_not_cover(U, golden):
+    from convexadam_amd import convexAdam_hyper_util as HU
+    g = golden("adam")
+    a = (dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]), 2)
+    with pytest.raises(ValueError):
+        U.adam_run(*a, mode="fast", storage="fp16")
+    with pytest.raises(ValueError):
+        U.adam_run(*a, mode="fast", smoother=HU.kovesi_spline(1.6))
+    with pytest.raises(ValueError):
+        U.adam_run(*a, mode="quick")
+    with pytest.raises(ValueError):
+        U.adam_run(*a, storage="fp8")
+
+
+@pytest.mark.parametrize("cfg", [dict(grid_sp=4, disp_hw=3, selected_niter=6, ic=True), dict(grid_sp=3, disp_hw=2, selected_niter=4, ic=False),
+                                 dict(grid_sp=4, disp_hw=3, selected_niter=5, ic=True, selected_smooth=3)])
+def test_pipeline_fast_adam_vs_oracle(M, orc, golden, cfg):
+    g = golden("pipeline")
+    kw = dict(mind_r=1, mind_d=2, grid_sp_adam=2, lambda_weight=1.25, **cfg)
+    out = host(M.register_pair_device(dev(g["fix"]), dev(g["mov"]), adam_mode="fast", **kw))
+    ref = orc.convex_adam_pipeline(g["fix"], g["mov"], adam_mode="fast", **kw)
+    assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), ref)
+    exact = orc.convex_adam_pipeline(g["fix"], g["mov"], **kw)
+    assert epe(ref, exact) < 1e-4            # a handful of iterations: the two modes are the same field to rounding
+
+
+BENCH_SHAPE = (160, 192, 224)
+BENCH_CFG = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6, disp_hw=6, selected_niter=80, selected_smooth=0, grid_sp_adam=2, ic=True)
+
+
+@pytest.mark.timeout(1800)
+def test_full_size_fast_adam_acceptance(M, U, orc, golden):
+    """BASELINE configs[1] at FULL size in adam_mode="fast" against the reference's own capture: the acceptance criteria registered in
+    SURVEY section 7 (hard part 1) and VERDICT round 3, and HIP == oracle-fast bit for bit at 80 iterations."""
+    from convexadam_amd.phantom import deformed_pair
+    g = golden("fullsize")
+    s = int(g["sub"])
+    fix, mov = deformed_pair(BENCH_SHAPE, 0, 4.0)
+    fd, md = fix.to(DEV), mov.to(DEV)
+    conv = M.register_pair_device(fd, md, adam_mode="fast", **dict(BENCH_CFG, lambda_weight=0))
+    assert torch.equal(conv, U.resize_trilinear(dev(g["c1_coarse_ic"])[None], BENCH_SHAPE)[0])          # convex stage: bit-identical
+    snaps = [int(v) for v in g["c1_snaps"]]
+    got = {}
+    for i, n in enumerate(snaps):
+        out = host(M.register_pair_device(fd, md, adam_mode="fast", **dict(BENCH_CFG, selected_niter=n)))
+        got[n] = out
+        e = epe(np.moveaxis(out[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["c1_adam_%d_sub" % n], 0, -1))
+        self_e = float(g["c1_self_perturbation_epe_sub"][i])
+        print("full size, adam_mode=fast, %2d iterations: HIP vs reference mean EPE %.3e (reference vs its 1-ulp-perturbed self: %.3e)" % (n, e, self_e))
+        if n == 1:
+            assert e <= 1e-6
+        elif n <= 40:
+            assert e < 1e-3
+        else:
+            exact = host(M.register_pair_device(fd, md, **dict(BENCH_CFG, selected_niter=n)))
+            e_exact = epe(np.moveaxis(exact[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["c1_adam_%d_sub" % n], 0, -1))
+            print("   exact mode: %.3e" % e_exact)
+            assert e <= self_e and e <= 1.15 * e_exact
+    ref = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), adam_mode="fast", **BENCH_CFG)
+    assert np.array_equal(np.moveaxis(got[80], 0, -1).astype(np.float64), ref)
+
+
+def test_batched_pairs_fast_mode_match_single_calls(M):
+    from convexadam_amd.phantom import phantom
+    shape = (40, 36, 44)
+    fx = [phantom(shape, i, 10 + i).to(DEV) for i in range(3)]
+    mv = [torch.roll(phantom(shape, i, 20 + i), (1, -1, 2), (0, 1, 2)).to(DEV) for i in range(3)]
+    kw = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=4, disp_hw=3, selected_niter=5, grid_sp_adam=2, ic=True)
+    outs = M.register_pairs_device(fx, mv, n_streams=2, adam_mode="fast", **kw)
+    for i in range(3):
+        assert torch.equal(outs[i], M.register_pair_device(fx[i], mv[i], adam_mode="fast", **kw))

@@ -439,3 +439,39 @@ def test_host_tables_match_the_fixtures_on_the_golden_host(orc, mkl):
         pytest.skip("this host's MKL code path differs from the one the goldens were generated on")
     gt = mkl.golden_tables()
     assert np.array_equal(t["exp"], gt["exp"]) and np.array_equal(t["sqrt"], gt["sqrt"])
+
+
+@pytest.mark.timeout(900)
+def test_fast_adam_mode_acceptance_against_the_reference_capture(orc, golden):
+    """adam_mode="fast" (orc_adam_run_fast: the arithmetic the HIP kernels of convexadam_amd/csrc/adamfast.hip follow bit for bit) at FULL
+    size against the field captured from the reference itself -- the acceptance criteria registered before the mode was built
+    (SURVEY section 7 hard part 1): 0 at one iteration, < 1e-3 at 20 and 40, and at 80 iterations no further from the
+    reference than the reference is from a 1-ulp-perturbed copy of itself and <= 1.15 x the exact restatement's own distance."""
+    from convexadam_amd.phantom import deformed_pair
+    g = golden("fullsize")
+    shape = (160, 192, 224)
+    fix, mov = deformed_pair(shape, 0, 4.0)
+    kw = dict(mind_r=1, mind_d=2, grid_sp=6, disp_hw=6, grid_sp_adam=2, ic=True)
+    _, st = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), lambda_weight=1.25, selected_niter=1, return_stages=True, **kw)
+    s = int(g["sub"])
+    snaps = [int(v) for v in g["c1_snaps"]]
+    res = {}
+    for mode in ("fast", "exact"):
+        for n in snaps if mode == "fast" else (80,):
+            r = orc.adam_run(st["F2"], st["M2"], st["P0"], 1.25, n, mode=mode, keep_last_step=False) if mode == "fast" else \
+                orc.adam_run(st["F2"], st["M2"], st["P0"], 1.25, n)
+            f = orc.resize_trilinear(r["U"] * np.float32(2), shape)
+            res[mode, n] = epe(np.moveaxis(f[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["c1_adam_%d_sub" % n], 0, -1))
+    print("fast mode vs reference capture:", {n: "%.3e" % res["fast", n] for n in snaps}, "exact at 80: %.3e" % res["exact", 80])
+    assert res["fast", 1] <= 1e-6 and res["fast", 20] < 1e-3 and res["fast", 40] < 1e-3
+    assert res["fast", 80] <= float(g["c1_self_perturbation_epe_sub"][snaps.index(80)])
+    assert res["fast", 80] <= 1.15 * res["exact", 80]
+
+
+def test_fast_box_is_the_three_chained_boxes(orc):
+    """orc_fast_box3x3 (separable sums, one scale) equals box3(box3(box3(.))) with per-stage zero padding to rounding, borders included."""
+    rng = np.random.default_rng(5)
+    for shape in ((3, 4, 5), (2, 2, 2), (9, 7, 11), (1, 6, 3)):
+        x = rng.standard_normal((3,) + shape).astype(np.float32)
+        ref = orc.box_zero(orc.box_zero(orc.box_zero(x, 3), 3), 3)
+        assert np.abs(orc.fast_box3x3(x) - ref).max() <= 4e-6 * max(1.0, float(np.abs(ref).max())), shape
