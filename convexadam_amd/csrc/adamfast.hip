@@ -292,13 +292,14 @@ static int launch_box3_fast_t(const float* in, float* out, int h, int w, int d, 
 
 // out = fastbox(in) (P == nullptr) or the Adam update of P, m, v with G = fastbox(in) (gsave optionally receives G); 3 channels.
 // Tile shapes <TZ, TY, TXQ> (option fbox_tile; all bit-identical): 1 = 8 x 10 x 24, 2 = 8 x 10 x 56, 3 = 16 x 10 x 24, 4 = 16 x 10 x 56,
-// 5 = 8 x 8 x 32, 6 = 4 x 10 x 24; 0 = automatic: the x extent (24 or 56 columns) that wastes fewer lanes on rows of d voxels.
+// 5 = 8 x 8 x 32, 6 = 4 x 10 x 24; 0 = automatic = 5 (measured on the benchmark grid 80 x 96 x 112: 5.65 ms per pair against 5.76 - 6.20
+// for the others -- the kernel moves 75 MB at ~4.3 TB/s whatever the tile, what differs is the tail of the last dispatch round).
 int launch_box3_fast(const float* in, float* out, int h, int w, int d, float* P, float* m, float* v, double bc1, double bc2,
                      float* gsave, hipStream_t s) {
     const double beta1 = 0.9, beta2 = 0.999;
     const AdamFastConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)(-(1.0 / bc1))};
     long long shape = options().fbox_tile;
-    if (shape <= 0 || shape > 6) shape = (cdiv(d, 56) * 56 <= cdiv(d, 24) * 24) ? 2 : 1;
+    if (shape <= 0 || shape > 6) shape = 5;
     switch (shape) {
         case 1: return launch_box3_fast_t<8, 10, 8>(in, out, h, w, d, P, m, v, ac, gsave, s);
         case 2: return launch_box3_fast_t<8, 10, 16>(in, out, h, w, d, P, m, v, ac, gsave, s);
