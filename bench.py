@@ -34,6 +34,11 @@ if ROOT not in sys.path:
 SHAPE = (160, 192, 224)
 CFG = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6, disp_hw=6, selected_niter=80, selected_smooth=0,
            grid_sp_adam=2, ic=True)
+# the mode `value` is timed in (round 4): the Adam loop in throughput arithmetic -- same mathematics, accepted by the criteria of SURVEY
+# section 7 against the reference's own capture (tests/test_gpu_fast_modes.py::test_full_size_fast_adam_acceptance); everything before
+# the Adam loop is bit-identical to the reference-order path.  TIMED_MODE_NAME goes into the JSON line.
+TIMED = dict(CFG, adam_mode="fast")
+TIMED_MODE_NAME = "adam_mode=fast (FMA / factored warp gradient, separable adjoint boxes, one-division update; forward boxes, MIND, correlation, coupled convex in the reference's order)"
 HBM_PEAK_GBS = 8000.0
 TOLERANCE_EPE = 1e-3          # north_star: mean end-point error against the reference's field, voxels
 
@@ -87,6 +92,8 @@ def reference_bits_check(fix, mov, dev):
     rb.set_mind_exp_table(exp_tbl, device=dev)
     rb.set_adam_sqrt_table(sqrt_codes_from_low_bitmaps(q["normal"], q["denormal"]), device=dev)
     rb.set_mean_threads(8)
+    horizons = (20, 40, 80)
+    golden_host = {}
     try:
         for _ in range(2):
             f = register_pair_device(fix, mov, **CFG)
@@ -96,6 +103,21 @@ def reference_bits_check(fix, mov, dev):
             f = register_pair_device(fix, mov, **CFG)
         torch.cuda.synchronize(dev)
         ms = (time.perf_counter() - t0) / 5 * 1e3
+        for n in horizons:
+            golden_host[n] = f if n == CFG["selected_niter"] else register_pair_device(fix, mov, **dict(CFG, selected_niter=n))
+    finally:
+        rb.disable()
+    # the reference's own reproducibility ACROSS HOSTS: the same reference-bits pipeline with the tables of the golden host (a Xeon) and
+    # with the tables of THIS host's torch (MKL picks its exp / sqrt code path by CPU model) -- two installs of the reference, one pair
+    cross = None
+    try:
+        rb.enable(dev, threads=8)
+        cross = {}
+        for n in horizons:
+            g2 = register_pair_device(fix, mov, **dict(CFG, selected_niter=n))
+            cross["epe_%dit" % n] = float((g2 - golden_host[n]).square().sum(0).sqrt().mean())
+    except Exception as e:                                      # a host whose torch has no MKL path etc.: report, do not fail the bench
+        cross = {"error": repr(e)}
     finally:
         rb.disable()
     s = int(g["sub"])
@@ -107,19 +129,58 @@ def reference_bits_check(fix, mov, dev):
                       and np.allclose(fd.square().sum((1, 2, 3)).numpy(), g["c1_adam_80_sumsq"], rtol=1e-14, atol=0))
     return dict(bit_identical_to_reference_capture=sub_equal and sums_equal, ms_per_pair=ms, pairs_per_s=1e3 / ms,
                 epe_vs_reference_80it=epe_sub, tolerance_met=bool(epe_sub < TOLERANCE_EPE),
+                reference_cross_host=dict(cross or {}, note="mean EPE (whole field, voxels) between the reference-bits pipeline with the GOLDEN host's MKL "
+                                          "tables and with THIS host's (reference_bits.enable: built from this host's torch.exp / torch.sqrt), 8-thread mean "
+                                          "in both: how far two installs of the reference are from each other on this pair"),
                 note="opt-in mode (convexadam_amd/reference_bits.py): MKL vsExp / vsSqrt of the golden host as tables + torch's 8-thread "
                      "mean; compared with the field captured from the reference at 80 iterations (tests/golden/fullsize.npz: every 8th "
                      "voxel per axis bit for bit, float64 sum and sum of squares of the whole field to 1e-14)")
 
 
-def default_mode_vs_reference(hip_field):
-    """Mean EPE of the DEFAULT build's field (the one `value` is timed on) against the field captured from the reference itself at
-    80 iterations on this very pair (tests/golden/fullsize.npz holds every 8th voxel per axis)."""
+def epe_vs_reference(hip_field, niter=80):
+    """Mean EPE of a HIP field against the field captured from the reference itself after `niter` Adam iterations on this very pair
+    (tests/golden/fullsize.npz holds every 8th voxel per axis for 1 / 20 / 40 / 80 iterations)."""
     import numpy as np
     g = np.load(os.path.join(ROOT, "tests", "golden", "fullsize.npz"))
     s = int(g["sub"])
-    d = hip_field[:, ::s, ::s, ::s].astype(np.float64) - g["c1_adam_80_sub"].astype(np.float64)
+    d = hip_field[:, ::s, ::s, ::s].astype(np.float64) - g["c1_adam_%d_sub" % niter].astype(np.float64)
     return float(np.sqrt((d ** 2).sum(0)).mean())
+
+
+def mode_parity(fix, mov, dev, timed_field):
+    """Outside the timed region: the timed mode and the exact (reference-order) mode against the reference's capture at 20 / 40 / 80
+    iterations, the exact mode's own speed, and the acceptance criteria the timed mode was built to."""
+    import numpy as np
+    from convexadam_amd.convex_adam_MIND import register_pair_device
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fullsize.npz"))
+    self_pert = float(g["c1_self_perturbation_epe_sub"][list(g["c1_snaps"]).index(80)])
+    out = {}
+    for name, cfg in (("timed_mode", TIMED), ("exact_mode", CFG)):
+        e = {}
+        for n in (1, 20, 40, 80):
+            f = timed_field if (name == "timed_mode" and n == 80) else register_pair_device(fix, mov, **dict(cfg, selected_niter=n)).cpu().numpy()
+            e["epe_vs_reference_%dit" % n] = epe_vs_reference(f, n)
+        out[name] = e
+    for _ in range(2):
+        register_pair_device(fix, mov, **CFG)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        register_pair_device(fix, mov, **CFG)
+    torch.cuda.synchronize(dev)
+    out["exact_mode"]["ms_per_pair"] = (time.perf_counter() - t0) / 5 * 1e3
+    out["exact_mode"]["note"] = "every operator in the reference's evaluation order (library expf / IEEE sqrt / exactly rounded mean); bit-identical to oracle/cvx_oracle.c"
+    t, x = out["timed_mode"], out["exact_mode"]
+    t["name"] = TIMED_MODE_NAME
+    t["tolerance_met_80it"] = bool(t["epe_vs_reference_80it"] < TOLERANCE_EPE)
+    t["acceptance"] = dict(convex_stage_bit_identical=True, epe_1it_le_1em6=bool(t["epe_vs_reference_1it"] <= 1e-6),
+                           epe_20it_lt_1em3=bool(t["epe_vs_reference_20it"] < 1e-3), epe_40it_lt_1em3=bool(t["epe_vs_reference_40it"] < 1e-3),
+                           epe_80it_le_reference_self_perturbation=bool(t["epe_vs_reference_80it"] <= self_pert),
+                           epe_80it_le_1p15x_exact_mode=bool(t["epe_vs_reference_80it"] <= 1.15 * x["epe_vs_reference_80it"]),
+                           reference_self_perturbation_epe_80it=self_pert,
+                           note="criteria registered before the mode was built (SURVEY section 7 hard part 1; VERDICT round 3 item 1); the convex stage "
+                                "(everything before the Adam loop) is the same code in both modes")
+    return out
 
 
 def cpu_baseline(fix, mov, hip_field):
@@ -130,14 +191,16 @@ def cpu_baseline(fix, mov, hip_field):
     oracle.build()
     cores = oracle.num_threads()
     t0 = time.time()
-    ref = oracle.convex_adam_pipeline(fix, mov, **CFG)            # (H,W,D,3) float64
+    ref, st = oracle.convex_adam_pipeline(fix, mov, return_stages=True, **CFG)            # (H,W,D,3) float64; the reference-order restatement is what is timed
     dt = time.time() - t0
+    # the timed HIP mode restated on the CPU (outside the baseline's clock): the same Adam loop in the fast arithmetic, from the stages above
+    r = oracle.adam_run(st["F2"], st["M2"], st["P0"], CFG["lambda_weight"], CFG["selected_niter"], mode="fast", keep_last_step=False)
+    ref = np.moveaxis(oracle.resize_trilinear(r["U"] * np.float32(CFG["grid_sp_adam"]), fix.shape), 0, -1).astype(np.float64)
     got = np.moveaxis(hip_field, 0, -1).astype(np.float64)
     epe = float(np.sqrt(((got - ref) ** 2).sum(-1)).mean())
     parity = dict(epe_vs_oracle=epe, bit_identical=bool(np.array_equal(got, ref)), max_abs_diff=float(np.abs(got - ref).max()),
-                  note="field of the last timed step vs oracle/cvx_oracle.c on the same pair, full size; oracle vs the reference itself: "
-                       "tests/golden/fullsize.npz (bit-identical convex stage, mean EPE 1.2e-3 after 80 iterations = below the reference's "
-                       "own 1-ulp sensitivity of 1.6e-3; in reference-bits mode bit-identical, see reference_bits_mode)")
+                  note="field of the last timed step vs oracle/cvx_oracle.c in the SAME mode (orc_adam_run_fast on the oracle's own convex stage) on the "
+                       "same pair, full size; the modes against the reference itself: timed_mode / exact_mode / reference_bits_mode below")
     base = dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port", seconds_per_pair=dt,
                 sample="1 full 160x192x224 pair (MIND r1 d2, gs6, hw6, ic, 80 Adam its) with oracle/cvx_oracle.c, "
                        "OpenMP over %d threads; reference PyTorch-CPU figure from BASELINE.md: 77.4 s/pair on 8 cores" % cores)
@@ -178,7 +241,7 @@ def main():
     out = torch.empty((3,) + SHAPE, dtype=torch.float32, device=dev)
 
     for _ in range(a.warmup):
-        register_pair_device(fix, mov, out=out, **CFG)
+        register_pair_device(fix, mov, out=out, **TIMED)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -187,7 +250,7 @@ def main():
     set_profiling(2)            # stage boundaries = hipEventRecord on the launch stream, read back after the timed region
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        register_pair_device(fix, mov, out=out, **CFG)
+        register_pair_device(fix, mov, out=out, **TIMED)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -206,13 +269,13 @@ def main():
     batched = None
     if not a.no_batched:
         outs = [out, torch.empty_like(out)]
-        register_pairs_device([fix, fix], [mov, mov], outs=outs, n_streams=2, **CFG)
+        register_pairs_device([fix, fix], [mov, mov], outs=outs, n_streams=2, **TIMED)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         tb = time.perf_counter()
         for _ in range(a.steps):
-            register_pairs_device([fix, fix], [mov, mov], outs=outs, n_streams=2, **CFG)
+            register_pairs_device([fix, fix], [mov, mov], outs=outs, n_streams=2, **TIMED)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -234,11 +297,11 @@ def main():
         fz, mz = (fix * m).contiguous(), (mov * m).contiguous()
         set_profiling(0)
         for _ in range(2):
-            register_pair_device(fz, mz, **CFG)
+            register_pair_device(fz, mz, **TIMED)
         torch.cuda.synchronize(dev)
         set_profiling(2)
         for _ in range(3):
-            register_pair_device(fz, mz, **CFG)
+            register_pair_device(fz, mz, **TIMED)
         torch.cuda.synchronize(dev)
         st = {}
         for name, ms in last_profile():
@@ -248,11 +311,11 @@ def main():
         cc_worst["ms_per_pair"] = sum(sum(v) / len(v) for v in st.values())
         # opt-in fast correlation mode (FMA + separable sums; same indices and a bit-identical field on this pair, but no proof: not the default)
         for _ in range(2):
-            register_pair_device(fix, mov, corr_mode="fast", **CFG)
+            register_pair_device(fix, mov, corr_mode="fast", **TIMED)
         torch.cuda.synchronize(dev)
         set_profiling(2)
         for _ in range(3):
-            fast_field = register_pair_device(fix, mov, corr_mode="fast", **CFG)
+            fast_field = register_pair_device(fix, mov, corr_mode="fast", **TIMED)
         torch.cuda.synchronize(dev)
         st = {}
         for name, ms in last_profile():
@@ -278,9 +341,10 @@ def main():
         hc = st.get("correlate", []) + st.get("correlate_rev", [])
         conv32 = register_pair_device(fix, mov, **dict(CFG, lambda_weight=0))
         conv16 = register_pair_device(fix, mov, storage="fp16", **dict(CFG, lambda_weight=0))
+        out32 = register_pair_device(fix, mov, **CFG)             # fp16 storage runs the reference-order Adam loop: compare like with like
         cc_worst["fp16"] = dict(ms_per_pair=t16 * 1e3, corr_ms=sum(hc) / max(len(hc), 1), adam_ms=sum(st.get("adam", [0.0])) / max(len(st.get("adam", [0.0])), 1),
                                 argmin_ms=sum(st.get("argmin", [0.0])) / max(len(st.get("argmin", [0.0])), 1),
-                                epe_vs_fp32_field=float((h16_field - out).square().sum(0).sqrt().mean()),
+                                epe_vs_fp32_field=float((h16_field - out32).square().sum(0).sqrt().mean()),
                                 convex_stage_voxels_changed=float((conv16 != conv32).any(0).float().mean()),
                                 convex_stage_epe=float((conv16 - conv32).square().sum(0).sqrt().mean()))
 
@@ -307,6 +371,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "mode": TIMED_MODE_NAME,
             "config": {"workload": "BASELINE configs[1]: 160x192x224 pair, MIND-SSC r1 d2, grid_sp 6, disp_hw 6, ic, "
                                    "lambda 1.25, grid_sp_adam 2, 80 Adam iterations, float32",
                        "pairs_per_gpu_per_step": 1, "parallelism": "one pair per GPU, no collectives"},
@@ -343,12 +408,9 @@ def main():
                                                 "flat cost regions; a pruned pass whose large candidate boxes exceed the cost of a coalesced scan streams the volume instead (bounded worst case)"}
         if n == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"], res["parity"] = cpu_baseline(fix.cpu().numpy(), mov.cpu().numpy(), field_of_timed_loop)
-            e = default_mode_vs_reference(field_of_timed_loop)
             res["parity"]["tolerance_epe"] = TOLERANCE_EPE
-            res["parity"]["default_mode"] = dict(epe_vs_reference_80it=e, tolerance_met=bool(e < TOLERANCE_EPE), ms_per_pair=res["ms_per_step"],
-                                                 note="the mode `value` is timed in: every operator in the reference's evaluation order, library expf / IEEE sqrt / exactly "
-                                                      "rounded mean instead of the reference host's MKL vsExp / vsSqrt and its 8-thread float sum (<= 1 ulp each; Adam(lr=1) "
-                                                      "amplifies that to ~1e-3 voxels after 80 iterations; the reference differs by 1.6e-3 from a 1-ulp perturbed copy of itself)")
+            res["parity"].update(mode_parity(fix, mov, dev, field_of_timed_loop))
+            res["parity"]["timed_mode"]["ms_per_pair"] = res["ms_per_step"]
             res["parity"]["reference_bits_mode"] = reference_bits_check(fix, mov, dev)
         print(json.dumps(res))
     if world > 1:
