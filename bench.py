@@ -183,13 +183,86 @@ def mode_parity(fix, mov, dev, timed_field):
     return out
 
 
+def api_path(fix, mov, dev, engine_ms):
+    """The drop-in call a user of the reference makes: convex_adam_pt(host array, host array) -> host (H,W,D,3) float64,
+    including both uploads, the registration, the device-side packing kernel and the transfer of the 165 MB result -- never part of `value`."""
+    import numpy as np
+    from convexadam_amd.convex_adam_MIND import convex_adam_pt, convex_adam_pt_many, register_pair_device
+    fh, mh = fix.cpu(), mov.cpu()                                   # pageable host tensors, as a caller would hold them
+    kw = dict(CFG, adam_mode="fast")
+    # raw PCIe rates of this box (pinned, 165 MB / 27.5 MB)
+    big = torch.empty(SHAPE + (3,), dtype=torch.float64, device=dev)
+    pin = torch.empty(SHAPE + (3,), dtype=torch.float64, pin_memory=True)
+    pin.copy_(big); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        pin.copy_(big, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    d2h = 3 * big.numel() * 8 / (time.perf_counter() - t0) / 1e9
+    t0 = time.perf_counter()
+    for _ in range(3):
+        big.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    h2d = 3 * big.numel() * 8 / (time.perf_counter() - t0) / 1e9
+    del big, pin
+    out = None
+    for _ in range(3):
+        out = convex_adam_pt(fh, mh, device=dev, **kw)
+    calls = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        out = convex_adam_pt(fh, mh, device=dev, **kw)
+        calls.append((time.perf_counter() - t0) * 1e3)
+    seq_ms = float(np.median(calls))
+    # the same result through the round-3 path: permute + dtype on the device, pageable download, numpy astype on the host
+    t0 = time.perf_counter()
+    disp = register_pair_device(fix, mov, **kw)
+    old = disp.permute(1, 2, 3, 0).to(torch.float16).cpu().numpy().astype(float)
+    old_ms = (time.perf_counter() - t0) * 1e3 + 0.0
+    same = bool(np.array_equal(old, out))
+    del old
+    m = 8
+    list(convex_adam_pt_many([(fh, mh)] * 2, device=dev, **kw))
+    t0 = time.perf_counter()
+    last = None
+    for last in convex_adam_pt_many([(fh, mh)] * m, device=dev, **kw):
+        pass
+    many_ms = (time.perf_counter() - t0) / m * 1e3
+    same = same and bool(np.array_equal(last, out))
+    nbytes_out = out.nbytes
+    bound = engine_ms + (nbytes_out / (d2h * 1e9) + 2 * fix.numel() * 4 / (h2d * 1e9)) * 1e3
+    return dict(ms_per_pair=seq_ms, ms_per_pair_mean=float(np.mean(calls)), ms_per_pair_max=float(np.max(calls)), pairs_per_s=1e3 / seq_ms, ms_per_pair_overlapped=many_ms, pairs_per_s_overlapped=1e3 / many_ms,
+                ms_per_pair_round3_path=old_ms, pcie_GBps=dict(d2h_pinned=d2h, h2d_pinned=h2d),
+                engine_plus_transfers_ms=bound, within_10pct_of_bound=bool(seq_ms <= 1.1 * bound), field_identical_to_round3_path=same,
+                output_bytes=nbytes_out,
+                note="convex_adam_pt(host, host) -> host (H,W,D,3) float64 with dtype=float16 (the reference's default) and adam_mode='fast': torch "
+                     "uploads, cvx_register_pair_f32, cvx_pack_field_f64 writing straight into pooled pinned host memory; ms_per_pair = median of 12 calls; 'overlapped' = "
+                     "convex_adam_pt_many (packing of pair i on a side stream beside the registration of pair i+1); bound = engine time + "
+                     "165 MB / measured D2H rate + 2 x 27.5 MB / measured H2D rate")
+
+
+def effective_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the round-4 GPU boxes show 256 CPUs
+    with cpu.max = 16 cores; 128 OpenMP threads on 16 cores' worth of quota only add throttling stalls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.999)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(fix, mov, hip_field):
     """Times the C oracle (oracle/, the parity checker) on the host cores for one full pair and -- outside every timed region --
     compares the field the timed HIP loop produced for the same pair with the oracle's field."""
     import numpy as np
     from oracle import oracle
     oracle.build()
-    cores = oracle.num_threads()
+    visible = oracle.num_threads()
+    cores = min(visible, effective_cores())
+    oracle.set_num_threads(cores)
     t0 = time.time()
     ref, st = oracle.convex_adam_pipeline(fix, mov, return_stages=True, **CFG)            # (H,W,D,3) float64; the reference-order restatement is what is timed
     dt = time.time() - t0
@@ -203,7 +276,8 @@ def cpu_baseline(fix, mov, hip_field):
                        "same pair, full size; the modes against the reference itself: timed_mode / exact_mode / reference_bits_mode below")
     base = dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port", seconds_per_pair=dt,
                 sample="1 full 160x192x224 pair (MIND r1 d2, gs6, hw6, ic, 80 Adam its) with oracle/cvx_oracle.c, "
-                       "OpenMP over %d threads; reference PyTorch-CPU figure from BASELINE.md: 77.4 s/pair on 8 cores" % cores)
+                       "OpenMP over %d threads (= the cores this container may use: %d CPUs visible, capped by the cgroup CPU quota); "
+                       "reference PyTorch-CPU figure from BASELINE.md: 77.4 s/pair on 8 cores" % (cores, visible))
     return base, parity
 
 
@@ -412,6 +486,7 @@ def main():
             res["parity"].update(mode_parity(fix, mov, dev, field_of_timed_loop))
             res["parity"]["timed_mode"]["ms_per_pair"] = res["ms_per_step"]
             res["parity"]["reference_bits_mode"] = reference_bits_check(fix, mov, dev)
+            res["api"] = api_path(fix, mov, dev, res["ms_per_step"])
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -67,6 +67,7 @@ SIGNATURES = {
     "cvx_mindssc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "cvx_avgpool_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cvx_round_f16_f32": (_i, [_vp, _i64, _vp]),
+    "cvx_pack_field_f64": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cvx_box_smooth_workspace_bytes": (_sz, [_i] * 5),
     "cvx_box_smooth_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "cvx_mask_erode_f32": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),

@@ -129,6 +129,12 @@ size_t cvx_box_smooth_workspace_bytes(int C, int H, int W, int D, int passes);
 int cvx_box_smooth_f32(const float* in, int C, int H, int W, int D, int k, int passes, float* out,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* output packing of convex_adam_pt                              convex_adam_MIND.py:198-202
+ *   field [3][H][W][D] float32 -> out [H][W][D][3] float64, each value first passed through the caller's `dtype` (quantize 0 = float32,
+ *   1 = float16 round to nearest even): `.cpu().to(dtype)` + np.stack(..., 3).astype(float).  out: device memory, or pinned host
+ *   memory that is mapped into the device's address space -- the kernel then writes the result straight into the caller's array */
+int cvx_pack_field_f64(const float* field, int H, int W, int D, int quantize, double* out, void* stream);
+
 /* masked feature extraction helpers                             convex_adam_MIND.py:36-54
  *   cvx_mask_erode_f32 : out = (AvgPool3d(3)(ReplicationPad3d(1)(mask)) > threshold) ? 1 : 0      (:40,43,48)
  *   cvx_gather_f32     : out[i] = src[index[i]]  (half-resolution nearest-in-mask gather, :45,50; the indices come from

@@ -179,3 +179,23 @@ def test_batched_pairs_fast_mode_match_single_calls(M):
     outs = M.register_pairs_device(fx, mv, n_streams=2, adam_mode="fast", **kw)
     for i in range(3):
         assert torch.equal(outs[i], M.register_pair_device(fx[i], mv[i], adam_mode="fast", **kw))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_drop_in_api_packs_the_field_on_the_device(M, dtype):
+    """Row O: convex_adam_pt returns (H,W,D,3) float64 after the `dtype` round trip of convex_adam_MIND.py:198-201; the packing kernel
+    (cvx_pack_field_f64 into pinned host memory) gives the very array the torch / numpy expression of the reference gives, the pooled
+    buffers are not recycled while a result is alive, and convex_adam_pt_many yields the same fields."""
+    from convexadam_amd.phantom import phantom
+    shape = (40, 36, 44)
+    fix = phantom(shape, 1, 10)
+    movs = [torch.roll(phantom(shape, 1, 11 + i), (2 - i, -1, 1 + i), (0, 1, 2)) for i in range(3)]
+    kw = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=4, disp_hw=3, selected_niter=4, grid_sp_adam=2, ic=True, adam_mode="fast")
+    outs = [M.convex_adam_pt(fix, mv, dtype=dtype, device=torch.device(DEV), **kw) for mv in movs]
+    for mv, out in zip(movs, outs):
+        disp = M.register_pair_device(fix.to(DEV), mv.to(DEV), **kw)
+        ref = disp.permute(1, 2, 3, 0).to(dtype).cpu().numpy().astype(float)
+        assert out.shape == shape + (3,) and out.dtype == np.float64 and np.array_equal(out, ref)
+    assert not np.array_equal(outs[0], outs[1])                      # three live results: three distinct buffers
+    many = list(M.convex_adam_pt_many([(fix, mv) for mv in movs], dtype=dtype, device=torch.device(DEV), **kw))
+    assert len(many) == 3 and all(np.array_equal(a, b) for a, b in zip(many, outs))
