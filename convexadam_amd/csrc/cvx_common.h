@@ -90,6 +90,7 @@ struct Options {
                                    //    {start, first data, end} in 100 MHz ticks (s_memrealtime) + placement there (0 = off)
     long long mind_mean_threads;   // 0: exactly rounded global mean in MINDSSC (default); T > 0: torch's own float sum with T threads
                                    //    (reference-bits mode; NOT a bit-identical variant -- it changes the clamp bounds by ulps)
+    long long edt_sequential;      // 1: squared distance transform with the sequential lower-envelope passes (one thread per line) instead of the tiled outward search
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };

@@ -120,7 +120,7 @@ def _make_labels(shape, idx, device, num_labels=13):
 
 
 # ---- scoring ----------------------------------------------------------------------------------------------------------------------
-def evaluate_item(disp, seg_fixed, seg_moving, key_fixed, key_moving, num_labels, robust=None):
+def evaluate_item(disp, seg_fixed, seg_moving, key_fixed, key_moving, num_labels, robust=None, cache=None):
     """disp (3,H,W,D) device field in voxels -> dict of the reference's evaluation scalars (computed on the device)."""
     from convexadam_amd import convexAdam_hyper_util as HU
     d = disp[None]
@@ -131,7 +131,7 @@ def evaluate_item(disp, seg_fixed, seg_moving, key_fixed, key_moving, num_labels
     dice0 = HU.dice_coeff(seg_fixed, seg_moving, num_labels + 1)
     tre, _ = HU.tre_at_keypoints(d, key_fixed, key_moving)                                 # convex_run_paired_mind.py:165-173
     tre0 = (key_fixed - key_moving).square().sum(-1).sqrt()
-    hd95 = HU.cupy_hd95(seg_fixed, warped, num_labels)                                     # convex_run_withconfig.py:143
+    hd95 = HU.cupy_hd95(seg_fixed, warped, num_labels, fixed_cache=cache)                  # convex_run_withconfig.py:143 (cache: the fixed map's transforms)
     if robust is None:                                                                      # the 30 % labels with the lowest initial overlap (:60-61)
         robust = dice0.topk(max(1, int(num_labels * 0.3)), largest=False).indices
     return dict(dice=float(dice.mean()), dice30=float(dice[robust].mean()), dice_before=float(dice0.mean()), jstd=jstd, folding=fold,
@@ -270,7 +270,7 @@ class PairData:
     """Validation pairs and their labels, made on demand and kept on the device (a few pairs per GPU fit easily in 288 GB)."""
 
     def __init__(self, shape, device):
-        self.shape, self.device, self.pairs, self.labels, self.coarse = tuple(shape), device, {}, {}, {}
+        self.shape, self.device, self.pairs, self.labels, self.coarse, self.hd = tuple(shape), device, {}, {}, {}, {}
         self.lock = threading.Lock()
 
     def pair(self, p):
@@ -290,6 +290,20 @@ class PairData:
             return self.labels[p]
 
 
+def _hd_cache(data, p):
+    """Per-pair cache of the fixed label map's distance transforms for HD95 (they do not depend on the field being scored); filled once,
+    under the lock, and synchronised because the other workers read it on their own streams."""
+    with data.lock:
+        if p not in data.hd:
+            from convexadam_amd import convexAdam_hyper_util as HU
+            c = {}
+            seg_f, seg_m, _, _, nl = data.labels[p]
+            HU.cupy_hd95(seg_f, seg_m, nl, fixed_cache=c)
+            torch.cuda.current_stream(data.device).synchronize()
+            data.hd[p] = c
+        return data.hd[p]
+
+
 def run_stage1_item(cfg, p, data):
     from convexadam_amd.convex_adam_MIND import register_pair_device
     fix, mov = data.pair(p)
@@ -298,7 +312,10 @@ def run_stage1_item(cfg, p, data):
     disp = register_pair_device(fix, mov, lambda_weight=0, ic=True, **cfg)                  # convex stage + inverse consistency (:100-128)
     torch.cuda.current_stream(data.device).synchronize()
     rec = dict(ms=(time.time() - t) * 1e3)
-    rec.update(evaluate_item(disp, *data.label(p)))
+    lab = data.label(p)
+    t = time.time()
+    rec.update(evaluate_item(disp, *lab, cache=_hd_cache(data, p)))
+    rec["eval_ms"] = (time.time() - t) * 1e3
     return rec
 
 
@@ -330,14 +347,19 @@ def run_stage2_item(best1, cfg2, p, data, smoothers):
     ms = (time.time() - t) * 1e3
     recs = []
     lab = data.label(p)
+    hdc = _hd_cache(data, p)
+    t_eval = time.time()
     for ii in range(len(SNAP_ITERS)):
         field = U.resize_trilinear(st["snapshots"][ii][None] * float(gsa), (H, W, D))
         for kk in range(N_EXTRA_SMOOTH):
             if kk > 0:
                 field = U.box_smooth(field, 3, 1)
             r = dict(snap=ii, smooth=kk, ms=ms)
-            r.update(evaluate_item(field[0], *lab))
+            r.update(evaluate_item(field[0], *lab, cache=hdc))
             recs.append(r)
+    eval_ms = (time.time() - t_eval) * 1e3
+    for r in recs:
+        r["eval_ms"] = eval_ms / len(recs)
     return recs
 
 
@@ -354,8 +376,8 @@ def main(argv=None):
     ap.add_argument("--static", action="store_true", help="round-robin assignment instead of the shared queue")
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercises queue, logs, resume and gather only (CPU/gloo)")
     ap.add_argument("--evaluate", action="store_true", help="round-1 mode: score every item on the device and rank the settings")
-    ap.add_argument("--workers", type=int, default=0, help="items in flight per rank, each on its own thread and HIP stream (0 = automatic: 2 on a GPU -- "
-                    "a second registration fills the issue slots one leaves idle, DESIGN.md section 9 -- 1 otherwise)")
+    ap.add_argument("--workers", type=int, default=0, help="items in flight per rank, each on its own thread and HIP stream (0 = automatic = 1: since round 4 "
+                    "the evaluation kernels fill the GPU on their own -- 2.67 s with one worker, 2.96 s with two on the 48-item example)")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", 0))
@@ -368,7 +390,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     two_stage = a.stage1 > 0
-    n_workers = a.workers if a.workers > 0 else (2 if use_gpu else 1)
+    n_workers = a.workers if a.workers > 0 else 1
     queue = WorkQueue(rank, world)
     run_id = dict(shape=list(a.shape), pairs=a.pairs, stage1=a.stage1, stage2=a.stage2, settings=a.settings, niter=a.niter, evaluate=bool(a.evaluate),
                   dry_run=bool(a.dry_run))
@@ -531,6 +553,20 @@ def main(argv=None):
         summary["wall_s"] = float(elapsed)
         n_items = summary.get("n_items") or (summary.get("stage1", {}).get("n_items", 0) + summary.get("stage2", {}).get("n_items", 0))
         summary["items_per_s"] = n_items / summary["wall_s"] if summary["wall_s"] > 0 else None
+        if two_stage and not a.dry_run:
+            # where the wall time went (summed over workers and ranks; two workers per rank overlap, so the parts may exceed the wall)
+            reg1 = sum(r.get("ms", 0.0) for r in seen.values())
+            ev1 = sum(r.get("eval_ms", 0.0) for r in seen.values())
+            ph = dict(stage1_registration_s=reg1 / 1e3, stage1_evaluation_s=ev1 / 1e3)
+            if "stage2" in summary:
+                items2 = {}
+                for e in flat:
+                    items2.setdefault((e["setting"], e["pair"]), []).append(e)
+                ph.update(stage2_mind_adam_s=sum(v[0].get("ms", 0.0) for v in items2.values()) / 1e3,
+                          stage2_evaluation_s=sum(e.get("eval_ms", 0.0) for e in flat) / 1e3, stage2_evaluations=len(flat))
+            ph["other_s"] = summary["wall_s"] * n_workers - sum(v for k, v in ph.items() if k.endswith("_s"))
+            ph["note"] = "seconds summed over the workers of all ranks (workers_per_rank overlap on one GPU); other = queue, logging, Python, idle"
+            summary["phases"] = ph
         if a.out:
             with open(a.out, "w") as f:
                 f.write(json.dumps(summary))

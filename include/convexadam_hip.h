@@ -403,9 +403,15 @@ int cvx_surface_hist_i64(const int* a_in2, const int* a_out2, const int* b_in2, 
                          void* stream);
 int cvx_hist_order_stats_i64(const int64_t* hist, int nbins, int64_t k0, int64_t k1, int64_t* out3, void* stream);
 int cvx_hist_percentile_neighbours_i64(const int64_t* hist, int nbins, float quantile, int64_t* out3, void* stream);
+/* the same for n_hist histograms [n_hist][nbins] in one launch -> out3 [n_hist][3] (all labels x both directions of one cupy_hd95 call) */
+int cvx_hist_percentile_neighbours_batch_i64(const int64_t* hist, int nbins, int n_hist, float quantile, int64_t* out3, void* stream);
 size_t cvx_edt_squared_workspace_bytes(int batch, int H, int W, int D);
 int cvx_edt_squared_i32(const float* obj, int batch, int H, int W, int D, int* d2, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* the same for the 2 n volumes (mask, complement) of n labels of ONE label map, read straight from the map: d2 [n][2][H][W][D];
+ * labels_host [n] (host array, n <= 64) -- the transforms cupy_hd95 needs at precision 1 (hyper_util:39-46) without materialising the masks */
+int cvx_edt_squared_labels_i32(const float* seg, int H, int W, int D, const int* labels_host, int n_labels, int* d2, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 #pragma GCC visibility pop
 
