@@ -25,14 +25,26 @@ __global__ __launch_bounds__(256) void k_warp_grad_fast(const float* __restrict_
                                                         int h, int w, int d, const float* __restrict__ U,
                                                         const float* __restrict__ bh, const float* __restrict__ bw,
                                                         const float* __restrict__ bd, float gsc2, float m2H, float m2W, float m2D,
-                                                        float* __restrict__ gU) {
+                                                        float* __restrict__ gU, int octant) {
     const size_t V = (size_t)h * w * d;
-    // 4 x 4 x 16 voxel tile per workgroup, XCD-aware tile order (as k_warp_grad, warp.hip)
+    // 4 x 4 x 16 voxel tile per workgroup.  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; XCD q = (qz, qy, qx) takes
+    // the q-th OCTANT of the tile grid (2 x 2 x 2 split) and walks it x, y, z: the tiles that share a face in y or z are then
+    // (ntx/2) resp. (ntx/2)(nty/2) positions apart instead of ntx resp. ntx nty, close enough in time to find the shared moving-feature
+    // records in the XCD's 4 MB L2 (octant == 0: the slab order of k_warp_grad, warp.hip)
     const int ntx = (d + 15) / 16, nty = (w + 3) / 4, ntz = (h + 3) / 4;
-    const int per_xcd = (int)(gridDim.x >> 3);
-    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (tile >= ntx * nty * ntz) return;
-    const int tbx = tile % ntx, tby = (tile / ntx) % nty, tbz = tile / (ntx * nty);
+    int tbx, tby, tbz;
+    if (octant) {
+        const int q = (int)(blockIdx.x & 7), i = (int)(blockIdx.x >> 3);
+        const int hx = (ntx + 1) >> 1, hy = (nty + 1) >> 1, hz = (ntz + 1) >> 1;
+        if (i >= hx * hy * hz) return;
+        tbx = (q & 1) * hx + i % hx; tby = ((q >> 1) & 1) * hy + (i / hx) % hy; tbz = (q >> 2) * hz + i / (hx * hy);
+        if (tbx >= ntx || tby >= nty || tbz >= ntz) return;
+    } else {
+        const int per_xcd = (int)(gridDim.x >> 3);
+        const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+        if (tile >= ntx * nty * ntz) return;
+        tbx = tile % ntx; tby = (tile / ntx) % nty; tbz = tile / (ntx * nty);
+    }
     const int x = tbx * 16 + (threadIdx.x & 15), y = tby * 4 + ((threadIdx.x >> 4) & 3), z = tbz * 4 + (threadIdx.x >> 6);
     if (x >= d || y >= w || z >= h) return;
     const unsigned p = (unsigned)((z * w + y) * d + x);
@@ -123,9 +135,11 @@ __global__ __launch_bounds__(256) void k_warp_grad_fast(const float* __restrict_
 int launch_warp_grad_fast(const float* Fcl, const float* Mcl, int C, int h, int w, int d, const float* U, const float* bh,
                           const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s) {
     const int CP = (C + 3) / 4 * 4;
-    const dim3 gv((unsigned)((cdiv(d, 16) * cdiv(w, 4) * cdiv(h, 4) + 7) / 8 * 8));     // multiple of the 8 XCDs
+    const int ntx = cdiv(d, 16), nty = cdiv(w, 4), ntz = cdiv(h, 4);
+    const int octant = options().warp_octant != 0 && ntx >= 2 && nty >= 2 && ntz >= 2;
+    const dim3 gv(octant ? (unsigned)(8 * ((ntx + 1) / 2) * ((nty + 1) / 2) * ((ntz + 1) / 2)) : (unsigned)((ntx * nty * ntz + 7) / 8 * 8));     // multiple of the 8 XCDs
     hipLaunchKernelGGL(k_warp_grad_fast, gv, dim3(256), 0, s, Fcl, Mcl, CP, h, w, d, U, bh, bw, bd, 2.0f * gsc, -2.0f * cH, -2.0f * cW,
-                       -2.0f * cD, gU);
+                       -2.0f * cD, gU, octant);
     return check_last("warp_grad_fast");
 }
 

@@ -6,8 +6,21 @@
  - <tag>_pmc_sq_counters.txt      SQ counters per kernel
  - pmc_hbm_traffic.json           bytes per launch of the correlation stage (read by bench.py for roofline.traffic)
  - <tag>_bench_line.json          the bench line of the same box
-FETCH_SIZE counts half of the bytes of a streamed read on gfx950 (calibrated on k_argmin: 270.5 MB streamed), WRITE_SIZE
-is exact; both are in KiB: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
+FETCH_SIZE counts half of the bytes of a 16-byte-per-lane streamed read on gfx950 (calibrated on k_argmin4: 270.5 MB streamed -> factor
+2.00) and ALL bytes of kernels that read shorter contiguous pieces (k_mind_finish_pool: 330.3 MB read, 330.5 MB counted -> factor 1.00);
+WRITE_SIZE is exact; both are in KiB.  bytes = (factor * FETCH_SIZE + WRITE_SIZE) * 1024 with the PER-KERNEL factor of FETCH_FACTOR
+(calibrated where the read volume is known, 2.0 -- an upper bound -- elsewhere; the table prints the factor it used and the factor-1 figure)."""
+
+# FETCH_SIZE correction per kernel (substring match): measured = known read bytes / counted bytes on the benchmark configuration
+FETCH_FACTOR = {"k_mind_finish_pool": 1.0, "k_argmin4": 2.0, "k_to_chunked": 2.0}
+DEFAULT_FACTOR = 2.0
+
+
+def fetch_factor(kernel):
+    for name, f in FETCH_FACTOR.items():
+        if name in kernel:
+            return f
+    return DEFAULT_FACTOR
 import collections
 import csv
 import glob
@@ -56,21 +69,23 @@ def main(src, tag):
         n = max(fc[k].get("FETCH_SIZE", 0), wc[k].get("WRITE_SIZE", 0))
         fe = fa[k].get("FETCH_SIZE", 0.0) / max(fc[k].get("FETCH_SIZE", 1), 1)
         wr = wa[k].get("WRITE_SIZE", 0.0) / max(wc[k].get("WRITE_SIZE", 1), 1)
-        rows.append((k, n, fe, wr, (2 * fe + wr) * 1024 / 1e6))
+        rows.append((k, n, fe, wr, (fetch_factor(k) * fe + wr) * 1024 / 1e6))
     rows.sort(key=lambda r: -r[4] * r[1])
     buf = io.StringIO()
     buf.write("# HBM traffic per launch from rocprofv3 PMC counters (two separate passes, MI355X_MICROARCH.md section HBM):\n"
               "#   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched\n"
               "#   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched\n"
-              "# Counters are in KiB; WRITE_SIZE is exact, FETCH_SIZE reads 1/2 of a streamed read on gfx950 -> bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.\n")
-    buf.write("%-44s %6s %14s %14s %18s\n" % ("kernel", "calls", "FETCH_KiB/call", "WRITE_KiB/call", "corrected_MB/call"))
+              "# Counters are in KiB; WRITE_SIZE is exact, FETCH_SIZE reads 1/2 of a 16-byte-per-lane streamed read on gfx950 and 1/1 of shorter pieces ->\n"
+              "# bytes = (factor*FETCH_SIZE + WRITE_SIZE) * 1024 with the per-kernel factor shown (calibrated: k_mind_finish_pool 1.00, k_argmin4 / k_to_chunked 2.00;\n"
+              "# 2.00 = upper bound elsewhere; the last column is the factor-1 lower bound).\n")
+    buf.write("%-44s %6s %14s %14s %6s %18s %14s\n" % ("kernel", "calls", "FETCH_KiB/call", "WRITE_KiB/call", "factor", "corrected_MB/call", "factor1_MB/call"))
     for k, n, fe, wr, mb in rows:
-        buf.write("%-44s %6d %14.1f %14.1f %18.1f\n" % (k[-44:], n, fe, wr, mb))
+        buf.write("%-44s %6d %14.1f %14.1f %6.2f %18.1f %14.1f\n" % (k[-44:], n, fe, wr, fetch_factor(k), mb, (fe + wr) * 1024 / 1e6))
     # calibration of the FETCH_SIZE factor on kernels whose read volume is known exactly (benchmark configuration): the guide's x2 holds for
     # accesses that fetch whole 128-byte lines (tallied at 64 B); kernels that read shorter contiguous pieces are counted 1:1
     V, v, K = 160 * 192 * 224, 26 * 32 * 37, 2197
     known = {"k_argmin4": K * v * 4, "k_mind_finish_pool": 12 * V * 4, "k_to_chunked": 12 * (V // 8) * 4, "k_resize<3>": None}
-    buf.write("# FETCH_SIZE calibration (known read bytes / counted bytes; x2 is applied to every kernel above, i.e. an UPPER bound where the factor is 1):\n")
+    buf.write("# FETCH_SIZE calibration on this run (known read bytes / counted bytes):\n")
     for k, n, fe, wr, mb in rows:
         for name, nbytes in known.items():
             if nbytes and name in k:
@@ -80,7 +95,7 @@ def main(src, tag):
     total = sum(r[4] for r in stage) * 1e6
     json.dump({"correlate_stage_bytes_per_launch": total, "source": "profiles/%s_pmc_hbm_traffic.txt" % tag,
                "kernels": {r[0]: r[4] * 1e6 for r in stage},
-               "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 summed over k_corr_prep, k_corr_fused (k_corr_tail_compact when the volume has an interleaved-order tail), per launch = per direction", "measured_at_commit": os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip(),
+               "formula": "(factor*FETCH_SIZE + WRITE_SIZE)*1024 (factor 2: 16-byte streaming reads) summed over k_corr_prep, k_corr_fused (k_corr_tail_compact when the volume has an interleaved-order tail), per launch = per direction", "measured_at_commit": os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip(),
                "corr_sources_sha16": corr_sha()},
               open(os.path.join(prof, "pmc_hbm_traffic.json"), "w"), indent=1)
     sa, sc = pmc(src + "/sq")
