@@ -557,7 +557,9 @@ static int launch_qpr(const float* in, float* out, int h, int w, int d, int nxt,
     unsigned grid = (unsigned)((3 * nyt * nxt * nzc + 7) / 8 * 8);
     static thread_local BMTable tbl;                                          // (2 KB, passed by value)
     tbl.n = 0;
-    if (options().box_wg_target <= 0 && nxt > 1 && h <= 4095) (void)bm_uneven_table(tbl, grid, h, 3 * nyt * nxt, options().box_uneven);
+    // the uneven work list encodes a dispatch model of 8 XCDs x 32 CUs: used only on a device of that shape (results do not depend on it)
+    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); (void)hipGetLastError(); return n; }();
+    if (cus == 256 && options().box_wg_target <= 0 && nxt > 1 && h <= 4095) (void)bm_uneven_table(tbl, grid, h, 3 * nyt * nxt, options().box_uneven);
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec = (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave);
     const bool arole = options().box_adam_role != 0 && G::NTA <= 1024;          // Adam update as a role of its own (two extra wavefronts)

@@ -205,11 +205,13 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const ST* __restrict__ ssd,
                                                      float* __restrict__ u, float coef, int K, int n, int h, int w, int d,
                                                      const float* __restrict__ smin, const PrevT* __restrict__ kprev, int limit,
                                                      unsigned long long* __restrict__ list, int* __restrict__ list_count,
-                                                     int* __restrict__ next_count, unsigned long long* __restrict__ keys, Prob2 o) {
+                                                     int* __restrict__ next_count, unsigned long long* __restrict__ keys,
+                                                     const unsigned long long* __restrict__ minkeys, Prob2 o) {
     if (blockIdx.y) {
         ssd = shifted(ssd, o.ssd); u = shifted(u, o.out); smin = shifted(smin, o.ws); kprev = shifted(kprev, o.ws);
         list = shifted(list, o.ws); list_count = shifted(list_count, o.ws); next_count = shifted(next_count, o.ws);
         keys = shifted(keys, o.ws);
+        if (minkeys) minkeys = shifted(minkeys, o.ws);
     }
     const size_t v = (size_t)h * w * d;
     const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,9 +224,10 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const ST* __restrict__ ssd,
     float uc, ub, ua;
     smooth_winner(kprev, mesh, K, h, w, d, x, uc, ub, ua);
     u[x] = uc; u[v + x] = ub; u[2 * v + x] = ua;
-    // a voxel whose cost column holds a NaN: torch.argmin returns the first NaN in every pass (the penalty is finite), which is the
-    // plain argmin's winner and stays it
-    if (sm_x != sm_x) { keys[x] = pack_min_key(sm_x, (unsigned)kp); return; }
+    // a voxel whose cost column holds a NaN: torch.argmin returns the first NaN in every pass (the penalty is finite), i.e. the plain
+    // argmin's winner, and stays it.  minkeys = the (cost, index) keys of the library's own minimum pass: on the public entry points the
+    // caller's `argmin` only seeds the first smoothing step and need not be the first NaN
+    if (sm_x != sm_x) { keys[x] = pack_min_key(sm_x, minkeys ? (unsigned)(minkeys[x] & 0xffffffffull) : (unsigned)kp); return; }
     const CandBox c = cand_box(mesh, uc, ub, ua, coef, K, n, kp, ssd_kp, sm_x);
     if (c.vol > limit) {                // hand the box over in chunks of 256 displacements: (voxel << 8 | chunk) work items
         const int nchunks = (int)((c.vol + 255) >> 8);
@@ -450,10 +453,10 @@ static int argmin_pass(const ST* ssd, const float* mesh, const float* u, float c
 template <typename PrevT, typename ST>
 static int argmin_pass_pruned(const ST* ssd, const float* mesh, float* u, float coef, int K, int n, int h, int w, int d,
                               const float* smin, const PrevT* kprev, unsigned long long* list, int* list_count, int* next_count,
-                              unsigned long long* keys, const Prob2& o, int nprob, hipStream_t s) {
+                              unsigned long long* keys, const unsigned long long* minkeys, const Prob2& o, int nprob, hipStream_t s) {
     const size_t v = (size_t)h * w * d;
     hipLaunchKernelGGL((k_argmin_voxel<PrevT, ST>), dim3((unsigned)cdiv64((int64_t)v, 64), nprob), dim3(64), 0, s, ssd, mesh, u, coef, K, n, h,
-                       w, d, smin, kprev, 8, list, list_count, next_count, keys, o);
+                       w, d, smin, kprev, 8, list, list_count, next_count, keys, minkeys, o);
     // worst case bounded by one coalesced scan per pass: a chunk of 256 scattered reads moves about 8 KB, the scan K * v * 4 bytes
     const long long above = options().prune_stream_above >= 0 ? options().prune_stream_above : (long long)((double)K * (double)v / 2048.0);
     const int stream_above = (int)(above > 0x7fffffff ? 0x7fffffff : above);
@@ -574,8 +577,10 @@ static int coupled_core(const ST* ssd, const int64_t* argmin, const float* mesh,
             // smoothing of the previous winners + pruned argmin; keys[1], keys[2] alternate (keys[0] may hold the minimum pass)
             unsigned long long* kc = keys[1 + (it & 1)];
             int rc;
-            if (it == 0) rc = argmin_pass_pruned<int, ST>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, idx, list, counts + (it & 1), counts + ((it + 1) & 1), kc, o, nprob, s);
-            else rc = argmin_pass_pruned<unsigned long long, ST>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, keys[1 + ((it - 1) & 1)], list, counts + (it & 1), counts + ((it + 1) & 1), kc, o, nprob, s);
+            // keys[0] holds the library's own minimum pass unless the caller vouched for `argmin` (then idx IS the plain argmin)
+            const unsigned long long* minkeys = (from_keys || !argmin_is_exact) ? keys[0] : nullptr;
+            if (it == 0) rc = argmin_pass_pruned<int, ST>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, idx, list, counts + (it & 1), counts + ((it + 1) & 1), kc, minkeys, o, nprob, s);
+            else rc = argmin_pass_pruned<unsigned long long, ST>(ssd, mesh, out, coeffs[it], K, n, h, w, d, smin, keys[1 + ((it - 1) & 1)], list, counts + (it & 1), counts + ((it + 1) & 1), kc, minkeys, o, nprob, s);
             if (rc) return rc;
         }
         hipLaunchKernelGGL(k_gather_box3<unsigned long long>, gv, dim3(256), 0, s, keys[1 + (5 & 1)], mesh, K, h, w, d, out, (unsigned long long*)nullptr, (int*)nullptr, o);

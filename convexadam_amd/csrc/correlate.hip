@@ -297,8 +297,8 @@ extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, i
         return CVX_OK;
     }
     if (variant)
-        return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_ex_f32: cost / n_box / fast / fp16 variants need the fused kernel (option corr_unfused is set, or rows of more than 1270 voxels)");
-    if (disp_hw > 8) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: disp_hw %d > 8 needs the fused kernel (option corr_unfused is set, or rows of more than 1270 voxels)", disp_hw);
+        return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_ex_f32: cost / n_box / fast / fp16 variants need the fused kernel (option corr_unfused is set, or the grid is outside its range: the fused kernel covers rows of d <= ~1270 voxels when the plane has w <= 320 / ceil((d + 6) / 4) rows, else (y tiles) d <= ~250)");
+    if (disp_hw > 8) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: disp_hw %d > 8 needs the fused kernel (option corr_unfused is set, or the grid is outside its range: the fused kernel covers rows of d <= ~1270 voxels when the plane has w <= 320 / ceil((d + 6) / 4) rows, else (y tiles) d <= ~250)", disp_hw);
     if (!corr_box2_supported(h, w, d, g.px))
         return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_f32: coarse rows of %d voxels are too long for the LDS box kernel", d);
     Carver cv(workspace, workspace_bytes);

@@ -172,6 +172,21 @@ def test_nan_in_the_cost_volume(U, orc, case):
         finally:
             _lib.lib().cvx_set_option(b"no_prune", 0)
         assert np.array_equal(host(soft)[0], want, equal_nan=True), no_prune
+    # the caller's argmin only SEEDS the first smoothing step (convex_adam_utils.py:96); it need not be the first NaN of a NaN column:
+    # every later pass recomputes the argmin and finds the first NaN (the pruned passes used to keep the caller's index)
+    K = rs.shape[0]
+    nan_cols = np.isnan(rs.reshape(K, -1)).any(0).reshape(shape)
+    bad = ra.copy()
+    bad[nan_cols] = (bad[nan_cols] + 7) % K
+    assert nan_cols.any() and not np.array_equal(bad, ra)
+    want_bad = orc.coupled_convex(rs, bad, mesh, hw)
+    for no_prune in (0, 1):
+        _lib.lib().cvx_set_option(b"no_prune", no_prune)
+        try:
+            soft = U.coupled_convex(ssd, dev(bad), dev(mesh)[:, :, None], 1, shape)
+        finally:
+            _lib.lib().cvx_set_option(b"no_prune", 0)
+        assert np.array_equal(host(soft)[0], want_bad, equal_nan=True), ("caller argmin off the first NaN", no_prune)
     ssd16, am16 = U.correlate(dev(f)[None], dev(m)[None], hw, 1, shape, 12, storage="fp16")       # half-precision volume: same rule
     ref16 = rs.astype(np.float16)
     assert np.array_equal(host(ssd16), ref16, equal_nan=True)
