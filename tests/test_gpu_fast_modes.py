@@ -199,3 +199,20 @@ def test_drop_in_api_packs_the_field_on_the_device(M, dtype):
     assert not np.array_equal(outs[0], outs[1])                      # three live results: three distinct buffers
     many = list(M.convex_adam_pt_many([(fix, mv) for mv in movs], dtype=dtype, device=torch.device(DEV), **kw))
     assert len(many) == 3 and all(np.array_equal(a, b) for a, b in zip(many, outs))
+
+
+def test_sweep_scores_are_the_same_in_both_adam_modes():
+    """VERDICT round 3, acceptance of the fast Adam mode: the evaluation scalars of a registration (Dice, Dice of the hard labels, TRE,
+    HD95, log-Jacobian std) agree to three digits between adam_mode "exact" and "fast"."""
+    from convexadam_amd import sweep as S
+    from convexadam_amd.convex_adam_MIND import register_pair_device
+    dev0 = torch.device(DEV)
+    data = S.PairData((64, 72, 80), dev0)
+    fix, mov = data.pair(0)
+    lab = data.label(0)
+    kw = dict(mind_r=1, mind_d=2, grid_sp=4, disp_hw=4, grid_sp_adam=2, lambda_weight=1.25, selected_niter=80, ic=True)
+    res = {m: S.evaluate_item(register_pair_device(fix, mov, adam_mode=m, **kw), *lab) for m in ("exact", "fast")}
+    for k in ("dice", "dice30", "tre", "hd95", "jstd"):
+        a, b = res["exact"][k], res["fast"][k]
+        assert abs(a - b) <= 1e-3 * max(abs(a), 1e-3) + 5e-4, (k, a, b)
+    assert res["fast"]["dice"] > res["fast"]["dice_before"] + 0.1
