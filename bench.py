@@ -129,9 +129,11 @@ def reference_bits_check(fix, mov, dev):
                       and np.allclose(fd.square().sum((1, 2, 3)).numpy(), g["c1_adam_80_sumsq"], rtol=1e-14, atol=0))
     return dict(bit_identical_to_reference_capture=sub_equal and sums_equal, ms_per_pair=ms, pairs_per_s=1e3 / ms,
                 epe_vs_reference_80it=epe_sub, tolerance_met=bool(epe_sub < TOLERANCE_EPE),
-                reference_cross_host=dict(cross or {}, note="mean EPE (whole field, voxels) between the reference-bits pipeline with the GOLDEN host's MKL "
+                reference_cross_host=dict(cross or {}, this_host_cpu=host_cpu_model(), golden_host_cpu="Intel Xeon (AVX-512), the build container that captured tests/golden",
+                                          note="mean EPE (whole field, voxels) between the reference-bits pipeline with the GOLDEN host's MKL "
                                           "tables and with THIS host's (reference_bits.enable: built from this host's torch.exp / torch.sqrt), 8-thread mean "
-                                          "in both: how far two installs of the reference are from each other on this pair"),
+                                          "in both: how far two installs of the reference are from each other on this pair.  MKL dispatches on the CPU model, so the figure depends on "
+                                          "THIS host: 1.29e-3 at 80 iterations on three boxes of the round-4 pool, 4.7e-4 on a fourth (DESIGN.md section 10.1)"),
                 note="opt-in mode (convexadam_amd/reference_bits.py): MKL vsExp / vsSqrt of the golden host as tables + torch's 8-thread "
                      "mean; compared with the field captured from the reference at 80 iterations (tests/golden/fullsize.npz: every 8th "
                      "voxel per axis bit for bit, float64 sum and sum of squares of the whole field to 1e-14)")
@@ -241,6 +243,16 @@ def api_path(fix, mov, dev, engine_ms):
                      "165 MB / measured D2H rate + 2 x 27.5 MB / measured H2D rate")
 
 
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def effective_cores():
     """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the round-4 GPU boxes show 256 CPUs
     with cpu.max = 16 cores; 128 OpenMP threads on 16 cores' worth of quota only add throttling stalls)."""
@@ -274,7 +286,7 @@ def cpu_baseline(fix, mov, hip_field):
     parity = dict(epe_vs_oracle=epe, bit_identical=bool(np.array_equal(got, ref)), max_abs_diff=float(np.abs(got - ref).max()),
                   note="field of the last timed step vs oracle/cvx_oracle.c in the SAME mode (orc_adam_run_fast on the oracle's own convex stage) on the "
                        "same pair, full size; the modes against the reference itself: timed_mode / exact_mode / reference_bits_mode below")
-    base = dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port", seconds_per_pair=dt,
+    base = dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port", seconds_per_pair=dt, host_cpu=host_cpu_model(),
                 sample="1 full 160x192x224 pair (MIND r1 d2, gs6, hw6, ic, 80 Adam its) with oracle/cvx_oracle.c, "
                        "OpenMP over %d threads (= the cores this container may use: %d CPUs visible, capped by the cgroup CPU quota); "
                        "reference PyTorch-CPU figure from BASELINE.md: 77.4 s/pair on 8 cores" % (cores, visible))
