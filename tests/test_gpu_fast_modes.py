@@ -216,3 +216,36 @@ def test_sweep_scores_are_the_same_in_both_adam_modes():
         a, b = res["exact"][k], res["fast"][k]
         assert abs(a - b) <= 1e-3 * max(abs(a), 1e-3) + 5e-4, (k, a, b)
     assert res["fast"]["dice"] > res["fast"]["dice_before"] + 0.1
+
+
+@pytest.mark.timeout(1800)
+def test_full_size_masked_config3_and_label_features_in_fast_adam_mode(M, U, orc, golden):
+    """BASELINE configs[2] (224x192x224, ellipsoid masks, disp_hw 8) and the multi-channel label-feature path of configs[3] through
+    adam_mode="fast": against the reference's capture the masked pipeline stays inside the north-star tolerance at 20 iterations, and
+    both are bit-identical to the oracle's fast restatement on caller-supplied features (C = 12 and C = 18: zero-padded feature chunks)."""
+    from convexadam_amd.phantom import deformed_pair, ellipsoid_mask
+    g = golden("fullsize")
+    s = int(g["sub"])
+    shape = (224, 192, 224)
+    fix, mov = deformed_pair(shape, 3, 10.0)
+    mf, mm = ellipsoid_mask(shape, 0.35), ellipsoid_mask(shape, 0.35, shift=(4, -3, 5))
+    kw = dict(lambda_weight=1.25, grid_sp=6, disp_hw=8, selected_niter=20, selected_smooth=0, grid_sp_adam=2, ic=True)
+    ff, fm = M.extract_features(fix, mov, 1, 2, True, mf, mm, device=torch.device(DEV), dtype=torch.float32)
+    out = host(M.register_pair_device(feat_fixed=ff[0], feat_moving=fm[0], adam_mode="fast", **kw))
+    e = epe(np.moveaxis(out[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["c3_adam_20_sub"], 0, -1))
+    exact = host(M.register_pair_device(feat_fixed=ff[0], feat_moving=fm[0], adam_mode="exact", **kw))
+    e_exact = epe(np.moveaxis(exact[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["c3_adam_20_sub"], 0, -1))
+    print("configs[2] full size, 20 Adam iterations: adam_mode=fast vs reference mean EPE %.3e (exact mode %.3e)" % (e, e_exact))
+    assert e < 1e-3
+    ref = orc.convex_adam_pipeline(None, None, features=(host(ff)[0], host(fm)[0]), adam_mode="fast", **kw)
+    assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), ref)
+    # label features (C = 18 -> five chunks, the last one half empty), smaller grid
+    rng = np.random.default_rng(7)
+    sh = (48, 40, 56)
+    lab_f = rng.integers(0, 18, sh).astype(np.float32)
+    lab_m = np.roll(lab_f, (1, -2, 1), (0, 1, 2))
+    f18, m18, _ = orc.label_features(lab_f, lab_m)
+    kw2 = dict(lambda_weight=1.25, grid_sp=4, disp_hw=3, selected_niter=6, grid_sp_adam=2, ic=True)
+    out2 = host(M.register_pair_device(feat_fixed=dev(f18), feat_moving=dev(m18), adam_mode="fast", **kw2))
+    ref2 = orc.convex_adam_pipeline(None, None, features=(f18, m18), adam_mode="fast", **kw2)
+    assert np.array_equal(np.moveaxis(out2, 0, -1).astype(np.float64), ref2)
