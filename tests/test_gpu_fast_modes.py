@@ -249,3 +249,43 @@ def test_full_size_masked_config3_and_label_features_in_fast_adam_mode(M, U, orc
     out2 = host(M.register_pair_device(feat_fixed=dev(f18), feat_moving=dev(m18), adam_mode="fast", **kw2))
     ref2 = orc.convex_adam_pipeline(None, None, features=(f18, m18), adam_mode="fast", **kw2)
     assert np.array_equal(np.moveaxis(out2, 0, -1).astype(np.float64), ref2)
+
+
+@pytest.mark.parametrize("shape", [(5, 7, 1100), (3, 700, 9), (700, 3, 9), (9, 11, 65), (2, 3, 1024), (6, 641, 4)])
+def test_edt_squared_paths_agree_with_scipy(shape):
+    """The round-4 distance-transform passes against scipy AND against the sequential passes they replace (option edt_sequential):
+    rows of more than 1024 voxels (the row pass falls back from ballots to lane scans), lines longer than 640 voxels (the tiled
+    outward search does not fit the LDS: sequential lower envelope), all-ones rows / planes, and the label-map entry point
+    (cvx_edt_squared_labels_i32: mask and complement straight from the map) against the same transforms of materialised masks."""
+    import ctypes as C
+    from scipy.ndimage import distance_transform_edt as edt
+    from convexadam_amd import _lib
+    from convexadam_amd import convexAdam_hyper_util as HU
+    from convexadam_amd._lib import check, lib, ptr, stream_ptr, workspace
+    L = lib()
+    rng = np.random.default_rng(sum(shape))
+    for pz in (0.3, 0.97, 0.9995):
+        m = (rng.random(shape) < pz).astype(np.float32)
+        m[tuple(s // 2 for s in shape)] = 0
+        want = np.round(edt(m).astype(np.float64) ** 2).astype(np.int64)
+        got = {}
+        for seq in (0, 1):
+            assert L.cvx_set_option(b"edt_sequential", seq) == 0
+            try:
+                got[seq] = host(HU.edt_squared(dev(m))).astype(np.int64)
+            finally:
+                L.cvx_set_option(b"edt_sequential", 0)
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want), (shape, pz)
+    seg = rng.integers(0, 4, shape).astype(np.float32)
+    labs = [1, 3]
+    H, W, D = shape
+    out = torch.empty((len(labs), 2, H, W, D), dtype=torch.int32, device=DEV)
+    nws = L.cvx_edt_squared_workspace_bytes(2 * len(labs), H, W, D)
+    ws = workspace(nws, torch.device(DEV))
+    arr = (C.c_int * len(labs))(*labs)
+    check(L.cvx_edt_squared_labels_i32(ptr(dev(seg)), H, W, D, C.cast(arr, C.c_void_p), len(labs), ptr(out), ptr(ws), nws, stream_ptr(torch.device(DEV))))
+    for i, lab in enumerate(labs):
+        inside = (seg == lab).astype(np.float32)
+        for k, obj in enumerate((inside, 1 - inside)):
+            if (obj == 0).any():
+                assert np.array_equal(host(out[i, k]), host(HU.edt_squared(dev(obj)))), (shape, lab, k)
