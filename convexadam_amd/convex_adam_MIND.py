@@ -34,8 +34,8 @@ _default_adam_mode = os.environ.get("CONVEXADAM_ADAM_MODE", "fast")
 def set_default_adam_mode(mode):
     """'fast' or 'exact'; returns the previous default."""
     global _default_adam_mode
-    if mode not in ("exact", "fast"):
-        raise ValueError("adam mode must be 'exact' or 'fast'")
+    if mode not in ("exact", "fast", "fast_all"):
+        raise ValueError("adam mode must be 'exact', 'fast' or 'fast_all'")
     prev, _default_adam_mode = _default_adam_mode, mode
     return prev
 
@@ -160,12 +160,12 @@ def register_pair_device(img_fixed=None, img_moving=None, feat_fixed=None, feat_
         raise UnboundLocalError("local variable 'disp_sample' referenced before assignment "
                                 "(selected_niter=0 with lambda_weight>0, convex_adam_MIND.py:181)")
     adam_mode = _resolve_adam_mode(adam_mode, n_spline_pools, storage)
-    if cost not in ("ssd", "sad") or corr_mode not in ("exact", "fast") or storage not in ("fp32", "fp16") or adam_mode not in ("exact", "fast"):
-        raise ValueError("cost must be 'ssd' or 'sad', corr_mode / adam_mode 'exact' or 'fast', storage 'fp32' or 'fp16'")
+    if cost not in ("ssd", "sad") or corr_mode not in ("exact", "fast") or storage not in ("fp32", "fp16") or adam_mode not in ("exact", "fast", "fast_all"):
+        raise ValueError("cost must be 'ssd' or 'sad', corr_mode 'exact' or 'fast', adam_mode 'exact', 'fast' or 'fast_all', storage 'fp32' or 'fp16'")
     p = PairParams(H, W, D, int(mind_r), int(mind_d), float(lambda_weight), int(grid_sp), int(disp_hw), int(selected_niter),
                    int(selected_smooth), int(grid_sp_adam), 1 if ic else 0, n_feat, float(cost_scale), 1 if cost == "sad" else 0,
                    int(n_box), int(n_spline_pools), 1 if corr_mode == "fast" else 0, 1 if storage == "fp16" else 0)
-    p.adam_fast = 1 if adam_mode == "fast" else 0
+    p.adam_fast = {"exact": 0, "fast": 1, "fast_all": 2}[adam_mode]
     L = lib()
     nws = L.cvx_register_pair_workspace_bytes(C.byref(p))
     if nws == 0:
@@ -203,7 +203,7 @@ def register_pair_snapshots_device(img_fixed=None, img_moving=None, feat_fixed=N
     sms = [int(v) for v in smooths]
     p = PairParams(H, W, D, int(mind_r), int(mind_d), float(lambda_weight), int(grid_sp), int(disp_hw), its[-1], 0, int(grid_sp_adam),
                    1 if ic else 0, n_feat, float(cost_scale), 0, 0, int(n_spline_pools), 0, 0)
-    p.adam_fast = 1 if _resolve_adam_mode(adam_mode, n_spline_pools) == "fast" else 0
+    p.adam_fast = {"exact": 0, "fast": 1, "fast_all": 2}[_resolve_adam_mode(adam_mode, n_spline_pools)]
     L = lib()
     it_arr = (C.c_int * len(its))(*its)
     sm_arr = (C.c_int * len(sms))(*sms)
@@ -233,7 +233,7 @@ def register_pairs_device(imgs_fixed, imgs_moving, outs=None, n_streams=2, mind_
         raise UnboundLocalError("local variable 'disp_sample' referenced before assignment (convex_adam_MIND.py:181)")
     p = PairParams(H, W, D, int(mind_r), int(mind_d), float(lambda_weight), int(grid_sp), int(disp_hw), int(selected_niter),
                    int(selected_smooth), int(grid_sp_adam), 1 if ic else 0, 0, float(cost_scale))
-    p.adam_fast = 1 if _resolve_adam_mode(adam_mode) == "fast" else 0
+    p.adam_fast = {"exact": 0, "fast": 1, "fast_all": 2}[_resolve_adam_mode(adam_mode)]
     L = lib()
     per = L.cvx_register_pair_workspace_bytes(C.byref(p))
     if per == 0:

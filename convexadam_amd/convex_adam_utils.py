@@ -214,13 +214,14 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
     convexadam_amd.convexAdam_hyper_util replaces the three 3^3 boxes (adam_run_withconfig_shiftSpline.py:217).
     storage="fp16": the loop keeps its copies of the features in half precision (rounded once; float32 arithmetic).
     mode="fast": throughput arithmetic (cvx_adam_run_fast_f32: FMA / factored warp gradient, separable adjoint boxes, one division in
-    the update; forward boxes in ATen's order) -- same mathematics, graded by end-point error; packaged smoother, float32 only."""
+    the update; forward boxes in ATen's order) -- same mathematics, graded by end-point error; packaged smoother, float32 only;
+    mode="fast_all": the forward boxes separable too (cvx_adam_run_fast_all_f32; faster, outside the fast mode's acceptance criteria)."""
     if storage not in ("fp32", "fp16"):
         raise ValueError("storage must be 'fp32' or 'fp16', got %r" % (storage,))
-    if mode not in ("exact", "fast"):
-        raise ValueError("mode must be 'exact' or 'fast', got %r" % (mode,))
-    if mode == "fast" and (smoother is not None or storage != "fp32"):
-        raise ValueError("mode='fast' supports the packaged three 3^3 boxes and float32 storage only")
+    if mode not in ("exact", "fast", "fast_all"):
+        raise ValueError("mode must be 'exact', 'fast' or 'fast_all', got %r" % (mode,))
+    if mode != "exact" and (smoother is not None or storage != "fp32"):
+        raise ValueError("mode=%r supports the packaged three 3^3 boxes and float32 storage only" % mode)
     F2 = f32c(require_device_tensor(feat_fix, "feat_fix"))
     M2 = f32c(require_device_tensor(feat_mov, "feat_mov"))
     _, Cn, h, w, d = [int(s) for s in F2.shape]
@@ -241,8 +242,9 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
     nws = lib().cvx_adam_workspace_bytes(Cn, h, w, d)
     ws = workspace(nws, dev)
     with torch.cuda.device(dev):
-        if mode == "fast":
-            check(lib().cvx_adam_run_fast_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
+        if mode in ("fast", "fast_all"):
+            fn = lib().cvx_adam_run_fast_f32 if mode == "fast" else lib().cvx_adam_run_fast_all_f32
+            check(fn(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
                                               int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
                                               C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf),
                                               ptr(ws), nws, stream_ptr(dev)))

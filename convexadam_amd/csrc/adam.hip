@@ -194,7 +194,7 @@ extern "C" int cvx_adam_run_smoother_f32(const float* F2, const float* M2, int C
                                          const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
                                          void* workspace, size_t workspace_bytes, void* stream) {
     return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
-                              snapshot_iters_host, n_snap, snapshots, sm, true, false, false, workspace, workspace_bytes, stream);
+                              snapshot_iters_host, n_snap, snapshots, sm, true, false, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int cvx_adam_run_fast_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
@@ -203,7 +203,16 @@ extern "C" int cvx_adam_run_fast_f32(const float* F2, const float* M2, int C, in
                                      const int* snapshot_iters_host, int n_snap, float* snapshots, void* workspace,
                                      size_t workspace_bytes, void* stream) {
     return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
-                              snapshot_iters_host, n_snap, snapshots, nullptr, true, false, true, workspace, workspace_bytes, stream);
+                              snapshot_iters_host, n_snap, snapshots, nullptr, true, false, 1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cvx_adam_run_fast_all_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
+                                         float lambda_weight, int niter, int step0, float cost_scale, const float* base_h,
+                                         const float* base_w, const float* base_d, float* U, float* grad_out,
+                                         const int* snapshot_iters_host, int n_snap, float* snapshots, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
+                              snapshot_iters_host, n_snap, snapshots, nullptr, true, false, 2, workspace, workspace_bytes, stream);
 }
 
 extern "C" int cvx_box3_fast_f32(const float* in, int h, int w, int d, float* out, void* stream) {
@@ -218,7 +227,7 @@ extern "C" int cvx_adam_run_ex_f32(const float* F2, const float* M2, int C, int 
                                    int feature_storage, void* workspace, size_t workspace_bytes, void* stream) {
     CVX_REQUIRE(feature_storage == 0 || feature_storage == 1, "cvx_adam_run_ex_f32: feature_storage must be 0 (float32) or 1 (fp16)");
     return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
-                              snapshot_iters_host, n_snap, snapshots, sm, true, feature_storage == 1, false, workspace, workspace_bytes, stream);
+                              snapshot_iters_host, n_snap, snapshots, sm, true, feature_storage == 1, 0, workspace, workspace_bytes, stream);
 }
 
 // keep_state = false (whole-pair pipeline): P, m, v are scratch there and the result is U of the LAST forward pass
@@ -226,7 +235,7 @@ extern "C" int cvx_adam_run_ex_f32(const float* F2, const float* M2, int C, int 
 int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
                        float lambda_weight, int niter, int step0, float cost_scale, const float* base_h, const float* base_w,
                        const float* base_d, float* U, float* grad_out, const int* snapshot_iters_host, int n_snap,
-                       float* snapshots, const cvx_smoother* sm, bool keep_state, bool f16_features, bool fast, void* workspace,
+                       float* snapshots, const cvx_smoother* sm, bool keep_state, bool f16_features, int fast, void* workspace,
                        size_t workspace_bytes, void* stream) {
     CVX_REQUIRE(F2 && M2 && P && m && v && U && base_h && base_w && base_d, "cvx_adam_run_f32: null pointer");
     CVX_REQUIRE(C > 0 && h > 1 && w > 1 && d > 1, "cvx_adam_run_f32: bad extent C=%d %dx%dx%d", C, h, w, d);
@@ -271,7 +280,8 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
         const double beta1 = 0.9, beta2 = 0.999;
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
         const AdamConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)(-(1.0 / bc1)), adam_sqrt_table()};
-        if (fused) { if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc; }
+        if (fast == 2) { if ((rc = launch_box3_fast(P, U, h, w, d, nullptr, nullptr, nullptr, 1.0, 1.0, nullptr, s))) return rc; }   // "fast_all": separable forward boxes too
+        else if (fused) { if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc; }
         else if ((rc = launch_smoother(P, U, t1, 3, h, w, d, *sm, false, s))) return rc;
         const bool last = it == niter - 1;
         if (!(last && !keep_state && !grad_out)) {

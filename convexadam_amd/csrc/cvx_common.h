@@ -351,7 +351,7 @@ __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& 
 int adam_run_impl(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v, float lambda_weight,
                   int niter, int step0, float cost_scale, const float* base_h, const float* base_w, const float* base_d, float* U,
                   float* grad_out, const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
-                  bool keep_state, bool f16_features, bool fast, void* workspace, size_t workspace_bytes, void* stream);
+                  bool keep_state, bool f16_features, int fast, void* workspace, size_t workspace_bytes, void* stream);   // fast: 0 exact, 1 fast, 2 fast_all
 // convex.hip: coupled convex regularisation behind cvx_coupled_convex_f32 (argmin_is_exact: see there)
 int coupled_convex_impl(const void* ssd, bool f16, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
                         bool argmin_is_exact, void* workspace, size_t workspace_bytes, void* stream);

@@ -180,8 +180,8 @@ static int validate(const cvx_pair_params* p) {
     CVX_REQUIRE((p->cost == 0 || p->cost == 1) && (p->n_box == 0 || p->n_box == 1 || p->n_box == 2) &&
                 (p->n_spline_pools == 0 || p->n_spline_pools == 2 || p->n_spline_pools == 3) && (p->corr_fast == 0 || p->corr_fast == 1) &&
                 (p->fp16_storage == 0 || p->fp16_storage == 1), "cvx_register_pair: bad variant fields (cost, n_box, n_spline_pools, corr_fast, fp16_storage)");
-    CVX_REQUIRE((p->adam_fast == 0 || p->adam_fast == 1) && p->reserved_[0] == 0 && p->reserved_[1] == 0 && p->reserved_[2] == 0,
-                "cvx_register_pair: adam_fast must be 0 or 1 and the reserved fields zero (struct laid out by an older header? check cvx_version())");
+    CVX_REQUIRE((p->adam_fast == 0 || p->adam_fast == 1 || p->adam_fast == 2) && p->reserved_[0] == 0 && p->reserved_[1] == 0 && p->reserved_[2] == 0,
+                "cvx_register_pair: adam_fast must be 0, 1 or 2 and the reserved fields zero (struct laid out by an older header? check cvx_version())");
     CVX_REQUIRE(!p->adam_fast || (p->n_spline_pools != 2 && !p->fp16_storage), "cvx_register_pair: adam_fast needs the packaged smoother and float32 storage");
     if (p->lambda_weight > 0) {
         CVX_REQUIRE(p->selected_niter >= 1, "cvx_register_pair: selected_niter must be >= 1 when lambda_weight > 0 "
@@ -399,7 +399,7 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
         const cvx_smoother two_pools = {0, 2, {3, 3, 0, 0}, {0.f, 0.f, 0.f, 0.f, 0.f}};            // task3_docker.py:191
         if ((rc = adam_run_impl(F(L.F2), F(L.M2), L.C, L.h2, L.w2, L.d2, F(L.P), F(L.m), F(L.v_), p->lambda_weight,
                                 p->selected_niter, 0, p->cost_scale, F(L.bh2), F(L.bw2), F(L.bd2), F(L.U), nullptr, snap_iters_host, n_snap,
-                                n_snap ? F(L.snaps) : nullptr, p->n_spline_pools == 2 ? &two_pools : nullptr, /*keep_state=*/false, f16, p->adam_fast != 0, ws + L.adam_ws,
+                                n_snap ? F(L.snaps) : nullptr, p->n_spline_pools == 2 ? &two_pools : nullptr, /*keep_state=*/false, f16, p->adam_fast, ws + L.adam_ws,
                                 cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2), stream))) return rc;
         mark("adam", s);
         // disp_hr = interpolate(fitted_grid * grid_sp_adam, (H,W,D))                            (:182)

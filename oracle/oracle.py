@@ -74,7 +74,7 @@ def lib():
                                                                             C.c_int, C.c_float, _f32p, C.c_void_p, C.c_void_p, C.POINTER(Smoother)]
         L.orc_fast_box3x3.argtypes = [_f32p, _f32p] + [C.c_int] * 4
         L.orc_adam_run_fast.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [_f32p, _f32p, _f32p, C.c_float, C.c_int,
-                                                                        C.c_int, C.c_float, _f32p, C.c_void_p, C.c_int]
+                                                                        C.c_int, C.c_float, _f32p, C.c_void_p, C.c_int, C.c_int]
         L.orc_label_features.argtypes = [_f32p, _f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_label_features.restype = C.c_int
         L.orc_feature_transform.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -275,16 +275,17 @@ def fast_box3x3(x):
 def adam_run(F2, M2, P, lambda_weight, niter, m=None, v=None, step0=0, cost_scale=12.0, want_grad=False, smoother=None, mode="exact",
              keep_last_step=True):
     """Runs `niter` Adam iterations in place on copies; returns dict(P, m, v, U, G, loss).
-    mode="fast": the tolerance-graded throughput arithmetic (orc_adam_run_fast; three 3^3 boxes only); keep_last_step=False skips the
+    mode="fast": the tolerance-graded throughput arithmetic (orc_adam_run_fast; three 3^3 boxes only), "fast_all": the same with the
+    forward boxes in separable arithmetic too (faster, but outside the acceptance criteria); keep_last_step=False skips the
     gradient + update of the final iteration like the whole-pair pipeline does (U is the same either way)."""
     F2 = _f(F2); M2 = _f(M2); c, h, w, d = F2.shape
     P = _f(P).copy(); m = np.zeros_like(P) if m is None else _f(m).copy(); v = np.zeros_like(P) if v is None else _f(v).copy()
     U = np.zeros_like(P); G = np.zeros_like(P) if want_grad else None; loss = np.zeros(max(niter, 1), np.float32)
-    if mode == "fast":
+    if mode in ("fast", "fast_all"):
         assert smoother is None, "fast mode: the packaged three 3^3 boxes only"
         lib().orc_adam_run_fast(F2.reshape(-1), M2.reshape(-1), c, h, w, d, P.reshape(-1), m.reshape(-1), v.reshape(-1),
                                 float(lambda_weight), int(niter), int(step0), float(cost_scale), U.reshape(-1),
-                                G.ctypes.data_as(C.c_void_p) if G is not None else None, 1 if keep_last_step else 0)
+                                G.ctypes.data_as(C.c_void_p) if G is not None else None, 1 if keep_last_step else 0, 1 if mode == "fast_all" else 0)
         return dict(P=P, m=m, v=v, U=U, G=G, loss=None)
     assert mode == "exact", mode
     lib().orc_adam_run_smoother(F2.reshape(-1), M2.reshape(-1), c, h, w, d, P.reshape(-1), m.reshape(-1), v.reshape(-1),

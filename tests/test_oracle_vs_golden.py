@@ -462,7 +462,16 @@ def test_fast_adam_mode_acceptance_against_the_reference_capture(orc, golden):
                 orc.adam_run(st["F2"], st["M2"], st["P0"], 1.25, n)
             f = orc.resize_trilinear(r["U"] * np.float32(2), shape)
             res[mode, n] = epe(np.moveaxis(f[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["c1_adam_%d_sub" % n], 0, -1))
-    print("fast mode vs reference capture:", {n: "%.3e" % res["fast", n] for n in snaps}, "exact at 80: %.3e" % res["exact", 80])
+    # adam_mode "fast_all" (forward boxes separable too) is offered but does NOT meet the criteria: the reason the forward boxes of
+    # "fast" keep ATen's order
+    for n in (20, 80):
+        r = orc.adam_run(st["F2"], st["M2"], st["P0"], 1.25, n, mode="fast_all", keep_last_step=False)
+        f = orc.resize_trilinear(r["U"] * np.float32(2), shape)
+        res["fast_all", n] = epe(np.moveaxis(f[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["c1_adam_%d_sub" % n], 0, -1))
+    assert res["fast_all", 20] > 3 * res["fast", 20] and res["fast_all", 80] > float(g["c1_self_perturbation_epe_sub"][snaps.index(80)])
+    assert res["fast_all", 80] < 3e-3
+    print("fast mode vs reference capture:", {n: "%.3e" % res["fast", n] for n in snaps}, "exact at 80: %.3e" % res["exact", 80],
+          "fast_all at 20 / 80: %.3e / %.3e" % (res["fast_all", 20], res["fast_all", 80]))
     assert res["fast", 1] <= 1e-6 and res["fast", 20] < 1e-3 and res["fast", 40] < 1e-3
     assert res["fast", 80] <= float(g["c1_self_perturbation_epe_sub"][snaps.index(80)])
     assert res["fast", 80] <= 1.15 * res["exact", 80]
