@@ -38,6 +38,7 @@ CFG = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6, disp_hw=6, selecte
 # section 7 against the reference's own capture (tests/test_gpu_fast_modes.py::test_full_size_fast_adam_acceptance); everything before
 # the Adam loop is bit-identical to the reference-order path.  TIMED_MODE_NAME goes into the JSON line.
 TIMED = dict(CFG, adam_mode="fast")
+EXACT = dict(CFG, adam_mode="exact")            # every operator in the reference's evaluation order (CFG alone would take the package default)
 TIMED_MODE_NAME = "adam_mode=fast (FMA / factored warp gradient, separable adjoint boxes, one-division update; forward boxes, MIND, correlation, coupled convex in the reference's order)"
 HBM_PEAK_GBS = 8000.0
 TOLERANCE_EPE = 1e-3          # north_star: mean end-point error against the reference's field, voxels
@@ -96,15 +97,15 @@ def reference_bits_check(fix, mov, dev):
     golden_host = {}
     try:
         for _ in range(2):
-            f = register_pair_device(fix, mov, **CFG)
+            f = register_pair_device(fix, mov, **EXACT)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(5):
-            f = register_pair_device(fix, mov, **CFG)
+            f = register_pair_device(fix, mov, **EXACT)
         torch.cuda.synchronize(dev)
         ms = (time.perf_counter() - t0) / 5 * 1e3
         for n in horizons:
-            golden_host[n] = f if n == CFG["selected_niter"] else register_pair_device(fix, mov, **dict(CFG, selected_niter=n))
+            golden_host[n] = f if n == CFG["selected_niter"] else register_pair_device(fix, mov, **dict(EXACT, selected_niter=n))
     finally:
         rb.disable()
     # the reference's own reproducibility ACROSS HOSTS: the same reference-bits pipeline with the tables of the golden host (a Xeon) and
@@ -114,7 +115,7 @@ def reference_bits_check(fix, mov, dev):
         rb.enable(dev, threads=8)
         cross = {}
         for n in horizons:
-            g2 = register_pair_device(fix, mov, **dict(CFG, selected_niter=n))
+            g2 = register_pair_device(fix, mov, **dict(EXACT, selected_niter=n))
             cross["epe_%dit" % n] = float((g2 - golden_host[n]).square().sum(0).sqrt().mean())
     except Exception as e:                                      # a host whose torch has no MKL path etc.: report, do not fail the bench
         cross = {"error": repr(e)}
@@ -132,8 +133,8 @@ def reference_bits_check(fix, mov, dev):
                 reference_cross_host=dict(cross or {}, this_host_cpu=host_cpu_model(), golden_host_cpu="Intel Xeon (AVX-512), the build container that captured tests/golden",
                                           note="mean EPE (whole field, voxels) between the reference-bits pipeline with the GOLDEN host's MKL "
                                           "tables and with THIS host's (reference_bits.enable: built from this host's torch.exp / torch.sqrt), 8-thread mean "
-                                          "in both: how far two installs of the reference are from each other on this pair.  MKL dispatches on the CPU model, so the figure depends on "
-                                          "THIS host: 1.29e-3 at 80 iterations on three boxes of the round-4 pool, 4.7e-4 on a fourth (DESIGN.md section 10.1)"),
+                                          "in both (exact Adam mode): how far two installs of the reference are from each other on this pair.  MKL dispatches on the CPU "
+                                          "model, so the figure belongs to THIS host's CPU"),
                 note="opt-in mode (convexadam_amd/reference_bits.py): MKL vsExp / vsSqrt of the golden host as tables + torch's 8-thread "
                      "mean; compared with the field captured from the reference at 80 iterations (tests/golden/fullsize.npz: every 8th "
                      "voxel per axis bit for bit, float64 sum and sum of squares of the whole field to 1e-14)")
@@ -157,18 +158,18 @@ def mode_parity(fix, mov, dev, timed_field):
     g = np.load(os.path.join(ROOT, "tests", "golden", "fullsize.npz"))
     self_pert = float(g["c1_self_perturbation_epe_sub"][list(g["c1_snaps"]).index(80)])
     out = {}
-    for name, cfg in (("timed_mode", TIMED), ("exact_mode", CFG)):
+    for name, cfg in (("timed_mode", TIMED), ("exact_mode", EXACT)):
         e = {}
         for n in (1, 20, 40, 80):
             f = timed_field if (name == "timed_mode" and n == 80) else register_pair_device(fix, mov, **dict(cfg, selected_niter=n)).cpu().numpy()
             e["epe_vs_reference_%dit" % n] = epe_vs_reference(f, n)
         out[name] = e
     for _ in range(2):
-        register_pair_device(fix, mov, **CFG)
+        register_pair_device(fix, mov, **EXACT)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(5):
-        register_pair_device(fix, mov, **CFG)
+        register_pair_device(fix, mov, **EXACT)
     torch.cuda.synchronize(dev)
     out["exact_mode"]["ms_per_pair"] = (time.perf_counter() - t0) / 5 * 1e3
     out["exact_mode"]["note"] = "every operator in the reference's evaluation order (library expf / IEEE sqrt / exactly rounded mean); bit-identical to oracle/cvx_oracle.c"
@@ -442,7 +443,7 @@ def main():
         hc = st.get("correlate", []) + st.get("correlate_rev", [])
         conv32 = register_pair_device(fix, mov, **dict(CFG, lambda_weight=0))
         conv16 = register_pair_device(fix, mov, storage="fp16", **dict(CFG, lambda_weight=0))
-        out32 = register_pair_device(fix, mov, **CFG)             # fp16 storage runs the reference-order Adam loop: compare like with like
+        out32 = register_pair_device(fix, mov, **EXACT)           # fp16 storage runs the reference-order Adam loop: compare like with like
         cc_worst["fp16"] = dict(ms_per_pair=t16 * 1e3, corr_ms=sum(hc) / max(len(hc), 1), adam_ms=sum(st.get("adam", [0.0])) / max(len(st.get("adam", [0.0])), 1),
                                 argmin_ms=sum(st.get("argmin", [0.0])) / max(len(st.get("argmin", [0.0])), 1),
                                 epe_vs_fp32_field=float((h16_field - out32).square().sum(0).sqrt().mean()),

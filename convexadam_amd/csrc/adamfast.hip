@@ -14,7 +14,7 @@
 //     pattern of U itself is what keeps the trajectory next to the reference's (measured on the CPU restatement: fast forward boxes
 //     alone move the 80-iteration field 2.2e-3 voxels away, everything else together 1.3e-3 -- the exact mode's own distance).
 // Every operation is a correctly rounded IEEE operation in a fixed order; oracle/cvx_oracle.c::orc_adam_run_fast restates it, and the
-// GPU tests compare bit for bit.  Roofline (profiles/r04_v2_*): every kernel boundary empties the per-XCD L2s, so both kernels stream
+// GPU tests compare bit for bit.  Roofline (profiles/r04_v3_*): every kernel boundary empties the per-XCD L2s, so both kernels stream
 // their operands from the Infinity Cache / HBM each iteration -- k_warp_grad_fast 125 MB in 22 us (5.7 TB/s, and at the same time at
 // the vector L1's limit: 27 gathers of 16 bytes per voxel = 371 MB at 19.5 TB/s of L1 hits), k_box3_fast 76 MB in 16 us (4.8 TB/s; a
 // device copy reaches 5.1): memory-bound, no MFMA (stencil + gather).
