@@ -255,7 +255,8 @@ def api_path(fix, mov, dev, engine_ms):
                 output_bytes=nbytes_out,
                 note="convex_adam_pt(host, host) -> host (H,W,D,3) float64 with dtype=float16 (the reference's default) and adam_mode='fast': torch "
                      "uploads, cvx_register_pair_f32, cvx_pack_field_f64 writing straight into pooled pinned host memory; ms_per_pair = median of 12 calls; 'overlapped' = "
-                     "convex_adam_pt_many (packing of pair i on a side stream beside the registration of pair i+1); bound = engine time + "
+                     "convex_adam_pt_many (pair i+1 uploaded from pinned staging on its own stream while pair i registers; the field of pair i packed into a device "
+                     "buffer and moved by a copy engine on a side stream); bound = engine time + "
                      "165 MB / measured D2H rate + 2 x 27.5 MB / measured H2D rate")
 
 
