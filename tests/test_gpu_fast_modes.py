@@ -291,3 +291,25 @@ def test_edt_squared_paths_agree_with_scipy(shape):
         for k, obj in enumerate((inside, 1 - inside)):
             if (obj == 0).any():
                 assert np.array_equal(host(out[i, k]), host(HU.edt_squared(dev(obj)))), (shape, lab, k)
+
+
+def test_convex_adam_pt_many_with_changing_shapes_and_early_exit(M):
+    """The pipelined batch API re-sizes its staging / device / pinned buffers when the volume shape changes, yields results in order, works
+    for a single pair and an empty iterable, and may be abandoned half way (pending copies finish on their streams)."""
+    from convexadam_amd.phantom import phantom
+    kw = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=4, disp_hw=2, selected_niter=3, grid_sp_adam=2, ic=True, adam_mode="fast")
+    shapes = [(40, 36, 44), (32, 48, 40), (32, 48, 40), (40, 36, 44), (24, 28, 36)]
+    pairs = [(phantom(sh, 3 + i, 30 + i), torch.roll(phantom(sh, 3 + i, 40 + i), (1, -1, 2), (0, 1, 2))) for i, sh in enumerate(shapes)]
+    want = [M.convex_adam_pt(f, m, dtype=torch.float32, device=torch.device(DEV), **kw).copy() for f, m in pairs]
+    got = list(M.convex_adam_pt_many(pairs, dtype=torch.float32, device=torch.device(DEV), **kw))
+    assert len(got) == len(want) and all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(got, want))
+    assert list(M.convex_adam_pt_many([], device=torch.device(DEV), **kw)) == []
+    one = list(M.convex_adam_pt_many(pairs[:1], dtype=torch.float32, device=torch.device(DEV), **kw))
+    assert len(one) == 1 and np.array_equal(one[0], want[0])
+    gen = M.convex_adam_pt_many(pairs, dtype=torch.float32, device=torch.device(DEV), **kw)
+    first = next(gen)
+    gen.close()
+    torch.cuda.synchronize()
+    assert np.array_equal(first, want[0])
+    again = M.convex_adam_pt(*pairs[1], dtype=torch.float32, device=torch.device(DEV), **kw)
+    assert np.array_equal(again, want[1])
