@@ -99,6 +99,9 @@ SIGNATURES = {
                                    _vp, _vp, _sz, _vp]),
     "cvx_adam_run_fast_all_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                                        _vp, _vp, _sz, _vp]),
+    "cvx_adam_run_mode_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                   _vp, C.POINTER(Smoother), _i, _vp, _sz, _vp]),
+    "cvx_smooth_fast_f32": (_i, [_vp, _i, _i, _i, C.POINTER(Smoother), _i, _vp, _vp]),
     "cvx_box3_fast_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "cvx_register_pair_workspace_bytes": (_sz, [C.POINTER(PairParams)]),
     "cvx_register_pair_f32": (_i, [_vp, _vp, _vp, _vp, C.POINTER(PairParams), _vp, _vp, _vp, _sz, _vp]),

@@ -188,6 +188,19 @@ def box_smooth(x, k, passes=1):
     return out if x.dtype == torch.float32 else out.to(x.dtype)
 
 
+def smooth_fast(x, smoother, backward=False):
+    """The separable restatement of a box-chain smoother (convexAdam_hyper_util.kovesi_spline) on a (1,3,h,w,d) / (3,h,w,d) device
+    tensor (cvx_smooth_fast_f32); backward = the adjoint."""
+    t = f32c(require_device_tensor(x, "x"))
+    h, w, d = [int(s) for s in t.shape[-3:]]
+    if t.numel() != 3 * h * w * d:
+        raise ValueError("smooth_fast expects three channels")
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        check(lib().cvx_smooth_fast_f32(ptr(t), h, w, d, C.byref(smoother.spec), 1 if backward else 0, ptr(out), stream_ptr(t.device)))
+    return out
+
+
 def box3_fast(x):
     """The separable restatement of box3(box3(box3(x))) (zero padding per stage) that adam_mode "fast" uses for the adjoint:
     x (1,3,h,w,d) or (3,h,w,d) device tensor -> same shape (cvx_box3_fast_f32)."""
@@ -220,8 +233,8 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
         raise ValueError("storage must be 'fp32' or 'fp16', got %r" % (storage,))
     if mode not in ("exact", "fast", "fast_all"):
         raise ValueError("mode must be 'exact', 'fast' or 'fast_all', got %r" % (mode,))
-    if mode != "exact" and (smoother is not None or storage != "fp32"):
-        raise ValueError("mode=%r supports the packaged three 3^3 boxes and float32 storage only" % mode)
+    if mode != "exact" and storage != "fp32":
+        raise ValueError("mode=%r supports float32 storage only" % mode)
     F2 = f32c(require_device_tensor(feat_fix, "feat_fix"))
     M2 = f32c(require_device_tensor(feat_mov, "feat_mov"))
     _, Cn, h, w, d = [int(s) for s in F2.shape]
@@ -243,10 +256,10 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
     ws = workspace(nws, dev)
     with torch.cuda.device(dev):
         if mode in ("fast", "fast_all"):
-            fn = lib().cvx_adam_run_fast_f32 if mode == "fast" else lib().cvx_adam_run_fast_all_f32
-            check(fn(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
+            check(lib().cvx_adam_run_mode_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
                                               int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
                                               C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf),
+                                              C.byref(smoother.spec) if smoother is not None else None, 1 if mode == "fast" else 2,
                                               ptr(ws), nws, stream_ptr(dev)))
         else:
             check(lib().cvx_adam_run_ex_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),

@@ -215,6 +215,22 @@ extern "C" int cvx_adam_run_fast_all_f32(const float* F2, const float* M2, int C
                               snapshot_iters_host, n_snap, snapshots, nullptr, true, false, 2, workspace, workspace_bytes, stream);
 }
 
+extern "C" int cvx_adam_run_mode_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v,
+                                     float lambda_weight, int niter, int step0, float cost_scale, const float* base_h,
+                                     const float* base_w, const float* base_d, float* U, float* grad_out,
+                                     const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm, int mode,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    CVX_REQUIRE(mode >= 0 && mode <= 2, "cvx_adam_run_mode_f32: mode must be 0 (exact), 1 (fast) or 2 (fast_all)");
+    return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
+                              snapshot_iters_host, n_snap, snapshots, sm, true, false, mode, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cvx_smooth_fast_f32(const float* in, int h, int w, int d, const cvx_smoother* sm, int backward, float* out, void* stream) {
+    CVX_REQUIRE(in && out && sm && h > 0 && w > 0 && d > 0, "cvx_smooth_fast_f32: bad arguments");
+    CVX_REQUIRE(sm->kind == 0, "cvx_smooth_fast_f32: box chains only (a Gaussian is three short 1-D convolutions already: cvx_smooth_f32)");
+    return cvx::launch_boxchain_fast(in, out, h, w, d, *sm, backward != 0, as_stream(stream));
+}
+
 extern "C" int cvx_box3_fast_f32(const float* in, int h, int w, int d, float* out, void* stream) {
     CVX_REQUIRE(in && out && in != out && h > 0 && w > 0 && d > 0, "cvx_box3_fast_f32: bad arguments");
     return cvx::launch_box3_fast(in, out, h, w, d, nullptr, nullptr, nullptr, 1.0, 1.0, nullptr, as_stream(stream));
@@ -258,8 +274,9 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
             for (int i = 0; i < sm->n_boxes; ++i) CVX_REQUIRE(sm->box_k[i] >= 1 && (sm->box_k[i] & 1), "cvx_adam_run_smoother_f32: box size must be odd");
         }
     }
-    if (fast && (!fused || f16_features))
-        return fail(CVX_ERR_UNSUPPORTED, "adam_mode fast: only the packaged three 3^3 boxes with float32 feature records");
+    if (fast && f16_features) return fail(CVX_ERR_UNSUPPORTED, "adam_mode fast: float32 feature records only");
+    if (fast && !fused && sm->kind == 0 && !boxchain_fast_supported(*sm, h, w, d))
+        return fail(CVX_ERR_UNSUPPORTED, "adam_mode fast: box chain outside the separable kernel's range (odd sizes <= 9, lines of at most 320 voxels)");
     const int CP = (C + 3) / 4 * 4;
     float* Fcl = cv.take<float>((size_t)CP * (V + 1));
     float* Mcl = cv.take<float>((size_t)CP * (V + 1));
@@ -280,7 +297,8 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
         const double beta1 = 0.9, beta2 = 0.999;
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
         const AdamConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)(-(1.0 / bc1)), adam_sqrt_table()};
-        if (fast == 2) { if ((rc = launch_box3_fast(P, U, h, w, d, nullptr, nullptr, nullptr, 1.0, 1.0, nullptr, s))) return rc; }   // "fast_all": separable forward boxes too
+        if (fast == 2 && fused) { if ((rc = launch_box3_fast(P, U, h, w, d, nullptr, nullptr, nullptr, 1.0, 1.0, nullptr, s))) return rc; }   // "fast_all": separable forward boxes too
+        else if (fast == 2 && sm->kind == 0) { if ((rc = launch_boxchain_fast(P, U, h, w, d, *sm, false, s))) return rc; }             // ... for a box chain of the sweep
         else if (fused) { if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc; }
         else if ((rc = launch_smoother(P, U, t1, 3, h, w, d, *sm, false, s))) return rc;
         const bool last = it == niter - 1;
@@ -288,7 +306,15 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
         float* gsave = (grad_out && it == niter - 1) ? grad_out : nullptr;
         if (fast) {
             if ((rc = launch_warp_grad_fast(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, s))) return rc;
-            if ((rc = launch_box3_fast(gU, nullptr, h, w, d, P, m, v, bc1, bc2, gsave, s))) return rc;
+            if (fused) { if ((rc = launch_box3_fast(gU, nullptr, h, w, d, P, m, v, bc1, bc2, gsave, s))) return rc; }
+            else {
+                // sweep smoothers: a box chain through the separable passes (adjoint = reversed box order), a Gaussian through its exact
+                // 1-D convolutions; the update as an element-wise kernel
+                if (sm->kind == 0) { if ((rc = launch_boxchain_fast(gU, t2, h, w, d, *sm, true, s))) return rc; }
+                else if ((rc = launch_smoother(gU, t2, t1, 3, h, w, d, *sm, true, s))) return rc;
+                if ((rc = launch_adam_update_fast(t2, P, m, v, 3 * V, bc1, bc2, s))) return rc;
+                if (gsave) (void)hipMemcpyAsync(gsave, t2, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice, s);
+            }
         } else {
         if ((rc = launch_warp_grad(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, f16_features, s))) return rc;
         if (fused) { if ((rc = launch_box3x3(gU, nullptr, h, w, d, true, P, m, v, ac, gsave, s))) return rc; }

@@ -295,6 +295,122 @@ __global__ __launch_bounds__(256) void k_box3_fast(const float* __restrict__ in,
     }
 }
 
+// ---- separable restatement of a CHAIN of zero-padded boxes (kovesi_spline of the sweep; oracle: orc_fast_boxchain) --------------------
+// Per axis (H, W, D) the boxes of the chain one after the other as 1-D sums out[i] = ((in[i-r] + in[i-r+1]) + ...) + in[i+r], zeros
+// outside the line; `reverse` = the adjoint's order (clipped boxes of different sizes do not commute at the borders); one
+// multiplication by 1 / prod k^3 at the end of the last pass.  One launch per axis: a workgroup stages 64 lines in LDS (two buffers),
+// every thread evaluates single outputs of a stage, one barrier per box.  Lines along H / W are 64 adjacent x columns (coalesced),
+// lines along D are 64 consecutive rows.  A pass may run in place (a workgroup reads its lines completely before it writes them).
+struct BoxChainArg { int n; int r[4]; float scale; };
+
+template <bool STRIDED>
+__global__ __launch_bounds__(256) void k_boxchain_pass(const float* __restrict__ in, float* __restrict__ out, int len, int ninner, size_t line_stride,
+                                                       size_t A, size_t B, int n_io, size_t nrows, BoxChainArg ch) {
+    extern __shared__ float bc_lds[];                     // two buffers of len * 64 floats
+    float* b0 = bc_lds;
+    float* b1 = bc_lds + (size_t)len * 64;
+    const int tid = threadIdx.x, n = len * 64;
+    size_t base = 0;
+    int nact = 64;                                        // lines of this tile inside the volume
+    if (STRIDED) {
+        const int x0 = (int)blockIdx.x * 64, o = (int)blockIdx.y;
+        base = (size_t)(o / n_io) * A + (size_t)(o % n_io) * B + x0;
+        nact = min(64, ninner - x0);
+        for (int e = tid; e < n; e += 256) {
+            const int i = e >> 6, t = e & 63;
+            b0[e] = t < nact ? in[base + t + (size_t)i * line_stride] : 0.0f;
+        }
+    } else {
+        const size_t row0 = (size_t)blockIdx.x * 64;
+        base = row0 * (size_t)len;
+        nact = (int)min((size_t)64, nrows - row0);
+        for (int e = tid; e < n; e += 256) {
+            const int row = e / len;
+            b0[e] = row < nact ? in[base + e] : 0.0f;   // [row][i], rows back to back
+        }
+    }
+    cvx_barrier();
+    for (int q = 0; q < ch.n; ++q) {
+        const int r = ch.r[q];
+        for (int e = tid; e < n; e += 256) {
+            // position i on the line and the LDS stride between neighbours of the line
+            const int i = STRIDED ? (e >> 6) : (e % len);
+            const int st = STRIDED ? 64 : 1;
+            float sacc = i - r >= 0 ? b0[e - r * st] : 0.0f;
+            for (int j = -r + 1; j <= r; ++j) {
+                const int ii = i + j;
+                sacc += (ii >= 0 && ii < len) ? b0[e + j * st] : 0.0f;
+            }
+            b1[e] = sacc;
+        }
+        cvx_barrier();
+        float* t = b0; b0 = b1; b1 = t;
+    }
+    if (STRIDED) {
+        for (int e = tid; e < n; e += 256) {
+            const int i = e >> 6, t = e & 63;
+            if (t < nact) out[base + t + (size_t)i * line_stride] = b0[e] * ch.scale;
+        }
+    } else {
+        for (int e = tid; e < n; e += 256)
+            if (e / len < nact) out[base + e] = b0[e] * ch.scale;
+    }
+}
+
+bool boxchain_fast_supported(const cvx_smoother& sm, int h, int w, int d) {
+    if (sm.kind != 0 || sm.n_boxes < 1 || sm.n_boxes > 4) return false;
+    for (int i = 0; i < sm.n_boxes; ++i)
+        if (sm.box_k[i] < 1 || !(sm.box_k[i] & 1) || sm.box_k[i] > 9) return false;
+    const int lmax = h > w ? (h > d ? h : d) : (w > d ? w : d);
+    return (size_t)lmax * 64 * 2 * sizeof(float) <= 160 * 1024;
+}
+
+// out = chain(in) for [3][h][w][d] (in == out allowed); reverse = adjoint order of the boxes
+int launch_boxchain_fast(const float* in, float* out, int h, int w, int d, const cvx_smoother& sm, bool reverse, hipStream_t s) {
+    if (!boxchain_fast_supported(sm, h, w, d)) return fail(CVX_ERR_UNSUPPORTED, "fast box chain: odd box sizes <= 9, at most 4 boxes, lines of at most 320 voxels");
+    BoxChainArg ch{};
+    ch.n = sm.n_boxes;
+    double prod = 1.0;
+    for (int i = 0; i < sm.n_boxes; ++i) {
+        const int k = sm.box_k[reverse ? sm.n_boxes - 1 - i : i];
+        ch.r[i] = k / 2;
+        prod *= (double)k * k * k;
+    }
+    const size_t V = (size_t)h * w * d;
+    static size_t granted_s = 0, granted_c = 0;
+    auto lds = [](int len) { return (size_t)len * 64 * 2 * sizeof(float); };
+    ensure_dynamic_lds(&k_boxchain_pass<true>, lds(h > w ? h : w), granted_s);
+    ensure_dynamic_lds(&k_boxchain_pass<false>, lds(d), granted_c);
+    ch.scale = 1.0f;
+    // along H: lines (c, y, x): base = c V + y d + x, elements w d apart
+    hipLaunchKernelGGL(k_boxchain_pass<true>, dim3((unsigned)cdiv(d, 64), (unsigned)(3 * w)), dim3(256), lds(h), s, in, out, h, d, (size_t)w * d, V,
+                       (size_t)d, w, (size_t)0, ch);
+    // along W: lines (c, z, x): base = (c h + z) w d + x, elements d apart
+    hipLaunchKernelGGL(k_boxchain_pass<true>, dim3((unsigned)cdiv(d, 64), (unsigned)(3 * h)), dim3(256), lds(w), s, out, out, w, d, (size_t)d,
+                       (size_t)w * d, (size_t)0, 1, (size_t)0, ch);
+    // along D: rows back to back
+    ch.scale = (float)(1.0 / prod);
+    const size_t nrows = (size_t)3 * h * w;
+    hipLaunchKernelGGL(k_boxchain_pass<false>, dim3((unsigned)cdiv64((int64_t)nrows, 64)), dim3(256), lds(d), s, out, out, d, 0, (size_t)1, (size_t)0,
+                       (size_t)0, 1, nrows, ch);
+    return check_last("boxchain_fast");
+}
+
+__global__ __launch_bounds__(256) void k_adam_update_fast(const float* __restrict__ G, float* __restrict__ P, float* __restrict__ m,
+                                                          float* __restrict__ v, size_t n, AdamFastConsts ac) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float Pv = P[i], mv = m[i], vv = v[i];
+    adam_update_fast(G[i], Pv, mv, vv, ac);
+    P[i] = Pv; m[i] = mv; v[i] = vv;
+}
+int launch_adam_update_fast(const float* G, float* P, float* m, float* v, size_t n, double bc1, double bc2, hipStream_t s) {
+    const double beta1 = 0.9, beta2 = 0.999;
+    const AdamFastConsts ac = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)(-(1.0 / bc1))};
+    hipLaunchKernelGGL(k_adam_update_fast, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, s, G, P, m, v, n, ac);
+    return check_last("adam_update_fast");
+}
+
 template <int TZ, int TY, int TXQ>
 static int launch_box3_fast_t(const float* in, float* out, int h, int w, int d, float* P, float* m, float* v, AdamFastConsts ac,
                               float* gsave, hipStream_t s) {

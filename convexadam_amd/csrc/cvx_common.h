@@ -386,5 +386,9 @@ int launch_warp_grad_fast(const float* Fcl, const float* Mcl, int C, int h, int 
                           const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s);
 int launch_box3_fast(const float* in, float* out, int h, int w, int d, float* P, float* m, float* v, double bc1, double bc2,
                      float* gsave, hipStream_t s);
+// the same arithmetic for a chain of boxes (the sweep's kovesi splines): three 1-D passes, [3][h][w][d], in == out allowed
+bool boxchain_fast_supported(const cvx_smoother& sm, int h, int w, int d);
+int launch_boxchain_fast(const float* in, float* out, int h, int w, int d, const cvx_smoother& sm, bool reverse, hipStream_t s);
+int launch_adam_update_fast(const float* G, float* P, float* m, float* v, size_t n, double bc1, double bc2, hipStream_t s);
 
 }  // namespace cvx

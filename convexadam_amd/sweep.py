@@ -319,7 +319,7 @@ def run_stage1_item(cfg, p, data):
     return rec
 
 
-def run_stage2_item(best1, cfg2, p, data, smoothers):
+def run_stage2_item(best1, cfg2, p, data, smoothers, adam_mode="exact"):
     """One 120-iteration Adam run from the stage-1 field, scored at 4 iterations x 4 smoothings (adam_run_withconfig_shiftSpline.py:159-246)."""
     from convexadam_amd import convex_adam_utils as U
     from convexadam_amd.convex_adam_MIND import register_pair_device
@@ -342,7 +342,7 @@ def run_stage2_item(best1, cfg2, p, data, smoothers):
     P0 = U.resize_trilinear(disp_hr[None], (h2, w2, d2)) / float(gsa)
     n_ch = int(F2.shape[1])
     _, st = U.adam_run(F2, M2, P0, lam, ADAM_ITERS, smoother=smoothers[cfg2["avg_n"]], cost_scale=float(n_ch), snapshot_iters=SNAP_ITERS,
-                       return_state=True)
+                       return_state=True, mode=adam_mode)
     torch.cuda.current_stream(data.device).synchronize()
     ms = (time.time() - t) * 1e3
     recs = []
@@ -376,6 +376,10 @@ def main(argv=None):
     ap.add_argument("--static", action="store_true", help="round-robin assignment instead of the shared queue")
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercises queue, logs, resume and gather only (CPU/gloo)")
     ap.add_argument("--evaluate", action="store_true", help="round-1 mode: score every item on the device and rank the settings")
+    ap.add_argument("--adam-mode", default="fast_all", choices=("exact", "fast", "fast_all"),
+                    help="arithmetic of the stage-2 Adam runs: exact = the reference's evaluation order, fast = throughput arithmetic with the forward "
+                         "smoother exact, fast_all = separable forward smoother too (default: the sweep grades by overlap scores, which agree to three "
+                         "digits between the modes, and the generic exact smoothers cost ~0.5 ms per iteration)")
     ap.add_argument("--workers", type=int, default=0, help="items in flight per rank, each on its own thread and HIP stream (0 = automatic = 1: since round 4 "
                     "the evaluation kernels fill the GPU on their own -- 2.67 s with one worker, 2.96 s with two on the 48-item example)")
     a = ap.parse_args(argv)
@@ -393,7 +397,7 @@ def main(argv=None):
     n_workers = a.workers if a.workers > 0 else 1
     queue = WorkQueue(rank, world)
     run_id = dict(shape=list(a.shape), pairs=a.pairs, stage1=a.stage1, stage2=a.stage2, settings=a.settings, niter=a.niter, evaluate=bool(a.evaluate),
-                  dry_run=bool(a.dry_run))
+                  dry_run=bool(a.dry_run), adam_mode=a.adam_mode)
     log = ResultLog(a.out, rank, a.resume, run_id)
     if world > 1:
         dist.barrier()                                                      # rank 0 has removed the files of an earlier run
@@ -476,7 +480,7 @@ def main(argv=None):
     if world > 1:
         dist.barrier()
     t0 = time.time()
-    summary = dict(world_size=world, shape=list(shape), pairs=a.pairs, workers_per_rank=n_workers)
+    summary = dict(world_size=world, shape=list(shape), pairs=a.pairs, workers_per_rank=n_workers, adam_mode=a.adam_mode)
     if two_stage:
         s1 = stage1_settings(a.stage1)
         if a.dry_run:
@@ -500,7 +504,7 @@ def main(argv=None):
                 w2 = lambda cfg, p: dict(evals=[dict(snap=i, smooth=k, dice=0.6 + 0.01 * i - 0.001 * k, dice30=0.5, jstd=0.1 + 0.01 * k, hd95=2.5, tre=0.8, folding=0.0, ms=0.0)   # noqa: E731
                                                 for i in range(len(SNAP_ITERS)) for k in range(N_EXTRA_SMOOTH)])
             else:
-                w2 = lambda cfg, p: dict(evals=run_stage2_item(best1, cfg, p, data, smoothers))                                     # noqa: E731
+                w2 = lambda cfg, p: dict(evals=run_stage2_item(best1, cfg, p, data, smoothers, a.adam_mode))                                     # noqa: E731
             mine2, fresh2 = run_phase("adam", s2, w2)
             all2 = gather_records(mine2, world)
             check_failures()

@@ -297,6 +297,20 @@ int cvx_adam_run_fast_all_f32(const float* F2, const float* M2, int C, int h, in
                               const float* base_h, const float* base_w, const float* base_d, float* U, float* grad_out,
                               const int* snapshot_iters_host, int n_snap, float* snapshots,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* the loop with a smoother of the sweep scripts in the arithmetic `mode` (0 exact = cvx_adam_run_smoother_f32, 1 fast, 2 fast_all):
+ * a box chain (kovesi_spline) runs its adjoint -- with mode 2 also the forward pass -- through the separable passes of
+ * cvx_smooth_fast_f32, a Gaussian keeps its exact 1-D convolutions; fast warp gradient and one-division update in both.  sm == NULL:
+ * the packaged three 3^3 boxes.  Bit-identical to oracle/cvx_oracle.c::orc_adam_run_fast_smoother. */
+int cvx_adam_run_mode_f32(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m,
+                          float* v, float lambda_weight, int niter, int step0, float cost_scale,
+                          const float* base_h, const float* base_w, const float* base_d, float* U, float* grad_out,
+                          const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm, int mode,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* separable restatement of a box-chain smoother (kovesi_spline, hyper_util:475-488) on a [3][h][w][d] field: per axis the boxes of the
+ * chain as 1-D sums with zero padding per stage, `backward` = the adjoint (reversed box order), one final multiplication by
+ * 1 / prod k^3; in == out allowed.  Equals cvx_smooth_f32 to rounding (3e-7 relative), three launches instead of one per box and 27 /
+ * 125-tap sums. */
+int cvx_smooth_fast_f32(const float* in, int h, int w, int d, const cvx_smoother* sm, int backward, float* out, void* stream);
 /* out = fastbox(in): the separable restatement of box3(box3(box3(.))) used for the adjoint in adam_mode "fast"; [C][h][w][d], C = 3 */
 int cvx_box3_fast_f32(const float* in, int h, int w, int d, float* out, void* stream);
 

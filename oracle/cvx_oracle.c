@@ -938,9 +938,66 @@ ORC_API void orc_fast_box3x3(const float* in, float* out, int C, int h, int w, i
     for (size_t i = 0; i < (size_t)C * V; ++i) out[i] = out[i] * r;
 }
 
+/* The separable restatement of a CHAIN of zero-padded box filters (kovesi_spline, self_configuring/convexAdam_hyper_util.py:475-488; the
+ * packaged three 3^3 boxes are the chain {3, 3, 3}): per axis (H, W, D) the boxes of the chain one after the other as 1-D sums
+ * out[i] = ((in[i-r] + in[i-r+1]) + ...) + in[i+r] with zeros outside the line, `reverse` = the adjoint's order of the boxes (the 1-D
+ * clipped boxes of DIFFERENT sizes do not commute at the borders; different axes do), then one multiplication by (float)(1 / prod k^3). */
+ORC_API void orc_fast_boxchain(const float* in, float* out, int C, int h, int w, int d, int n_boxes, const int* box_k, int reverse) {
+    const size_t V = (size_t)h * w * d;
+    const int dims[3] = {h, w, d};
+    const size_t strides[3] = {(size_t)w * d, (size_t)d, 1};
+    if (out != in) memcpy(out, in, sizeof(float) * (size_t)C * V);
+    double prod = 1.0;
+    for (int i = 0; i < n_boxes; ++i) prod *= (double)box_k[i] * box_k[i] * box_k[i];
+    for (int axis = 0; axis < 3; ++axis) {
+        const int n = dims[axis];
+        const size_t st = strides[axis];
+        const size_t nlines = (size_t)C * V / (size_t)n;
+#pragma omp parallel
+        {
+            float* a = (float*)calloc((size_t)(n + 16), sizeof(float));
+            float* b = (float*)calloc((size_t)(n + 16), sizeof(float));
+#pragma omp for schedule(static)
+            for (size_t l = 0; l < nlines; ++l) {
+                size_t base;
+                if (axis == 0) base = (l / ((size_t)w * d)) * V + l % ((size_t)w * d);
+                else if (axis == 1) base = (l / d) * ((size_t)w * d) + l % d;
+                else base = l * (size_t)d;
+                for (int i = 0; i < n + 16; ++i) a[i] = b[i] = 0.0f;
+                for (int i = 0; i < n; ++i) a[i + 8] = out[base + (size_t)i * st];
+                for (int q = 0; q < n_boxes; ++q) {
+                    const int r = box_k[reverse ? n_boxes - 1 - q : q] / 2;
+                    for (int i = 0; i < n; ++i) {
+                        float sacc = a[i + 8 - r];
+                        for (int j = -r + 1; j <= r; ++j) sacc += a[i + 8 + j];
+                        b[i + 8] = sacc;
+                    }
+                    float* t = a; a = b; b = t;
+                    for (int i = 0; i < 8; ++i) { a[i] = 0.0f; a[n + 8 + i] = 0.0f; }
+                }
+                for (int i = 0; i < n; ++i) out[base + (size_t)i * st] = a[i + 8];
+            }
+            free(a); free(b);
+        }
+    }
+    const float rr = (float)(1.0 / prod);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < (size_t)C * V; ++i) out[i] = out[i] * rr;
+}
+
+ORC_API void orc_adam_run_fast_smoother(const float* F2, const float* M2, int C, int h, int w, int d, float* P,
+                               float* m, float* v, float lambda_weight, int niter, int step0, float cost_scale,
+                               float* U, float* G, int keep_last_step, int fast_forward, const orc_smoother* sm);
 ORC_API void orc_adam_run_fast(const float* F2, const float* M2, int C, int h, int w, int d, float* P,
                                float* m, float* v, float lambda_weight, int niter, int step0, float cost_scale,
                                float* U, float* G, int keep_last_step, int fast_forward) {
+    orc_adam_run_fast_smoother(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, U, G, keep_last_step, fast_forward, NULL);
+}
+/* sm == NULL: the packaged three 3^3 boxes.  A box chain (kind 0): the adjoint -- and with fast_forward the forward pass -- through
+ * orc_fast_boxchain; a Gaussian (kind 1) keeps the exact smoother both ways (it is three short 1-D convolutions already). */
+ORC_API void orc_adam_run_fast_smoother(const float* F2, const float* M2, int C, int h, int w, int d, float* P,
+                               float* m, float* v, float lambda_weight, int niter, int step0, float cost_scale,
+                               float* U, float* G, int keep_last_step, int fast_forward, const orc_smoother* sm) {
     const size_t V = (size_t)h * w * d;
     float* t1 = (float*)malloc(sizeof(float) * 3 * V);
     float* gU = (float*)malloc(sizeof(float) * 3 * V);
@@ -956,9 +1013,11 @@ ORC_API void orc_adam_run_fast(const float* F2, const float* M2, int C, int h, i
     const float gsc2 = 2.0f * gsc;
     const float gmx = (float)d / 2.0f, gmy = (float)w / 2.0f, gmz = (float)h / 2.0f;
     const orc_smoother boxes3 = {0, 3, {3, 3, 3, 0}, {0, 0, 0, 0, 0}};
+    if (!sm) sm = &boxes3;
+    const int chain = sm->kind == 0;
     for (int it = 0; it < niter; ++it) {
-        if (fast_forward) orc_fast_box3x3(P, U, 3, h, w, d);   /* adam_mode "fast_all": NOT accepted by the criteria above (2.29e-3 at 80 iterations) */
-        else orc_smooth(P, U, 3, h, w, d, &boxes3, 0);       /* forward boxes: ATen's order, as in orc_adam_run */
+        if (fast_forward && chain) orc_fast_boxchain(P, U, 3, h, w, d, sm->n_boxes, sm->box_k, 0);   /* adam_mode "fast_all": NOT accepted by the criteria above (2.29e-3 at 80 iterations) */
+        else orc_smooth(P, U, 3, h, w, d, sm, 0);            /* forward smoother: ATen's order, as in orc_adam_run */
         if (it == niter - 1 && !keep_last_step) break;      /* the pipeline never observes the last gradient / update */
 #pragma omp parallel for schedule(static)
         for (size_t p = 0; p < V; ++p) {
@@ -1012,7 +1071,8 @@ ORC_API void orc_adam_run_fast(const float* F2, const float* M2, int C, int h, i
                 gU[(size_t)a * V + p] = acc;
             }
         }
-        orc_fast_box3x3(gU, t1, 3, h, w, d);
+        if (chain) orc_fast_boxchain(gU, t1, 3, h, w, d, sm->n_boxes, sm->box_k, 1);
+        else orc_smooth(gU, t1, 3, h, w, d, sm, 1);
         if (G) memcpy(G, t1, sizeof(float) * 3 * V);
         const int step = step0 + it + 1;
         const double beta1 = 0.9, beta2 = 0.999;

@@ -75,6 +75,9 @@ def lib():
         L.orc_fast_box3x3.argtypes = [_f32p, _f32p] + [C.c_int] * 4
         L.orc_adam_run_fast.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [_f32p, _f32p, _f32p, C.c_float, C.c_int,
                                                                         C.c_int, C.c_float, _f32p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_fast_boxchain.argtypes = [_f32p, _f32p] + [C.c_int] * 5 + [C.c_void_p, C.c_int]
+        L.orc_adam_run_fast_smoother.argtypes = [_f32p, _f32p] + [C.c_int] * 4 + [_f32p, _f32p, _f32p, C.c_float, C.c_int,
+                                                                                 C.c_int, C.c_float, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_label_features.argtypes = [_f32p, _f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_label_features.restype = C.c_int
         L.orc_feature_transform.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -272,6 +275,15 @@ def fast_box3x3(x):
     out = np.empty_like(x); lib().orc_fast_box3x3(x.reshape(-1), out.reshape(-1), c, h, w, d); return out
 
 
+def fast_boxchain(x, sizes, reverse=False):
+    """Fast-mode restatement of a chain of zero-padded box filters (kovesi_spline): separable sums, one final scale; reverse = adjoint order."""
+    x = _f(x); c, h, w, d = x.shape
+    out = np.empty_like(x)
+    arr = (C.c_int * len(sizes))(*[int(k) for k in sizes])
+    lib().orc_fast_boxchain(x.reshape(-1), out.reshape(-1), c, h, w, d, len(sizes), C.cast(arr, C.c_void_p), 1 if reverse else 0)
+    return out
+
+
 def adam_run(F2, M2, P, lambda_weight, niter, m=None, v=None, step0=0, cost_scale=12.0, want_grad=False, smoother=None, mode="exact",
              keep_last_step=True):
     """Runs `niter` Adam iterations in place on copies; returns dict(P, m, v, U, G, loss).
@@ -282,10 +294,10 @@ def adam_run(F2, M2, P, lambda_weight, niter, m=None, v=None, step0=0, cost_scal
     P = _f(P).copy(); m = np.zeros_like(P) if m is None else _f(m).copy(); v = np.zeros_like(P) if v is None else _f(v).copy()
     U = np.zeros_like(P); G = np.zeros_like(P) if want_grad else None; loss = np.zeros(max(niter, 1), np.float32)
     if mode in ("fast", "fast_all"):
-        assert smoother is None, "fast mode: the packaged three 3^3 boxes only"
-        lib().orc_adam_run_fast(F2.reshape(-1), M2.reshape(-1), c, h, w, d, P.reshape(-1), m.reshape(-1), v.reshape(-1),
-                                float(lambda_weight), int(niter), int(step0), float(cost_scale), U.reshape(-1),
-                                G.ctypes.data_as(C.c_void_p) if G is not None else None, 1 if keep_last_step else 0, 1 if mode == "fast_all" else 0)
+        lib().orc_adam_run_fast_smoother(F2.reshape(-1), M2.reshape(-1), c, h, w, d, P.reshape(-1), m.reshape(-1), v.reshape(-1),
+                                         float(lambda_weight), int(niter), int(step0), float(cost_scale), U.reshape(-1),
+                                         G.ctypes.data_as(C.c_void_p) if G is not None else None, 1 if keep_last_step else 0,
+                                         1 if mode == "fast_all" else 0, C.cast(C.pointer(smoother), C.c_void_p) if smoother is not None else None)
         return dict(P=P, m=m, v=v, U=U, G=G, loss=None)
     assert mode == "exact", mode
     lib().orc_adam_run_smoother(F2.reshape(-1), M2.reshape(-1), c, h, w, d, P.reshape(-1), m.reshape(-1), v.reshape(-1),

@@ -116,8 +116,6 @@ def test_adam_fast_rejects_what_it_does_not_cover(U, golden):
     with pytest.raises(ValueError):
         U.adam_run(*a, mode="fast", storage="fp16")
     with pytest.raises(ValueError):
-        U.adam_run(*a, mode="fast", smoother=HU.kovesi_spline(1.6))
-    with pytest.raises(ValueError):
         U.adam_run(*a, mode="quick")
     with pytest.raises(ValueError):
         U.adam_run(*a, storage="fp8")
@@ -313,3 +311,42 @@ def test_convex_adam_pt_many_with_changing_shapes_and_early_exit(M):
     assert np.array_equal(first, want[0])
     again = M.convex_adam_pt(*pairs[1], dtype=torch.float32, device=torch.device(DEV), **kw)
     assert np.array_equal(again, want[1])
+
+
+@pytest.mark.parametrize("sigma", [1.3, 1.6, 1.9, 2.2, 2.5, 2.8])
+@pytest.mark.parametrize("shape", [(9, 11, 70), (20, 7, 13), (3, 3, 3), (16, 24, 130)])
+def test_smooth_fast_box_chains_vs_oracle(U, orc, sigma, shape):
+    """The separable restatement of the sweep's kovesi splines (box chains [3,3,3] .. [5,5,5,5]), forward and adjoint (reversed box order:
+    clipped boxes of different sizes do not commute at the borders): bit-identical to orc_fast_boxchain, equal to the exact chain to rounding."""
+    from convexadam_amd import convexAdam_hyper_util as HU
+    sm = HU.kovesi_spline(sigma, 4)
+    rng = np.random.default_rng(int(sigma * 10) + sum(shape))
+    x = rng.standard_normal((3,) + shape).astype(np.float32)
+    osm = orc.make_smoother(sm.sizes)
+    for backward in (False, True):
+        got = host(U.smooth_fast(dev(x), sm, backward=backward))
+        assert np.array_equal(got, orc.fast_boxchain(x, sm.sizes, reverse=backward)), (sm.sizes, backward)
+        ref = orc.smooth(x, osm, backward=backward)
+        assert np.abs(got - ref).max() <= 4e-6 * max(1.0, float(np.abs(ref).max())), (sm.sizes, backward)
+
+
+@pytest.mark.parametrize("mode", ["fast", "fast_all"])
+@pytest.mark.parametrize("which", ["kovesi 1.6", "kovesi 1.9", "kovesi 2.8", "gauss 0.7"])
+def test_adam_fast_with_sweep_smoothers_vs_oracle(U, orc, golden, which, mode):
+    """The sweep's Adam loop (adam_run_withconfig_shiftSpline.py:217) in the throughput arithmetic: box chains through the separable passes
+    (adjoint always, forward in "fast_all"), a Gaussian through its exact 1-D convolutions; fast warp gradient and update in both."""
+    from convexadam_amd import convexAdam_hyper_util as HU
+    g = golden("adam")
+    kind, val = which.split()
+    if kind == "kovesi":
+        mod = HU.kovesi_spline(float(val), 4)
+        osm = orc.make_smoother(mod.sizes)
+    else:
+        mod = HU.GaussianSmoothing(float(val))
+        osm = orc.make_smoother(gauss_w=np.array(list(mod.spec.gauss_w), np.float32))
+    Ud, st = U.adam_run(dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]), 4, return_state=True, smoother=mod, mode=mode)
+    r = orc.adam_run(g["F2"], g["M2"], g["P0"], float(g["lam"]), 4, want_grad=True, smoother=osm, mode=mode)
+    assert np.array_equal(host(Ud)[0], r["U"]) and np.array_equal(host(st["G"])[0], r["G"])
+    assert np.array_equal(host(st["P"])[0], r["P"]) and np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
+    e = orc.adam_run(g["F2"], g["M2"], g["P0"], float(g["lam"]), 4, smoother=osm)
+    assert np.abs(r["U"] - e["U"]).max() < 1e-4                       # the same optimisation to rounding
