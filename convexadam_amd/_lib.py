@@ -123,6 +123,7 @@ SIGNATURES = {
     "cvx_surface_hist_i64": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "cvx_hist_order_stats_i64": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
     "cvx_hist_percentile_neighbours_i64": (_i, [_vp, _i, _f, _vp, _vp]),
+    "cvx_surface_hist_batch_i64": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "cvx_hist_percentile_neighbours_batch_i64": (_i, [_vp, _i, _i, _f, _vp, _vp]),
     "cvx_edt_squared_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "cvx_edt_squared_i32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

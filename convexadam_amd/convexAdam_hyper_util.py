@@ -318,12 +318,14 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None):
             flag = torch.zeros(2 * len(present), dtype=torch.int32, device=dev)
             out3 = torch.empty((len(present), 2, 3), dtype=torch.int64, device=dev)
             quant = float(np.true_divide(95, np.float32(100)))               # numpy: q / float32(100) for float32 data
+            # dist1[surf2] and dist2[surf1] (:48) for every label: one launch over a device table of volume addresses
+            tab = []
             for j, lab in enumerate(present):
                 pair = (dist_f[j], dist_m[j])
-                # dist1[surf2] and dist2[surf1]                                                   (:48)
                 for k in range(2):
-                    a_in, a_out, b_in = pair[k][0], pair[k][1], pair[1 - k][0]
-                    check(L.cvx_surface_hist_i64(ptr(a_in), ptr(a_out), ptr(b_in), n, nbins, ptr(hist[2 * j + k]), ptr(flag[2 * j + k:]), sp))
+                    tab += [pair[k][0].data_ptr(), pair[k][1].data_ptr(), pair[1 - k][0].data_ptr()]
+            tab_d = torch.tensor(tab, dtype=torch.int64).to(dev)
+            check(L.cvx_surface_hist_batch_i64(ptr(tab_d), 2 * len(present), n, nbins, ptr(hist), ptr(flag), sp))
             check(L.cvx_hist_percentile_neighbours_batch_i64(ptr(hist), nbins, 2 * len(present), quant, ptr(out3), sp))
             res = out3.cpu().numpy()
             if int(flag.cpu().max()) != 0:

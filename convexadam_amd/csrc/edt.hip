@@ -440,6 +440,50 @@ extern "C" int cvx_surface_hist_i64(const int* a_in2, const int* a_out2, const i
     return check_last("surface_hist");
 }
 
+// all (label, direction) histograms of one cupy_hd95 call in ONE launch: blockIdx.y = histogram h, its three volumes from a device table
+// of addresses tab[3 h .. 3 h + 2] = (a_in2, a_out2, b_in2); hist [n_hist][nbins], overflow [n_hist] (26 launches of ~35 us -> one)
+__global__ __launch_bounds__(256) void k_surface_hist_batch(const unsigned long long* __restrict__ tab, size_t n, int nbins,
+                                                            unsigned long long* __restrict__ hist_all, int* __restrict__ overflow_all) {
+    constexpr int LB = 2048;
+    __shared__ unsigned int low[LB];
+    const int h = blockIdx.y;
+    const int* a_in2 = reinterpret_cast<const int*>(tab[3 * h]);
+    const int* a_out2 = reinterpret_cast<const int*>(tab[3 * h + 1]);
+    const int* b_in2 = reinterpret_cast<const int*>(tab[3 * h + 2]);
+    unsigned long long* hist = hist_all + (size_t)h * nbins;
+    int* overflow = overflow_all + h;
+    for (int i = threadIdx.x; i < LB; i += blockDim.x) low[i] = 0;
+    cvx_barrier();
+    auto count = [&](size_t i) {
+        const int bin = a_in2[i] + a_out2[i];
+        if (bin < 0 || bin >= nbins) { *overflow = 1; return; }
+        if (bin < LB) atomicAdd(&low[bin], 1u);
+        else atomicAdd(&hist[bin], 1ull);
+    };
+    const size_t n4 = ((reinterpret_cast<uintptr_t>(b_in2) & 15) == 0) ? n / 4 : 0;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
+        const int4 b = reinterpret_cast<const int4*>(b_in2)[q];
+        if (b.x == 1) count(4 * q);
+        if (b.y == 1) count(4 * q + 1);
+        if (b.z == 1) count(4 * q + 2);
+        if (b.w == 1) count(4 * q + 3);
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (b_in2[i] == 1) count(i);
+    cvx_barrier();
+    for (int i = threadIdx.x; i < LB && i < nbins; i += blockDim.x)
+        if (low[i]) atomicAdd(&hist[i], (unsigned long long)low[i]);
+}
+extern "C" int cvx_surface_hist_batch_i64(const void* const* volumes_dev, int n_hist, int64_t n, int nbins, int64_t* hist, int* overflow, void* stream) {
+    CVX_REQUIRE(volumes_dev && hist && overflow && n_hist > 0 && n_hist <= 65535 && n > 0 && nbins > 0, "cvx_surface_hist_batch_i64: bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(hist, 0, sizeof(int64_t) * (size_t)nbins * n_hist, s) != hipSuccess || hipMemsetAsync(overflow, 0, sizeof(int) * n_hist, s) != hipSuccess)
+        return fail(CVX_ERR_LAUNCH, "cvx_surface_hist_batch_i64: memset failed");
+    const unsigned nb = (unsigned)(cdiv64(n, 4096) < 256 ? (cdiv64(n, 4096) ? cdiv64(n, 4096) : 1) : 256);
+    hipLaunchKernelGGL(k_surface_hist_batch, dim3(nb, n_hist), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(volumes_dev), (size_t)n, nbins,
+                       reinterpret_cast<unsigned long long*>(hist), overflow);
+    return check_last("surface_hist_batch");
+}
 extern "C" int cvx_hist_order_stats_i64(const int64_t* hist, int nbins, int64_t k0, int64_t k1, int64_t* out3, void* stream) {
     CVX_REQUIRE(hist && out3, "cvx_hist_order_stats_i64: null pointer");
     CVX_REQUIRE(nbins > 0, "cvx_hist_order_stats_i64: bad size");

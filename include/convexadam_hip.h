@@ -427,6 +427,9 @@ int cvx_surface_hist_i64(const int* a_in2, const int* a_out2, const int* b_in2, 
                          void* stream);
 int cvx_hist_order_stats_i64(const int64_t* hist, int nbins, int64_t k0, int64_t k1, int64_t* out3, void* stream);
 int cvx_hist_percentile_neighbours_i64(const int64_t* hist, int nbins, float quantile, int64_t* out3, void* stream);
+/* cvx_surface_hist_i64 for n_hist (a, b) combinations in one launch: volumes_dev = DEVICE table of 3 n_hist addresses (a_in2, a_out2, b_in2
+ * per histogram), hist [n_hist][nbins], overflow [n_hist] */
+int cvx_surface_hist_batch_i64(const void* const* volumes_dev, int n_hist, int64_t n, int nbins, int64_t* hist, int* overflow, void* stream);
 /* the same for n_hist histograms [n_hist][nbins] in one launch -> out3 [n_hist][3] (all labels x both directions of one cupy_hd95 call) */
 int cvx_hist_percentile_neighbours_batch_i64(const int64_t* hist, int nbins, int n_hist, float quantile, int64_t* out3, void* stream);
 size_t cvx_edt_squared_workspace_bytes(int batch, int H, int W, int D);
