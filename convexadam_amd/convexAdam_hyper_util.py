@@ -244,16 +244,21 @@ def edt_squared(obj):
     return out
 
 
-def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None):
+def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=None):
     """hyper_util.py:32-51: 95th-percentile symmetric surface distance for labels 1 .. num_labels (30 where a label is absent from
     either map), float64 tensor on the device of `fixed`.  Per label on the device: masks on the nearest-upsampled grid, exact
     squared Euclidean distance transforms of the mask and of its complement (csrc/edt.hip), histogram of dist_a over the
     surface of b (edt == 1); the percentile is read from the histogram (two order statistics), so no sort and no host copy of a
     volume.  Three host synchronisations per call (label range, label presence, results).  `precision` must be a positive integer (the
     reference's call sites use the default 1).
+    method (not in the reference): "surface" (default at precision 1, <= 255 labels, H, W <= 2047) computes the distances at the surface
+    voxels alone -- bit planes of both maps + a ring search per surface voxel (csrc/surfdist.hip), no volume-sized transform; "edt" is the
+    path described above (the only one for precision > 1).  Both give the same float64 results bit for bit (exact integer squared
+    distances either way); "surface" needs two host synchronisations (label counts, results).
     fixed_cache (not in the reference): a dict the caller keeps per FIXED label map -- the sweep scores many fields against the same
-    fixed segmentation (16 per Adam run), and the two distance transforms of every fixed label do not depend on the field; they are
-    computed on the first call and reused (13 labels at 160x192x224: 715 MB)."""
+    fixed segmentation (16 per Adam run), and what is derived from the fixed map alone does not depend on the field: its bit planes
+    ("surface": 1 MB per label at 160x192x224) or the two distance transforms of every fixed label ("edt": 715 MB for 13 labels);
+    computed on the first call and reused."""
     if int(precision) != precision or precision < 1:
         raise NotImplementedError("cupy_hd95: only integer precision >= 1 (nearest up-sampling) is implemented")
     p = int(precision)
@@ -268,7 +273,6 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None):
     L = lib()
     dev = fx.device
     sp = stream_ptr(dev)
-    hd95 = np.zeros(nl, np.float64)
     n = Ho * Wo * Do
 
     def transforms(seg, labs):
@@ -293,6 +297,57 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None):
             check(L.cvx_edt_squared_i32(ptr(obj), 2 * len(part), Ho, Wo, Do, ptr(out[g0:g0 + len(part)]), ptr(ws), nws, sp))
         return out
 
+    if method is None:
+        method = "surface" if (p == 1 and nl <= 255 and H <= 2047 and W <= 2047) else "edt"
+    if method not in ("surface", "edt"):
+        raise ValueError("cupy_hd95: method must be 'surface' or 'edt'")
+    if method == "surface":
+        if not (p == 1 and 1 <= nl <= 255 and H <= 2047 and W <= 2047):
+            raise NotImplementedError("cupy_hd95: method 'surface' needs precision 1, 1 .. 255 labels and H, W <= 2047")
+        with torch.cuda.device(dev):
+            # label range (F.one_hot, :33) and presence in one pass: voxel counts of the integer values 0 .. num_labels in both maps
+            counts = torch.empty((3, nl + 1), dtype=torch.int64, device=dev)
+            check(L.cvx_label_overlap_i64(ptr(fx), ptr(mv), n, nl + 1, ptr(counts), sp))
+            cnt = counts.cpu().numpy()
+            if int(cnt[0].sum()) != n or int(cnt[1].sum()) != n:
+                raise RuntimeError("cupy_hd95: class values must be in 0 .. num_labels (F.one_hot, :33)")
+            present = [i for i in range(1, nl + 1) if cnt[0, i] > 0 and cnt[1, i] > 0]
+            res = None
+            if present:
+                nwords = int(L.cvx_label_bits_bytes(H, W, D, nl)) // 8
+
+                def planes(seg):
+                    b = torch.empty(nwords, dtype=torch.int64, device=dev)
+                    check(L.cvx_label_bits_u64(ptr(seg), H, W, D, nl, ptr(b), sp))
+                    return b
+
+                if fixed_cache is not None:
+                    key = ("bits", nl)
+                    if key not in fixed_cache:
+                        fixed_cache[key] = planes(fx)
+                    bits_f = fixed_cache[key]
+                else:
+                    bits_f = planes(fx)
+                bits_m = planes(mv)
+                hist = torch.zeros((nl, 2, nbins), dtype=torch.int64, device=dev)
+                tail = torch.zeros(nl * 2 * 3 + nl, dtype=torch.int64, device=dev)       # out3 [nl][2][3] | overflow [nl][2] int32
+                out3, flag = tail[:nl * 6], tail[nl * 6:].view(torch.int32)
+                act = [0, 0, 0, 0]
+                for lab in present:
+                    act[lab >> 6] |= 1 << (lab & 63)
+                act4 = (C.c_uint64 * 4)(*act)
+                # k = 0: dist1[surf2] (surface of the moving map against the fixed planes), k = 1: dist2[surf1] (:48)
+                for k, (seg_b, bits_a) in enumerate(((mv, bits_f), (fx, bits_m))):
+                    check(L.cvx_surface_distance_hist_i64(ptr(seg_b), ptr(bits_a), H, W, D, nl, C.cast(act4, C.c_void_p), nbins,
+                                                          C.c_void_p(hist.data_ptr() + 8 * k * nbins), 2 * nbins,
+                                                          C.c_void_p(flag.data_ptr() + 4 * k), 2, sp))
+                quant = float(np.true_divide(95, np.float32(100)))               # numpy: q / float32(100) for float32 data
+                check(L.cvx_hist_percentile_neighbours_batch_i64(ptr(hist), nbins, 2 * nl, quant, ptr(out3), sp))
+                host = tail.cpu().numpy()
+                if np.any(host[nl * 6:].view(np.int32)[[2 * (lab - 1) + k for lab in present for k in range(2)]] != 0):
+                    raise RuntimeError("cupy_hd95: squared distance exceeds the histogram range")
+                res = host[:nl * 6].reshape(nl, 2, 3)[[lab - 1 for lab in present]]
+        return _hd95_from_order_stats(res, present, nl, precision, dev)
     with torch.cuda.device(dev):
         # label range (F.one_hot, :33) and presence in one pass: voxel counts of labels 0 .. num_labels in both maps
         lohi = torch.stack([fx.min(), fx.max(), mv.min(), mv.max()]).cpu()
@@ -330,21 +385,28 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None):
             res = out3.cpu().numpy()
             if int(flag.cpu().max()) != 0:
                 raise RuntimeError("cupy_hd95: squared distance exceeds the histogram range")
-        for i in range(nl):
-            hd95[i] = 30
-        for j, lab in enumerate(present):
-            pk = []
-            for k in range(2):
-                b0, b1, m = [int(v) for v in res[j, k]]
-                if m == 0:
-                    pk.append(float("nan"))                                  # numpy: percentile of an empty selection
-                    continue
-                _, _, gamma = percentile_neighbours(m, 95)
-                # float32 distances (float64_distances=False, :40): correctly rounded square roots of exact integers
-                lo = np.sqrt(np.float64(b0)).astype(np.float32)
-                hi = np.sqrt(np.float64(b1)).astype(np.float32)
-                pk.append(float(percentile_linear_from_sorted_pair(lo, hi, gamma)))
-            hd95[lab - 1] = np.maximum(pk[0], pk[1])
+        if not present:
+            res = None
+    return _hd95_from_order_stats(res, present, nl, precision, dev)
+
+
+def _hd95_from_order_stats(res, present, nl, precision, dev):
+    """res [len(present)][2][3] = (lower neighbour, upper neighbour, count) of the squared surface distances per direction -> the
+    reference's per-label values (hyper_util.py:48-51): 30 for a label absent from either map."""
+    hd95 = np.full(nl, 30, np.float64)
+    for j, lab in enumerate(present):
+        pk = []
+        for k in range(2):
+            b0, b1, m = [int(v) for v in res[j, k]]
+            if m == 0:
+                pk.append(float("nan"))                                  # numpy: percentile of an empty selection
+                continue
+            _, _, gamma = percentile_neighbours(m, 95)
+            # float32 distances (float64_distances=False, :40): correctly rounded square roots of exact integers
+            lo = np.sqrt(np.float64(b0)).astype(np.float32)
+            hi = np.sqrt(np.float64(b1)).astype(np.float32)
+            pk.append(float(percentile_linear_from_sorted_pair(lo, hi, gamma)))
+        hd95[lab - 1] = np.maximum(pk[0], pk[1])
     # true division on the host (like the CPU capture of the reference); torch's device kernel would multiply by the reciprocal,
     # 1 ulp off for a precision that is not a power of two
     return torch.as_tensor(hd95 * 1 / precision).to(dev)

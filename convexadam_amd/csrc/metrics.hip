@@ -68,7 +68,11 @@ __global__ __launch_bounds__(256) void k_jacobian_stats(const float* __restrict_
         neg += j < 0.0f ? 1.0 : 0.0;
     }
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); s2 += __shfl_down(s2, o); neg += __shfl_down(neg, o); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], s); atomicAdd(&acc[1], s2); atomicAdd(&acc[2], neg); }
+    // one set of atomics per workgroup (round 4: 24 K double atomics on three addresses took 0.3 ms of a 0.36 ms call)
+    __shared__ double part[4][3];
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = s; part[threadIdx.x >> 6][1] = s2; part[threadIdx.x >> 6][2] = neg; }
+    cvx_barrier();
+    if (threadIdx.x < 3) atomicAdd(&acc[threadIdx.x], (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
 __global__ __launch_bounds__(256) void k_warp_nearest(const float* __restrict__ seg, const float* __restrict__ disp, int H, int W,
@@ -154,7 +158,7 @@ extern "C" int cvx_jacobian_stats_f64(const float* jac, int64_t n, double* acc3,
     CVX_REQUIRE(jac && acc3 && n > 0, "cvx_jacobian_stats_f64: bad arguments");
     hipStream_t s = as_stream(stream);
     if (hipMemsetAsync(acc3, 0, 3 * sizeof(double), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "jacobian_stats: memset failed");
-    const int nb = (int)(cdiv64(n, 256 * 8) < 2048 ? cdiv64(n, 256 * 8) : 2048);
+    const int nb = (int)(cdiv64(n, 256 * 8) < 1024 ? cdiv64(n, 256 * 8) : 1024);
     hipLaunchKernelGGL(k_jacobian_stats, dim3(nb), dim3(256), 0, s, jac, (size_t)n, acc3);
     return check_last("jacobian_stats");
 }

@@ -439,6 +439,20 @@ int cvx_edt_squared_i32(const float* obj, int batch, int H, int W, int D, int* d
  * labels_host [n] (host array, n <= 64) -- the transforms cupy_hd95 needs at precision 1 (hyper_util:39-46) without materialising the masks */
 int cvx_edt_squared_labels_i32(const float* seg, int H, int W, int D, const int* labels_host, int n_labels, int* d2, void* workspace,
                                size_t workspace_bytes, void* stream);
+/* cupy_hd95 (hyper_util.py:32-51) without volume-sized transforms: the reference reads its four distance transforms per label on the
+ * SURFACE of the other map only (dist1[surf2], dist2[surf1], :48), so the distances are computed at those voxels alone.
+ *   cvx_label_bits_u64            : one bit per (label, voxel) of a label map: bits [num_labels][H*W][ceil(D/64)] (bit z%64 of word z/64 of
+ *                                   row h*W+w of plane l-1 <=> seg[h][w][z] == l); cvx_label_bits_bytes = its size
+ *   cvx_surface_distance_hist_i64 : every voxel of seg_b carrying an ACTIVE label l (bit l of the 256-bit host mask active4[4]) with an
+ *                                   in-bounds 6-neighbour of another value (inside distance exactly 1, :41/:45) adds one count to
+ *                                   hist[(l-1)*hist_stride + d2], d2 = exact squared distance to the nearest voxel of map a outside l
+ *                                   (voxel inside l in a) or inside l (voxel outside) = (edt(a==l) + edt(a!=l))**2 there; overflow
+ *                                   [(l-1)*overflow_stride] = 1 if map a holds no such voxel.  hist / overflow are accumulated into:
+ *                                   zero them first.  1 .. 255 labels; H, W <= 2047 */
+size_t cvx_label_bits_bytes(int H, int W, int D, int num_labels);
+int cvx_label_bits_u64(const float* seg, int H, int W, int D, int num_labels, uint64_t* bits, void* stream);
+int cvx_surface_distance_hist_i64(const float* seg_b, const uint64_t* bits_a, int H, int W, int D, int num_labels, const uint64_t* active4,
+                                  int nbins, int64_t* hist, int64_t hist_stride, int* overflow, int overflow_stride, void* stream);
 
 #pragma GCC visibility pop
 
