@@ -130,7 +130,7 @@ SIGNATURES = {
     "cvx_edt_squared_labels_i32": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "cvx_label_bits_bytes": (_sz, [_i, _i, _i, _i]),
     "cvx_label_bits_u64": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "cvx_surface_distance_hist_i64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i, _vp]),
+    "cvx_surface_distance_hist_i64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i, _i, _vp]),
 }
 
 _lib = None

@@ -244,6 +244,11 @@ def edt_squared(obj):
     return out
 
 
+# cupy_hd95(method="surface"): rows searched around a surface voxel before the call falls back to the distance transforms (the cost of a
+# voxel grows with the square of its distance to the other surface; the transforms' cost does not depend on it)
+HD95_SURFACE_MAX_RADIUS = 48
+
+
 def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=None):
     """hyper_util.py:32-51: 95th-percentile symmetric surface distance for labels 1 .. num_labels (30 where a label is absent from
     either map), float64 tensor on the device of `fixed`.  Per label on the device: masks on the nearest-upsampled grid, exact
@@ -254,7 +259,8 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=N
     method (not in the reference): "surface" (default at precision 1, <= 255 labels, H, W <= 2047) computes the distances at the surface
     voxels alone -- bit planes of both maps + a ring search per surface voxel (csrc/surfdist.hip), no volume-sized transform; "edt" is the
     path described above (the only one for precision > 1).  Both give the same float64 results bit for bit (exact integer squared
-    distances either way); "surface" needs two host synchronisations (label counts, results).
+    distances either way); "surface" needs two host synchronisations (label counts, results) and hands the call over to "edt" when
+    a surface voxel lies more than HD95_SURFACE_MAX_RADIUS rows from the other map's label (badly registered pairs).
     fixed_cache (not in the reference): a dict the caller keeps per FIXED label map -- the sweep scores many fields against the same
     fixed segmentation (16 per Adam run), and what is derived from the fixed map alone does not depend on the field: its bit planes
     ("surface": 1 MB per label at 160x192x224) or the two distance transforms of every fixed label ("edt": 715 MB for 13 labels);
@@ -340,11 +346,14 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=N
                 for k, (seg_b, bits_a) in enumerate(((mv, bits_f), (fx, bits_m))):
                     check(L.cvx_surface_distance_hist_i64(ptr(seg_b), ptr(bits_a), H, W, D, nl, C.cast(act4, C.c_void_p), nbins,
                                                           C.c_void_p(hist.data_ptr() + 8 * k * nbins), 2 * nbins,
-                                                          C.c_void_p(flag.data_ptr() + 4 * k), 2, sp))
+                                                          C.c_void_p(flag.data_ptr() + 4 * k), 2, int(HD95_SURFACE_MAX_RADIUS), sp))
                 quant = float(np.true_divide(95, np.float32(100)))               # numpy: q / float32(100) for float32 data
                 check(L.cvx_hist_percentile_neighbours_batch_i64(ptr(hist), nbins, 2 * nl, quant, ptr(out3), sp))
                 host = tail.cpu().numpy()
-                if np.any(host[nl * 6:].view(np.int32)[[2 * (lab - 1) + k for lab in present for k in range(2)]] != 0):
+                flags = host[nl * 6:].view(np.int32)[[2 * (lab - 1) + k for lab in present for k in range(2)]]
+                if np.any(flags == 2):               # a surface voxel farther than HD95_SURFACE_MAX_RADIUS rows from its target: the ring
+                    return cupy_hd95(fixed, moving, num_labels, precision, fixed_cache, method="edt")   # search would crawl; transforms
+                if np.any(flags != 0):
                     raise RuntimeError("cupy_hd95: squared distance exceeds the histogram range")
                 res = host[:nl * 6].reshape(nl, 2, 3)[[lab - 1 for lab in present]]
         return _hd95_from_order_stats(res, present, nl, precision, dev)

@@ -39,23 +39,35 @@ __global__ __launch_bounds__(256) void k_label_bits(const float* __restrict__ se
 }
 
 // distance along D from voxel z to the nearest set bit of a row of `nseg` words (the complement of the row if `invert`); INT_MAX if none
+__device__ __forceinline__ int nearest_in_word(unsigned long long m, int sg, int zw, int zb, int z) {
+    if (!m) return INT_MAX;
+    if (sg < zw) return z - (sg * 64 + 63 - __builtin_clzll(m));
+    if (sg > zw) return sg * 64 + __builtin_ctzll(m) - z;
+    const unsigned long long left = m & ((2ull << zb) - 1ull), right = m & ~((1ull << zb) - 1ull);
+    const int dl = left ? zb - (63 - __builtin_clzll(left)) : INT_MAX, dr = right ? __builtin_ctzll(right) - zb : INT_MAX;
+    return min(dl, dr);
+}
 __device__ __forceinline__ int nearest_in_row(const unsigned long long* __restrict__ rowbits, int nseg, int D, int z, bool invert) {
     const int zw = z >> 6, zb = z & 63;
+    const unsigned long long tail = (D & 63) ? (1ull << (D & 63)) - 1ull : ~0ull;
     int best = INT_MAX;
+    if (nseg <= 4) {                                         // all words in flight before the first is used (D <= 256: the common case)
+        unsigned long long m[4];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) m[sg] = rowbits[min(sg, nseg - 1)];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            unsigned long long v = invert ? ~m[sg] : m[sg];
+            if (sg == nseg - 1) v &= tail;
+            if (sg < nseg) best = min(best, nearest_in_word(v, sg, zw, zb, z));
+        }
+        return best;
+    }
     for (int sg = 0; sg < nseg; ++sg) {
         unsigned long long m = rowbits[sg];
         if (invert) m = ~m;
-        if (sg == nseg - 1 && (D & 63)) m &= (1ull << (D & 63)) - 1ull;
-        if (!m) continue;
-        int dist;
-        if (sg < zw) dist = z - (sg * 64 + 63 - __builtin_clzll(m));
-        else if (sg > zw) dist = sg * 64 + __builtin_ctzll(m) - z;
-        else {
-            const unsigned long long left = m & ((2ull << zb) - 1ull), right = m & ~((1ull << zb) - 1ull);
-            const int dl = left ? zb - (63 - __builtin_clzll(left)) : INT_MAX, dr = right ? __builtin_ctzll(right) - zb : INT_MAX;
-            dist = min(dl, dr);
-        }
-        best = min(best, dist);
+        if (sg == nseg - 1) m &= tail;
+        best = min(best, nearest_in_word(m, sg, zw, zb, z));
     }
     return best;
 }
@@ -64,7 +76,7 @@ __device__ __forceinline__ int nearest_in_row(const unsigned long long* __restri
 __global__ __launch_bounds__(256) void k_surface_dist_hist(const float* __restrict__ segb, const unsigned long long* __restrict__ bits_a, int H,
                                                            int W, int D, int nseg, int nl, ActiveLabels act, int nbins,
                                                            unsigned long long* __restrict__ hist_all, size_t hist_stride,
-                                                           int* __restrict__ overflow_all, int overflow_stride) {
+                                                           int* __restrict__ overflow_all, int overflow_stride, int max_radius) {
     // surface voxels are close to the other surface: almost every count lands in a few low bins, accumulated per workgroup in LDS
     constexpr int LL = 64, LB = 64;
     __shared__ unsigned int low[LL * LB];
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(256) void k_surface_dist_hist(const float* __restri
         //           is final; what is left goes to the wavefront-wide ring search below
         // (the lanes of a wavefront share the row segment, so lanes of the same label read the same words: one cache line per load.
         // Reading them through the scalar unit instead -- a loop over the labels present, uniform addresses -- was 2-4 x slower.)
-        int d2 = 0;
+        int d2 = 0, seed = INT_MAX;
         if (surf) {
             const unsigned long long* plane = bits_a + (size_t)(l - 1) * nrows * nseg;
             const int zb = lane;
@@ -126,6 +138,7 @@ __global__ __launch_bounds__(256) void k_surface_dist_hist(const float* __restri
                         if (win) best = min(best, dh * dh + dw * dw + ((win & 4u) ? 0 : (win & 10u) ? 1 : 4));
                     }
                 if (best <= 8) d2 = best;
+                else seed = best;                                                          // 9 .. 12: an upper bound for the ring search
             }
         }
         {   // one LDS / global atomic per distinct (label, distance) of the wavefront
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(256) void k_surface_dist_hist(const float* __restri
                 if (lane == leader) {
                     const int q = k >> 4, bin = k & 15;
                     const unsigned cnt = (unsigned)__builtin_popcountll(same);
-                    if (bin >= nbins) overflow_all[(size_t)q * overflow_stride] = 1;
+                    if (bin >= nbins) atomicMax(&overflow_all[(size_t)q * overflow_stride], 1);
                     else if (q < LL) atomicAdd(&low[q * LB + bin], cnt);
                     else atomicAdd(&hist_all[(size_t)q * hist_stride + bin], (unsigned long long)cnt);
                 }
@@ -153,7 +166,8 @@ __global__ __launch_bounds__(256) void k_surface_dist_hist(const float* __restri
             const int ql = __shfl(l, b), z = sg * 64 + b;
             const unsigned long long* plane = bits_a + (size_t)(ql - 1) * nrows * nseg;
             const bool inside = (plane[(size_t)row * nseg + sg] >> b) & 1ull;          // inside l in map a: distance to the complement
-            int best = INT_MAX;
+            int best = __shfl(seed, b);
+            bool gave_up = false;
             for (int i0 = 0;; i0 += 64) {
                 const int idx = i0 + lane;
                 int s = (int)sqrtf((float)idx);                                       // floor(sqrt(idx)); idx < 2^24
@@ -162,6 +176,7 @@ __global__ __launch_bounds__(256) void k_surface_dist_hist(const float* __restri
                 const int r = (s + 1) >> 1;                                           // ring of cell idx: smallest r with (2r+1)^2 > idx
                 const int r0 = __shfl(r, 0);
                 if (r0 > rmax || (long long)r0 * r0 >= best) break;
+                if (max_radius > 0 && r0 > max_radius) { gave_up = true; break; }
                 int dh = 0, dw = 0;
                 if (r > 0) {
                     const int t = idx - (2 * r - 1) * (2 * r - 1), side = t / (2 * r), pos = t - side * 2 * r;
@@ -178,7 +193,8 @@ __global__ __launch_bounds__(256) void k_surface_dist_hist(const float* __restri
                 best = min(best, cand);
             }
             if (lane == 0) {
-                if (best < 0 || best >= nbins) overflow_all[(size_t)(ql - 1) * overflow_stride] = 1;     // no voxel of the wanted kind in map a
+                if (gave_up) atomicMax(&overflow_all[(size_t)(ql - 1) * overflow_stride], 2);
+                else if (best < 0 || best >= nbins) atomicMax(&overflow_all[(size_t)(ql - 1) * overflow_stride], 1);   // no voxel of the wanted kind in map a
                 else if (ql <= LL && best < LB) atomicAdd(&low[(ql - 1) * LB + best], 1u);
                 else atomicAdd(&hist_all[(size_t)(ql - 1) * hist_stride + best], 1ull);
             }
@@ -210,9 +226,9 @@ extern "C" int cvx_label_bits_u64(const float* seg, int H, int W, int D, int num
 }
 
 extern "C" int cvx_surface_distance_hist_i64(const float* seg_b, const uint64_t* bits_a, int H, int W, int D, int num_labels, const uint64_t* active4,
-                                             int nbins, int64_t* hist, int64_t hist_stride, int* overflow, int overflow_stride, void* stream) {
+                                             int nbins, int64_t* hist, int64_t hist_stride, int* overflow, int overflow_stride, int max_radius, void* stream) {
     CVX_REQUIRE(seg_b && bits_a && hist && overflow && active4 && H > 0 && W > 0 && D > 0 && num_labels > 0 && num_labels <= 255 && nbins > 0 &&
-                    hist_stride >= nbins && overflow_stride >= 1,
+                    hist_stride >= nbins && overflow_stride >= 1 && max_radius >= 0,
                 "cvx_surface_distance_hist_i64: bad arguments (1 .. 255 labels)");
     CVX_REQUIRE(H <= 2047 && W <= 2047 && D <= 32768, "cvx_surface_distance_hist_i64: extent too large (H, W <= 2047, D <= 32768)");
     ActiveLabels act;
@@ -223,6 +239,6 @@ extern "C" int cvx_surface_distance_hist_i64(const float* seg_b, const uint64_t*
     const int64_t wgs = cdiv64(waves, 4) < 4096 ? cdiv64(waves, 4) : 4096;
     hipLaunchKernelGGL(k_surface_dist_hist, dim3((unsigned)wgs), dim3(256), 0, as_stream(stream), seg_b,
                        reinterpret_cast<const unsigned long long*>(bits_a), H, W, D, nseg, num_labels, act, nbins,
-                       reinterpret_cast<unsigned long long*>(hist), (size_t)hist_stride, overflow, overflow_stride);
+                       reinterpret_cast<unsigned long long*>(hist), (size_t)hist_stride, overflow, overflow_stride, max_radius);
     return check_last("surface_distance_hist");
 }

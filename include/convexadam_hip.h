@@ -447,12 +447,15 @@ int cvx_edt_squared_labels_i32(const float* seg, int H, int W, int D, const int*
  *                                   in-bounds 6-neighbour of another value (inside distance exactly 1, :41/:45) adds one count to
  *                                   hist[(l-1)*hist_stride + d2], d2 = exact squared distance to the nearest voxel of map a outside l
  *                                   (voxel inside l in a) or inside l (voxel outside) = (edt(a==l) + edt(a!=l))**2 there; overflow
- *                                   [(l-1)*overflow_stride] = 1 if map a holds no such voxel.  hist / overflow are accumulated into:
- *                                   zero them first.  1 .. 255 labels; H, W <= 2047 */
+ *                                   [(l-1)*overflow_stride] = 1 if map a holds no such voxel.  The cost of one voxel grows with the
+ *                                   square of its distance (the transforms' cost does not depend on it): max_radius > 0 bounds the
+ *                                   search to rows (h', w') within max_radius of the voxel's row; a voxel that needs more is not
+ *                                   counted and overflow = 2 (use the transforms then), 0 = unbounded.  hist / overflow are
+ *                                   accumulated into: zero them first.  1 .. 255 labels; H, W <= 2047 */
 size_t cvx_label_bits_bytes(int H, int W, int D, int num_labels);
 int cvx_label_bits_u64(const float* seg, int H, int W, int D, int num_labels, uint64_t* bits, void* stream);
 int cvx_surface_distance_hist_i64(const float* seg_b, const uint64_t* bits_a, int H, int W, int D, int num_labels, const uint64_t* active4,
-                                  int nbins, int64_t* hist, int64_t hist_stride, int* overflow, int overflow_stride, void* stream);
+                                  int nbins, int64_t* hist, int64_t hist_stride, int* overflow, int overflow_stride, int max_radius, void* stream);
 
 #pragma GCC visibility pop
 

@@ -63,7 +63,7 @@ def surface_hist_numpy(seg_b, seg_a, nl, active, nbins):
     return hist, over
 
 
-def run_surface_hist(seg_b, seg_a, nl, active):
+def run_surface_hist(seg_b, seg_a, nl, active, max_radius=0):
     from convexadam_amd._lib import check, lib, ptr, stream_ptr
     L = lib()
     H, W, D = seg_a.shape
@@ -78,7 +78,7 @@ def run_surface_hist(seg_b, seg_a, nl, active):
     for lab in active:
         act[lab >> 6] |= 1 << (lab & 63)
     act4 = (C.c_uint64 * 4)(*act)
-    check(L.cvx_surface_distance_hist_i64(ptr(b), ptr(bits), H, W, D, nl, C.cast(act4, C.c_void_p), nbins, ptr(hist), nbins, ptr(over), 1, sp))
+    check(L.cvx_surface_distance_hist_i64(ptr(b), ptr(bits), H, W, D, nl, C.cast(act4, C.c_void_p), nbins, ptr(hist), nbins, ptr(over), 1, max_radius, sp))
     return host(bits), host(hist), host(over), nbins
 
 
@@ -131,6 +131,12 @@ def test_surface_distance_far_targets_and_missing_targets():
     want, wover = surface_hist_numpy(b, a, 2, [1], nbins)
     assert np.array_equal(hist, want) and not over.any() and hist[0].sum() > 0
     assert hist[0, 19 ** 2 + 32 ** 2 + 67 ** 2] == 1                                    # from the surface voxel (0, 0, 2)
+    # a bounded search gives up on those voxels (flag 2: the caller switches to the transforms) but still counts what it reaches
+    bits, hist, over, nbins = run_surface_hist(b, a, 2, [1], max_radius=5)
+    assert over[0] == 2 and hist.sum() == 0
+    a[1, 3, 0] = 1
+    bits, hist, over, nbins = run_surface_hist(b, a, 2, [1], max_radius=5)
+    assert over[0] == 0 and np.array_equal(hist, surface_hist_numpy(b, a, 2, [1], nbins)[0])
     a[:] = 1
     bits, hist, over, nbins = run_surface_hist(b, a, 2, [1])
     assert over[0] == 1 and over[1] == 0 and hist.sum() == 0
@@ -154,6 +160,12 @@ def test_hd95_surface_method_equals_edt_method_and_oracle(HU, morc, shape, nl):
         for _ in range(2):
             assert np.array_equal(host(HU.cupy_hd95(fa, fb, nl, fixed_cache=cache)), want)
         assert ("bits", nl) in cache
+        old = HU.HD95_SURFACE_MAX_RADIUS
+        HU.HD95_SURFACE_MAX_RADIUS = 1                                                   # force the hand-over to the transforms
+        try:
+            assert np.array_equal(host(HU.cupy_hd95(fa, fb, nl, fixed_cache=cache)), want)
+        finally:
+            HU.HD95_SURFACE_MAX_RADIUS = old
     with pytest.raises(NotImplementedError):
         HU.cupy_hd95(fa, fb, nl, precision=2, method="surface")
     with pytest.raises(ValueError):

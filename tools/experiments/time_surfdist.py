@@ -23,7 +23,7 @@ L = lib()
 H, W, D = shape
 nbins = (H - 1) ** 2 + (W - 1) ** 2 + (D - 1) ** 2 + 2
 sp = stream_ptr(dev)
-act4 = (C.c_uint64 * 4)((1 << (nl + 1)) - 2, 0, 0, 0)
+act4 = (C.c_uint64 * 4)(int(os.environ.get("ACT", str((1 << (nl + 1)) - 2)), 0), 0, 0, 0)
 
 
 def planes(seg):
@@ -36,7 +36,7 @@ for name, b, a in (("moving surface vs fixed planes", warped, seg_f), ("fixed su
     bits = planes(a)
     hist = torch.zeros((nl, nbins), dtype=torch.int64, device=dev)
     over = torch.zeros(nl, dtype=torch.int32, device=dev)
-    run = lambda: check(L.cvx_surface_distance_hist_i64(ptr(b), ptr(bits), H, W, D, nl, C.cast(act4, C.c_void_p), nbins, ptr(hist), nbins, ptr(over), 1, sp))  # noqa: E731
+    run = lambda: check(L.cvx_surface_distance_hist_i64(ptr(b), ptr(bits), H, W, D, nl, C.cast(act4, C.c_void_p), nbins, ptr(hist), nbins, ptr(over), 1, 0, sp))  # noqa: E731
     run()
     torch.cuda.synchronize()
     h = hist.sum(0).cpu()
