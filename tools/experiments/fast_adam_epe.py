@@ -1,6 +1,6 @@
 """CPU: EPE of the oracle's fast Adam mode vs the reference capture (tests/golden/fullsize.npz) at 1/20/40/80 iterations."""
 import sys, time, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); os.chdir(ROOT)
 import numpy as np
 from oracle import oracle as orc
@@ -24,6 +24,10 @@ modes = sys.argv[1:] or ["exact", "fast"]
 for mode in modes:
     for n in (1, 20, 40, 80):
         t = time.time()
-        r = orc.adam_run(F2, M2, P0, 1.25, n, mode=mode, keep_last_step=False) if mode == "fast" else orc.adam_run(F2, M2, P0, 1.25, n)
+        if mode == "fast_f16":          # fast arithmetic on features rounded once to half precision
+            h = lambda x: x.astype(np.float16).astype(np.float32)  # noqa: E731
+            r = orc.adam_run(h(F2), h(M2), P0, 1.25, n, mode="fast", keep_last_step=False)
+        else:
+            r = orc.adam_run(F2, M2, P0, 1.25, n, mode=mode, keep_last_step=False) if mode == "fast" else orc.adam_run(F2, M2, P0, 1.25, n)
         f = orc.resize_trilinear(r["U"] * np.float32(2), shape)
         print(mode, n, "epe_sub %.4e" % epe(f[:, ::s, ::s, ::s], g["c1_adam_%d_sub" % n]), "t=%.1fs" % (time.time() - t), flush=True)
