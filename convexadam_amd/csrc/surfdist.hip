@@ -164,6 +164,9 @@ __global__ __launch_bounds__(256) void k_surface_dist_hist(const float* __restri
             const int b = __builtin_ctzll(todo);
             todo &= todo - 1ull;
             const int ql = __shfl(l, b), z = sg * 64 + b;
+            // a label that has already exceeded the radius is void for the caller (flag 2: the whole call goes to the transforms): the
+            // other far voxels of that label are not searched any more -- a badly registered pair costs little before it is handed over
+            if (max_radius > 0 && __hip_atomic_load(&overflow_all[(size_t)(ql - 1) * overflow_stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2) continue;
             const unsigned long long* plane = bits_a + (size_t)(ql - 1) * nrows * nseg;
             const bool inside = (plane[(size_t)row * nseg + sg] >> b) & 1ull;          // inside l in map a: distance to the complement
             int best = __shfl(seed, b);

@@ -450,7 +450,8 @@ int cvx_edt_squared_labels_i32(const float* seg, int H, int W, int D, const int*
  *                                   [(l-1)*overflow_stride] = 1 if map a holds no such voxel.  The cost of one voxel grows with the
  *                                   square of its distance (the transforms' cost does not depend on it): max_radius > 0 bounds the
  *                                   search to rows (h', w') within max_radius of the voxel's row; a voxel that needs more is not
- *                                   counted and overflow = 2 (use the transforms then), 0 = unbounded.  hist / overflow are
+ *                                   counted, overflow = 2 and the remaining far voxels of that label are skipped (the label's
+ *                                   histogram is void: use the transforms then), 0 = unbounded.  hist / overflow are
  *                                   accumulated into: zero them first.  1 .. 255 labels; H, W <= 2047 */
 size_t cvx_label_bits_bytes(int H, int W, int D, int num_labels);
 int cvx_label_bits_u64(const float* seg, int H, int W, int D, int num_labels, uint64_t* bits, void* stream);

@@ -217,6 +217,43 @@ def trial_metrics(rng, t):
     return ok, ("metrics", sh, conv, nl)
 
 
+def trial_hd95(rng, t):
+    """cupy_hd95: the surface-only path (bit planes + cube / ring searches) against the transforms and the scipy restatement, on blob and
+    noise label maps with rows of 1 .. 3+ words, labels missing from either map, and a small search radius now and then (hand-over)."""
+    from convexadam_amd import convexAdam_hyper_util as HU
+    from oracle import metrics_oracle as morc
+    sh = (int(rng.integers(3, 40)), int(rng.integers(3, 40)), int(rng.choice([rng.integers(3, 40), rng.integers(60, 70), rng.integers(120, 200)])))
+    nl = int(rng.integers(1, 16))
+    if rng.integers(0, 3):
+        cell = int(rng.integers(2, 7))
+        a = rng.integers(0, nl + 1, [max(1, -(-s // cell)) for s in sh])
+        a = np.kron(a, np.ones((cell,) * 3, np.int64))[: sh[0], : sh[1], : sh[2]]
+    else:
+        a = rng.integers(0, nl + 1, sh)
+    b = np.roll(a, tuple(int(v) for v in rng.integers(-3, 4, 3)), (0, 1, 2))
+    if rng.integers(0, 2):
+        b = np.where(rng.random(sh) < 0.02, rng.integers(0, nl + 1, sh), b)
+    if nl > 1 and rng.integers(0, 2):
+        b[b == int(rng.integers(1, nl + 1))] = 0
+    fa, fb = dev(a.astype(np.float32)), dev(b.astype(np.float32))
+    old = HU.HD95_SURFACE_MAX_RADIUS
+    HU.HD95_SURFACE_MAX_RADIUS = int(rng.choice([old, old, 2, 6]))
+    try:
+        res, errs = [], []
+        for call in (lambda: host(HU.cupy_hd95(fa, fb, nl)), lambda: host(HU.cupy_hd95(fa, fb, nl, method="edt")), lambda: morc.hd95(a, b, nl, 1)):
+            try:
+                res.append(call()); errs.append(False)
+            except (RuntimeError, ValueError):           # a label filling a whole map: no outside voxel (scipy: undefined feature transform)
+                res.append(None); errs.append(True)
+        if any(errs[:2]):
+            ok = errs[0] == errs[1]
+        else:
+            ok = np.array_equal(res[0], res[1]) and (errs[2] or np.array_equal(res[0], res[2]))
+    finally:
+        HU.HD95_SURFACE_MAX_RADIUS = old
+    return ok, ("hd95", sh, nl)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=10.0)
@@ -238,7 +275,7 @@ def main():
         orc.set_exp_table(t["exp"], t["exp_first"], t["exp_count"])
         orc.set_sqrt_table(t["sqrt"])
     rng = np.random.default_rng(a.seed)
-    kinds = [trial_pipeline, trial_pipeline, trial_masked, trial_labels, trial_adam, trial_adam, trial_convex_ops, trial_mind, trial_operators, trial_metrics]
+    kinds = [trial_pipeline, trial_pipeline, trial_masked, trial_labels, trial_adam, trial_adam, trial_convex_ops, trial_mind, trial_operators, trial_metrics, trial_hd95]
     if a.only:
         kinds = [k for k in kinds if any(tok in k.__name__ for tok in a.only.replace(',', ' ').split())]
     t0, n, bad, count = time.time(), 0, [], {}
