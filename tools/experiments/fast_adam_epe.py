@@ -28,6 +28,6 @@ for mode in modes:
             h = lambda x: x.astype(np.float16).astype(np.float32)  # noqa: E731
             r = orc.adam_run(h(F2), h(M2), P0, 1.25, n, mode="fast", keep_last_step=False)
         else:
-            r = orc.adam_run(F2, M2, P0, 1.25, n, mode=mode, keep_last_step=False) if mode == "fast" else orc.adam_run(F2, M2, P0, 1.25, n)
+            r = orc.adam_run(F2, M2, P0, 1.25, n, mode=mode, keep_last_step=False) if mode != "exact" else orc.adam_run(F2, M2, P0, 1.25, n)
         f = orc.resize_trilinear(r["U"] * np.float32(2), shape)
         print(mode, n, "epe_sub %.4e" % epe(f[:, ::s, ::s, ::s], g["c1_adam_%d_sub" % n]), "t=%.1fs" % (time.time() - t), flush=True)
