@@ -127,11 +127,19 @@ def evaluate_item(disp, seg_fixed, seg_moving, key_fixed, key_moving, num_labels
     jac = HU.jacobian_determinant_3d(d, False)                                             # convex_run_withconfig.py:137
     jstd, fold = HU.jacobian_log_std_and_folding(jac)                                      # :148-150
     warped = HU.warp_labels_nearest(seg_moving, d)                                         # :141
-    dice = HU.dice_coeff(seg_fixed, warped, num_labels + 1)                                # :142
-    dice0 = HU.dice_coeff(seg_fixed, seg_moving, num_labels + 1)
+    counts = HU.label_overlap_counts(seg_fixed, warped, num_labels + 1)                    # shared by Dice and HD95
+    dice = HU.dice_coeff(seg_fixed, warped, num_labels + 1, counts=counts)                 # :142
+    # what does not depend on the field is computed once per pair (kept in the caller's per-pair cache)
+    before = cache.get("before") if cache is not None else None
+    if before is None:
+        dice0 = HU.dice_coeff(seg_fixed, seg_moving, num_labels + 1)
+        tre0 = (key_fixed - key_moving).square().sum(-1).sqrt()
+        before = (dice0, tre0)
+        if cache is not None:
+            cache["before"] = before
+    dice0, tre0 = before
     tre, _ = HU.tre_at_keypoints(d, key_fixed, key_moving)                                 # convex_run_paired_mind.py:165-173
-    tre0 = (key_fixed - key_moving).square().sum(-1).sqrt()
-    hd95 = HU.cupy_hd95(seg_fixed, warped, num_labels, fixed_cache=cache)                  # convex_run_withconfig.py:143 (cache: the fixed map's transforms)
+    hd95 = HU.cupy_hd95(seg_fixed, warped, num_labels, fixed_cache=cache, counts=counts)   # convex_run_withconfig.py:143 (cache: the fixed map's bit planes)
     if robust is None:                                                                      # the 30 % labels with the lowest initial overlap (:60-61)
         robust = dice0.topk(max(1, int(num_labels * 0.3)), largest=False).indices
     return dict(dice=float(dice.mean()), dice30=float(dice[robust].mean()), dice_before=float(dice0.mean()), jstd=jstd, folding=fold,
