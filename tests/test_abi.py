@@ -110,6 +110,16 @@ def test_argument_validation_without_gpu(L):
     assert L.cvx_edt_squared_i32(dummy, 1, 40000, 40000, 4, dummy, dummy, 1 << 40, None) == -1 and b"int32" in L.cvx_last_error()
     assert L.cvx_edt_squared_i32(dummy, 2, 4, 4, 4, dummy, dummy, 16, None) == -2
     assert L.cvx_edt_squared_i32(dummy, 0, 4, 4, 4, dummy, dummy, 1 << 20, None) == -1
+    # surface-only HD95 (surfdist.hip): one bit per (label, voxel), 64 voxels along D per word
+    assert L.cvx_label_bits_bytes(160, 192, 224, 13) == 13 * 160 * 192 * 4 * 8 and L.cvx_label_bits_bytes(4, 4, 65, 2) == 2 * 16 * 2 * 8
+    assert L.cvx_label_bits_bytes(4, 4, 0, 2) == 0
+    assert L.cvx_label_bits_u64(dummy, 4, 4, 4, 256, dummy, None) == -1 and b"255" in L.cvx_last_error()
+    assert L.cvx_label_bits_u64(None, 4, 4, 4, 3, dummy, None) == -1
+    act = (C.c_uint64 * 4)(2, 0, 0, 0)
+    assert L.cvx_surface_distance_hist_i64(dummy, dummy, 4, 4, 4, 3, C.cast(act, C.c_void_p), 8, dummy, 4, dummy, 1, 0, None) == -1   # stride < nbins
+    assert L.cvx_surface_distance_hist_i64(dummy, dummy, 4, 4, 4, 3, None, 8, dummy, 8, dummy, 1, 0, None) == -1                       # no label mask
+    assert L.cvx_surface_distance_hist_i64(dummy, dummy, 4096, 4, 4, 3, C.cast(act, C.c_void_p), 8, dummy, 8, dummy, 1, 0, None) == -1 and b"2047" in L.cvx_last_error()
+    assert L.cvx_surface_distance_hist_i64(dummy, dummy, 4, 4, 4, 3, C.cast(act, C.c_void_p), 8, dummy, 8, dummy, 1, -1, None) == -1   # negative radius
 
 
 def test_workspace_queries(L):
