@@ -484,6 +484,24 @@ def main():
                          "traffic_stale": traffic_stale, "algorithmic_bytes": alg_bytes, "avg_launch_ms": corr_ms},
             "stages_ms": {k: sum(vs) / len(vs) for k, vs in stage_ms.items()},
         }
+        # the same accounting for the other stages and for the pair (every logical tensor touched once per logical pass);
+        # the graded `roofline` above stays the correlation kernel, the dominant stage BY TIME is the Adam loop
+        sm = res["stages_ms"]
+        V, g2 = SHAPE[0] * SHAPE[1] * SHAPE[2], CFG["grid_sp_adam"]
+        v2 = (SHAPE[0] // g2) * (SHAPE[1] // g2) * (SHAPE[2] // g2)
+        its = CFG["selected_niter"]
+        alg = {"mind": 2 * (2 * V * 4 + 12 * v2 * 4 + 12 * v * 4),                        # per image: two reads (global mean), pooled outputs only
+               "correlate": alg_bytes, "correlate_rev": alg_bytes,
+               "adam": its * (2 * 12 * v2 * 4 + 10 * 3 * v2 * 4)}                         # F2 + M2 + p, m, v read+write + U and dU write+read
+        by_stage = {}
+        for k, bts in alg.items():
+            if sm.get(k):
+                by_stage[k] = {"algorithmic_bytes": bts, "ms": sm[k], "achieved_GBps": bts / (sm[k] * 1e-3) / 1e9, "frac": bts / (sm[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        pair_bytes = alg["mind"] + 2 * (alg_bytes + 6 * K * v * 4) + alg["adam"] + 3 * V * 4 * 4
+        by_stage["pair"] = {"algorithmic_bytes": pair_bytes, "ms": res["ms_per_step"], "achieved_GBps": pair_bytes / (res["ms_per_step"] * 1e-3) / 1e9,
+                            "frac": pair_bytes / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "coupled convex counted at 6 full reads of the cost volume per direction (SURVEY 8(d)); the branch-and-bound passes read less"}
+        res["roofline_by_stage"] = by_stage
         if batched is not None:
             res["batched_2streams"] = batched
         if cc_worst is not None and cc_worst.get("fast_corr_ms"):
