@@ -178,3 +178,25 @@ def test_hd95_surface_method_equals_edt_method_and_oracle(HU, morc, shape, nl):
     for method in ("surface", "edt"):
         with pytest.raises(RuntimeError):
             HU.cupy_hd95(full, fb, nl, method=method)                                   # label 1 fills the fixed map: no outside voxel
+
+
+def test_hd95_surface_equals_transforms_at_full_size(HU):
+    """BASELINE's full extent (160 x 192 x 224, 13 labels, the sweep's synthetic anatomy): the surface-only path == the whole-volume
+    transforms on a warped label map (rough surfaces, wrap-around slabs far from their label), with the fixed side cached."""
+    from convexadam_amd import sweep
+    shape = (160, 192, 224)
+    seg_f, seg_m, _, _, nl = sweep._make_labels(shape, 1, torch.device(DEV))
+    g = torch.Generator().manual_seed(9)
+    disp = torch.zeros((1, 3) + shape)
+    disp[0, 0], disp[0, 1], disp[0, 2] = 2.0, -1.0, 3.0
+    disp += 0.4 * torch.randn(disp.shape, generator=g)
+    warped = HU.warp_labels_nearest(seg_m, disp.to(DEV))
+    cache_s, cache_e = {}, {}
+    s = host(HU.cupy_hd95(seg_f, warped, nl, fixed_cache=cache_s))
+    e = host(HU.cupy_hd95(seg_f, warped, nl, fixed_cache=cache_e, method="edt"))
+    assert np.array_equal(s, e) and np.isfinite(s).all() and (s > 0).all()
+    counts = HU.label_overlap_counts(seg_f, warped, nl + 1)
+    assert np.array_equal(host(HU.cupy_hd95(seg_f, warped, nl, fixed_cache=cache_s, counts=counts)), s)
+    assert np.array_equal(HU.dice_coeff(seg_f, warped, nl + 1, counts=counts).numpy(), HU.dice_coeff(seg_f, warped, nl + 1).numpy())
+    with pytest.raises(ValueError):
+        HU.cupy_hd95(seg_f, warped, nl, counts=counts[:, :-1])
