@@ -70,6 +70,7 @@ SIGNATURES = {
     "cvx_pack_field_f64": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cvx_box_smooth_workspace_bytes": (_sz, [_i] * 5),
     "cvx_box_smooth_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "cvx_box_grow_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cvx_mask_erode_f32": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "cvx_gather_f32": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "cvx_select_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),

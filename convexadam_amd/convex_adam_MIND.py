@@ -159,6 +159,17 @@ def register_pair_device(img_fixed=None, img_moving=None, feat_fixed=None, feat_
         # the reference reads `disp_sample` after a loop that never ran (:181)
         raise UnboundLocalError("local variable 'disp_sample' referenced before assignment "
                                 "(selected_niter=0 with lambda_weight>0, convex_adam_MIND.py:181)")
+    if selected_smooth > 0 and selected_smooth % 2 == 0:
+        # The reference announces "+1" for an even kernel and then overwrites its own fix (:185-189): three avg_pool3d(k, stride 1,
+        # padding k//2) that each make every axis one voxel longer -- it returns (H+3, W+3, D+3, 3).  Restated as it behaves: the pair
+        # without smoothing, then the three growing pools (cvx_box_grow_f32).  With lambda_weight <= 0 the block is never reached (:155).
+        from .convex_adam_utils import box_smooth
+        if out is not None and lambda_weight > 0:
+            raise ValueError("register_pair_device: an even selected_smooth returns a (3,H+3,W+3,D+3) field; `out` is not supported")
+        disp = register_pair_device(img_fixed, img_moving, feat_fixed, feat_moving, mind_r, mind_d, lambda_weight, grid_sp, disp_hw,
+                                    selected_niter, 0, grid_sp_adam, ic, cost_scale, out, profile, cost, n_box, n_spline_pools, corr_mode,
+                                    storage, adam_mode)
+        return box_smooth(disp[None], int(selected_smooth), 3)[0] if lambda_weight > 0 else disp
     adam_mode = _resolve_adam_mode(adam_mode, n_spline_pools, storage)
     if cost not in ("ssd", "sad") or corr_mode not in ("exact", "fast") or storage not in ("fp32", "fp16") or adam_mode not in ("exact", "fast", "fast_all"):
         raise ValueError("cost must be 'ssd' or 'sad', corr_mode 'exact' or 'fast', adam_mode 'exact', 'fast' or 'fast_all', storage 'fp32' or 'fp16'")
@@ -373,9 +384,8 @@ def convex_adam_pt(
     img_fixed = validate_image(img_fixed).float()
     img_moving = validate_image(img_moving).float()
     if selected_smooth > 0 and selected_smooth % 2 == 0:
-        # the reference prints this and then overwrites its own fix (:185-189), growing the volume;
-        # an even kernel has no sensible meaning here, so refuse instead of silently changing shape
-        raise ValueError("selected_smooth should be an odd number")
+        print('selected_smooth should be an odd number, adding 1')       # the reference's message (:187); its fix is overwritten at :189,
+                                                                         # so the field grows to (H+3, W+3, D+3, 3) -- restated in register_pair_device
     H, W, D = img_fixed.shape
     t0 = time.time()
     if use_mask:

@@ -176,10 +176,20 @@ def grid_sample(vol, grid):
 
 
 def box_smooth(x, k, passes=1):
-    """`passes` x F.avg_pool3d(x, k, stride=1, padding=k//2) for (1,C,H,W,D).  (convex_adam_MIND.py:166,191)"""
+    """`passes` x F.avg_pool3d(x, k, stride=1, padding=k//2) for (1,C,H,W,D).  (convex_adam_MIND.py:166,191)
+    Odd k keeps the extent; an even k returns (1,C,H+passes,W+passes,D+passes) like torch."""
     x = require_device_tensor(x, "x")
     _, Cn, H, W, D = [int(s) for s in x.shape]
     a = f32c(x)
+    if int(k) > 0 and int(k) % 2 == 0:
+        # an even kernel makes every axis one voxel longer per pool (padding k//2 on both sides of k taps): what the reference's even
+        # `selected_smooth` does (convex_adam_MIND.py:184-191)
+        for _ in range(int(passes)):
+            out = torch.empty((1, Cn, H + 1, W + 1, D + 1), dtype=torch.float32, device=a.device)
+            with torch.cuda.device(a.device):
+                check(lib().cvx_box_grow_f32(ptr(a), Cn, H, W, D, int(k), ptr(out), stream_ptr(a.device)))
+            a, H, W, D = out, H + 1, W + 1, D + 1
+        return a if x.dtype == torch.float32 else a.to(x.dtype)
     out = torch.empty_like(a)
     nws = lib().cvx_box_smooth_workspace_bytes(Cn, H, W, D, int(passes))
     ws = workspace(max(nws, 256), a.device)

@@ -87,6 +87,25 @@ __global__ __launch_bounds__(256) void k_box_zero(const float* __restrict__ in, 
     out[i] = BACKWARD ? s : fdiv(s, div);
 }
 
+// the same with an EVEN kernel: padding k/2 on both sides of a window of k taps -> (H+1, W+1, D+1); output o covers inputs
+// o-k/2 .. o+k/2-1 (the reference's even `selected_smooth`, convex_adam_MIND.py:184-191: its "+1" is overwritten at :189)
+__global__ __launch_bounds__(256) void k_box_grow(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W, int D, int k) {
+    const int Ho = H + 1, Wo = W + 1, Do = D + 1;
+    const size_t n = (size_t)C * Ho * Wo * Do;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)(i % Do), w = (int)((i / Do) % Wo), h = (int)((i / ((size_t)Do * Wo)) % Ho);
+    const int c = (int)(i / ((size_t)Do * Wo * Ho));
+    const int p = k / 2;
+    const int h0 = max(h - p, 0), h1 = min(h - p + k, H), w0 = max(w - p, 0), w1 = min(w - p + k, W), d0 = max(d - p, 0), d1 = min(d - p + k, D);
+    const float* ic = in + (size_t)c * H * W * D;
+    float s = 0.0f;
+    for (int z = h0; z < h1; ++z)
+        for (int y = w0; y < w1; ++y)
+            for (int x = d0; x < d1; ++x) s += ic[((size_t)z * W + y) * D + x];
+    out[i] = fdiv(s, (float)(k * k * k));
+}
+
 int launch_box_zero(const float* in, float* out, int C, int H, int W, int D, int k, bool backward, hipStream_t s) {
     const size_t n = (size_t)C * H * W * D;
     const dim3 grid((unsigned)cdiv64((int64_t)n, 256));
@@ -480,6 +499,16 @@ extern "C" int cvx_box_smooth_f32(const float* in, int C, int H, int W, int D, i
         src = dst;
     }
     return CVX_OK;
+}
+
+extern "C" int cvx_box_grow_f32(const float* in, int C, int H, int W, int D, int k, float* out, void* stream) {
+    CVX_REQUIRE(in && out && in != out, "cvx_box_grow_f32: null pointer or in-place");
+    CVX_REQUIRE(C > 0 && H > 0 && W > 0 && D > 0, "cvx_box_grow_f32: bad extent");
+    CVX_REQUIRE(k >= 2 && !(k & 1) && k <= 64, "cvx_box_grow_f32: kernel %d must be even, 2 .. 64 (odd kernels: cvx_box_smooth_f32)", k);
+    CVX_REQUIRE(k / 2 <= H && k / 2 <= W && k / 2 <= D, "cvx_box_grow_f32: padding %d exceeds the extent (avg_pool3d: pad <= kernel / 2 and input >= pad)", k / 2);
+    const size_t n = (size_t)C * (H + 1) * (W + 1) * (D + 1);
+    hipLaunchKernelGGL(k_box_grow, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, as_stream(stream), in, out, C, H, W, D, k);
+    return check_last("box_grow");
 }
 
 extern "C" int cvx_resize_trilinear_f32(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D,

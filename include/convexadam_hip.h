@@ -128,6 +128,11 @@ int cvx_round_f16_f32(float* x, int64_t n, void* stream);
 size_t cvx_box_smooth_workspace_bytes(int C, int H, int W, int D, int passes);
 int cvx_box_smooth_f32(const float* in, int C, int H, int W, int D, int k, int passes, float* out,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* the same operator with an EVEN kernel k (ONE pass): padding k/2 on both sides of k taps makes every axis one voxel longer --
+ * out [C][H+1][W+1][D+1].  This is what the reference does with an even `selected_smooth` (its "+1" is overwritten,
+ * convex_adam_MIND.py:185-189): three such pools, the returned field is (H+3, W+3, D+3, 3).  The whole-pair entries keep refusing an
+ * even `selected_smooth` (their output is [3][H][W][D]); the Python mirror runs the pair without smoothing and applies this three times. */
+int cvx_box_grow_f32(const float* in, int C, int H, int W, int D, int k, float* out, void* stream);
 
 /* output packing of convex_adam_pt                              convex_adam_MIND.py:198-202
  *   field [3][H][W][D] float32 -> out [H][W][D][3] float64, each value first passed through the caller's `dtype` (quantize 0 = float32,

@@ -171,6 +171,31 @@ ORC_API void orc_box_zero(const float* in, float* out, int C, int H, int W, int 
         }
 }
 
+/* The same operator with an EVEN kernel (the reference's even `selected_smooth`, convex_adam_MIND.py:184-191: the announced "+1" is
+ * overwritten at :189): padding k/2 on both sides of a window of k taps makes every axis ONE voxel longer -- out is (H+1, W+1, D+1),
+ * output o covers inputs o-k/2 .. o+k/2-1; raster-order sum of the in-range taps from 0, one division by k^3 (count_include_pad). */
+ORC_API void orc_box_grow(const float* in, float* out, int C, int H, int W, int D, int k) {
+    const int p = k / 2, Ho = H + 1, Wo = W + 1, Do = D + 1;
+    const float div = (float)(k * k * k);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int c = 0; c < C; ++c)
+        for (int h = 0; h < Ho; ++h) {
+            const float* ic = in + (size_t)c * H * W * D;
+            float* oc = out + (size_t)c * Ho * Wo * Do;
+            for (int w = 0; w < Wo; ++w)
+                for (int d = 0; d < Do; ++d) {
+                    const int h0 = h - p < 0 ? 0 : h - p, h1 = h - p + k > H ? H : h - p + k;
+                    const int w0 = w - p < 0 ? 0 : w - p, w1 = w - p + k > W ? W : w - p + k;
+                    const int d0 = d - p < 0 ? 0 : d - p, d1 = d - p + k > D ? D : d - p + k;
+                    float s = 0.0f;
+                    for (int z = h0; z < h1; ++z)
+                        for (int y = w0; y < w1; ++y)
+                            for (int x = d0; x < d1; ++x) s += ic[((size_t)z * W + y) * D + x];
+                    oc[((size_t)h * Wo + w) * Do + d] = s / div;
+                }
+        }
+}
+
 /* adjoint of orc_box_zero as ATen's avg_pool3d_backward evaluates it: every output position o (in
  * raster order) adds gradOut[o]/k^3 to each input position of its window; gathered here per input
  * position in that same order of arrival. */

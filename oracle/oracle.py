@@ -58,6 +58,7 @@ def lib():
         L.orc_disp_mesh.argtypes = [C.c_int, _f32p]
         L.orc_box_zero.argtypes = [_f32p, _f32p] + [C.c_int] * 5
         L.orc_box_zero_backward.argtypes = [_f32p, _f32p] + [C.c_int] * 5
+        L.orc_box_grow.argtypes = [_f32p, _f32p] + [C.c_int] * 5
         L.orc_avgpool_stride.argtypes = [_f32p, _f32p] + [C.c_int] * 5
         L.orc_box3_replicate.argtypes = [_f32p, _f32p] + [C.c_int] * 3
         L.orc_mindssc.argtypes = [_f32p] + [C.c_int] * 5 + [_f32p, C.POINTER(C.c_float)]
@@ -174,6 +175,13 @@ def disp_mesh(hw):
 def box_zero(x, k=3):
     x = _f(x); c, h, w, d = x.shape
     out = np.empty_like(x); lib().orc_box_zero(x.reshape(-1), out.reshape(-1), c, h, w, d, k); return out
+
+
+def box_grow(x, k):
+    """avg_pool3d(k EVEN, stride 1, padding k//2): (c, h, w, d) -> (c, h+1, w+1, d+1) (convex_adam_MIND.py:184-191 with an even selected_smooth)."""
+    x = _f(x); c, h, w, d = x.shape
+    assert k > 0 and k % 2 == 0
+    out = np.empty((c, h + 1, w + 1, d + 1), np.float32); lib().orc_box_grow(x.reshape(-1), out.reshape(-1), c, h, w, d, k); return out
 
 
 def box_zero_backward(x, k=3):
@@ -371,7 +379,7 @@ def convex_adam_pipeline(img_fixed, img_moving, mind_r=1, mind_d=2, lambda_weigh
         st.update(P0=P0, U=r["U"], F2=F2, M2=M2)
         disp_hr = resize_trilinear(r["U"] * np.float32(g), (H, W, D))
         if selected_smooth > 0:
-            for _ in range(3):
-                disp_hr = box_zero(disp_hr, selected_smooth)
+            for _ in range(3):      # an even kernel grows the field by one voxel per axis and pool (the reference overwrites its own "+1", :185-189)
+                disp_hr = box_zero(disp_hr, selected_smooth) if selected_smooth % 2 else box_grow(disp_hr, selected_smooth)
     out = np.stack([disp_hr[0], disp_hr[1], disp_hr[2]], 3).astype(np.float64)
     return (out, st) if return_stages else out

@@ -93,6 +93,9 @@ def test_argument_validation_without_gpu(L):
     assert L.cvx_correlate_f32(dummy, dummy, 12, 4, 4, 4, 2, dummy, None, dummy, 16, None) == -2         # workspace too small
     assert L.cvx_box_smooth_f32(dummy, 3, 4, 4, 4, 4, 1, C.c_void_p(512), None, 0, None) == -1           # even kernel
     assert b"odd" in L.cvx_last_error()
+    assert L.cvx_box_grow_f32(dummy, 3, 4, 4, 4, 3, C.c_void_p(512), None) == -1 and b"even" in L.cvx_last_error()   # odd kernel: the other entry
+    assert L.cvx_box_grow_f32(dummy, 3, 4, 4, 4, 2, dummy, None) == -1                                               # in place
+    assert L.cvx_box_grow_f32(dummy, 3, 4, 4, 1, 4, C.c_void_p(512), None) == -1 and b"padding" in L.cvx_last_error()
     # evaluation operators: null pointers and degenerate extents
     assert L.cvx_jacobian_det_f32(None, 8, 8, 8, 0, None, None) == -1
     assert L.cvx_jacobian_det_f32(dummy, 4, 8, 8, 0, dummy, None) == -1 and b"crop" in L.cvx_last_error()

@@ -1496,3 +1496,30 @@ def test_reference_bits_enable_with_this_hosts_own_tables_vs_oracle(M, orc, mkl,
     assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), ref)
     if not t["matches_golden_host"]:
         assert not np.array_equal(ref, g["adam_20"])            # another host, another reference result
+
+
+def test_even_selected_smooth_vs_oracle_and_reference(M, U, orc, golden):
+    """The reference's even `selected_smooth` (convex_adam_MIND.py:184-191: three growing pools, (H+3, W+3, D+3, 3)) through the drop-in
+    call: cvx_box_grow_f32 == the oracle's pool == torch's (golden), the returned field == the oracle's bit for bit and the reference's
+    capture within the short-horizon tolerance; the whole-pair C entry keeps refusing (its output is [3][H][W][D])."""
+    from convexadam_amd import _lib
+    from convexadam_amd.phantom import phantom
+    g = golden("even_smooth")
+    x = dev(g["pool_in"])[None]
+    for k in (2, 4, 6):
+        assert np.array_equal(host(U.box_smooth(x, k, 1))[0], g["pool%d" % k]), k
+    assert tuple(U.box_smooth(x, 2, 3).shape) == (1, 3) + tuple(s + 3 for s in g["pool_in"].shape[1:])
+    shape = tuple(int(v) for v in g["shape"])
+    fix = phantom(shape, 7, 70)
+    mov = torch.roll(phantom(shape, 7, 71), (1, -1, 2), (0, 1, 2))
+    kw = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=4, disp_hw=2, selected_niter=3, grid_sp_adam=2, ic=True)
+    for k in (2, 4):
+        out = M.convex_adam_pt(fix, mov, dtype=torch.float32, device=torch.device(DEV), selected_smooth=k, **kw)
+        ref = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), selected_smooth=k, **kw)
+        assert out.shape == tuple(s + 3 for s in shape) + (3,) and out.dtype == np.float64
+        assert np.array_equal(out, ref), k
+        assert float(np.sqrt(((out - g["k%d" % k]) ** 2).sum(-1)).mean()) < 1e-5
+    out0 = M.convex_adam_pt(fix, mov, dtype=torch.float32, device=torch.device(DEV), lambda_weight=0, grid_sp=4, disp_hw=2, selected_smooth=2)
+    assert out0.shape == shape + (3,)                                                    # never reaches the smoothing block (:155)
+    with pytest.raises(_lib.CvxError):
+        M.register_pairs_device([dev(fix.numpy())], [dev(mov.numpy())], selected_smooth=2, **kw)

@@ -484,3 +484,26 @@ def test_fast_box_is_the_three_chained_boxes(orc):
         x = rng.standard_normal((3,) + shape).astype(np.float32)
         ref = orc.box_zero(orc.box_zero(orc.box_zero(x, 3), 3), 3)
         assert np.abs(orc.fast_box3x3(x) - ref).max() <= 4e-6 * max(1.0, float(np.abs(ref).max())), shape
+
+
+def test_even_selected_smooth_grows_the_field_like_the_reference(orc, golden):
+    """convex_adam_MIND.py:184-191 with an EVEN selected_smooth: the reference overwrites its own "+1" (:189), so each of the three
+    avg_pool3d(k, stride 1, padding k//2) makes every axis one voxel longer and convex_adam_pt returns (H+3, W+3, D+3, 3).  The growing
+    pool is bit-exact against torch's; the whole call against the reference's capture within the short-horizon tolerance (3 iterations)."""
+    import torch
+    from convexadam_amd.phantom import phantom
+
+    g = golden("even_smooth")
+    for k in (2, 4, 6):
+        assert np.array_equal(orc.box_grow(g["pool_in"], k), g["pool%d" % k]), k
+    shape = tuple(int(v) for v in g["shape"])
+    fix = phantom(shape, 7, 70)
+    mov = torch.roll(phantom(shape, 7, 71), (1, -1, 2), (0, 1, 2))
+    for k in (2, 4):
+        out = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=4, disp_hw=2, selected_niter=3,
+                                       selected_smooth=k, grid_sp_adam=2, ic=True)
+        assert out.shape == tuple(s + 3 for s in shape) + (3,) == g["k%d" % k].shape
+        assert epe(out, g["k%d" % k]) < 1e-5, k
+    # lambda_weight <= 0 never reaches the smoothing block (:155): the even kernel is ignored
+    a = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), lambda_weight=0, grid_sp=4, disp_hw=2, selected_smooth=2)
+    assert a.shape == shape + (3,)
