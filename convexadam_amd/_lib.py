@@ -120,6 +120,7 @@ SIGNATURES = {
     "cvx_feature_transform_i32": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "cvx_feature_flat_index_i64": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cvx_label_mask_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "cvx_label_mask_scaled_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "cvx_edt_sqdist_i32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "cvx_surface_hist_i64": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "cvx_hist_order_stats_i64": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),

@@ -265,8 +265,8 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=N
     either map), float64 tensor on the device of `fixed`.  Per label on the device: masks on the nearest-upsampled grid, exact
     squared Euclidean distance transforms of the mask and of its complement (csrc/edt.hip), histogram of dist_a over the
     surface of b (edt == 1); the percentile is read from the histogram (two order statistics), so no sort and no host copy of a
-    volume.  Three host synchronisations per call (label range, label presence, results).  `precision` must be a positive integer (the
-    reference's call sites use the default 1).
+    volume.  Three host synchronisations per call (label range, label presence, results).  `precision` is any positive scale factor of
+    F.interpolate's nearest mode (:33-34; the reference's call sites use the default 1).
     method (not in the reference): "surface" (default at precision 1, <= 255 labels, H, W <= 2047) computes the distances at the surface
     voxels alone -- bit planes of both maps + a ring search per surface voxel (csrc/surfdist.hip), no volume-sized transform; "edt" is the
     path described above (the only one for precision > 1).  Both give the same float64 results bit for bit (exact integer squared
@@ -278,15 +278,19 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=N
     fixed segmentation (16 per Adam run), and what is derived from the fixed map alone does not depend on the field: its bit planes
     ("surface": 1 MB per label at 160x192x224) or the two distance transforms of every fixed label ("edt": 715 MB for 13 labels);
     computed on the first call and reused."""
-    if int(precision) != precision or precision < 1:
-        raise NotImplementedError("cupy_hd95: only integer precision >= 1 (nearest up-sampling) is implemented")
-    p = int(precision)
+    prec = float(precision)
+    if not (prec > 0.0) or prec == float("inf"):
+        raise ValueError("cupy_hd95: precision must be a positive number")
+    p = int(prec) if prec.is_integer() else None                # None: a non-integer scale factor of F.interpolate (:33-34)
     fx = f32c(require_device_tensor(fixed, "fixed"))
     mv = f32c(require_device_tensor(moving, "moving"))
     if fx.shape != mv.shape or fx.dim() != 3:
         raise ValueError("cupy_hd95: label maps must be (H, W, D) tensors of the same shape")
     H, W, D = [int(v) for v in fx.shape]
-    Ho, Wo, Do = H * p, W * p, D * p
+    # upsample_nearest3d with scale_factor: extent (int64)(n * s) per axis, source index by ATen's nearest_idx (csrc/edt.hip::nearest_src)
+    Ho, Wo, Do = (H * p, W * p, D * p) if p else (int(H * prec), int(W * prec), int(D * prec))
+    if min(Ho, Wo, Do) < 1:
+        raise RuntimeError("cupy_hd95: Input and output sizes should be greater than 0 (%dx%dx%d at precision %g)" % (H, W, D, prec))
     nbins = (Ho - 1) ** 2 + (Wo - 1) ** 2 + (Do - 1) ** 2 + 2
     nl = int(num_labels)
     L = lib()
@@ -312,7 +316,10 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=N
         for g0 in range(0, len(labs), group):
             part = labs[g0:g0 + group]
             for i, lab in enumerate(part):
-                check(L.cvx_label_mask_f32(ptr(seg), H, W, D, lab, p, ptr(obj[i, 0]), ptr(obj[i, 1]), None, sp))
+                if p and p <= 8:
+                    check(L.cvx_label_mask_f32(ptr(seg), H, W, D, lab, p, ptr(obj[i, 0]), ptr(obj[i, 1]), None, sp))
+                else:
+                    check(L.cvx_label_mask_scaled_f32(ptr(seg), H, W, D, lab, Ho, Wo, Do, float(np.float32(1.0 / prec)), ptr(obj[i, 0]), ptr(obj[i, 1]), None, sp))
             check(L.cvx_edt_squared_i32(ptr(obj), 2 * len(part), Ho, Wo, Do, ptr(out[g0:g0 + len(part)]), ptr(ws), nws, sp))
         return out
 
@@ -381,7 +388,7 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=N
         present = [i for i in range(1, nl + 1) if cnt[0, i] > 0 and cnt[1, i] > 0]
         if present:
             if fixed_cache is not None:
-                key = ("edt", p, nl)
+                key = ("edt", prec, nl)
                 if key not in fixed_cache:
                     labs_f = [i for i in range(1, nl + 1) if cnt[0, i] > 0]
                     fixed_cache[key] = (labs_f, transforms(fx, labs_f))

@@ -227,20 +227,21 @@ __global__ __launch_bounds__(128) void k_edt_envelope(int* __restrict__ vol, int
 }
 
 // ---- Hausdorff-95 building blocks (reference: cupy_hd95, self_configuring/convexAdam_hyper_util.py:32-51) ----------
-// inside = (nearest-upsampled label map == label), outside = 1 - inside; nearest index as in ATen's upsample_nearest3d with a
-// given scale factor: src = min(floor(dst * (1.0f / p)), in - 1) in float32 (:33-34)
-__global__ __launch_bounds__(256) void k_label_mask(const float* __restrict__ seg, int H, int W, int D, float label, int p,
+// inside = (nearest-resampled label map == label), outside = 1 - inside; nearest index as in ATen's upsample_nearest3d with a given
+// scale factor (nearest_idx, UpSample.h): identity when the extent is unchanged, dst >> 1 when it doubles, else
+// src = min(floor(dst * sc), in - 1) in float32 with sc = float32(1 / scale_factor) (:33-34); (Ho, Wo, Do) = the resampled extent
+__device__ __forceinline__ int nearest_src(int dst, int n_in, int n_out, float sc) {
+    return n_out == n_in ? dst : n_out == 2 * n_in ? dst >> 1 : min((int)floorf((float)dst * sc), n_in - 1);
+}
+__global__ __launch_bounds__(256) void k_label_mask(const float* __restrict__ seg, int H, int W, int D, float label, int Ho, int Wo, int Do, float sc,
                                                     float* __restrict__ inside, float* __restrict__ outside,
                                                     unsigned long long* __restrict__ count) {
-    const int Ho = H * p, Wo = W * p, Do = D * p;
     const size_t Vo = (size_t)Ho * Wo * Do;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool in = false;
     if (i < Vo) {
         const int x = (int)(i % Do), y = (int)((i / Do) % Wo), z = (int)(i / ((size_t)Do * Wo));
-        const float sc = 1.0f / (float)p;
-        const int sz = min((int)floorf((float)z * sc), H - 1), sy = min((int)floorf((float)y * sc), W - 1),
-                  sx = min((int)floorf((float)x * sc), D - 1);
+        const int sz = nearest_src(z, H, Ho, sc), sy = nearest_src(y, W, Wo, sc), sx = nearest_src(x, D, Do, sc);
         in = seg[((size_t)sz * W + sy) * D + sx] == label;
         inside[i] = in ? 1.0f : 0.0f;
         outside[i] = in ? 0.0f : 1.0f;
@@ -413,9 +414,23 @@ extern "C" int cvx_label_mask_f32(const float* seg, int H, int W, int D, int lab
     hipStream_t s = as_stream(stream);
     const size_t Vo = (size_t)H * W * D * precision * precision * precision;
     if (count && hipMemsetAsync(count, 0, sizeof(int64_t), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "cvx_label_mask_f32: memset failed");
-    hipLaunchKernelGGL(k_label_mask, dim3((unsigned)cdiv64((int64_t)Vo, 256)), dim3(256), 0, s, seg, H, W, D, (float)label, precision,
-                       inside, outside, reinterpret_cast<unsigned long long*>(count));
+    hipLaunchKernelGGL(k_label_mask, dim3((unsigned)cdiv64((int64_t)Vo, 256)), dim3(256), 0, s, seg, H, W, D, (float)label, H * precision, W * precision,
+                       D * precision, 1.0f / (float)precision, inside, outside, reinterpret_cast<unsigned long long*>(count));
     return check_last("label_mask");
+}
+
+extern "C" int cvx_label_mask_scaled_f32(const float* seg, int H, int W, int D, int label, int Ho, int Wo, int Do, float scale_inv, float* inside,
+                                         float* outside, int64_t* count, void* stream) {
+    CVX_REQUIRE(seg && inside && outside, "cvx_label_mask_scaled_f32: null pointer");     // count may be NULL
+    CVX_REQUIRE(H > 0 && W > 0 && D > 0 && Ho > 0 && Wo > 0 && Do > 0, "cvx_label_mask_scaled_f32: bad extent %dx%dx%d -> %dx%dx%d", H, W, D, Ho, Wo, Do);
+    CVX_REQUIRE(scale_inv > 0.0f && scale_inv <= 1.0e6f, "cvx_label_mask_scaled_f32: scale_inv must be float32(1 / scale_factor) > 0");
+    CVX_REQUIRE((double)Ho * Wo * Do < 2147483647.0 * 4.0, "cvx_label_mask_scaled_f32: resampled volume too large");
+    hipStream_t s = as_stream(stream);
+    const size_t Vo = (size_t)Ho * Wo * Do;
+    if (count && hipMemsetAsync(count, 0, sizeof(int64_t), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "cvx_label_mask_scaled_f32: memset failed");
+    hipLaunchKernelGGL(k_label_mask, dim3((unsigned)cdiv64((int64_t)Vo, 256)), dim3(256), 0, s, seg, H, W, D, (float)label, Ho, Wo, Do, scale_inv, inside, outside,
+                       reinterpret_cast<unsigned long long*>(count));
+    return check_last("label_mask_scaled");
 }
 
 extern "C" int cvx_edt_sqdist_i32(const float* obj, const int* feat, int H, int W, int D, int* d2, void* stream) {

@@ -427,6 +427,11 @@ int cvx_feature_flat_index_i64(const int* feat, int H, int W, int D, int W_full,
  *                              lower-envelope passes) for `batch` independent volumes [batch][H][W][D]; 0 on zero voxels */
 int cvx_label_mask_f32(const float* seg, int H, int W, int D, int label, int precision, float* inside, float* outside,
                        int64_t* count, void* stream);
+/* the same for ANY scale factor of F.interpolate(.., scale_factor=s) in nearest mode (cupy_hd95 with a non-integer `precision`):
+ * (Ho, Wo, Do) = (int)(extent * s) per axis, scale_inv = (float)(1.0 / s); per axis the source index is dst when the extent is
+ * unchanged, dst >> 1 when it doubles, else min(floor(dst * scale_inv), in - 1) in float32 (ATen nearest_idx) */
+int cvx_label_mask_scaled_f32(const float* seg, int H, int W, int D, int label, int Ho, int Wo, int Do, float scale_inv, float* inside,
+                              float* outside, int64_t* count, void* stream);
 int cvx_edt_sqdist_i32(const float* obj, const int* feat, int H, int W, int D, int* d2, void* stream);
 int cvx_surface_hist_i64(const int* a_in2, const int* a_out2, const int* b_in2, int64_t n, int nbins, int64_t* hist, int* overflow,
                          void* stream);

@@ -168,13 +168,22 @@ def hd95(fixed, moving, num_labels, precision=1):
     definitions: float32 Euclidean distances, linear-interpolation percentile).  fixed, moving: (H,W,D) integer label maps."""
     from scipy.ndimage import distance_transform_edt
     fixed, moving = np.asarray(fixed).astype(np.int64), np.asarray(moving).astype(np.int64)
-    p = int(precision)
+    prec = float(precision)
 
-    def up(mask):                                       # upsample_nearest3d with scale_factor p: src = min(floor(dst * (1/p)), in - 1)
+    def up(mask):
+        """upsample_nearest3d with scale_factor `precision` (F.interpolate, :33-34): extent (int64)(n * s); source index by ATen's
+        nearest_idx (UpSample.h): dst when the extent is unchanged, dst >> 1 when it doubles, else min(floor(dst * float32(1 / s)), n - 1)
+        evaluated in float32."""
         idx = []
         for n in mask.shape:
-            dst = np.arange(n * p, dtype=np.float32)
-            idx.append(np.minimum(np.floor(dst * (np.float32(1.0) / np.float32(p))).astype(np.int64), n - 1))
+            no = int(n * prec)
+            dst = np.arange(no)
+            if no == n:
+                idx.append(dst)
+            elif no == 2 * n:
+                idx.append(dst >> 1)
+            else:
+                idx.append(np.minimum(np.floor(dst.astype(np.float32) * np.float32(1.0 / prec)).astype(np.int64), n - 1))
         return mask[np.ix_(*idx)]
 
     def edt32(m):

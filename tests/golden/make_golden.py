@@ -302,6 +302,11 @@ def hd95_goldens():
     out = dict(seg_fixed=seg_f.numpy(), seg_moving=seg_m.numpy())
     out["hd95_p1"] = HU.cupy_hd95(seg_f.long(), seg_m.long(), 6).numpy()       # label 6 absent from both
     out["hd95_p2"] = HU.cupy_hd95(seg_f.long(), seg_m.long(), 6, precision=2).numpy()
+    # non-integer precisions (round 4): F.interpolate(.., scale_factor=p) in nearest mode -- output extent floor(n * p), source index
+    # min(floor(dst * float32(1 / p)), n - 1)
+    out["hd95_p1_5"] = HU.cupy_hd95(seg_f.long(), seg_m.long(), 6, precision=1.5).numpy()
+    out["hd95_p0_5"] = HU.cupy_hd95(seg_f.long(), seg_m.long(), 6, precision=0.5).numpy()
+    out["hd95_p2_5"] = HU.cupy_hd95(seg_f.long(), seg_m.long(), 6, precision=2.5).numpy()
     save("hd95", **out)
 
 

@@ -106,6 +106,8 @@ def test_argument_validation_without_gpu(L):
     # Hausdorff-95 building blocks
     assert L.cvx_label_mask_f32(dummy, 4, 4, 4, 1, 0, dummy, dummy, dummy, None) == -1 and b"precision" in L.cvx_last_error()
     assert L.cvx_label_mask_f32(dummy, 4, 4, 4, 1, 1, None, dummy, dummy, None) == -1          # count alone may be NULL
+    assert L.cvx_label_mask_scaled_f32(dummy, 4, 4, 4, 1, 6, 6, 0, C.c_float(1 / 1.5), dummy, dummy, None, None) == -1 and b"extent" in L.cvx_last_error()
+    assert L.cvx_label_mask_scaled_f32(dummy, 4, 4, 4, 1, 6, 6, 6, C.c_float(0.0), dummy, dummy, None, None) == -1 and b"scale_inv" in L.cvx_last_error()
     assert L.cvx_edt_sqdist_i32(dummy, dummy, 40000, 40000, 4, dummy, None) == -1 and b"int32" in L.cvx_last_error()
     assert L.cvx_surface_hist_i64(dummy, dummy, dummy, 0, 8, dummy, dummy, None) == -1
     assert L.cvx_hist_order_stats_i64(dummy, 0, 0, 0, dummy, None) == -1

@@ -826,8 +826,17 @@ def test_hd95_vs_golden_and_oracle(HU, morc, golden):
             assert np.array_equal(got, morc.hd95(a, b, 4, prec)), (shape, prec)
     with pytest.raises(RuntimeError):
         HU.cupy_hd95(sf, sm, 3)                                                         # label 5 present: one_hot would fail
-    with pytest.raises(NotImplementedError):
-        HU.cupy_hd95(sf, sm, 6, precision=0.5)
+    # any positive scale factor of F.interpolate's nearest mode (round 4; captured from the reference like the integer ones)
+    for key, prec in (("hd95_p1_5", 1.5), ("hd95_p0_5", 0.5), ("hd95_p2_5", 2.5)):
+        assert np.array_equal(host(HU.cupy_hd95(sf, sm, 6, precision=prec)), g[key]), key
+    a = rng.integers(0, 4, (7, 9, 11))
+    b = np.roll(a, (1, 0, -1), (0, 1, 2))
+    for prec in (0.7, 1.3, 2.05, 3.0, 9.0):                                             # 2.05: 20 -> 41 voxels; 9: beyond the integer kernel's range
+        assert np.array_equal(host(HU.cupy_hd95(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), 4, precision=prec)), morc.hd95(a, b, 4, prec)), prec
+    with pytest.raises(ValueError):
+        HU.cupy_hd95(sf, sm, 6, precision=0)
+    with pytest.raises(RuntimeError):
+        HU.cupy_hd95(sf, sm, 6, precision=0.01)                                         # an empty resampled volume (torch: sizes should be greater than 0)
 
 
 def test_file_wrapper_writes_the_field_as_nifti(M, tmp_path):

@@ -280,6 +280,10 @@ def test_hd95_oracle_vs_reference_golden(golden):
     assert np.array_equal(mo.hd95(g["seg_fixed"], g["seg_moving"], 6), g["hd95_p1"])
     assert np.array_equal(mo.hd95(g["seg_fixed"], g["seg_moving"], 6, 2), g["hd95_p2"])
     assert g["hd95_p1"][3] == 30 and g["hd95_p1"][5] == 30 and g["hd95_p2"][3] == 15
+    # non-integer scale factors (F.interpolate's nearest mode: extent (int)(n * s), index min(floor(dst * float32(1 / s)), n - 1))
+    for key, prec in (("hd95_p1_5", 1.5), ("hd95_p0_5", 0.5), ("hd95_p2_5", 2.5)):
+        assert np.array_equal(mo.hd95(g["seg_fixed"], g["seg_moving"], 6, prec), g[key]), key
+    assert g["hd95_p1_5"][3] == 20 and g["hd95_p0_5"][3] == 60
 
 
 def test_percentile_restatement_vs_numpy():
