@@ -238,7 +238,7 @@ extern "C" int cvx_surface_distance_hist_i64(const float* seg_b, const uint64_t*
     for (int i = 0; i < 4; ++i) act.m[i] = active4[i];
     const int nseg = (D + 63) / 64;
     const int64_t waves = (int64_t)H * W * nseg;
-    CVX_REQUIRE(waves <= INT_MAX, "cvx_surface_distance_hist_i64: volume too large");
+    CVX_REQUIRE(waves <= INT_MAX - 65536, "cvx_surface_distance_hist_i64: volume too large");      // the kernel's wave index is an int that steps past the end by up to one grid
     const int64_t wgs = cdiv64(waves, 4) < 4096 ? cdiv64(waves, 4) : 4096;
     hipLaunchKernelGGL(k_surface_dist_hist, dim3((unsigned)wgs), dim3(256), 0, as_stream(stream), seg_b,
                        reinterpret_cast<const unsigned long long*>(bits_a), H, W, D, nseg, num_labels, act, nbins,
