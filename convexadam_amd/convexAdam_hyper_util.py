@@ -265,7 +265,7 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=N
     either map), float64 tensor on the device of `fixed`.  Per label on the device: masks on the nearest-upsampled grid, exact
     squared Euclidean distance transforms of the mask and of its complement (csrc/edt.hip), histogram of dist_a over the
     surface of b (edt == 1); the percentile is read from the histogram (two order statistics), so no sort and no host copy of a
-    volume.  Three host synchronisations per call (label range, label presence, results).  `precision` is any positive scale factor of
+    volume.  Two host synchronisations per call (label counts, results).  `precision` is any positive scale factor of
     F.interpolate's nearest mode (:33-34; the reference's call sites use the default 1).
     method (not in the reference): "surface" (default at precision 1, <= 255 labels, H, W <= 2047) computes the distances at the surface
     voxels alone -- bit planes of both maps + a ring search per surface voxel (csrc/surfdist.hip), no volume-sized transform; "edt" is the
@@ -372,19 +372,20 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=N
                 host = tail.cpu().numpy()
                 flags = host[nl * 6:].view(np.int32)[[2 * (lab - 1) + k for lab in present for k in range(2)]]
                 if np.any(flags == 2):               # a surface voxel farther than HD95_SURFACE_MAX_RADIUS rows from its target: the ring
-                    return cupy_hd95(fixed, moving, num_labels, precision, fixed_cache, method="edt")   # search would crawl; transforms
+                    # the search would crawl: the transforms take over.  The fixed map's transforms are NOT kept in the caller's cache here
+                    # (715 MB per pair at 160x192x224, for a case that should be rare)
+                    return cupy_hd95(fixed, moving, num_labels, precision, None, method="edt", counts=cnt)
                 if np.any(flags != 0):
                     raise RuntimeError("cupy_hd95: squared distance exceeds the histogram range")
                 res = host[:nl * 6].reshape(nl, 2, 3)[[lab - 1 for lab in present]]
         return _hd95_from_order_stats(res, present, nl, precision, dev)
     with torch.cuda.device(dev):
         # label range (F.one_hot, :33) and presence in one pass: voxel counts of labels 0 .. num_labels in both maps
-        lohi = torch.stack([fx.min(), fx.max(), mv.min(), mv.max()]).cpu()
-        if float(lohi[0]) < 0 or float(lohi[2]) < 0 or float(lohi[1]) > nl or float(lohi[3]) > nl:
+        cnt = label_overlap_counts(fx, mv, nl + 1) if counts is None else counts
+        if cnt.shape != (3, nl + 1):
+            raise ValueError("cupy_hd95: counts must be label_overlap_counts(fixed, moving, num_labels + 1)")
+        if int(cnt[0].sum()) != int(fx.numel()) or int(cnt[1].sum()) != int(fx.numel()):
             raise RuntimeError("cupy_hd95: class values must be in 0 .. num_labels (F.one_hot, :33)")
-        counts = torch.empty((3, nl + 1), dtype=torch.int64, device=dev)
-        check(L.cvx_label_overlap_i64(ptr(fx), ptr(mv), int(fx.numel()), nl + 1, ptr(counts), sp))
-        cnt = counts.cpu().numpy()
         present = [i for i in range(1, nl + 1) if cnt[0, i] > 0 and cnt[1, i] > 0]
         if present:
             if fixed_cache is not None:
