@@ -35,17 +35,29 @@ __global__ __launch_bounds__(256) void k_warp_grad_fast(const float* __restrict_
     // records in the XCD's 4 MB L2 (octant == 0: the slab order of k_warp_grad, warp.hip)
     const int ntx = (d + 15) / 16, nty = (w + 3) / 4, ntz = (h + 3) / 4;
     int tbx, tby, tbz;
-    if (octant) {
+    if (octant == 1) {
         const int q = (int)(blockIdx.x & 7), i = (int)(blockIdx.x >> 3);
         const int hx = (ntx + 1) >> 1, hy = (nty + 1) >> 1, hz = (ntz + 1) >> 1;
         if (i >= hx * hy * hz) return;
         tbx = (q & 1) * hx + i % hx; tby = ((q >> 1) & 1) * hy + (i / hx) % hy; tbz = (q >> 2) * hz + i / (hx * hy);
         if (tbx >= ntx || tby >= nty || tbz >= ntz) return;
-    } else {
+    } else if (octant == 0) {
         const int per_xcd = (int)(gridDim.x >> 3);
         const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
         if (tile >= ntx * nty * ntz) return;
         tbx = tile % ntx; tby = (tile / ntx) % nty; tbz = tile / (ntx * nty);
+    } else {
+        // z-groups: x fastest, then G = `octant` z-adjacent tiles, then y: the tiles that share planes in z follow each other within ntx
+        // launches (their records are still in the XCD's L2), the ones that share rows in y within G ntx
+        const int per_xcd = (int)(gridDim.x >> 3), G = octant;
+        const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+        const int ntzq = (ntz + G - 1) / G;
+        if (tile >= ntx * nty * ntzq * G) return;
+        const int zq = tile / (ntx * nty * G), r1 = tile - zq * (ntx * nty * G);
+        tby = r1 / (G * ntx);
+        const int r2 = r1 - tby * G * ntx, zi = r2 / ntx;
+        tbx = r2 - zi * ntx; tbz = G * zq + zi;
+        if (tbz >= ntz) return;
     }
     const int x = tbx * 16 + (threadIdx.x & 15), y = tby * 4 + ((threadIdx.x >> 4) & 3), z = tbz * 4 + (threadIdx.x >> 6);
     if (x >= d || y >= w || z >= h) return;
@@ -138,8 +150,10 @@ int launch_warp_grad_fast(const float* Fcl, const float* Mcl, int C, int h, int 
                           const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s) {
     const int CP = (C + 3) / 4 * 4;
     const int ntx = cdiv(d, 16), nty = cdiv(w, 4), ntz = cdiv(h, 4);
-    const int octant = options().warp_octant != 0 && ntx >= 2 && nty >= 2 && ntz >= 2;
-    const dim3 gv(octant ? (unsigned)(8 * ((ntx + 1) / 2) * ((nty + 1) / 2) * ((ntz + 1) / 2)) : (unsigned)((ntx * nty * ntz + 7) / 8 * 8));     // multiple of the 8 XCDs
+    const int oc = (int)options().warp_octant;
+    const int octant = oc >= 2 && oc <= 64 ? oc : (oc == 1 && ntx >= 2 && nty >= 2 && ntz >= 2) ? 1 : 0;       // >= 2: z-groups of that many tiles
+    const dim3 gv(octant == 1 ? (unsigned)(8 * ((ntx + 1) / 2) * ((nty + 1) / 2) * ((ntz + 1) / 2))
+                  : octant >= 2 ? (unsigned)((ntx * nty * ((ntz + octant - 1) / octant) * octant + 7) / 8 * 8) : (unsigned)((ntx * nty * ntz + 7) / 8 * 8));     // multiple of the 8 XCDs
     hipLaunchKernelGGL(k_warp_grad_fast, gv, dim3(256), 0, s, Fcl, Mcl, CP, h, w, d, U, bh, bw, bd, 2.0f * gsc, -2.0f * cH, -2.0f * cW,
                        -2.0f * cD, gU, octant);
     return check_last("warp_grad_fast");

@@ -55,7 +55,7 @@ static Options env_options() {
             env_ll("CVX_NO_PRUNE", 0),     env_ll("CVX_CORR_UNFUSED", 0), env_ll("CVX_CORR_FUSED_ALL", 0), env_ll("CVX_PRUNE_STREAM_ABOVE", -1), env_ll("CVX_CF_CENSUS", 0), env_ll("CVX_CF_PRIO", 136),
             env_ll("CVX_WARP_FLAT", 0),    env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 0),
             env_ll("CVX_BOX_XSPLIT", -1),  env_ll("CVX_BOX_CPT", 4),      env_ll("CVX_BOX_UNEVEN", 200), env_ll("CVX_BOX_ADAM_ROLE", 0), env_ll("CVX_BOX_DPP", 0),      env_ll("CVX_BOX_PK", 0),       env_ll("CVX_BOX_PRIO", 0),     env_ll("CVX_LABEL_POW_BLOCK", 32), 0,                             env_ll("CVX_MIND_MEAN_THREADS", 0),
-            env_ll("CVX_EDT_SEQUENTIAL", 0), env_ll("CVX_WARP_OCTANT", 0), env_ll("CVX_FBOX_TILE", 0)};
+            env_ll("CVX_EDT_SEQUENTIAL", 0), env_ll("CVX_WARP_OCTANT", 4), env_ll("CVX_FBOX_TILE", 0)};
 }
 static cvx_context& default_context() {
     static cvx_context c = [] { cvx_context d; d.opt = env_options(); return d; }();

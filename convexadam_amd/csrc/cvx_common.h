@@ -91,7 +91,7 @@ struct Options {
     long long mind_mean_threads;   // 0: exactly rounded global mean in MINDSSC (default); T > 0: torch's own float sum with T threads
                                    //    (reference-bits mode; NOT a bit-identical variant -- it changes the clamp bounds by ulps)
     long long edt_sequential;      // 1: squared distance transform with the sequential lower-envelope passes (one thread per line) instead of the tiled outward search
-    long long warp_octant;         // adam_mode "fast" warp kernel: 1 = every XCD works on one octant of the tile grid (measured: no gain, 5.82 vs 5.65-5.84 ms per pair), 0 = contiguous slabs (default)
+    long long warp_octant;         // adam_mode "fast" warp kernel, tile order inside an XCD's share: G >= 2 (default 4) = x fastest, then G z-adjacent tiles, then y (the tiles that share planes follow each other: FETCH_SIZE -13 %, 5.64 -> 5.59 ms per pair); 0 = plain slabs (x, y, z); 1 = one octant of the tile grid per XCD (measured: no gain)
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };

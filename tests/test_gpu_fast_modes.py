@@ -97,6 +97,29 @@ def test_adam_fast_grid_shapes_vs_oracle(U, orc, shape, C):
     assert np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
 
 
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 4, 7, 64])
+def test_warp_tile_orders_are_bit_identical(U, orc, order):
+    """The fast warp kernel's tile order inside an XCD's share (option warp_octant: plain slabs, octants, z-groups of G tiles -- the
+    default is 4) only changes which workgroup computes which tile: grids whose tile counts are no multiples of the group size, with
+    more / fewer z tiles than a group."""
+    from convexadam_amd._lib import lib
+    L = lib()
+    old = L.cvx_get_option(b"warp_octant")
+    assert old == 4
+    try:
+        assert L.cvx_set_option(b"warp_octant", order) == 0
+        for shape in ((21, 9, 35), (6, 11, 18), (34, 5, 16)):
+            rng = np.random.default_rng(sum(shape))
+            F2 = rng.random((12,) + shape, dtype=np.float32)
+            M2 = rng.random((12,) + shape, dtype=np.float32)
+            P0 = (1.5 * rng.standard_normal((3,) + shape)).astype(np.float32)
+            Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.25, 2, return_state=True, mode="fast")
+            r = orc.adam_run(F2, M2, P0, 1.25, 2, want_grad=True, mode="fast")
+            assert np.array_equal(host(Ud)[0], r["U"]) and np.array_equal(host(st["G"])[0], r["G"]), (order, shape)
+    finally:
+        L.cvx_set_option(b"warp_octant", old)
+
+
 def test_adam_fast_resume_and_snapshots(U, orc, golden):
     """4 + 3 iterations through the optimiser state equal 7 in one call; snapshots are the U of the listed iterations."""
     g = golden("adam")
