@@ -25,12 +25,13 @@ __device__ __forceinline__ void consumer(const float4* __restrict__ dst, float* 
     }
     if (acc == 12345.f) out[0] = acc;
 }
-__global__ __launch_bounds__(512) void k_fused(const float4* src, float4* dst, size_t n4, int nprod, int steps, unsigned* done, unsigned* stats, float* out) {
+__global__ __launch_bounds__(512) void k_fused(const float4* src, float4* dst, size_t n4, int nprod, int steps, unsigned* done, unsigned* stats, float* out, int mode) {
     if ((int)blockIdx.x < nprod) { producer(src, dst, n4, blockIdx.x, nprod, done); return; }
     __shared__ unsigned ok;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && mode == 0) ok = 1;
+    if (threadIdx.x == 0 && mode != 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nprod && spins < 20000000u) { ++spins; __builtin_amdgcn_s_sleep(20); }
+        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nprod && spins < 20000000u) { ++spins; if (mode == 2) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); } else __builtin_amdgcn_s_sleep(20); }
         ok = spins < 20000000u;
         if (!ok) atomicAdd(&stats[0], 1u);
         atomicAdd(&stats[1], spins > 0 ? 1u : 0u);
@@ -49,7 +50,7 @@ int main() {
     hipMalloc(&src, n4 * 16); hipMalloc(&dst, n4 * 16); hipMalloc(&done, 4); hipMalloc(&stats, 16); hipMalloc(&out, 4);
     hipMemset(src, 0, n4 * 16); hipMemset(dst, 0, n4 * 16);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int nprod : {640, 1024}) for (int ncons : {504}) for (int steps : {20}) {
+    for (int nprod : {640, 1024}) for (int ncons : {504}) for (int steps : {20}) for (int mode : {0, 1, 2}) {
         float ms_seq = 0, ms_fused = 0;
         for (int rep = 0; rep < 3; ++rep) {
             hipMemset(done, 0, 4);
@@ -58,12 +59,12 @@ int main() {
             hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms_seq, a, b);
             hipMemset(stats, 0, 16);
             hipEventRecord(a);
-            for (int i = 0; i < 20; ++i) { hipMemsetAsync(done, 0, 4, 0); hipLaunchKernelGGL(k_fused, dim3(nprod + ncons), dim3(512), 0, 0, src, dst, n4, nprod, steps, done, stats, out); }
+            for (int i = 0; i < 20; ++i) { hipMemsetAsync(done, 0, 4, 0); hipLaunchKernelGGL(k_fused, dim3(nprod + ncons), dim3(512), 0, 0, src, dst, n4, nprod, steps, done, stats, out, mode); }
             hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms_fused, a, b);
         }
         unsigned st[4]; hipMemcpy(st, stats, 16, hipMemcpyDeviceToHost);
-        printf("producers %4d consumers %3d steps %2d: two kernels %.1f us, one grid %.1f us (incl. a 4-byte memset); consumers timed out %u, had to wait %u of %d, longest wait %u polls\n",
-               nprod, ncons, steps, ms_seq * 50, ms_fused * 50, st[0], st[1], 20 * ncons, st[2]);
+        printf("mode %d (0 no wait, 1 poll, 2 poll with long sleep) producers %4d consumers %3d steps %2d: two kernels %.1f us, one grid %.1f us (incl. a 4-byte memset); consumers timed out %u, had to wait %u of %d, longest wait %u polls\n",
+               mode, nprod, ncons, steps, ms_seq * 50, ms_fused * 50, st[0], st[1], 20 * ncons, st[2]);
     }
     return 0;
 }
