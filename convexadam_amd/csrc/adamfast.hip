@@ -317,57 +317,69 @@ __global__ __launch_bounds__(256) void k_box3_fast(const float* __restrict__ in,
 // lines along D are 64 consecutive rows.  A pass may run in place (a workgroup reads its lines completely before it writes them).
 struct BoxChainArg { int n; int r[4]; float scale; };
 
-template <bool STRIDED>
+// NL = lines per workgroup (64 / 32 / 16 by line length: two buffers of len * NL floats must leave several workgroups per CU -- with 64
+// lines of 224 voxels a workgroup took 115 KB and a full-resolution pass ran at 0.3 TB/s)
+template <bool STRIDED, int NL>
 __global__ __launch_bounds__(256) void k_boxchain_pass(const float* __restrict__ in, float* __restrict__ out, int len, int ninner, size_t line_stride,
                                                        size_t A, size_t B, int n_io, size_t nrows, BoxChainArg ch) {
-    extern __shared__ float bc_lds[];                     // two buffers of len * 64 floats
+    extern __shared__ float bc_lds[];                     // two buffers of len * NL floats
     float* b0 = bc_lds;
-    float* b1 = bc_lds + (size_t)len * 64;
-    const int tid = threadIdx.x, n = len * 64;
+    float* b1 = bc_lds + (size_t)len * NL;
+    const int tid = threadIdx.x, n = len * NL;
     size_t base = 0;
-    int nact = 64;                                        // lines of this tile inside the volume
+    int nact = NL;                                        // lines of this tile inside the volume
+    // contiguous variant: element e = row * len + i; (row, i) of e = tid advance by 256 without a division per element
+    const int i_first = STRIDED ? 0 : tid % len, r_first = STRIDED ? 0 : tid / len, di = STRIDED ? 0 : 256 % len, dr = STRIDED ? 0 : 256 / len;
     if (STRIDED) {
-        const int x0 = (int)blockIdx.x * 64, o = (int)blockIdx.y;
+        const int x0 = (int)blockIdx.x * NL, o = (int)blockIdx.y;
         base = (size_t)(o / n_io) * A + (size_t)(o % n_io) * B + x0;
-        nact = min(64, ninner - x0);
+        nact = min(NL, ninner - x0);
         for (int e = tid; e < n; e += 256) {
-            const int i = e >> 6, t = e & 63;
+            const int i = e / NL, t = e % NL;
             b0[e] = t < nact ? in[base + t + (size_t)i * line_stride] : 0.0f;
         }
     } else {
-        const size_t row0 = (size_t)blockIdx.x * 64;
+        const size_t row0 = (size_t)blockIdx.x * NL;
         base = row0 * (size_t)len;
-        nact = (int)min((size_t)64, nrows - row0);
+        nact = (int)min((size_t)NL, nrows - row0);
+        int row = r_first, i = i_first;
         for (int e = tid; e < n; e += 256) {
-            const int row = e / len;
             b0[e] = row < nact ? in[base + e] : 0.0f;   // [row][i], rows back to back
+            i += di; row += dr;
+            if (i >= len) { i -= len; ++row; }
         }
     }
     cvx_barrier();
     for (int q = 0; q < ch.n; ++q) {
         const int r = ch.r[q];
+        int ic = i_first;
         for (int e = tid; e < n; e += 256) {
             // position i on the line and the LDS stride between neighbours of the line
-            const int i = STRIDED ? (e >> 6) : (e % len);
-            const int st = STRIDED ? 64 : 1;
+            const int i = STRIDED ? (e / NL) : ic;
+            constexpr int st = STRIDED ? NL : 1;
             float sacc = i - r >= 0 ? b0[e - r * st] : 0.0f;
             for (int j = -r + 1; j <= r; ++j) {
                 const int ii = i + j;
                 sacc += (ii >= 0 && ii < len) ? b0[e + j * st] : 0.0f;
             }
             b1[e] = sacc;
+            if (!STRIDED) { ic += di; if (ic >= len) ic -= len; }
         }
         cvx_barrier();
         float* t = b0; b0 = b1; b1 = t;
     }
     if (STRIDED) {
         for (int e = tid; e < n; e += 256) {
-            const int i = e >> 6, t = e & 63;
+            const int i = e / NL, t = e % NL;
             if (t < nact) out[base + t + (size_t)i * line_stride] = b0[e] * ch.scale;
         }
     } else {
-        for (int e = tid; e < n; e += 256)
-            if (e / len < nact) out[base + e] = b0[e] * ch.scale;
+        int row = r_first, i = i_first;
+        for (int e = tid; e < n; e += 256) {
+            if (row < nact) out[base + e] = b0[e] * ch.scale;
+            i += di; row += dr;
+            if (i >= len) { i -= len; ++row; }
+        }
     }
 }
 
@@ -376,7 +388,7 @@ bool boxchain_fast_supported(const cvx_smoother& sm, int h, int w, int d) {
     for (int i = 0; i < sm.n_boxes; ++i)
         if (sm.box_k[i] < 1 || !(sm.box_k[i] & 1) || sm.box_k[i] > 9) return false;
     const int lmax = h > w ? (h > d ? h : d) : (w > d ? w : d);
-    return (size_t)lmax * 64 * 2 * sizeof(float) <= 160 * 1024;
+    return lmax <= 320;                                  // 16 lines of 320 voxels in two buffers: 41 KB
 }
 
 // out = chain(in) for [3][h][w][d] (in == out allowed); reverse = adjoint order of the boxes
@@ -391,22 +403,29 @@ int launch_boxchain_fast(const float* in, float* out, int h, int w, int d, const
         prod *= (double)k * k * k;
     }
     const size_t V = (size_t)h * w * d;
-    static size_t granted_s = 0, granted_c = 0;
-    auto lds = [](int len) { return (size_t)len * 64 * 2 * sizeof(float); };
-    ensure_dynamic_lds(&k_boxchain_pass<true>, lds(h > w ? h : w), granted_s);
-    ensure_dynamic_lds(&k_boxchain_pass<false>, lds(d), granted_c);
-    ch.scale = 1.0f;
-    // along H: lines (c, y, x): base = c V + y d + x, elements w d apart
-    hipLaunchKernelGGL(k_boxchain_pass<true>, dim3((unsigned)cdiv(d, 64), (unsigned)(3 * w)), dim3(256), lds(h), s, in, out, h, d, (size_t)w * d, V,
-                       (size_t)d, w, (size_t)0, ch);
-    // along W: lines (c, z, x): base = (c h + z) w d + x, elements d apart
-    hipLaunchKernelGGL(k_boxchain_pass<true>, dim3((unsigned)cdiv(d, 64), (unsigned)(3 * h)), dim3(256), lds(w), s, out, out, w, d, (size_t)d,
-                       (size_t)w * d, (size_t)0, 1, (size_t)0, ch);
-    // along D: rows back to back
-    ch.scale = (float)(1.0 / prod);
+    auto nl_of = [](int len) { return len <= 64 ? 64 : len <= 128 ? 32 : 16; };
+    auto lds = [](int len, int nl) { return (size_t)len * nl * 2 * sizeof(float); };
     const size_t nrows = (size_t)3 * h * w;
-    hipLaunchKernelGGL(k_boxchain_pass<false>, dim3((unsigned)cdiv64((int64_t)nrows, 64)), dim3(256), lds(d), s, out, out, d, 0, (size_t)1, (size_t)0,
-                       (size_t)0, 1, nrows, ch);
+    // one pass: strided (lines along H or W: NL adjacent x columns per workgroup) or contiguous (lines along D: NL consecutive rows)
+    auto pass = [&](bool strided, const float* src, float* dst, int len, int gy, size_t line_stride, size_t A, size_t B, int n_io) {
+        const int nl = nl_of(len);
+        const size_t bytes = lds(len, nl);
+#define CVX_BC(S, N)                                                                                                                      \
+        do {                                                                                                                              \
+            static size_t granted = 0;                                                                                                    \
+            ensure_dynamic_lds(&k_boxchain_pass<S, N>, bytes, granted);                                                                   \
+            if (S) hipLaunchKernelGGL((k_boxchain_pass<S, N>), dim3((unsigned)cdiv(d, N), (unsigned)gy), dim3(256), bytes, s, src, dst, len, d, line_stride, A, B, n_io, (size_t)0, ch); \
+            else hipLaunchKernelGGL((k_boxchain_pass<S, N>), dim3((unsigned)cdiv64((int64_t)nrows, N)), dim3(256), bytes, s, src, dst, len, 0, (size_t)1, (size_t)0, (size_t)0, 1, nrows, ch); \
+        } while (0)
+        if (strided) { if (nl == 64) CVX_BC(true, 64); else if (nl == 32) CVX_BC(true, 32); else CVX_BC(true, 16); }
+        else { if (nl == 64) CVX_BC(false, 64); else if (nl == 32) CVX_BC(false, 32); else CVX_BC(false, 16); }
+#undef CVX_BC
+    };
+    ch.scale = 1.0f;
+    pass(true, in, out, h, 3 * w, (size_t)w * d, V, (size_t)d, w);           // along H: lines (c, y, x): base = c V + y d + x, elements w d apart
+    pass(true, out, out, w, 3 * h, (size_t)d, (size_t)w * d, (size_t)0, 1);  // along W: lines (c, z, x): base = (c h + z) w d + x, elements d apart
+    ch.scale = (float)(1.0 / prod);
+    pass(false, out, out, d, 0, (size_t)1, (size_t)0, (size_t)0, 1);         // along D: rows back to back
     return check_last("boxchain_fast");
 }
 
