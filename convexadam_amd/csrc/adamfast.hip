@@ -317,6 +317,33 @@ __global__ __launch_bounds__(256) void k_box3_fast(const float* __restrict__ in,
 // lines along D are 64 consecutive rows.  A pass may run in place (a workgroup reads its lines completely before it writes them).
 struct BoxChainArg { int n; int r[4]; float scale; };
 
+// one box of half-width R over the NL staged lines: a thread takes FOUR consecutive positions of a line and reads the 4 + 2 R taps they
+// share once; every output is still its own left-to-right sum ((t[i-R] + t[i-R+1]) + ...) + t[i+R] with zeros outside the line
+template <bool STRIDED, int NL, int R>
+__device__ __forceinline__ void bc_stage(const float* __restrict__ b0, float* __restrict__ b1, int len, int tid) {
+    const int nq = (len + 3) >> 2;                                  // quads per line
+    constexpr int st = STRIDED ? NL : 1;
+    for (int item = tid; item < nq * NL; item += 256) {
+        // strided: the NL lines are the fast index (adjacent lanes = adjacent lines: conflict-free); contiguous: quads of a row are adjacent
+        const int line = STRIDED ? item % NL : item / nq, i0 = 4 * (STRIDED ? item / NL : item % nq);
+        const float* p = b0 + (STRIDED ? (size_t)i0 * NL + line : (size_t)line * len + i0);
+        float v[4 + 2 * R];
+#pragma unroll
+        for (int u = 0; u < 4 + 2 * R; ++u) {
+            const int ii = i0 - R + u;
+            v[u] = (ii >= 0 && ii < len) ? p[(u - R) * st] : 0.0f;
+        }
+        float* o = b1 + (STRIDED ? (size_t)i0 * NL + line : (size_t)line * len + i0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sacc = v[j];
+#pragma unroll
+            for (int u = 1; u <= 2 * R; ++u) sacc += v[j + u];
+            if (i0 + j < len) o[j * st] = sacc;
+        }
+    }
+}
+
 // NL = lines per workgroup (64 / 32 / 16 by line length: two buffers of len * NL floats must leave several workgroups per CU -- with 64
 // lines of 224 voxels a workgroup took 115 KB and a full-resolution pass ran at 0.3 TB/s)
 template <bool STRIDED, int NL>
@@ -352,19 +379,11 @@ __global__ __launch_bounds__(256) void k_boxchain_pass(const float* __restrict__
     cvx_barrier();
     for (int q = 0; q < ch.n; ++q) {
         const int r = ch.r[q];
-        int ic = i_first;
-        for (int e = tid; e < n; e += 256) {
-            // position i on the line and the LDS stride between neighbours of the line
-            const int i = STRIDED ? (e / NL) : ic;
-            constexpr int st = STRIDED ? NL : 1;
-            float sacc = i - r >= 0 ? b0[e - r * st] : 0.0f;
-            for (int j = -r + 1; j <= r; ++j) {
-                const int ii = i + j;
-                sacc += (ii >= 0 && ii < len) ? b0[e + j * st] : 0.0f;
-            }
-            b1[e] = sacc;
-            if (!STRIDED) { ic += di; if (ic >= len) ic -= len; }
-        }
+        if (r == 1) bc_stage<STRIDED, NL, 1>(b0, b1, len, tid);
+        else if (r == 2) bc_stage<STRIDED, NL, 2>(b0, b1, len, tid);
+        else if (r == 3) bc_stage<STRIDED, NL, 3>(b0, b1, len, tid);
+        else if (r == 4) bc_stage<STRIDED, NL, 4>(b0, b1, len, tid);
+        else bc_stage<STRIDED, NL, 0>(b0, b1, len, tid);
         cvx_barrier();
         float* t = b0; b0 = b1; b1 = t;
     }
