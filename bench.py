@@ -34,12 +34,13 @@ if ROOT not in sys.path:
 SHAPE = (160, 192, 224)
 CFG = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=6, disp_hw=6, selected_niter=80, selected_smooth=0,
            grid_sp_adam=2, ic=True)
-# the mode `value` is timed in (round 4): the Adam loop in throughput arithmetic -- same mathematics, accepted by the criteria of SURVEY
-# section 7 against the reference's own capture (tests/test_gpu_fast_modes.py::test_full_size_fast_adam_acceptance); everything before
-# the Adam loop is bit-identical to the reference-order path.  TIMED_MODE_NAME goes into the JSON line.
+# the mode `value` is timed in: the Adam loop in throughput arithmetic (opt-in adam_mode="fast"; the PACKAGE default is "exact" since round 5) --
+# same mathematics, graded against four full-size captures of the reference (tests/golden/fullsize.npz, fullsize2.npz; `parity.timed_mode`);
+# everything before the Adam loop is bit-identical to the reference-order path.  The line also carries `value_exact_mode` (every operator in the
+# reference's order) and `value_at_tolerance` (the reference-bits mode, the only one inside the literal 1e-3).  TIMED_MODE_NAME goes into the JSON line.
 TIMED = dict(CFG, adam_mode="fast")
 EXACT = dict(CFG, adam_mode="exact")            # every operator in the reference's evaluation order (CFG alone would take the package default)
-TIMED_MODE_NAME = "adam_mode=fast (FMA / factored warp gradient, separable adjoint boxes, one-division update; forward boxes, MIND, correlation, coupled convex in the reference's order)"
+TIMED_MODE_NAME = "adam_mode=fast (opt-in: FMA / factored warp gradient, separable adjoint boxes; forward boxes, regulariser gradient, Adam update, MIND, correlation, coupled convex in the reference's order)"
 HBM_PEAK_GBS = 8000.0
 TOLERANCE_EPE = 1e-3          # north_star: mean end-point error against the reference's field, voxels
 
@@ -74,6 +75,16 @@ def pmc_traffic():
         return float(j["correlate_stage_bytes_per_launch"]), j.get("measured_at_commit"), j.get("corr_sources_sha16") != corr_sources_sha()
     except Exception:
         return None, None, True
+
+
+def pmc_extra(key):
+    """Another figure of profiles/pmc_hbm_traffic.json (None when absent)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")) as f:
+            v = json.load(f).get(key)
+        return float(v) if v is not None else None
+    except Exception:
+        return None
 
 
 def reference_bits_check(fix, mov, dev):
@@ -150,20 +161,60 @@ def epe_vs_reference(hip_field, niter=80):
     return float(np.sqrt((d ** 2).sum(0)).mean())
 
 
+CAPTURES = ("c1", "c4", "c5", "c6")
+
+
+def capture_registration(tag, dev):
+    """(golden dict, shape, callable(mode, niter) -> (3,H,W,D) device field) for one full-size capture of the reference
+    (tests/golden/fullsize.npz: c1 = the benchmark pair; fullsize2.npz: c4 another seed / 6-voxel warp, c5 exact-zero background, c6 18-label
+    maps through the nnUNet path).  Inputs are regenerated from seeds (convexadam_amd/phantom.py); data files only."""
+    import numpy as np
+    from convexadam_amd import phantom as ph
+    from convexadam_amd.convex_adam_MIND import register_pair_device
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fullsize.npz" if tag == "c1" else "fullsize2.npz"))
+    if tag == "c6":
+        from convexadam_amd.convex_adam_nnUNet import extract_features
+        shape = (160, 192, 160)
+        lab, labm = ph.warped_label_pair(shape, 18, 11, 0.05)
+        ff, fm = extract_features(lab, labm, device=dev)
+        return g, shape, lambda mode, n: register_pair_device(feat_fixed=ff[0], feat_moving=fm[0], **dict(CFG, adam_mode=mode, selected_niter=n))
+    shape = SHAPE
+    a, b = {"c1": lambda: ph.deformed_pair(shape, 0, 4.0), "c4": lambda: ph.deformed_pair(shape, 2, 6.0), "c5": lambda: ph.zero_background_pair(shape, 0, 4.0)}[tag]()
+    a, b = a.to(dev).contiguous(), b.to(dev).contiguous()
+    return g, shape, lambda mode, n: register_pair_device(a, b, **dict(CFG, adam_mode=mode, selected_niter=n))
+
+
 def mode_parity(fix, mov, dev, timed_field):
-    """Outside the timed region: the timed mode and the exact (reference-order) mode against the reference's capture at 20 / 40 / 80
-    iterations, the exact mode's own speed, and the acceptance criteria the timed mode was built to."""
+    """Outside the timed region: the timed mode and the exact (reference-order) mode against FOUR full-size captures of the reference at
+    1 / 20 / 40 / 80 iterations, next to the reference's distance from a 1-ulp-perturbed copy of itself, and the exact mode's own speed."""
     import numpy as np
     from convexadam_amd.convex_adam_MIND import register_pair_device
-    g = np.load(os.path.join(ROOT, "tests", "golden", "fullsize.npz"))
-    self_pert = float(g["c1_self_perturbation_epe_sub"][list(g["c1_snaps"]).index(80)])
-    out = {}
-    for name, cfg in (("timed_mode", TIMED), ("exact_mode", EXACT)):
-        e = {}
-        for n in (1, 20, 40, 80):
-            f = timed_field if (name == "timed_mode" and n == 80) else register_pair_device(fix, mov, **dict(cfg, selected_niter=n)).cpu().numpy()
-            e["epe_vs_reference_%dit" % n] = epe_vs_reference(f, n)
-        out[name] = e
+
+    def epe_sub(field, g, tag, n):
+        s_ = int(g["sub"])
+        d = field[:, ::s_, ::s_, ::s_].cpu().numpy().astype(np.float64) - g["%s_adam_%d_sub" % (tag, n)].astype(np.float64)
+        return float(np.sqrt((d ** 2).sum(0)).mean())
+
+    caps = {}
+    for tag in CAPTURES:
+        g, shape, reg = capture_registration(tag, dev)
+        snaps = [int(v) for v in g[tag + "_snaps"]]
+        self_p = [float(v) for v in g[tag + "_self_perturbation_epe_sub"]]
+        e = {"epe_vs_reference_%dit" % n: epe_sub(reg("fast", n), g, tag, n) for n in snaps}
+        e["exact_mode_epe_vs_reference_80it"] = epe_sub(reg("exact", 80), g, tag, 80)
+        e["reference_self_perturbation_epe"] = dict(zip(["%dit" % n for n in snaps], self_p))
+        e["ratio_to_self_perturbation_80it"] = e["epe_vs_reference_80it"] / self_p[snaps.index(80)]
+        e["ratio_to_exact_mode_80it"] = e["epe_vs_reference_80it"] / e["exact_mode_epe_vs_reference_80it"]
+        e["criteria_round3"] = dict(epe_1it_le_1em6=bool(e["epe_vs_reference_1it"] <= 1e-6), epe_20it_lt_1em3=bool(e["epe_vs_reference_20it"] < 1e-3),
+                                    epe_40it_lt_1em3=bool(e["epe_vs_reference_40it"] < 1e-3),
+                                    epe_80it_le_reference_self_perturbation=bool(e["ratio_to_self_perturbation_80it"] <= 1.0),
+                                    epe_80it_le_1p15x_exact_mode=bool(e["ratio_to_exact_mode_80it"] <= 1.15))
+        caps[tag] = e
+        del reg
+        torch.cuda.empty_cache()
+    out = {"timed_mode": dict(caps["c1"]), "exact_mode": {}}
+    for n in (1, 20, 40, 80):
+        out["exact_mode"]["epe_vs_reference_%dit" % n] = epe_vs_reference(register_pair_device(fix, mov, **dict(EXACT, selected_niter=n)).cpu().numpy(), n)
     for _ in range(2):
         register_pair_device(fix, mov, **EXACT)
     torch.cuda.synchronize(dev)
@@ -172,8 +223,9 @@ def mode_parity(fix, mov, dev, timed_field):
         register_pair_device(fix, mov, **EXACT)
     torch.cuda.synchronize(dev)
     out["exact_mode"]["ms_per_pair"] = (time.perf_counter() - t0) / 5 * 1e3
-    out["exact_mode"]["note"] = "every operator in the reference's evaluation order (library expf / IEEE sqrt / exactly rounded mean); bit-identical to oracle/cvx_oracle.c"
-    # adam_mode "fast_all" (forward boxes separable too): faster, but outside the acceptance criteria -- reported, never `value`
+    out["exact_mode"]["pairs_per_s"] = 1e3 / out["exact_mode"]["ms_per_pair"]
+    out["exact_mode"]["note"] = "the PACKAGE DEFAULT: every operator in the reference's evaluation order (library expf / IEEE sqrt / exactly rounded mean); bit-identical to oracle/cvx_oracle.c"
+    # adam_mode "fast_all" (forward boxes separable too): faster, further from the reference on every capture at 20 iterations -- reported, never `value`
     fa = {}
     for n in (20, 40, 80):
         fa["epe_vs_reference_%dit" % n] = epe_vs_reference(register_pair_device(fix, mov, **dict(CFG, adam_mode="fast_all", selected_niter=n)).cpu().numpy(), n)
@@ -184,20 +236,27 @@ def mode_parity(fix, mov, dev, timed_field):
     torch.cuda.synchronize(dev)
     fa["ms_per_pair"] = (time.perf_counter() - t0) / 5 * 1e3
     fa["pairs_per_s"] = 1e3 / fa["ms_per_pair"]
-    fa["accepted"] = bool(fa["epe_vs_reference_80it"] <= self_pert)
-    fa["note"] = ("opt-in adam_mode='fast_all': the timed mode with the FORWARD boxes in separable arithmetic as well; not accepted by the criteria "
+    fa["accepted"] = False
+    fa["note"] = ("opt-in adam_mode='fast_all': the timed mode with the FORWARD boxes in separable arithmetic as well "
                   "(the regulariser differentiates U twice: a 1-2 ulp difference in U moves the trajectory), offered for callers that grade by overlap scores")
     out["fast_all_mode"] = fa
-    t, x = out["timed_mode"], out["exact_mode"]
+    t = out["timed_mode"]
     t["name"] = TIMED_MODE_NAME
     t["tolerance_met_80it"] = bool(t["epe_vs_reference_80it"] < TOLERANCE_EPE)
-    t["acceptance"] = dict(convex_stage_bit_identical=True, epe_1it_le_1em6=bool(t["epe_vs_reference_1it"] <= 1e-6),
-                           epe_20it_lt_1em3=bool(t["epe_vs_reference_20it"] < 1e-3), epe_40it_lt_1em3=bool(t["epe_vs_reference_40it"] < 1e-3),
-                           epe_80it_le_reference_self_perturbation=bool(t["epe_vs_reference_80it"] <= self_pert),
-                           epe_80it_le_1p15x_exact_mode=bool(t["epe_vs_reference_80it"] <= 1.15 * x["epe_vs_reference_80it"]),
-                           reference_self_perturbation_epe_80it=self_pert,
-                           note="criteria registered before the mode was built (SURVEY section 7 hard part 1; VERDICT round 3 item 1); the convex stage "
-                                "(everything before the Adam loop) is the same code in both modes")
+    t["captures"] = caps
+    r_self = [caps[c]["ratio_to_self_perturbation_80it"] for c in CAPTURES]
+    r_exact = [caps[c]["ratio_to_exact_mode_80it"] for c in CAPTURES]
+    t["worst_ratio_to_self_perturbation_80it"] = max(r_self)
+    t["worst_ratio_to_exact_mode_80it"] = max(r_exact)
+    t["mean_epe_80it"] = dict(timed_mode=float(np.mean([caps[c]["epe_vs_reference_80it"] for c in CAPTURES])),
+                              exact_mode=float(np.mean([caps[c]["exact_mode_epe_vs_reference_80it"] for c in CAPTURES])),
+                              reference_self_perturbation=float(np.mean([caps[c]["reference_self_perturbation_epe"]["80it"] for c in CAPTURES])))
+    t["criteria_round3_all_captures_met"] = bool(all(all(caps[c]["criteria_round3"].values()) for c in CAPTURES))
+    t["note"] = ("four full-size captures of the reference (c1 = this benchmark pair, c4 another seed / 6-voxel warp, c5 exact-zero background, c6 18-label maps "
+                 "through the nnUNet path).  Convex stage bit-identical, 0 at one iteration and < 1e-3 at 20 / 40 iterations on all four.  At 80 iterations every "
+                 "arithmetic -- the reference after a 1-ulp perturbation of its own warped features, the exact-order restatement, this mode -- is 1-3e-3 voxel from the "
+                 "reference; the two 80-iteration criteria registered in round 3 on ONE pair (<= the self-perturbation distance, <= 1.15 x the exact mode's) are NOT met "
+                 "on all captures (criteria_round3 per capture; the exact mode itself misses the first on c4), so adam_mode='fast' is opt-in and 'exact' the package default")
     return out
 
 
@@ -366,6 +425,17 @@ def main():
     for name, ms in last_profile():
         stage_ms.setdefault(name, []).append(ms)
     set_profiling(0)
+    # per-kernel durations of the Adam loop (outside the timed region): cvx_set_profiling(3) records one event behind every kernel of the loop
+    kernel_ms = {}
+    if rank == 0 and not a.no_batched:          # (the rocprofv3 passes of tools/profile_round.sh run with --no-batched: one pair per PMC pass)
+        set_profiling(3)
+        for _ in range(3):
+            register_pair_device(fix, mov, out=out, **TIMED)
+        torch.cuda.synchronize(dev)
+        for name, ms in last_profile():
+            if name.startswith("adam."):
+                kernel_ms.setdefault(name, []).append(ms)
+        set_profiling(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -505,6 +575,30 @@ def main():
                             "frac": pair_bytes / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "note": "coupled convex counted at 6 full reads of the cost volume per direction (SURVEY 8(d)); the branch-and-bound passes read less"}
         res["roofline_by_stage"] = by_stage
+        # the pair with the coupled-convex stage at its MEASURED bytes (PMC passes of tools/profile_round.sh; the branch-and-bound passes touch ~1 % of
+        # the 6 x 270 MB the reference's formulation streams): the figure to quote for "fraction of the HBM roofline of the whole pair"
+        cc_meas = pmc_extra("coupled_convex_bytes_per_pair")
+        if cc_meas is not None:
+            pb = pair_bytes - 2 * 6 * K * v * 4 + cc_meas
+            by_stage["pair_measured_coupled_convex"] = {"algorithmic_bytes": pb, "coupled_convex_measured_bytes": cc_meas, "ms": res["ms_per_step"],
+                                                        "achieved_GBps": pb / (res["ms_per_step"] * 1e-3) / 1e9, "frac": pb / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                        "note": "as `pair`, with the coupled-convex stage counted at the HBM bytes its kernels actually move (rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/pmc_hbm_traffic.json)"}
+        if kernel_ms:
+            import statistics
+            kb = {"adam.forward_boxes": 2 * 3 * v2 * 4,                              # P read, U written
+                  "adam.warp_gradient": 2 * 12 * v2 * 4 + 2 * 3 * v2 * 4,            # F2, M2 read (gather: cache-perfect), U read, dU written
+                  "adam.adjoint_update": 7 * 3 * v2 * 4}                             # dU read; P, m, v read and written
+            rk = {}
+            for name, bts in kb.items():
+                if kernel_ms.get(name):
+                    us = statistics.median(kernel_ms[name]) * 1e3
+                    rk[name] = {"algorithmic_bytes": bts, "us": us, "achieved_GBps": bts / (us * 1e-6) / 1e9, "frac": bts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "launches_timed": len(kernel_ms[name])}
+            rk["iteration"] = {"algorithmic_bytes": sum(kb.values()), "us": sum(r["us"] for r in rk.values()),
+                               "note": "median interval between consecutive hipEvents on the launch stream (cvx_set_profiling(3): one event behind every kernel of the "
+                                       "loop, 3 pairs x 79 iterations, outside the timed region; an interval = the kernel + its boundary); SURVEY 8(d) bytes: 185.8 MB per iteration"}
+            rk["iteration"]["frac"] = rk["iteration"]["algorithmic_bytes"] / (rk["iteration"]["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            res["roofline_by_kernel"] = rk
         if batched is not None:
             res["batched_2streams"] = batched
         if cc_worst is not None and cc_worst.get("fast_corr_ms"):
@@ -525,6 +619,8 @@ def main():
                                         "note": "opt-in storage='fp16' (the reference's GPU default dtype, convex_adam_MIND.py:79): cost volumes and the Adam loop's "
                                                 "feature records are real __half buffers, float32 accumulation; bit-identical to the oracle's fp16 restatement, graded "
                                                 "against the float32 field by end-point error and by the fraction of convex-stage voxels whose displacement changed"}
+        if cc_worst is not None and cc_worst.get("ms_per_pair"):
+            res["value_zero_background"] = 1e3 / cc_worst["ms_per_pair"]          # the timed mode on the same pair with an exact-zero background (skull-stripped-like)
         if cc_worst is not None:
             res["coupled_convex_ms"] = {"phantom": res["stages_ms"].get("coupled_convex"), "zero_background": cc_worst.get("coupled_convex"),
                                         "zero_background_ms_per_pair": cc_worst.get("ms_per_pair"),
@@ -536,6 +632,10 @@ def main():
             res["parity"].update(mode_parity(fix, mov, dev, field_of_timed_loop))
             res["parity"]["timed_mode"]["ms_per_pair"] = res["ms_per_step"]
             res["parity"]["reference_bits_mode"] = reference_bits_check(fix, mov, dev)
+            # what the line means for someone who asks "pairs/s at < 1e-3 voxel of the reference after 80 iterations"
+            res["tolerance_met"] = bool(res["parity"]["timed_mode"]["tolerance_met_80it"])
+            res["value_at_tolerance"] = res["parity"]["reference_bits_mode"]["pairs_per_s"] if res["parity"]["reference_bits_mode"]["tolerance_met"] else None
+            res["value_exact_mode"] = res["parity"]["exact_mode"]["pairs_per_s"]
             res["api"] = api_path(fix, mov, dev, res["ms_per_step"])
         print(json.dumps(res))
     if world > 1:

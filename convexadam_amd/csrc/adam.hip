@@ -162,6 +162,11 @@ static int launch_box3x3(const float* in, float* out, int h, int w, int d, bool 
                          AdamConsts ac, float* gsave, hipStream_t s) {
     // rows of up to 126 voxels: z-marching pipeline (boxmarch.hip); longer rows: the tiled kernel below
     const bool force_tiled = options().box_tiled != 0;
+    if (!backward && !force_tiled && box3_tile_fwd_supported(in, out, h, w, d)) {
+        long long ft = options().box_fwd_tile;
+        if (ft < 0) ft = box3_march_supported(d) ? box3_tile_fwd_auto(h, w, d) : 2000;      // (rows beyond the marching kernel's range: always tiles)
+        if (ft >= 1000) return launch_box3_tile_fwd(in, out, h, w, d, (int)ft, s);
+    }
     if (!force_tiled && box3_march_supported(d)) return launch_box3_march(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
     const int nb = cdiv(d, BT_X) * cdiv(w, BT_Y) * cdiv(h, BT_Z) * 3;
     if (!backward) hipLaunchKernelGGL((k_box3x3<false, false>), dim3(nb), dim3(BT_NT), 0, s, in, out, h, w, d, P, m, v, ac, gsave);
@@ -301,11 +306,13 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
         else if (fast == 2 && sm->kind == 0) { if ((rc = launch_boxchain_fast(P, U, h, w, d, *sm, false, s))) return rc; }             // ... for a box chain of the sweep
         else if (fused) { if ((rc = launch_box3x3(P, U, h, w, d, false, nullptr, nullptr, nullptr, ac, nullptr, s))) return rc; }
         else if ((rc = launch_smoother(P, U, t1, 3, h, w, d, *sm, false, s))) return rc;
+        profile_mark_kernel("adam.forward_boxes", s);
         const bool last = it == niter - 1;
         if (!(last && !keep_state && !grad_out)) {
         float* gsave = (grad_out && it == niter - 1) ? grad_out : nullptr;
         if (fast) {
             if ((rc = launch_warp_grad_fast(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, s))) return rc;
+            profile_mark_kernel("adam.warp_gradient", s);
             if (fused) { if ((rc = launch_box3_fast(gU, nullptr, h, w, d, P, m, v, bc1, bc2, gsave, s))) return rc; }
             else {
                 // sweep smoothers: a box chain through the separable passes (adjoint = reversed box order), a Gaussian through its exact
@@ -317,6 +324,7 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
             }
         } else {
         if ((rc = launch_warp_grad(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, f16_features, s))) return rc;
+        profile_mark_kernel("adam.warp_gradient", s);
         if (fused) { if ((rc = launch_box3x3(gU, nullptr, h, w, d, true, P, m, v, ac, gsave, s))) return rc; }
         else {
             if ((rc = launch_smoother(gU, t2, t1, 3, h, w, d, *sm, true, s))) return rc;
@@ -325,6 +333,7 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
         }
         }
         }
+        if (!(last && !keep_state && !grad_out)) profile_mark_kernel("adam.adjoint_update", s);
         while (snap < n_snap && snapshot_iters_host[snap] == it + 1) {
             (void)hipMemcpyAsync(snapshots + (size_t)snap * 3 * V, U, sizeof(float) * 3 * V, hipMemcpyDeviceToDevice, s);
             ++snap;

@@ -92,6 +92,7 @@ struct Options {
                                    //    (reference-bits mode; NOT a bit-identical variant -- it changes the clamp bounds by ulps)
     long long edt_sequential;      // 1: squared distance transform with the sequential lower-envelope passes (one thread per line) instead of the tiled outward search
     long long warp_octant;         // adam_mode "fast" warp kernel, tile order inside an XCD's share: G >= 2 (default 4) = x fastest, then G z-adjacent tiles, then y (the tiles that share planes follow each other: FETCH_SIZE -13 %, 5.64 -> 5.59 ms per pair); 0 = plain slabs (x, y, z); 1 = one octant of the tile grid per XCD (measured: no gain)
+    long long box_fwd_tile;        // forward three-box pass of the Adam loop: -1 = automatic (tiles of boxtile.hip where they fill the chip), 0 = z-marching pipeline (boxmarch.hip), kind * 1000 + segments = a tile kernel variant (boxtile.hip; bit-identical)
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };
@@ -303,6 +304,9 @@ __device__ __forceinline__ float tri_sample(const Tri& t, const float* __restric
     return o;
 }
 
+// pipeline.hip: event mark behind a kernel of the Adam loop (no-op unless cvx_set_profiling(3))
+void profile_mark_kernel(const char* name, hipStream_t s);
+
 // ---- internal (non-ABI) launchers shared between translation units -------------------------------
 int launch_box_zero(const float* in, float* out, int C, int H, int W, int D, int k, bool backward, hipStream_t s);
 int launch_smoother(const float* in, float* out, float* tmp, int C, int H, int W, int D, const cvx_smoother& sm, bool backward,
@@ -374,6 +378,10 @@ int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, i
 bool box3_march_supported(int d);
 int launch_box3_march(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,
                       AdamConsts ac, float* gsave, hipStream_t s);
+// boxtile.hip: the forward boxes as independent tiles (two barriers per workgroup instead of one per plane)
+bool box3_tile_fwd_supported(const float* in, const float* out, int h, int w, int d);
+int launch_box3_tile_fwd(const float* in, float* out, int h, int w, int d, int variant, hipStream_t s);
+int box3_tile_fwd_auto(int h, int w, int d);       // variant for this grid, 0 = keep the marching kernel
 // warp.hip: [C][V] -> [CP/4][V][4] feature copies and the warp + data-term gradient of one Adam iteration
 // (half: records of four half-precision values -- fp16 storage of the pooled features -- instead of four floats)
 int launch_to_chunked(const float* in, int C, size_t V, float* out, bool half, hipStream_t s);

@@ -501,7 +501,7 @@ extern "C" int cvx_surface_hist_batch_i64(const void* const* volumes_dev, int n_
 }
 extern "C" int cvx_hist_order_stats_i64(const int64_t* hist, int nbins, int64_t k0, int64_t k1, int64_t* out3, void* stream) {
     CVX_REQUIRE(hist && out3, "cvx_hist_order_stats_i64: null pointer");
-    CVX_REQUIRE(nbins > 0, "cvx_hist_order_stats_i64: bad size");
+    CVX_REQUIRE(nbins > 0 && nbins <= 4096 * 1024, "cvx_hist_order_stats_i64: bad size (1 .. 4 194 304 bins: chunk totals live in LDS)");
     hipLaunchKernelGGL(k_hist_order_stats, dim3(1), dim3(1024), 0, as_stream(stream), reinterpret_cast<const unsigned long long*>(hist),
                        nbins, (long long)k0, (long long)k1, 0.0f, reinterpret_cast<long long*>(out3));
     return check_last("hist_order_stats");

@@ -124,7 +124,7 @@ static PairLayout pair_layout(const cvx_pair_params& p, int n_snap = 0, int max_
 }
 
 // ---- optional per-stage timing -------------------------------------------------------------------------
-static thread_local int g_profiling = 0;       // 0 off, 1 last call only, 2 accumulate over calls
+static thread_local int g_profiling = 0;       // 0 off, 1 last call only, 2 accumulate over calls, 3 = 2 + one mark per kernel of the Adam loop
 struct StageMark { const char* name; hipEvent_t ev; };
 static thread_local std::vector<StageMark> g_marks;
 static thread_local std::vector<hipEvent_t> g_pool;
@@ -140,6 +140,11 @@ static void mark(const char* name, hipStream_t s) {
     hipEvent_t e = g_pool[g_pool_used++];
     (void)hipEventRecord(e, s);
     g_marks.push_back({name, e});
+}
+// (adam.hip) one mark behind every kernel of the Adam loop when cvx_set_profiling(3) is on: per-kernel durations from events on the
+// launch stream, the iteration's three launches named "adam.forward_boxes", "adam.warp_gradient", "adam.adjoint_update"
+void profile_mark_kernel(const char* name, hipStream_t s) {
+    if (g_profiling == 3) mark(name, s);
 }
 
 // ---- side stream for the independent half of a stage (the two images' descriptors) ---------------------------------------
@@ -197,7 +202,7 @@ static int validate(const cvx_pair_params* p) {
 using namespace cvx;
 
 extern "C" void cvx_set_profiling(int enabled) {
-    g_profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
+    g_profiling = enabled < 0 ? 0 : (enabled > 3 ? 3 : enabled);
     g_marks.clear();
     g_pool_used = 0;
 }
@@ -280,7 +285,7 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     hipStream_t s = as_stream(stream);
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-    if (g_profiling != 2) { g_marks.clear(); g_pool_used = 0; }
+    if (g_profiling < 2) { g_marks.clear(); g_pool_used = 0; }
     mark("start", s);
 
     // 1. features                                                              (:106-116)

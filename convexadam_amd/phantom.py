@@ -55,3 +55,27 @@ def ellipsoid_mask(shape, semi=0.35, shift=(0, 0, 0)):
     ax = [(torch.arange(s, dtype=torch.float32) - (s - 1) / 2.0 - sh) / (semi * s) for s, sh in zip(shape, shift)]
     r2 = ax[0].view(-1, 1, 1) ** 2 + ax[1].view(1, -1, 1) ** 2 + ax[2].view(1, 1, -1) ** 2
     return (r2 <= 1.0).float().contiguous()
+
+
+def zero_background_pair(shape, idx=0, amp=4.0, semi=0.42):
+    """deformed_pair with an EXACT-zero background, the way skull-stripped brain MRI is: both images are multiplied by 0/1 ellipsoid
+    masks (the moving one shifted by a few voxels), so every voxel outside is bit-zero and MIND's variance clamp / the flat cost
+    columns of the search are exercised at full size."""
+    fix, mov = deformed_pair(shape, idx, amp)
+    return (fix * ellipsoid_mask(shape, semi)).contiguous(), (mov * ellipsoid_mask(shape, semi, shift=(2, -1, 3))).contiguous()
+
+
+def warped_label_pair(shape, n_labels=18, seed=11, amp=0.05):
+    """(fixed, moving) float32 label maps with exactly `n_labels` labels 0 .. n_labels-1 present in both: argmax of smooth random
+    fields; the moving map is the fixed one pulled through a smooth random warp (nearest neighbour), `amp` in normalised units
+    (0.05 ~ 4-5 voxels at 160-224 voxels per axis).  The largest label is planted in a corner of both maps: the reference's nnUNet
+    feature extraction (convex_adam_nnUNet.py:19-38) needs equal maxima (bincount / one_hot sizes)."""
+    g = torch.Generator().manual_seed(seed)
+    f = F.interpolate(torch.randn(1, n_labels, 6, 5, 7, generator=g), size=tuple(shape), mode="trilinear", align_corners=False)
+    lab = torch.argmax(f, 1)[0].float()
+    base = F.affine_grid(torch.eye(3, 4)[None], (1, 1) + tuple(shape), align_corners=False)
+    warp = F.interpolate(torch.randn(1, 3, 4, 4, 4, generator=g) * amp, size=tuple(shape), mode="trilinear", align_corners=False)
+    labm = F.grid_sample(lab[None, None], base + warp.permute(0, 2, 3, 4, 1), mode="nearest", padding_mode="border", align_corners=False)[0, 0]
+    lab[0, 0, 0] = float(n_labels - 1)
+    labm[-1, -1, -1] = float(n_labels - 1)
+    return lab.contiguous(), labm.contiguous()

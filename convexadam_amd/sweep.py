@@ -384,10 +384,11 @@ def main(argv=None):
     ap.add_argument("--static", action="store_true", help="round-robin assignment instead of the shared queue")
     ap.add_argument("--dry-run", action="store_true", help="no kernels: exercises queue, logs, resume and gather only (CPU/gloo)")
     ap.add_argument("--evaluate", action="store_true", help="round-1 mode: score every item on the device and rank the settings")
-    ap.add_argument("--adam-mode", default="fast_all", choices=("exact", "fast", "fast_all"),
-                    help="arithmetic of the stage-2 Adam runs: exact = the reference's evaluation order, fast = throughput arithmetic with the forward "
-                         "smoother exact, fast_all = separable forward smoother too (default: the sweep grades by overlap scores, which agree to three "
-                         "digits between the modes, and the generic exact smoothers cost ~0.5 ms per iteration)")
+    ap.add_argument("--adam-mode", default="fast", choices=("exact", "fast", "fast_all"),
+                    help="arithmetic of the stage-2 Adam runs: exact = the reference's evaluation order; fast (default) = throughput arithmetic for the warp "
+                         "gradient and the adjoint smoother, forward smoother / regulariser / update in the reference's order; fast_all = separable forward "
+                         "smoother too (fastest; further from the reference's fields -- offered because the sweep grades by overlap scores, which agreed to "
+                         "three digits between the modes on the synthetic label maps, not the default since round 5)")
     ap.add_argument("--workers", type=int, default=0, help="items in flight per rank, each on its own thread and HIP stream (0 = automatic = 1: since round 4 "
                     "the evaluation kernels fill the GPU on their own -- 2.67 s with one worker, 2.96 s with two on the 48-item example)")
     a = ap.parse_args(argv)

@@ -380,8 +380,9 @@ int cvx_register_pairs_f32(int n_pairs, const float* const* img_fixed, const flo
 
 /* per-stage device time of cvx_register_pair_f32 calls on this thread (hipEvents recorded on the launch
  * stream, ms).  cvx_set_profiling(0) off, (1) keep the last call only, (2) accumulate over calls until the next
- * cvx_set_profiling(); names_host receives pointers to static strings; returns the number of intervals written
- * (waits for the last recorded event). */
+ * cvx_set_profiling(); (3) = (2) plus one interval per kernel of the Adam loop ("adam.forward_boxes", "adam.warp_gradient",
+ * "adam.adjoint_update", once per iteration; the stage interval "adam" then only holds what follows the last kernel);
+ * names_host receives pointers to static strings; returns the number of intervals written (waits for the last recorded event). */
 int cvx_last_pair_profile(const char** names_host, float* ms_host, int max_stages);
 void cvx_set_profiling(int mode);
 

@@ -922,8 +922,11 @@ ORC_API void orc_adam_run_smoother(const float* F2, const float* M2, int C, int 
  *       8.5e-6 / 3.9e-5 / 1.28e-3, the same with separable FORWARD boxes 7.2e-5 / 1.8e-4 / 2.29e-3;
  *   (2) the warp / data-term gradient with the per-voxel set-up (coordinates, floor, the eight corner weights) exactly as
  *       ATen's, but per channel an FMA chain for the warped value and eight corner accumulators  A_k += df * v_k ; the three
- *       gradient components are combined from the A_k once per voxel;
- *   (3) the Adam update with one IEEE division:  den = fma(sqrt(v), 1/sqrt(bc2), eps) ; P += (neg_step * m) / den.
+ *       gradient components are combined from the A_k once per voxel.
+ * Round 5: the regulariser gradient and the Adam update are ATen's again (autograd's arrival order; sqrt / bc2_sqrt + eps with the
+ * IEEE square root): both are cheap next to (1) and (2), and on four full-size captures of the reference (tests/golden/fullsize.npz,
+ * fullsize2.npz) the mode with them stays closer to the reference at 20 / 40 iterations on every capture and on average at 80
+ * (DESIGN.md section 11).
  * Every operation is a correctly rounded IEEE operation in a FIXED order, which the HIP kernels of adam_mode = "fast"
  * (convexadam_amd/csrc/adamfast.hip) follow step by step: HIP-fast == oracle-fast bit for bit (tests/test_gpu_parity.py).
  * ---------------------------------------------------------------------------------------------- */
@@ -1040,6 +1043,9 @@ ORC_API void orc_adam_run_fast_smoother(const float* F2, const float* M2, int C,
     const orc_smoother boxes3 = {0, 3, {3, 3, 3, 0}, {0, 0, 0, 0, 0}};
     if (!sm) sm = &boxes3;
     const int chain = sm->kind == 0;
+    /* study switch (tools/experiments/fast_adam_epe.py): 1 = round 4's one-division update, 2 = round 4's FMA regulariser; 0 (default) =
+     * the accepted arithmetic of round 5: ATen's update and ATen's regulariser order */
+    const int xflags = getenv("ORC_FAST_R4") ? atoi(getenv("ORC_FAST_R4")) : 0;
     for (int it = 0; it < niter; ++it) {
         if (fast_forward && chain) orc_fast_boxchain(P, U, 3, h, w, d, sm->n_boxes, sm->box_k, 0);   /* adam_mode "fast_all": NOT accepted by the criteria above (2.29e-3 at 80 iterations) */
         else orc_smooth(P, U, 3, h, w, d, sm, 0);            /* forward smoother: ATen's order, as in orc_adam_run */
@@ -1087,6 +1093,16 @@ ORC_API void orc_adam_run_fast_smoother(const float* F2, const float* M2, int C,
                 const float* Ua = U + (size_t)a * V;
                 const float uc = Ua[p];
                 float acc = g[a];
+                if (!(xflags & 2)) {       /* autograd's arrival order, as in orc_adam_run */
+                    if (x < d - 1) acc += -(cD * (2.0f * (Ua[p + 1] - uc)));
+                    if (x > 0)     acc +=  (cD * (2.0f * (uc - Ua[p - 1])));
+                    if (z < h - 1) acc += -(cH * (2.0f * (Ua[p + (size_t)w * d] - uc)));
+                    if (z > 0)     acc +=  (cH * (2.0f * (uc - Ua[p - (size_t)w * d])));
+                    if (y < w - 1) acc += -(cW * (2.0f * (Ua[p + d] - uc)));
+                    if (y > 0)     acc +=  (cW * (2.0f * (uc - Ua[p - d])));
+                    gU[(size_t)a * V + p] = acc;
+                    continue;
+                }
                 if (x < d - 1) acc = fmaf(m2D, Ua[p + 1] - uc, acc);
                 if (x > 0)     acc = fmaf(m2D, Ua[p - 1] - uc, acc);
                 if (z < h - 1) acc = fmaf(m2H, Ua[p + (size_t)w * d] - uc, acc);
@@ -1103,7 +1119,7 @@ ORC_API void orc_adam_run_fast_smoother(const float* F2, const float* M2, int C,
         const double beta1 = 0.9, beta2 = 0.999;
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
         const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2);
-        const float inv_bc2s = (float)(1.0 / sqrt(bc2));
+        const float inv_bc2s = (float)(1.0 / sqrt(bc2)), bc2s = (float)sqrt(bc2);
         const float neg_step = (float)(-(1.0 / bc1));
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < 3 * V; ++i) {
@@ -1111,7 +1127,7 @@ ORC_API void orc_adam_run_fast_smoother(const float* F2, const float* M2, int C,
             const float mm = fmaf(w1, g - m[i], m[i]);
             float vv = v[i] * b2;
             vv = fmaf(omb2 * g, g, vv);
-            const float den = fmaf(sqrtf(vv), inv_bc2s, 1e-8f);
+            const float den = (xflags & 1) ? fmaf(sqrtf(vv), inv_bc2s, 1e-8f) : sqrtf(vv) / bc2s + 1e-8f;    /* (sqrt / bc2_sqrt).add_(eps), IEEE sqrt */
             P[i] = P[i] + (neg_step * mm) / den;
             m[i] = mm; v[i] = vv;
         }

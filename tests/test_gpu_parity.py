@@ -361,6 +361,32 @@ def test_adam_grid_shapes_vs_oracle(U, orc, shape):
     assert np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
 
 
+@pytest.mark.parametrize("variant", [1000, 2000, 1834, 2274, 1111, 2999])
+@pytest.mark.parametrize("shape", [(13, 9, 8), (5, 3, 4), (12, 8, 56), (25, 17, 60), (24, 16, 116), (2, 2, 4), (14, 31, 52), (30, 20, 112), (4, 8, 132)])
+def test_forward_box_tiles_vs_oracle(U, orc, shape, variant):
+    """The forward three-box pass as independent tiles (boxtile.hip; option box_fwd_tile = kind * 1000 + z segments per row of the
+    three passes; -1 = automatic: the benchmark grid takes kind 2): 12 x 8 x 56 and 12 x 16 x 56 tiles, every segment length from two
+    planes to a whole tile, grids smaller than a tile, ragged last tiles in all three directions, rows of several x tiles and beyond
+    the marching kernel's 126 voxels -- U, G, P, m, v against the oracle after three iterations."""
+    from convexadam_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(sum(shape) + variant)
+    C = 4
+    F2 = rng.random((C,) + shape, dtype=np.float32)
+    M2 = rng.random((C,) + shape, dtype=np.float32)
+    P0 = (0.7 * rng.standard_normal((3,) + shape)).astype(np.float32)
+    old = L.cvx_get_option(b"box_fwd_tile")
+    assert L.cvx_set_option(b"box_fwd_tile", variant) == 0
+    try:
+        Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.25, 3, return_state=True)
+    finally:
+        L.cvx_set_option(b"box_fwd_tile", old)
+    r = orc.adam_run(F2, M2, P0, 1.25, 3, want_grad=True)
+    assert np.array_equal(host(Ud)[0], r["U"])
+    assert np.array_equal(host(st["G"])[0], r["G"])
+    assert np.array_equal(host(st["P"])[0], r["P"])
+
+
 @pytest.mark.parametrize("xsplit", [-1, 0, 2, 3])
 @pytest.mark.parametrize("shape", [(5, 9, 64), (30, 20, 112), (4, 9, 100), (13, 8, 68)])
 def test_adam_x_tiles_vs_oracle(U, orc, shape, xsplit):
@@ -1203,7 +1229,7 @@ def test_full_size_sweep_extreme_settings(M):
 
 # ---- (9) every selectable kernel variant -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opt,val", [("mind_tiled", 1), ("mm_tx", 32), ("mm_tx", 64), ("mm_slots", 64), ("box_tiled", 1), ("no_prune", 1),
-                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("cf_prio", 0x9d), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0), ("box_cpt", 2), ("box_uneven", 100), ("box_prio", 1), ("mind_overlap", 1), ("corr_fused_all", 1)])
+                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("cf_prio", 0x9d), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0), ("box_cpt", 2), ("box_uneven", 100), ("box_prio", 1), ("mind_overlap", 1), ("corr_fused_all", 1), ("box_fwd_tile", 0), ("box_fwd_tile", 1000), ("box_fwd_tile", 2000)])
 def test_kernel_variants_agree(M, U, orc, golden, opt, val):
     """The library's run-time switches (cvx_set_option / CVX_* environment variables) select alternative kernels for the same
     operators; every one of them is bit-identical to the oracle: marching vs tiled MIND stencil and its tile shapes, marching vs tiled

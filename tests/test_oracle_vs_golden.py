@@ -445,40 +445,86 @@ def test_host_tables_match_the_fixtures_on_the_golden_host(orc, mkl):
     assert np.array_equal(t["exp"], gt["exp"]) and np.array_equal(t["sqrt"], gt["sqrt"])
 
 
-@pytest.mark.timeout(900)
-def test_fast_adam_mode_acceptance_against_the_reference_capture(orc, golden):
-    """adam_mode="fast" (orc_adam_run_fast: the arithmetic the HIP kernels of convexadam_amd/csrc/adamfast.hip follow bit for bit) at FULL
-    size against the field captured from the reference itself -- the acceptance criteria registered before the mode was built
-    (SURVEY section 7 hard part 1): 0 at one iteration, < 1e-3 at 20 and 40, and at 80 iterations no further from the
-    reference than the reference is from a 1-ulp-perturbed copy of itself and <= 1.15 x the exact restatement's own distance."""
-    from convexadam_amd.phantom import deformed_pair
-    g = golden("fullsize")
-    shape = (160, 192, 224)
-    fix, mov = deformed_pair(shape, 0, 4.0)
+def fullsize_case(tag):
+    """Inputs of the full-size captures (tests/golden/fullsize.npz: c1; fullsize2.npz: c4-c6), regenerated from seeds: (kind, shape, a, b)."""
+    from convexadam_amd import phantom as ph
+    if tag == "c1":
+        return ("images", (160, 192, 224)) + ph.deformed_pair((160, 192, 224), 0, 4.0)          # the benchmark pair
+    if tag == "c4":
+        return ("images", (160, 192, 224)) + ph.deformed_pair((160, 192, 224), 2, 6.0)          # another seed, 6-voxel warp
+    if tag == "c5":
+        return ("images", (160, 192, 224)) + ph.zero_background_pair((160, 192, 224), 0, 4.0)   # EXACT-zero background
+    return ("labels", (160, 192, 160)) + ph.warped_label_pair((160, 192, 160), 18, 11, 0.05)     # 18 labels, nnUNet path (C >= 16)
+
+
+FULLSIZE_TAGS = ("c1", "c4", "c5", "c6")
+# The envelope the throughput mode is held to at 80 iterations (see the test below): no capture further than 1.6 x the reference's own
+# 1-ulp self-perturbation distance, and not further than it on average over the captures.
+FAST_80_ENVELOPE = 1.6
+
+
+def fullsize_stages(orc, g, tag):
+    """Oracle pipeline of one capture up to the start of the Adam loop; asserts the convex stage bit for bit against the reference."""
+    kind, shape, a, b = fullsize_case(tag)
     kw = dict(mind_r=1, mind_d=2, grid_sp=6, disp_hw=6, grid_sp_adam=2, ic=True)
-    _, st = orc.convex_adam_pipeline(fix.numpy(), mov.numpy(), lambda_weight=1.25, selected_niter=1, return_stages=True, **kw)
+    if kind == "labels":
+        ff, fm, _ = orc.label_features(a.numpy(), b.numpy(), 10.0)
+        assert ff.shape[0] == int(g["c6_n_ch"]) >= 16
+        _, st = orc.convex_adam_pipeline(None, None, lambda_weight=1.25, selected_niter=1, return_stages=True, features=(ff, fm), **kw)
+    else:
+        if tag == "c5":
+            assert np.allclose([float((a == 0).float().mean()), float((b == 0).float().mean())], g["c5_zero_fraction"]) and float((a == 0).float().mean()) > 0.5
+        _, st = orc.convex_adam_pipeline(a.numpy(), b.numpy(), lambda_weight=1.25, selected_niter=1, return_stages=True, **kw)
+    scale = ((np.array(st["fs"].shape[1:], np.float32) - 1) / np.float32(2)).reshape(3, 1, 1, 1)
+    assert np.array_equal((st["ice"][::-1] * scale) * np.float32(6), g[tag + "_coarse_ic"]), tag + ": convex stage differs from the reference"
+    return shape, st
+
+
+def horizons(orc, g, tag, shape, st, mode):
+    """Mean EPE of one oracle Adam run against the reference capture at 1 / 20 / 40 / 80 iterations (one 80-iteration run, observed
+    at every horizon through the optimiser state)."""
     s = int(g["sub"])
-    snaps = [int(v) for v in g["c1_snaps"]]
-    res = {}
-    for mode in ("fast", "exact"):
-        for n in snaps if mode == "fast" else (80,):
-            r = orc.adam_run(st["F2"], st["M2"], st["P0"], 1.25, n, mode=mode, keep_last_step=False) if mode == "fast" else \
-                orc.adam_run(st["F2"], st["M2"], st["P0"], 1.25, n)
-            f = orc.resize_trilinear(r["U"] * np.float32(2), shape)
-            res[mode, n] = epe(np.moveaxis(f[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["c1_adam_%d_sub" % n], 0, -1))
-    # adam_mode "fast_all" (forward boxes separable too) is offered but does NOT meet the criteria: the reason the forward boxes of
-    # "fast" keep ATen's order (DESIGN.md section 10.1)
-    for n in (20, 80):
-        r = orc.adam_run(st["F2"], st["M2"], st["P0"], 1.25, n, mode="fast_all", keep_last_step=False)
+    res, state, done = {}, None, 0
+    for n in [int(v) for v in g[tag + "_snaps"]]:
+        r = orc.adam_run(st["F2"], st["M2"], st["P0"] if state is None else state["P"], 1.25, n - done, mode=mode,
+                         m=None if state is None else state["m"], v=None if state is None else state["v"], step0=done)
+        state, done = r, n
         f = orc.resize_trilinear(r["U"] * np.float32(2), shape)
-        res["fast_all", n] = epe(np.moveaxis(f[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["c1_adam_%d_sub" % n], 0, -1))
-    assert res["fast_all", 20] > 3 * res["fast", 20] and res["fast_all", 80] > float(g["c1_self_perturbation_epe_sub"][snaps.index(80)])
-    assert res["fast_all", 80] < 3e-3
-    print("fast mode vs reference capture:", {n: "%.3e" % res["fast", n] for n in snaps}, "exact at 80: %.3e" % res["exact", 80],
-          "fast_all at 20 / 80: %.3e / %.3e" % (res["fast_all", 20], res["fast_all", 80]))
-    assert res["fast", 1] <= 1e-6 and res["fast", 20] < 1e-3 and res["fast", 40] < 1e-3
-    assert res["fast", 80] <= float(g["c1_self_perturbation_epe_sub"][snaps.index(80)])
-    assert res["fast", 80] <= 1.15 * res["exact", 80]
+        res[n] = epe(np.moveaxis(f[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["%s_adam_%d_sub" % (tag, n)], 0, -1))
+    return res
+
+
+@pytest.mark.timeout(1500)
+def test_fast_adam_mode_against_four_reference_captures(orc, golden):
+    """adam_mode="fast" (orc_adam_run_fast: the arithmetic the HIP kernels of convexadam_amd/csrc/adamfast.hip follow bit for bit) at FULL
+    size against fields captured from the reference itself: the benchmark pair (c1) and the three captures VERDICT round 4 asked for
+    (c4 another seed and a 6-voxel warp, c5 an EXACT-zero background, c6 18-label maps through convex_adam_nnUNet: C >= 16).
+
+    What holds on every capture and is asserted: convex stage bit-identical; mean EPE 0 after one iteration; < 1e-3 after 20 and 40.
+    At 80 iterations every arithmetic is 1-3e-3 voxel from the reference -- the reference itself after a 1-ulp perturbation of its
+    warped features (1.6 / 1.8 / 2.1 / 2.7e-3 on c1 / c4 / c5 / c6), the exact-order restatement with this library's libm (1.2 / 2.2 /
+    1.3 / 0.6e-3), the fast mode (1.4 / 2.7 / 1.2 / 1.3e-3).  The criteria registered in round 3 for ONE pair (<= the self-perturbation
+    distance AND <= 1.15 x the exact mode's) do NOT survive the wider set: the fast mode misses the first on c4 (as does the exact mode)
+    and the second on c1 / c4 / c6 -- which is why "exact" is the package default again (convex_adam_MIND.py) and the fast mode is
+    opt-in.  Asserted here as a regression envelope, not as an acceptance: no capture beyond FAST_80_ENVELOPE x its self-perturbation
+    distance, and on average over the captures not beyond it.  adam_mode="fast_all" (separable forward boxes too) is further away on
+    every capture at 20 iterations and on average at 80."""
+    g1, g2 = golden("fullsize"), golden("fullsize2")
+    table = {}
+    for tag in FULLSIZE_TAGS:
+        g = g1 if tag == "c1" else g2
+        shape, st = fullsize_stages(orc, g, tag)
+        fast = horizons(orc, g, tag, shape, st, "fast")
+        self_e = [float(v) for v in g[tag + "_self_perturbation_epe_sub"]]
+        table[tag] = (fast, self_e)
+        print(tag, "fast mode vs reference capture:", {n: "%.3e" % v for n, v in fast.items()}, "| reference vs its 1-ulp-perturbed self:", ["%.3e" % v for v in self_e], flush=True)
+        assert fast[1] <= 1e-6 and fast[20] < 1e-3 and fast[40] < 1e-3, tag
+        assert fast[80] <= FAST_80_ENVELOPE * self_e[3], tag
+        if tag == "c1":                                   # (one capture is enough to keep the other modes' relation on record)
+            fa = horizons(orc, g, tag, shape, st, "fast_all")
+            print("   fast_all:", {n: "%.3e" % v for n, v in fa.items()})
+            assert fa[20] > 3 * fast[20] and fa[80] > fast[80] and fa[80] < 3e-3
+    assert np.mean([table[t][0][80] for t in FULLSIZE_TAGS]) <= np.mean([table[t][1][3] for t in FULLSIZE_TAGS])
 
 
 def test_fast_box_is_the_three_chained_boxes(orc):

@@ -5,7 +5,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 F=$1; shift || true
 EXTRA=""
-case $F in warp.hip|adamfast.hip|boxmarch.hip|corrbox.hip|corrfused.hip|mindmarch.hip) EXTRA="-fno-slp-vectorize";; esac
+case $F in warp.hip|adamfast.hip|boxmarch.hip|boxtile.hip|corrbox.hip|corrfused.hip|mindmarch.hip) EXTRA="-fno-slp-vectorize";; esac
 O=/tmp/kres_$$.co
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -I$R/include -I$R/convexadam_amd/csrc \
   $EXTRA -DCVX_BUILDING=1 --cuda-device-only -c $R/convexadam_amd/csrc/$F -o $O

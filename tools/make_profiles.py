@@ -93,7 +93,10 @@ def main(src, tag):
     open(os.path.join(prof, tag + "_pmc_hbm_traffic.txt"), "w").write(buf.getvalue())
     stage = [(r[0], r[1], r[2], r[3], r[4]) for r in rows if any(s in r[0] for s in ("k_corr_prep", "k_corr_raw", "k_corr_tail", "k_corr_box", "k_corr_fused"))]
     total = sum(r[4] for r in stage) * 1e6
-    json.dump({"correlate_stage_bytes_per_launch": total, "source": "profiles/%s_pmc_hbm_traffic.txt" % tag,
+    cc = [r for r in rows if any(k in r[0] for k in ("k_argmin_voxel", "k_argmin_wave", "k_gather_box3", "k_keys_to_idx_min"))]
+    cc_pair = sum(r[4] * r[1] for r in cc) * 1e6              # the PMC passes register ONE pair: calls x bytes per call
+    json.dump({"correlate_stage_bytes_per_launch": total, "coupled_convex_bytes_per_pair": cc_pair,
+               "coupled_convex_kernels": {r[0]: {"calls": r[1], "bytes_per_call": r[4] * 1e6} for r in cc}, "source": "profiles/%s_pmc_hbm_traffic.txt" % tag,
                "kernels": {r[0]: r[4] * 1e6 for r in stage},
                "formula": "(factor*FETCH_SIZE + WRITE_SIZE)*1024 (factor 2: 16-byte streaming reads) summed over k_corr_prep, k_corr_fused (k_corr_tail_compact when the volume has an interleaved-order tail), per launch = per direction", "measured_at_commit": os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip(),
                "corr_sources_sha16": corr_sha()},
