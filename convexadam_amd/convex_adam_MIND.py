@@ -335,6 +335,17 @@ class _PinnedPool:
 _out_pool = _PinnedPool()
 
 
+_tls = threading.local()
+
+
+def _stage_pins():
+    """The calling thread's four pinned input-staging slots of convex_adam_pt_many (re-used across calls; a slot is re-allocated when the
+    image shape changes)."""
+    if not hasattr(_tls, "pins"):
+        _tls.pins = [None] * 4
+    return _tls.pins
+
+
 def upload_image(img, device):
     """Host image -> float32 device tensor (torch's own upload: 27.5 MB in 0.56 ms on the round-4 boxes, as fast as a copy from pinned
     memory).  NB: this path deliberately runs NO multi-threaded host work -- a 128-thread torch CPU copy into a pinned staging buffer
@@ -458,7 +469,9 @@ def convex_adam_pt_many(pairs, dtype: torch.dtype = torch.float16, device: torch
     up = torch.cuda.Stream(device)
     bufs = [None, None, None]                            # rotating device fields: pair i's is read by the side stream while pair i + 1 registers
     stage = [None, None]                                 # packed fields on the device
-    pins, pin_free = [None] * 4, [None] * 4              # pinned staging for two pairs in flight + the events that free them
+    # pinned staging for two pairs in flight + the events that free them; the buffers outlive the call (per thread: hipHostMalloc of
+    # 4 x 27.5 MB cost ~10 ms per generator, 1.2 ms per pair of an 8-pair sweep)
+    pins, pin_free = _stage_pins(), [None] * 4
 
     def upload(k, img_fixed, img_moving):
         out = []
