@@ -505,12 +505,12 @@ def main():
         cc_worst["fast_field_identical"] = bool(torch.equal(fast_field, out))
         # fp16 STORAGE (the reference's GPU default dtype): both cost volumes and the Adam loop's feature records are __half
         for _ in range(2):
-            register_pair_device(fix, mov, storage="fp16", **CFG)
+            register_pair_device(fix, mov, storage="fp16", **TIMED)
         torch.cuda.synchronize(dev)
         set_profiling(2)
         t16 = time.perf_counter()
         for _ in range(5):
-            h16_field = register_pair_device(fix, mov, storage="fp16", **CFG)
+            h16_field = register_pair_device(fix, mov, storage="fp16", **TIMED)
         torch.cuda.synchronize(dev)
         t16 = (time.perf_counter() - t16) / 5
         st = {}
@@ -520,7 +520,7 @@ def main():
         hc = st.get("correlate", []) + st.get("correlate_rev", [])
         conv32 = register_pair_device(fix, mov, **dict(CFG, lambda_weight=0))
         conv16 = register_pair_device(fix, mov, storage="fp16", **dict(CFG, lambda_weight=0))
-        out32 = register_pair_device(fix, mov, **EXACT)           # fp16 storage runs the reference-order Adam loop: compare like with like
+        out32 = out                                               # the float32 field of the timed mode (fp16 storage runs the same Adam arithmetic since round 5)
         cc_worst["fp16"] = dict(ms_per_pair=t16 * 1e3, corr_ms=sum(hc) / max(len(hc), 1), adam_ms=sum(st.get("adam", [0.0])) / max(len(st.get("adam", [0.0])), 1),
                                 argmin_ms=sum(st.get("argmin", [0.0])) / max(len(st.get("argmin", [0.0])), 1),
                                 epe_vs_fp32_field=float((h16_field - out32).square().sum(0).sqrt().mean()),
@@ -619,8 +619,8 @@ def main():
                                         "stages_ms": {"correlate": h["corr_ms"], "argmin": h["argmin_ms"], "adam": h["adam_ms"]},
                                         "epe_vs_fp32_field": h["epe_vs_fp32_field"], "convex_stage_voxels_changed": h["convex_stage_voxels_changed"],
                                         "convex_stage_epe": h["convex_stage_epe"],
-                                        "note": "opt-in storage='fp16' (the reference's GPU default dtype, convex_adam_MIND.py:79): cost volumes and the Adam loop's "
-                                                "feature records are real __half buffers, float32 accumulation; bit-identical to the oracle's fp16 restatement, graded "
+                                        "note": "opt-in storage='fp16' (the reference's GPU default dtype, convex_adam_MIND.py:79) with the timed mode's Adam arithmetic: cost volumes and the Adam loop's "
+                                                "feature records are real __half buffers (the warp kernel gathers 8-byte records), float32 accumulation; bit-identical to the oracle's fp16 restatement, graded "
                                                 "against the float32 field by end-point error and by the fraction of convex-stage voxels whose displacement changed"}
         if cc_worst is not None and cc_worst.get("ms_per_pair"):
             res["value_zero_background"] = 1e3 / cc_worst["ms_per_pair"]          # the timed mode on the same pair with an exact-zero background (skull-stripped-like)

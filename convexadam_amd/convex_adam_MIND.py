@@ -29,7 +29,7 @@ _DEFAULT_DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 # strength of ONE full-size capture of the reference; round 5 captured three more and the mode does not meet the 80-iteration criteria
 # on all of them -- tests/test_oracle_vs_golden.py::test_fast_adam_mode_against_four_reference_captures, DESIGN.md section 11 -- so the
 # throughput arithmetic is opt-in: adam_mode="fast".)  A defaulted call falls back to "exact" where the fast loop does not exist
-# (two-pool spline, fp16 storage); an explicit adam_mode="fast" there raises.
+# (two-pool spline); an explicit adam_mode="fast" there raises.
 _default_adam_mode = os.environ.get("CONVEXADAM_ADAM_MODE", "exact")
 if _default_adam_mode not in ("exact", "fast", "fast_all"):
     raise ValueError("CONVEXADAM_ADAM_MODE must be 'exact', 'fast' or 'fast_all', not %r" % (_default_adam_mode,))
@@ -50,7 +50,7 @@ def default_adam_mode():
 
 def _resolve_adam_mode(adam_mode, n_spline_pools=3, storage="fp32"):
     if adam_mode is None:
-        return _default_adam_mode if (n_spline_pools != 2 and storage == "fp32") else "exact"
+        return _default_adam_mode if n_spline_pools != 2 else "exact"
     return adam_mode
 
 

@@ -235,7 +235,7 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
     initial control grid P0 (1,3,h,w,d) in grid units.  Returns disp_sample of the last forward pass
     (1,3,h,w,d) [and optionally snapshots / optimiser state].  `smoother` = a GaussianSmoothing / kovesi_spline object of
     convexadam_amd.convexAdam_hyper_util replaces the three 3^3 boxes (adam_run_withconfig_shiftSpline.py:217).
-    storage="fp16": the loop keeps its copies of the features in half precision (rounded once; float32 arithmetic).
+    storage="fp16": the loop keeps its copies of the features in half precision (rounded once; float32 arithmetic; every mode).
     mode="fast": throughput arithmetic (cvx_adam_run_fast_f32: FMA / factored warp gradient, separable adjoint boxes, one division in
     the update; forward boxes in ATen's order) -- same mathematics, graded by end-point error; packaged smoother, float32 only;
     mode="fast_all": the forward boxes separable too (cvx_adam_run_fast_all_f32; faster, outside the fast mode's acceptance criteria)."""
@@ -243,8 +243,6 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
         raise ValueError("storage must be 'fp32' or 'fp16', got %r" % (storage,))
     if mode not in ("exact", "fast", "fast_all"):
         raise ValueError("mode must be 'exact', 'fast' or 'fast_all', got %r" % (mode,))
-    if mode != "exact" and storage != "fp32":
-        raise ValueError("mode=%r supports float32 storage only" % mode)
     F2 = f32c(require_device_tensor(feat_fix, "feat_fix"))
     M2 = f32c(require_device_tensor(feat_mov, "feat_mov"))
     _, Cn, h, w, d = [int(s) for s in F2.shape]
@@ -269,8 +267,8 @@ def adam_run(feat_fix, feat_mov, P0, lambda_weight, niter, cost_scale=12.0, snap
             check(lib().cvx_adam_run_mode_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
                                               int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),
                                               C.cast(snap_arr, C.c_void_p) if snaps else None, len(snaps), ptr(snap_buf),
-                                              C.byref(smoother.spec) if smoother is not None else None, 1 if mode == "fast" else 2,
-                                              ptr(ws), nws, stream_ptr(dev)))
+                                              C.byref(smoother.spec) if smoother is not None else None,
+                                              (1 if mode == "fast" else 2) + (16 if storage == "fp16" else 0), ptr(ws), nws, stream_ptr(dev)))
         else:
             check(lib().cvx_adam_run_ex_f32(ptr(F2), ptr(M2), Cn, h, w, d, ptr(P), ptr(m), ptr(v), float(lambda_weight), int(niter),
                                             int(step0), float(cost_scale), ptr(bh), ptr(bw), ptr(bd), ptr(U), ptr(G),

@@ -225,9 +225,9 @@ extern "C" int cvx_adam_run_mode_f32(const float* F2, const float* M2, int C, in
                                      const float* base_w, const float* base_d, float* U, float* grad_out,
                                      const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm, int mode,
                                      void* workspace, size_t workspace_bytes, void* stream) {
-    CVX_REQUIRE(mode >= 0 && mode <= 2, "cvx_adam_run_mode_f32: mode must be 0 (exact), 1 (fast) or 2 (fast_all)");
+    CVX_REQUIRE((mode & ~16) >= 0 && (mode & ~16) <= 2, "cvx_adam_run_mode_f32: mode must be 0 (exact), 1 (fast) or 2 (fast_all), + 16 for half-precision feature records");
     return cvx::adam_run_impl(F2, M2, C, h, w, d, P, m, v, lambda_weight, niter, step0, cost_scale, base_h, base_w, base_d, U, grad_out,
-                              snapshot_iters_host, n_snap, snapshots, sm, true, false, mode, workspace, workspace_bytes, stream);
+                              snapshot_iters_host, n_snap, snapshots, sm, true, (mode & 16) != 0, mode & 3, workspace, workspace_bytes, stream);
 }
 
 extern "C" int cvx_smooth_fast_f32(const float* in, int h, int w, int d, const cvx_smoother* sm, int backward, float* out, void* stream) {
@@ -279,7 +279,6 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
             for (int i = 0; i < sm->n_boxes; ++i) CVX_REQUIRE(sm->box_k[i] >= 1 && (sm->box_k[i] & 1), "cvx_adam_run_smoother_f32: box size must be odd");
         }
     }
-    if (fast && f16_features) return fail(CVX_ERR_UNSUPPORTED, "adam_mode fast: float32 feature records only");
     if (fast && !fused && sm->kind == 0 && !boxchain_fast_supported(*sm, h, w, d))
         return fail(CVX_ERR_UNSUPPORTED, "adam_mode fast: box chain outside the separable kernel's range (odd sizes <= 9, lines of at most 320 voxels)");
     const int CP = (C + 3) / 4 * 4;
@@ -311,7 +310,7 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
         if (!(last && !keep_state && !grad_out)) {
         float* gsave = (grad_out && it == niter - 1) ? grad_out : nullptr;
         if (fast) {
-            if ((rc = launch_warp_grad_fast(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, s))) return rc;
+            if ((rc = launch_warp_grad_fast(Fcl, Mcl, C, h, w, d, U, base_h, base_w, base_d, gsc, cH, cW, cD, gU, f16_features, s))) return rc;
             profile_mark_kernel("adam.warp_gradient", s);
             if (fused) { if ((rc = launch_box3_fast(gU, nullptr, h, w, d, P, m, v, bc1, bc2, gsave, s))) return rc; }
             else {

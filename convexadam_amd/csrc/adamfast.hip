@@ -26,6 +26,18 @@
 namespace cvx {
 
 // ---- warp + data-term gradient + regulariser gradient -----------------------------------------------------------------------
+// HALF: records of four half-precision values (8 bytes; warp.hip::k_to_chunked_h -- fp16 STORAGE of the pooled features, the reference's
+// GPU default dtype, convex_adam_MIND.py:79) widened to float32 on load: half the gather traffic of a memory-bound kernel.
+typedef _Float16 h16x4f __attribute__((ext_vector_type(4)));
+template <bool HALF>
+__device__ __forceinline__ float4 wf_load_rec(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, unsigned uni_off) {
+    if (HALF) {
+        const h16x4f v = __builtin_bit_cast(h16x4f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)uni_off, 0));
+        return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+    }
+    return buffer_load16(rsrc, lane_off, uni_off);
+}
+template <bool HALF>
 __global__ __launch_bounds__(256) void k_warp_grad_fast(const float* __restrict__ F2, const float* __restrict__ M2, int CP,
                                                         int h, int w, int d, const float* __restrict__ U,
                                                         const float* __restrict__ bh, const float* __restrict__ bw,
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(256) void k_warp_grad_fast(const float* __restrict_
     const bool zin0 = (unsigned)z0 < (unsigned)h, zin1 = (unsigned)z1 < (unsigned)h, yin0 = (unsigned)y0 < (unsigned)w,
                yin1 = (unsigned)y1 < (unsigned)w, xin0 = (unsigned)x0 < (unsigned)d, xin1 = (unsigned)x1 < (unsigned)d;
     const int r00 = (z0 * w + y0) * d, r01 = (z0 * w + y1) * d, r10 = (z1 * w + y0) * d, r11 = (z1 * w + y1) * d;
-    constexpr unsigned REC = 16u;                                 // bytes per record (four float32 channels)
+    constexpr unsigned REC = HALF ? 8u : 16u;                     // bytes per record (four channels)
     const unsigned zero_rec = (unsigned)V * REC;                  // record V of every chunk is all zero (corners outside the volume)
     unsigned off[8];
     off[0] = (zin0 && yin0 && xin0) ? (unsigned)(r00 + x0) * REC : zero_rec; off[1] = (zin0 && yin0 && xin1) ? (unsigned)(r00 + x1) * REC : zero_rec;
@@ -93,10 +105,10 @@ __global__ __launch_bounds__(256) void k_warp_grad_fast(const float* __restrict_
         float vv[8][4], fv[4];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float4 q = buffer_load16(mr, off[k], coff);
+            const float4 q = wf_load_rec<HALF>(mr, off[k], coff);
             vv[k][0] = q.x; vv[k][1] = q.y; vv[k][2] = q.z; vv[k][3] = q.w;
         }
-        const float4 fq = buffer_load16(fr, foff, coff);
+        const float4 fq = wf_load_rec<HALF>(fr, foff, coff);
         fv[0] = fq.x; fv[1] = fq.y; fv[2] = fq.z; fv[3] = fq.w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(256) void k_warp_grad_fast(const float* __restrict_
 }
 
 int launch_warp_grad_fast(const float* Fcl, const float* Mcl, int C, int h, int w, int d, const float* U, const float* bh,
-                          const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s) {
+                          const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, bool half, hipStream_t s) {
     const int CP = (C + 3) / 4 * 4;
     // 32-bit byte offsets into the chunked feature volumes (buffer descriptors): same limit as launch_warp_grad (warp.hip)
     if ((size_t)(CP / 4) * ((size_t)h * w * d + 1) * 16 >= ((size_t)1 << 31)) return fail(CVX_ERR_UNSUPPORTED, "warp_grad_fast: control grid too large (%zu voxels x %d channels)", (size_t)h * w * d, C);
@@ -160,7 +172,8 @@ int launch_warp_grad_fast(const float* Fcl, const float* Mcl, int C, int h, int 
     const int octant = oc >= 2 && oc <= 64 ? oc : (oc == 1 && ntx >= 2 && nty >= 2 && ntz >= 2) ? 1 : 0;       // >= 2: z-groups of that many tiles
     const dim3 gv(octant == 1 ? (unsigned)(8 * ((ntx + 1) / 2) * ((nty + 1) / 2) * ((ntz + 1) / 2))
                   : octant >= 2 ? (unsigned)((ntx * nty * ((ntz + octant - 1) / octant) * octant + 7) / 8 * 8) : (unsigned)((ntx * nty * ntz + 7) / 8 * 8));     // multiple of the 8 XCDs
-    hipLaunchKernelGGL(k_warp_grad_fast, gv, dim3(256), 0, s, Fcl, Mcl, CP, h, w, d, U, bh, bw, bd, 2.0f * gsc, cH, cW, cD, gU, octant);
+    if (half) hipLaunchKernelGGL(k_warp_grad_fast<true>, gv, dim3(256), 0, s, Fcl, Mcl, CP, h, w, d, U, bh, bw, bd, 2.0f * gsc, cH, cW, cD, gU, octant);
+    else hipLaunchKernelGGL(k_warp_grad_fast<false>, gv, dim3(256), 0, s, Fcl, Mcl, CP, h, w, d, U, bh, bw, bd, 2.0f * gsc, cH, cW, cD, gU, octant);
     return check_last("warp_grad_fast");
 }
 

@@ -391,7 +391,7 @@ int launch_warp_grad(const float* Fcl, const float* Mcl, int C, int h, int w, in
 // update in the epilogue (P != nullptr: in-place update of P, m, v with G = box(in); P == nullptr: out = box(in)); bc1, bc2 = the bias
 // corrections 1 - beta^step of this iteration
 int launch_warp_grad_fast(const float* Fcl, const float* Mcl, int C, int h, int w, int d, const float* U, const float* bh,
-                          const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, hipStream_t s);
+                          const float* bw, const float* bd, float gsc, float cH, float cW, float cD, float* gU, bool half, hipStream_t s);
 int launch_box3_fast(const float* in, float* out, int h, int w, int d, float* P, float* m, float* v, double bc1, double bc2,
                      float* gsave, hipStream_t s);
 // the same arithmetic for a chain of boxes (the sweep's kovesi splines): three 1-D passes, [3][h][w][d], in == out allowed

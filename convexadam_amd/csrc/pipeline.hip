@@ -187,7 +187,7 @@ static int validate(const cvx_pair_params* p) {
                 (p->fp16_storage == 0 || p->fp16_storage == 1), "cvx_register_pair: bad variant fields (cost, n_box, n_spline_pools, corr_fast, fp16_storage)");
     CVX_REQUIRE((p->adam_fast == 0 || p->adam_fast == 1 || p->adam_fast == 2) && p->reserved_[0] == 0 && p->reserved_[1] == 0 && p->reserved_[2] == 0,
                 "cvx_register_pair: adam_fast must be 0, 1 or 2 and the reserved fields zero (struct laid out by an older header? check cvx_version())");
-    CVX_REQUIRE(!p->adam_fast || (p->n_spline_pools != 2 && !p->fp16_storage), "cvx_register_pair: adam_fast needs the packaged smoother and float32 storage");
+    CVX_REQUIRE(!p->adam_fast || p->n_spline_pools != 2, "cvx_register_pair: adam_fast needs the packaged smoother (three 3^3 boxes)");
     if (p->lambda_weight > 0) {
         CVX_REQUIRE(p->selected_niter >= 1, "cvx_register_pair: selected_niter must be >= 1 when lambda_weight > 0 "
                     "(the reference raises UnboundLocalError, convex_adam_MIND.py:181)");

@@ -347,7 +347,8 @@ typedef struct cvx_pair_params {
     int adam_fast;       /* 2: adam_mode "fast_all" (cvx_adam_run_fast_all_f32: forward boxes separable too, outside the acceptance criteria);
                             1: adam_mode "fast" -- throughput arithmetic of the Adam loop (cvx_adam_run_fast_f32): same mathematics as
                             convex_adam_MIND.py:163-179, graded by end-point error against the reference's field instead of by bits.
-                            Needs the packaged smoother (n_spline_pools 0 / 3) and float32 storage */
+                            Needs the packaged smoother (n_spline_pools 0 / 3); with fp16_storage the warp kernel gathers 8-byte records
+                            (half the traffic of the loop's memory-bound kernel) */
     int reserved_[3];    /* must be zero */
 } cvx_pair_params;
 

@@ -137,11 +137,32 @@ def test_adam_fast_rejects_what_it_does_not_cover(U, golden):
     g = golden("adam")
     a = (dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]), 2)
     with pytest.raises(ValueError):
-        U.adam_run(*a, mode="fast", storage="fp16")
-    with pytest.raises(ValueError):
         U.adam_run(*a, mode="quick")
     with pytest.raises(ValueError):
         U.adam_run(*a, storage="fp8")
+
+
+@pytest.mark.parametrize("mode", ["fast", "fast_all"])
+def test_adam_fast_fp16_feature_records_vs_oracle(U, M, orc, golden, mode):
+    """storage="fp16" in the throughput modes (round 5): the warp kernel gathers 8-byte records of four half-precision values; the
+    oracle's restatement is the same loop on features rounded once to half precision.  Stand-alone loop (C = 5: a half-empty chunk)
+    and the whole pipeline (cost volumes stored as __half too)."""
+    g = golden("adam")
+    h16 = lambda x: np.asarray(x, np.float32).astype(np.float16).astype(np.float32)      # noqa: E731
+    a = (dev(g["F2"])[None], dev(g["M2"])[None], dev(g["P0"])[None], float(g["lam"]))
+    Ud, st = U.adam_run(*a, 7, return_state=True, mode=mode, storage="fp16")
+    r = orc.adam_run(h16(g["F2"]), h16(g["M2"]), g["P0"], float(g["lam"]), 7, mode=mode)
+    assert np.array_equal(host(Ud)[0], r["U"]) and np.array_equal(host(st["P"])[0], r["P"]) and np.array_equal(host(st["v"])[0], r["v"])
+    rng = np.random.default_rng(11)
+    shape = (9, 10, 28)
+    F2 = rng.random((5,) + shape, dtype=np.float32); M2 = rng.random((5,) + shape, dtype=np.float32)
+    P0 = (0.7 * rng.standard_normal((3,) + shape)).astype(np.float32)
+    Ud = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.25, 4, mode=mode, storage="fp16")
+    assert np.array_equal(host(Ud)[0], orc.adam_run(h16(F2), h16(M2), P0, 1.25, 4, mode=mode)["U"])
+    gp = golden("pipeline")
+    kw = dict(mind_r=1, mind_d=2, grid_sp_adam=2, lambda_weight=1.25, grid_sp=4, disp_hw=3, selected_niter=6, ic=True)
+    out = host(M.register_pair_device(dev(gp["fix"]), dev(gp["mov"]), adam_mode=mode, storage="fp16", **kw))
+    assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), orc.convex_adam_pipeline(gp["fix"], gp["mov"], adam_mode=mode, storage="fp16", **kw))
 
 
 @pytest.mark.parametrize("mode", ["fast", "fast_all"])
