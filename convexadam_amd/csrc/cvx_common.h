@@ -93,6 +93,7 @@ struct Options {
     long long edt_sequential;      // 1: squared distance transform with the sequential lower-envelope passes (one thread per line) instead of the tiled outward search
     long long warp_octant;         // adam_mode "fast" warp kernel, tile order inside an XCD's share: G >= 2 (default 4) = x fastest, then G z-adjacent tiles, then y (the tiles that share planes follow each other: FETCH_SIZE -13 %, 5.64 -> 5.59 ms per pair); 0 = plain slabs (x, y, z); 1 = one octant of the tile grid per XCD (measured: no gain)
     long long box_fwd_tile;        // forward three-box pass of the Adam loop: -1 = automatic (tiles of boxtile.hip where they fill the chip), 0 = z-marching pipeline (boxmarch.hip), kind * 1000 + segments = a tile kernel variant (boxtile.hip; bit-identical)
+    long long box_walk;            // 1 (default): single zero-padded box filters (sweep smoothers, final smoothing) through the z-walking kernel; 0 = one thread per output (bit-identical)
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };

@@ -106,8 +106,106 @@ __global__ __launch_bounds__(256) void k_box_grow(const float* __restrict__ in, 
     out[i] = fdiv(s, (float)(k * k * k));
 }
 
+// ---- the same forward filter as a z-walk: every tap is read once per thread and plane ----------------------------------------------
+// k_box_zero reads k^3 taps per output through a dependent chain of global loads (27 / 125 loads per output: 0.3-1.9 ms per filter of
+// the sweep's kovesi chains).  Here a thread owns CPT consecutive columns of one row and a segment of L planes and walks along z: per
+// plane it loads its k rows x (CPT + 2R) columns once and adds them, in ATen's raster order, to a ring of k running sums -- the sum of
+// output plane o starts at plane o - R from +0.0 and is complete after plane o + R, i.e. the very chain of additions of the reference's
+// loop (z slowest, then y, then x; taps outside the volume contribute nothing: +0.0, which leaves every partial sum unchanged).
+// k^3 additions per output + one exact division; a segment pays 2R extra planes of additions for its L outputs.
+template <int R, int CPT>
+__global__ __launch_bounds__(256) void k_box_walk(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W, int D, int L, int nq) {
+    constexpr int K = 2 * R + 1, WC = CPT + 2 * R;
+    const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;         // (c, y, q)
+    if (item >= (size_t)C * W * nq) return;
+    const int q = (int)(item % nq), y = (int)((item / nq) % W), c = (int)(item / ((size_t)nq * W));
+    const int x0 = q * CPT, z0 = (int)blockIdx.y * L, zend = min(z0 + L, H);
+    const size_t plane = (size_t)W * D;
+    const float* ic = in + (size_t)c * H * plane;
+    float* oc = out + (size_t)c * H * plane;
+    bool rok[K];
+    unsigned roff[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { const int yy = y - R + i; rok[i] = yy >= 0 && yy < W; roff[i] = (unsigned)((rok[i] ? yy : 0) * D + x0); }
+    bool cl[R], cr[R];                                                        // halo columns inside the row?
+#pragma unroll
+    for (int t = 0; t < R; ++t) { cl[t] = x0 - R + t >= 0; cr[t] = x0 + CPT + t < D; }
+    float sum[K][CPT];
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) sum[r][j] = 0.0f;
+    constexpr float DIVF = (float)(K * K * K);
+    for (int p = z0 - R; p < zend + R; ++p) {
+        if (p >= 0 && p < H) {                                                // (uniform) a plane outside the volume adds nothing
+            const float* pp = ic + (size_t)p * plane;
+            float w[K][WC];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float* rp = pp + roff[i];
+                if (CPT == 4) {
+                    const float4 a = rok[i] ? *reinterpret_cast<const float4*>(rp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    w[i][R] = a.x; w[i][R + 1] = a.y; w[i][R + 2] = a.z; w[i][R + 3] = a.w;
+                } else {
+                    const float2 a = rok[i] ? *reinterpret_cast<const float2*>(rp) : make_float2(0.f, 0.f);
+                    w[i][R] = a.x; w[i][R + 1] = a.y;
+                }
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    w[i][t] = (rok[i] && cl[t]) ? rp[t - R] : 0.0f;
+                    w[i][R + CPT + t] = (rok[i] && cr[t]) ? rp[CPT + t] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+#pragma unroll
+                for (int t = 0; t < K; ++t)
+#pragma unroll
+                    for (int r = 0; r < K; ++r)
+#pragma unroll
+                        for (int j = 0; j < CPT; ++j) sum[r][j] += w[i][j + t];
+        }
+        const int o = p - R;                                                  // the output plane this plane completes
+        if (o >= z0 && o < zend) {
+            float* op = oc + ((size_t)o * W + y) * D + x0;
+            float v[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) v[j] = (K == 3 || K == 5 || K == 7) ? div_exact<(K == 3 || K == 5 || K == 7) ? K * K * K : 27>(sum[0][j]) : fdiv(sum[0][j], DIVF);
+            if (CPT == 4) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[CPT - 2], v[CPT - 1]);
+            else *reinterpret_cast<float2*>(op) = make_float2(v[0], v[1]);
+        }
+#pragma unroll
+        for (int r = 0; r + 1 < K; ++r)
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) sum[r][j] = sum[r + 1][j];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) sum[K - 1][j] = 0.0f;
+    }
+}
+
+template <int R>
+static int launch_box_walk_r(const float* in, float* out, int C, int H, int W, int D, hipStream_t s) {
+    // columns per thread and planes per segment from the volume: enough wavefronts for the chip first, then long segments
+    const size_t quads4 = (size_t)C * W * (D / 4);
+    const bool cpt2 = quads4 * H < ((size_t)1 << 22);                         // small grids (the Adam control grid at grid_sp_adam 2): two columns per thread
+    const int cpt = cpt2 ? 2 : 4, nq = D / cpt;
+    const size_t items = (size_t)C * W * nq;
+    int L = 16;
+    while (L > 4 && items * (size_t)cdiv(H, L) < (size_t)256 * 256 * 6) L -= 4;            // ~6 wavefronts per SIMD wanted
+    const dim3 grid((unsigned)cdiv64((int64_t)items, 256), (unsigned)cdiv(H, L));
+    if (cpt2) hipLaunchKernelGGL((k_box_walk<R, 2>), grid, dim3(256), 0, s, in, out, C, H, W, D, L, nq);
+    else hipLaunchKernelGGL((k_box_walk<R, 4>), grid, dim3(256), 0, s, in, out, C, H, W, D, L, nq);
+    return check_last("box_walk");
+}
+
 int launch_box_zero(const float* in, float* out, int C, int H, int W, int D, int k, bool backward, hipStream_t s) {
     const size_t n = (size_t)C * H * W * D;
+    const bool al = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (!backward && al && D % 4 == 0 && in != out && options().box_walk != 0) {
+        if (k == 3) return launch_box_walk_r<1>(in, out, C, H, W, D, s);
+        if (k == 5) return launch_box_walk_r<2>(in, out, C, H, W, D, s);
+        if (k == 7) return launch_box_walk_r<3>(in, out, C, H, W, D, s);
+    }
     const dim3 grid((unsigned)cdiv64((int64_t)n, 256));
     if (backward) hipLaunchKernelGGL(k_box_zero<true>, grid, dim3(256), 0, s, in, out, C, H, W, D, k);
     else hipLaunchKernelGGL(k_box_zero<false>, grid, dim3(256), 0, s, in, out, C, H, W, D, k);
