@@ -501,7 +501,7 @@ def main():
             st.setdefault(name, []).append(ms)
         set_profiling(0)
         fc = st.get("correlate", []) + st.get("correlate_rev", [])
-        cc_worst["fast_corr_ms"] = sum(fc) / max(len(fc), 1)
+        cc_worst["fast_corr_ms"] = sum(fc) / max(len(fc), 1) / (1 if "correlate_rev" in st else 2)      # per direction
         cc_worst["fast_field_identical"] = bool(torch.equal(fast_field, out))
         # fp16 STORAGE (the reference's GPU default dtype): both cost volumes and the Adam loop's feature records are __half
         for _ in range(2):
@@ -518,6 +518,8 @@ def main():
             st.setdefault(name, []).append(ms)
         set_profiling(0)
         hc = st.get("correlate", []) + st.get("correlate_rev", [])
+        if "correlate_rev" not in st:
+            hc = [t_ / 2 for t_ in hc]                              # per direction
         conv32 = register_pair_device(fix, mov, **dict(CFG, lambda_weight=0))
         conv16 = register_pair_device(fix, mov, storage="fp16", **dict(CFG, lambda_weight=0))
         out32 = out                                               # the float32 field of the timed mode (fp16 storage runs the same Adam arithmetic since round 5)
@@ -532,7 +534,11 @@ def main():
         h, w, d = (s // CFG["grid_sp"] for s in SHAPE)
         K = (2 * CFG["disp_hw"] + 1) ** 3
         v = h * w * d
-        alg_bytes = K * v * 4 + 2 * 12 * v * 4
+        # both directions of the pair go through ONE launch of the fused kernel (option corr_dual, round 5): the stage interval "correlate" then
+        # covers 2 x (K v 4 written + 2 C v 4 read) and there is no "correlate_rev" interval
+        corr_dual = "correlate_rev" not in stage_ms
+        alg_dir = K * v * 4 + 2 * 12 * v * 4
+        alg_bytes = (2 if corr_dual else 1) * alg_dir
         corr = stage_ms.get("correlate", []) + stage_ms.get("correlate_rev", [])
         corr_ms = sum(corr) / max(len(corr), 1)
         achieved = alg_bytes / (corr_ms * 1e-3) / 1e9 if corr_ms > 0 else 0.0
@@ -554,7 +560,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 160x192x224 pair, MIND-SSC r1 d2, grid_sp 6, disp_hw 6, ic, "
                                    "lambda 1.25, grid_sp_adam 2, 80 Adam iterations, float32",
                        "pairs_per_gpu_per_step": 1, "parallelism": "one pair per GPU, no collectives"},
-            "roofline": {"kernel": "correlate stage = k_corr_prep + k_corr_fused (raw SSD + both boxes in one kernel, one direction)",
+            "roofline": {"kernel": "correlate stage = 2 x k_corr_prep + ONE k_corr_fused launch for both directions of the pair (raw SSD + both boxes in one kernel)" if corr_dual
+                                   else "correlate stage = k_corr_prep + k_corr_fused (raw SSD + both boxes in one kernel, one direction)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_measured_at_commit": traffic_commit,
                          "traffic_stale": traffic_stale, "algorithmic_bytes": alg_bytes, "avg_launch_ms": corr_ms},
@@ -567,13 +574,13 @@ def main():
         v2 = (SHAPE[0] // g2) * (SHAPE[1] // g2) * (SHAPE[2] // g2)
         its = CFG["selected_niter"]
         alg = {"mind": 2 * (2 * V * 4 + 12 * v2 * 4 + 12 * v * 4),                        # per image: two reads (global mean), pooled outputs only
-               "correlate": alg_bytes, "correlate_rev": alg_bytes,
+               "correlate": alg_bytes, "correlate_rev": alg_dir,
                "adam": its * (2 * 12 * v2 * 4 + 10 * 3 * v2 * 4)}                         # F2 + M2 + p, m, v read+write + U and dU write+read
         by_stage = {}
         for k, bts in alg.items():
             if sm.get(k):
                 by_stage[k] = {"algorithmic_bytes": bts, "ms": sm[k], "achieved_GBps": bts / (sm[k] * 1e-3) / 1e9, "frac": bts / (sm[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        pair_bytes = alg["mind"] + 2 * (alg_bytes + 6 * K * v * 4) + alg["adam"] + 3 * V * 4 * 4
+        pair_bytes = alg["mind"] + 2 * (alg_dir + 6 * K * v * 4) + alg["adam"] + 3 * V * 4 * 4
         by_stage["pair"] = {"algorithmic_bytes": pair_bytes, "ms": res["ms_per_step"], "achieved_GBps": pair_bytes / (res["ms_per_step"] * 1e-3) / 1e9,
                             "frac": pair_bytes / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "note": "coupled convex counted at 6 full reads of the cost volume per direction (SURVEY 8(d)); the branch-and-bound passes read less"}
@@ -605,7 +612,7 @@ def main():
         if batched is not None:
             res["batched_2streams"] = batched
         if cc_worst is not None and cc_worst.get("fast_corr_ms"):
-            fa = alg_bytes / (cc_worst["fast_corr_ms"] * 1e-3) / 1e9
+            fa = alg_dir / (cc_worst["fast_corr_ms"] * 1e-3) / 1e9
             res["roofline_fast_mode"] = {"kernel": "k_corr_prep + k_corr_fused<5,1> (corr_mode='fast': FMA, separable box sums; opt-in)", "achieved": fa,
                                          "unit": "GB/s", "frac": fa / HBM_PEAK_GBS, "avg_launch_ms": cc_worst["fast_corr_ms"],
                                          "final_field_bit_identical_to_exact_mode": cc_worst["fast_field_identical"]}

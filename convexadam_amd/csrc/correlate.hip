@@ -244,7 +244,7 @@ using namespace cvx;
 // y tiles); for C >= 16 its raw stage -- one third of the wavefronts -- carries most of the work and the round-1 kernels (all wavefronts
 // on the raw SSD, then the box pipeline) are faster when their raw intermediate is affordable (tools/time_corr.py: C = 32 at 26x32x37,
 // hw 6: 0.40 vs 0.63 ms), so they stay the default there; option corr_fused_all = 1 selects the fused kernel for every C.
-static bool corr_use_unfused(int C, int h, int w, int d, int hw, bool variant) {
+bool cvx::corr_use_unfused(int C, int h, int w, int d, int hw, bool variant) {
     if (!corr_fused_supported(C, h, w, d, hw)) return true;
     if (variant || options().corr_fused_all != 0 || C < 16 || hw > 8) return false;      // (the round-1 raw kernel is instantiated for hw <= 8)
     const CorrGeom g = corr_geom(C, h, w, d, hw);

@@ -395,17 +395,30 @@ __device__ __forceinline__ void cf_roles(int role, const float* Fp, const float*
     else cf_box<G, false, true, FAST, false, F16, OT, TILED>(g, it, S1, S1, lds, ssd);
 }
 
+// A launch may carry a SECOND problem of the same geometry (the reverse direction of a pair, pipeline.hip): blocks items1 .. 2 items1 - 1
+// work on (Fp2, Mp2, tail2, ssd2).  One launch of 2 x 507 items instead of two of 507: a CU whose first-dispatched workgroup has finished
+// (at ~76 % of a single launch) takes an item of the other direction instead of idling until the boundary.  Measured
+// (option corr_dual, round 5): 0.360 ms for both directions against 0.374, but 540 MB of fresh cost volume no longer fit the 256 MB
+// Infinity Cache and the plain argmin passes that follow pay 0.05 ms more than the correlation saved -- off by default.
+struct CFSecond { const float* Fp; const float* Mp; const float* tail; void* ssd; int items1; };
+
 template <int GMAX, int MODE, bool CASC, bool TILED>
-__global__ __launch_bounds__(1024, (CASC ? 4 : 8)) void k_corr_fused(const float* __restrict__ Fp, const float* __restrict__ Mp,
-                                                        const float* __restrict__ tail, CFGeom g, void* __restrict__ ssd) {
+__global__ __launch_bounds__(1024, (CASC ? 4 : 8)) void k_corr_fused(const float* __restrict__ Fp1, const float* __restrict__ Mp1,
+                                                        const float* __restrict__ tail1, CFGeom g, void* __restrict__ ssd1, CFSecond two) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int n = g.n, nn = n * n;
+    const bool second_problem = two.items1 > 0 && (int)blockIdx.x >= two.items1;           // (uniform)
+    const float* __restrict__ Fp = second_problem ? two.Fp : Fp1;
+    const float* __restrict__ Mp = second_problem ? two.Mp : Mp1;
+    const float* __restrict__ tail = second_problem ? two.tail : tail1;
+    void* __restrict__ ssd = second_problem ? two.ssd : ssd1;
+    const int bx = second_problem ? (int)blockIdx.x - two.items1 : (int)blockIdx.x;
     CFItem it;
     // items: the large last groups first (they take longest), then the groups of four; y tiles innermost
     int pair;
-    const int bi = TILED ? (int)blockIdx.x / g.nyt : (int)blockIdx.x;
-    it.y0 = TILED ? ((int)blockIdx.x - bi * g.nyt) * g.T : 0;
+    const int bi = TILED ? bx / g.nyt : bx;
+    it.y0 = TILED ? (bx - bi * g.nyt) * g.T : 0;
     if (bi < nn) { it.grp = g.ng - 1; pair = bi; }
     else { const int b = bi - nn; it.grp = b / nn; pair = b - it.grp * nn; }
     it.iH = pair % n; it.iW = pair / n;
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(1024, (CASC ? 4 : 8)) void k_corr_fused(const float
     {
         // issue priority of this wavefront: the raw stage is the longest instruction stream of every sub-interval and runs above the
         // boxes; with two workgroups on a CU (one launch round of 257..512 items) the one dispatched second may be given its own pair
-        const bool second = gridDim.x > 256 && gridDim.x <= 512 && blockIdx.x >= 256;
+        const bool second = two.items1 == 0 && gridDim.x > 256 && gridDim.x <= 512 && blockIdx.x >= 256;
         const int pr = (g.prio >> ((second ? 0 : 4) + (role == 0 ? 2 : 0))) & 3;
         if (pr == 1) __builtin_amdgcn_s_setprio(1);
         else if (pr == 2) __builtin_amdgcn_s_setprio(2);
@@ -504,27 +517,36 @@ void launch_corr_prep_generic(const float* fix, const float* mov, int C, int h, 
 void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int sad, float* tail, hipStream_t s);
 
 template <int MODE, bool CASC, bool TILED>
-static void cf_launch_c(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, void* ssd, hipStream_t s) {
+static void cf_launch_c(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, void* ssd, const CFSecond* second, hipStream_t s) {
     constexpr bool ONEBOX = (MODE & 4) != 0;
     const size_t lds = sizeof(float) * (16 + (ONEBOX ? 1 : 2) * (size_t)(CF_GMAX + 2) * gl.PF);
     static size_t granted = 0;
     ensure_dynamic_lds(&k_corr_fused<CF_GMAX, MODE, CASC, TILED>, lds, granted);
     const int items = gl.n * gl.n * gl.ng * gl.nyt;
-    hipLaunchKernelGGL((k_corr_fused<CF_GMAX, MODE, CASC, TILED>), dim3(items), dim3((ONEBOX ? 2 : 3) * 64 * gl.wpr), lds, s, Fp, Mp, tail, gl, ssd);
+    CFSecond two = {nullptr, nullptr, nullptr, nullptr, 0};
+    if (second) { two = *second; two.items1 = items; }
+    hipLaunchKernelGGL((k_corr_fused<CF_GMAX, MODE, CASC, TILED>), dim3(second ? 2 * items : items), dim3((ONEBOX ? 2 : 3) * 64 * gl.wpr), lds, s, Fp, Mp, tail, gl, ssd, two);
 }
 template <int MODE>
-static void cf_launch(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, void* ssd, hipStream_t s) {
+static void cf_launch(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, void* ssd, hipStream_t s, const CFSecond* second = nullptr) {
     // C >= 16: ATen's cascade channel sum; tiled: planes taller than one role holds (both are separate instantiations so that the
     // packaged configuration keeps its 64-register budget)
-    if (gl.C >= 16) { if (gl.tiled) cf_launch_c<MODE, true, true>(gl, Fp, Mp, tail, ssd, s); else cf_launch_c<MODE, true, false>(gl, Fp, Mp, tail, ssd, s); }
-    else if (gl.tiled) cf_launch_c<MODE, false, true>(gl, Fp, Mp, tail, ssd, s);
-    else cf_launch_c<MODE, false, false>(gl, Fp, Mp, tail, ssd, s);
+    if (gl.C >= 16) { if (gl.tiled) cf_launch_c<MODE, true, true>(gl, Fp, Mp, tail, ssd, second, s); else cf_launch_c<MODE, true, false>(gl, Fp, Mp, tail, ssd, second, s); }
+    else if (gl.tiled) cf_launch_c<MODE, false, true>(gl, Fp, Mp, tail, ssd, second, s);
+    else cf_launch_c<MODE, false, false>(gl, Fp, Mp, tail, ssd, second, s);
 }
 
 // opts: cost 0 = SSD / 1 = SAD, n_box 2 / 1, fast 0 / 1 (fast: SSD with two boxes only)
 // f16: 0 float32 cost volume; 1 values rounded to half precision, float32 buffer; 2 the buffer holds __half (fp16 storage)
 int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
                       void* ssd, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    return launch_corr_fused_dual(fix, mov, C, h, w, d, hw, cost, n_box, fast, f16, ssd, nullptr, workspace, workspace_bytes, nullptr, s);
+}
+
+// ssd_rev != nullptr: BOTH directions of a pair in one launch -- ssd = correlate(fix, mov), ssd_rev = correlate(mov, fix); workspace_rev
+// = a second workspace of corr_fused_workspace_bytes (the reverse direction's padded feature copies)
+int launch_corr_fused_dual(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
+                           void* ssd, void* ssd_rev, void* workspace, size_t workspace_bytes, void* workspace_rev, hipStream_t s) {
     const CFGeom g = cf_geom(C, h, w, d, hw);
     // every argument check comes before the first launch: a refused call leaves nothing on the stream
     if (workspace_bytes < corr_fused_workspace_bytes(C, h, w, d, hw)) return fail(CVX_ERR_WORKSPACE, "correlate (fused): workspace too small");
@@ -538,18 +560,30 @@ int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, i
     unsigned long long* census_buf = cv.take<unsigned long long>((size_t)4 * g.n * g.n * g.ng * g.nyt);
     launch_corr_prep_generic(fix, mov, C, h, w, d, hw, g.RS, hw, g.dq, Fp, Mp, s);
     if (g.ntail > 0 && !fast) launch_corr_tail_compact(fix, mov, C, h, w, d, hw, cost, tail, s);
+    CFSecond two = {nullptr, nullptr, nullptr, nullptr, 0};
+    if (ssd_rev) {
+        if (!workspace_rev) return fail(CVX_ERR_WORKSPACE, "correlate (fused, both directions): second workspace missing");
+        Carver cr(workspace_rev, workspace_bytes);
+        float* Fp2 = cr.take<float>((size_t)C * h * w * g.RS);
+        float* Mp2 = cr.take<float>((size_t)C * g.hq * g.wq * g.dq + 8);
+        float* tail2 = cr.take<float>((size_t)32 * g.n);
+        launch_corr_prep_generic(mov, fix, C, h, w, d, hw, g.RS, hw, g.dq, Fp2, Mp2, s);
+        if (g.ntail > 0 && !fast) launch_corr_tail_compact(mov, fix, C, h, w, d, hw, cost, tail2, s);
+        two.Fp = Fp2; two.Mp = Mp2; two.tail = tail2; two.ssd = ssd_rev;
+    }
+    const CFSecond* sec = ssd_rev ? &two : nullptr;
     CFGeom gl = g;
     gl.prio = (int)options().cf_prio;
-    gl.dbg = options().cf_census ? census_buf : nullptr;      // debugging aid: per-workgroup start / end / placement in the workspace
-    if (fast && f16 == 2) cf_launch<1 + 8 + 16>(gl, Fp, Mp, tail, ssd, s);
-    else if (fast && f16) cf_launch<9>(gl, Fp, Mp, tail, ssd, s);
-    else if (fast) cf_launch<1>(gl, Fp, Mp, tail, ssd, s);
-    else if (f16 == 2) cf_launch<8 + 16>(gl, Fp, Mp, tail, ssd, s);
-    else if (f16) cf_launch<8>(gl, Fp, Mp, tail, ssd, s);
-    else if (cost == 0 && n_box == 2) cf_launch<0>(gl, Fp, Mp, tail, ssd, s);
-    else if (cost == 0) cf_launch<4>(gl, Fp, Mp, tail, ssd, s);
-    else if (n_box == 2) cf_launch<2>(gl, Fp, Mp, tail, ssd, s);
-    else cf_launch<6>(gl, Fp, Mp, tail, ssd, s);
+    gl.dbg = (options().cf_census && !ssd_rev) ? census_buf : nullptr;      // debugging aid: per-workgroup start / end / placement in the workspace
+    if (fast && f16 == 2) cf_launch<1 + 8 + 16>(gl, Fp, Mp, tail, ssd, s, sec);
+    else if (fast && f16) cf_launch<9>(gl, Fp, Mp, tail, ssd, s, sec);
+    else if (fast) cf_launch<1>(gl, Fp, Mp, tail, ssd, s, sec);
+    else if (f16 == 2) cf_launch<8 + 16>(gl, Fp, Mp, tail, ssd, s, sec);
+    else if (f16) cf_launch<8>(gl, Fp, Mp, tail, ssd, s, sec);
+    else if (cost == 0 && n_box == 2) cf_launch<0>(gl, Fp, Mp, tail, ssd, s, sec);
+    else if (cost == 0) cf_launch<4>(gl, Fp, Mp, tail, ssd, s, sec);
+    else if (n_box == 2) cf_launch<2>(gl, Fp, Mp, tail, ssd, s, sec);
+    else cf_launch<6>(gl, Fp, Mp, tail, ssd, s, sec);
     return check_last("corr_fused");
 }
 

@@ -94,6 +94,9 @@ struct Options {
     long long warp_octant;         // adam_mode "fast" warp kernel, tile order inside an XCD's share: G >= 2 (default 4) = x fastest, then G z-adjacent tiles, then y (the tiles that share planes follow each other: FETCH_SIZE -13 %, 5.64 -> 5.59 ms per pair); 0 = plain slabs (x, y, z); 1 = one octant of the tile grid per XCD (measured: no gain)
     long long box_fwd_tile;        // forward three-box pass of the Adam loop: -1 = automatic (tiles of boxtile.hip where they fill the chip), 0 = z-marching pipeline (boxmarch.hip), kind * 1000 + segments = a tile kernel variant (boxtile.hip; bit-identical)
     long long box_walk;            // 1 (default): single zero-padded box filters (sweep smoothers, final smoothing) through the z-walking kernel; 0 = one thread per output (bit-identical)
+    long long corr_dual;           // 1: the whole-pair pipeline evaluates both directions' cost volumes in ONE launch of the fused correlation kernel (bit-identical; measured: the
+                                   //    correlation stage 0.374 -> 0.360 ms for both directions, frac 0.183 -> 0.190, but the plain argmin of the first volume then reads it from HBM instead of the Infinity
+                                   //    Cache -- 0.106 -> 0.157 ms for both -- so the pair is 0.02 ms SLOWER); 0 (default) = one launch per direction
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };
@@ -375,6 +378,11 @@ bool corr_fused_supported(int C, int h, int w, int d, int hw);
 size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw);
 int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
                       void* ssd, void* workspace, size_t workspace_bytes, hipStream_t s);
+// both directions of a pair in ONE launch (ssd_rev = correlate(mov, fix); workspace_rev: a second workspace of the same size)
+int launch_corr_fused_dual(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
+                           void* ssd, void* ssd_rev, void* workspace, size_t workspace_bytes, void* workspace_rev, hipStream_t s);
+// correlate.hip: would cvx_correlate_ex_f32 take the unfused round-1 kernels for this problem?
+bool corr_use_unfused(int C, int h, int w, int d, int hw, bool variant);
 // boxmarch.hip: three chained 3^3 boxes (forward / adjoint / adjoint + Adam) for rows of at most 126 voxels
 bool box3_march_supported(int d);
 int launch_box3_march(const float* in, float* out, int h, int w, int d, bool backward, float* P, float* m, float* v,

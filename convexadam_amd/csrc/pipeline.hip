@@ -60,7 +60,7 @@ struct PairLayout {
     int H, W, D, h, w, d, h2, w2, d2, C, K;
     size_t V, v, V2;
     // byte offsets into the workspace (0 = not used)
-    size_t featF, featM, mind_ws, mind_ws2, fs, ms, corr_ws, ssd, argmin, mesh, conv_ws, ssd2, argmin2, conv_ws2, soft, soft2, in1, in2, ic1, ic2, ic_ws,
+    size_t featF, featM, mind_ws, mind_ws2, fs, ms, corr_ws, corr_ws2, ssd, argmin, mesh, conv_ws, ssd2, argmin2, conv_ws2, soft, soft2, in1, in2, ic1, ic2, ic_ws,
         upin, disp_hr, F2, M2, P, m, v_, U, adam_ws, smooth_ws, snaps, bh, bw, bd, bh2, bw2, bd2, total;
 };
 
@@ -90,6 +90,7 @@ static PairLayout pair_layout(const cvx_pair_params& p, int n_snap = 0, int max_
     L.fs = take(u, f * L.C * L.v);
     L.ms = take(u, f * L.C * L.v);
     L.corr_ws = take(u, cvx_correlate_workspace_bytes(L.C, L.h, L.w, L.d, p.disp_hw));
+    L.corr_ws2 = p.ic ? take(u, corr_fused_workspace_bytes(L.C, L.h, L.w, L.d, p.disp_hw)) : 0;      // the reverse direction's padded copies (both directions in one launch)
     // fp16 storage: the cost volumes hold __half (half the bytes written by the correlation kernel and read by every argmin pass)
     const size_t ssd_elem = p.fp16_storage ? 2 : f;
     L.ssd = take(u, ssd_elem * (size_t)L.K * L.v);
@@ -344,22 +345,40 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     if (p->fp16_storage) {                      // features are stored in half precision by the reference's GPU default (MIND:79)
         if ((rc = cvx_round_f16_f32(F(L.fs), (int64_t)L.C * L.v, stream)) || (rc = cvx_round_f16_f32(F(L.ms), (int64_t)L.C * L.v, stream))) return rc;
     }
+    // Both directions' cost volumes in ONE launch of the fused kernel when the pair is inverse consistent (option corr_dual): the stage
+    // interval "correlate" then covers both directions and "correlate_rev" is not recorded.
+    const bool dual = p->ic && options().corr_dual != 0 && !corr_use_unfused(L.C, L.h, L.w, L.d, p->disp_hw, variant) && p->disp_hw <= CVX_MAX_DISP_HW;
+    const bool no_prune = options().no_prune != 0;        // streaming coupled passes need int64 winners
+    int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
+    unsigned long long* keys2 = p->ic ? Carver(ws + L.conv_ws2, vws).take<unsigned long long>(L.v) : nullptr;
+    if (dual) {
+        const size_t fws = corr_fused_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);
+        if ((rc = launch_corr_fused_dual(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, copt.cost, copt.n_box, copt.fast, copt.f16, F(L.ssd), F(L.ssd2),
+                                         ws + L.corr_ws, fws, ws + L.corr_ws2, s))) return rc;
+        mark("correlate", s);
+        if (no_prune) rc = launch_argmin(F(L.ssd), f16, nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s);
+        else rc = launch_argmin_keys(F(L.ssd), f16, L.K, L.v, keys, s);
+        if (rc) return rc;
+        mark("argmin", s);
+        if (no_prune) rc = launch_argmin(F(L.ssd2), f16, nullptr, nullptr, 0.0f, false, L.K, L.v, keys2, am2, s);
+        else rc = launch_argmin_keys(F(L.ssd2), f16, L.K, L.v, keys2, s);
+        if (rc) return rc;
+        mark("argmin_rev", s);
+    } else {
     if ((rc = cvx_correlate_ex_f32(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, variant ? &copt : nullptr, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
     mark("correlate", s);
-    const bool no_prune = options().no_prune != 0;        // streaming coupled passes need int64 winners
     if (no_prune) rc = launch_argmin(F(L.ssd), f16, nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s);
     else rc = launch_argmin_keys(F(L.ssd), f16, L.K, L.v, keys, s);            // keys stay in the coupled workspace's first buffer
     if (rc) return rc;
     mark("argmin", s);
-    int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
     if (p->ic) {                                // reverse direction (:136-138): same operators with the roles swapped
-        unsigned long long* keys2 = Carver(ws + L.conv_ws2, vws).take<unsigned long long>(L.v);
         if ((rc = cvx_correlate_ex_f32(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, variant ? &copt : nullptr, F(L.ssd2), nullptr, ws + L.corr_ws, cws, stream))) return rc;
         mark("correlate_rev", s);
         if (no_prune) rc = launch_argmin(F(L.ssd2), f16, nullptr, nullptr, 0.0f, false, L.K, L.v, keys2, am2, s);
         else rc = launch_argmin_keys(F(L.ssd2), f16, L.K, L.v, keys2, s);
         if (rc) return rc;
         mark("argmin_rev", s);
+    }
     }
     // both coupled-convex solves in the same launches (ic) or the forward one alone
     if ((rc = coupled_convex_dual_impl(F(L.ssd), no_prune ? am : nullptr, F(L.soft), ws + L.conv_ws, p->ic ? F(L.ssd2) : nullptr, f16, no_prune ? am2 : nullptr,

@@ -92,7 +92,9 @@ def main(src, tag):
                 buf.write("#   %-40s reads %7.1f MB, FETCH_SIZE %7.1f MB -> factor %.2f\n" % (k[-40:], nbytes / 1e6, fe * 1024 / 1e6, nbytes / (fe * 1024)))
     open(os.path.join(prof, tag + "_pmc_hbm_traffic.txt"), "w").write(buf.getvalue())
     stage = [(r[0], r[1], r[2], r[3], r[4]) for r in rows if any(s in r[0] for s in ("k_corr_prep", "k_corr_raw", "k_corr_tail", "k_corr_box", "k_corr_fused"))]
-    total = sum(r[4] for r in stage) * 1e6
+    # per launch of the fused kernel: since round 5 ONE launch carries both directions of the pair (with two k_corr_prep launches)
+    nfused = max([r[1] for r in stage if "k_corr_fused" in r[0] or "k_corr_box" in r[0]] + [1])
+    total = sum(r[4] * r[1] for r in stage) * 1e6 / nfused
     cc = [r for r in rows if any(k in r[0] for k in ("k_argmin_voxel", "k_argmin_wave", "k_gather_box3", "k_keys_to_idx_min"))]
     cc_pair = sum(r[4] * r[1] for r in cc) * 1e6              # the PMC passes register ONE pair: calls x bytes per call
     json.dump({"correlate_stage_bytes_per_launch": total, "coupled_convex_bytes_per_pair": cc_pair,
