@@ -42,6 +42,15 @@ def field(t):
 LARGE = False          # --large: extents of 96 .. 224 voxels (x tiles, uneven z chunks, y-tiled correlation, streaming fallbacks)
 
 
+def _draw_options(rng):
+    """Bit-identical kernel variants added in round 5, drawn per trial (process default context)."""
+    from convexadam_amd import _lib
+    L = _lib.lib()
+    L.cvx_set_option(b"box_fwd_tile", int(rng.choice([-1, 0, 1000, 2000, 1834, 2274, 1222])))
+    L.cvx_set_option(b"box_walk", int(rng.integers(0, 2)))
+    L.cvx_set_option(b"corr_dual", int(rng.integers(0, 2)))
+
+
 def trial_pipeline(rng, t):
     gs, gsa, hw = int(rng.choice([2, 3, 4, 5, 6, 7])), int(rng.choice([1, 2, 3, 4])), int(rng.integers(1, 11))
     big = rng.random() < 0.3
@@ -63,6 +72,9 @@ def trial_pipeline(rng, t):
                dict(storage="fp16", n_spline_pools=2)][int(rng.integers(0, 6))]
     elif r < 0.7:
         var = dict(adam_mode="fast")           # round 4: the throughput arithmetic of the Adam loop against its own oracle restatement
+        if rng.random() < 0.3:
+            var["storage"] = "fp16"            # round 5: 8-byte half-precision feature records in the throughput loop
+    _draw_options(rng)                         # round 5: tile forward boxes, z-walking box filters, both directions in one correlation launch
     fix = phantom(shape, 1000 + t, 2000 + t)
     mov = torch.roll(phantom(shape, 1000 + t, 3000 + t), (1, -1, 2), (0, 1, 2))
     out = field(M.register_pair_device(fix.to(DEV), mov.to(DEV), **kw, **var))
@@ -116,10 +128,13 @@ def trial_adam(rng, t):
     P0 = (float(rng.choice([0.3, 1.0, 3.0])) * rng.standard_normal((3,) + shape)).astype(np.float32)
     lam, nit = float(rng.choice([0.5, 1.0, 1.25])), int(rng.integers(1, 5))
     mod, sm, storage = None, None, "fp32"
+    _draw_options(rng)
     r = rng.random()
-    if r > 0.7:                                 # round 4: adam_mode "fast" (orc_adam_run_fast), also with resumed state
-        Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], lam, nit, return_state=True, mode="fast")
-        ref = orc.adam_run(F2, M2, P0, lam, nit, want_grad=True, mode="fast")
+    if r > 0.7:                                 # round 4: adam_mode "fast" (orc_adam_run_fast), also with resumed state; round 5: half-precision records
+        st16 = "fp16" if rng.random() < 0.3 else "fp32"
+        h16 = (lambda a: a.astype(np.float16).astype(np.float32)) if st16 == "fp16" else (lambda a: a)
+        Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], lam, nit, return_state=True, mode="fast", storage=st16)
+        ref = orc.adam_run(h16(F2), h16(M2), P0, lam, nit, want_grad=True, mode="fast")
         ok = all(np.array_equal(host(st[k])[0], ref[k]) for k in ("P", "m", "v", "G")) and np.array_equal(host(Ud)[0], ref["U"])
         return ok, ("adam-fast", shape, C, lam, nit)
     if r < 0.2:
