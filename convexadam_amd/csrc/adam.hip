@@ -162,10 +162,10 @@ static int launch_box3x3(const float* in, float* out, int h, int w, int d, bool 
                          AdamConsts ac, float* gsave, hipStream_t s) {
     // rows of up to 126 voxels: z-marching pipeline (boxmarch.hip); longer rows: the tiled kernel below
     const bool force_tiled = options().box_tiled != 0;
-    if (!backward && !force_tiled && box3_tile_fwd_supported(in, out, h, w, d)) {
-        long long ft = options().box_fwd_tile;
+    if (!force_tiled && (backward ? (out || P) && box3_tile_supported(in, out, h, w, d, P, m, v, gsave) : box3_tile_fwd_supported(in, out, h, w, d))) {
+        long long ft = backward ? options().box_bwd_tile : options().box_fwd_tile;
         if (ft < 0) ft = box3_march_supported(d) ? box3_tile_fwd_auto(h, w, d) : 2000;      // (rows beyond the marching kernel's range: always tiles)
-        if (ft >= 1000) return launch_box3_tile_fwd(in, out, h, w, d, (int)ft, s);
+        if (ft >= 1000) return launch_box3_tile(in, out, h, w, d, (int)ft, backward, P, m, v, ac, gsave, s);
     }
     if (!force_tiled && box3_march_supported(d)) return launch_box3_march(in, out, h, w, d, backward, P, m, v, ac, gsave, s);
     const int nb = cdiv(d, BT_X) * cdiv(w, BT_Y) * cdiv(h, BT_Z) * 3;

@@ -102,9 +102,14 @@ __device__ __forceinline__ void bt_walk(int L, Load load, Prep prep, Emit emit) 
 
 // TZ x TY x (4 TXQ) output tile, NW wavefronts, NS1 / NS2 / NS3 z segments per row in passes 1 / 2 / 3 (run-time: they only cut the
 // planes of a row into work items)
-template <int TZ, int TY, int TXQ, int NW, int WPS>
-__global__ __launch_bounds__(64 * NW, WPS) void k_box3_tile_fwd(const float* __restrict__ in, float* __restrict__ out, int h, int w, int d,
-                                                           int ntz, int nty, int ntx, int ntiles, int NS1, int NS2, int NS3) {
+// BACKWARD: ATen's avg_pool3d_backward order of the three adjoint boxes -- every tap is gradOut / 27 (IEEE division, the dividend may be
+// -0.0), the sums are plain: the global taps are divided when they are consumed, stages 1 and 2 are stored divided, the last pass keeps
+// the sum; ADAM: the last pass applies torch.optim.Adam's update to P, m, v in place (gsave optionally receives G) instead of storing G.
+template <int TZ, int TY, int TXQ, int NW, int WPS, bool BACKWARD, bool ADAM>
+__global__ __launch_bounds__(64 * NW, WPS) void k_box3_tile(const float* __restrict__ in, float* __restrict__ out, int h, int w, int d,
+                                                           int ntz, int nty, int ntx, int ntiles, int NS1, int NS2, int NS3,
+                                                           float* __restrict__ P, float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
+                                                           float* __restrict__ gsave) {
     constexpr int TX = 4 * TXQ, RS = TX + 4;                          // LDS row stride (floats): stage 1 holds TX + 4 columns
     constexpr int Z1 = TZ + 4, Y1 = TY + 4, Z2 = TZ + 2, Y2 = TY + 2;
     constexpr int SLOTS = NW * 4;                                      // 16-lane items per round
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_box3_tile_fwd(const float* __r
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     const size_t V = (size_t)h * w * d;
     const float* ic = in + (size_t)c * V;
-    float* oc = out + (size_t)c * V;
+    float* oc = out ? out + (size_t)c * V : nullptr;
     const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ic), 0, (int)(V * sizeof(float)), 0x00020000);
     const int tid = threadIdx.x, q = tid & 15, slot = tid >> 4;
     const int wd = w * d;
@@ -150,6 +155,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_box3_tile_fwd(const float* __r
             }
         };
         auto prep = [&](BTWin& t) {
+            if (BACKWARD) {                       // taps of the adjoint: gradOut / 27, sign of zero kept
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 1; j <= 4; ++j) t.w[i][j] = t.w[i][j] == 0.0f ? t.w[i][j] : div_exact<27>(t.w[i][j]);
+            }
             // column 4q - 1 = the last value of the left neighbour's quad, 4q + 4 = the first of the right one's; the row ends
             // receive 0: they only feed the discarded columns i = 0 and i = 63
 #pragma unroll
@@ -226,53 +237,77 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_box3_tile_fwd(const float* __r
                     t.w[i][0] = a.x; t.w[i][1] = a.y; t.w[i][2] = a.z; t.w[i][3] = a.w; t.w[i][4] = e.x; t.w[i][5] = e.y;
                 }
             };
-            float* orow = oc + ((size_t)(z0 + p0) * w + gy) * d + gx;
+            const size_t o0 = ((size_t)(z0 + p0) * w + gy) * d + gx;
             auto emit = [&](int k, const float (&fin)[4]) {
-                if (z0 + p0 + k < h)
-                    *reinterpret_cast<float4*>(orow + (size_t)k * wd) =
-                        make_float4(div_exact<27>(fin[0]), div_exact<27>(fin[1]), div_exact<27>(fin[2]), div_exact<27>(fin[3]));
+                if (z0 + p0 + k >= h) return;
+                const size_t o = o0 + (size_t)k * wd;
+                if (!BACKWARD) {
+                    *reinterpret_cast<float4*>(oc + o) = make_float4(div_exact<27>(fin[0]), div_exact<27>(fin[1]), div_exact<27>(fin[2]), div_exact<27>(fin[3]));
+                } else if (!ADAM) {
+                    *reinterpret_cast<float4*>(oc + o) = make_float4(fin[0], fin[1], fin[2], fin[3]);
+                } else {
+                    float* Pc = P + (size_t)c * V + o; float* mc = m + (size_t)c * V + o; float* vc = v + (size_t)c * V + o;
+                    const float4 p4 = *reinterpret_cast<const float4*>(Pc), m4 = *reinterpret_cast<const float4*>(mc), v4 = *reinterpret_cast<const float4*>(vc);
+                    float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) adam_update(fin[j], pp[j], mm[j], vv[j], ac);
+                    *reinterpret_cast<float4*>(Pc) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                    *reinterpret_cast<float4*>(mc) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                    *reinterpret_cast<float4*>(vc) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    if (gsave) *reinterpret_cast<float4*>(gsave + (size_t)c * V + o) = make_float4(fin[0], fin[1], fin[2], fin[3]);
+                }
             };
             bt_walk(L, load, [](BTWin&) {}, emit);
         }
     }
 }
 
-// rows of whole 16-byte quads, 16-byte aligned volumes, every tile extent at least the pipeline's minimum; 3 channels
-bool box3_tile_fwd_supported(const float* in, const float* out, int h, int w, int d) {
+// rows of whole 16-byte quads, 16-byte aligned volumes; 3 channels
+bool box3_tile_supported(const float* in, const float* out, int h, int w, int d, const float* P, const float* m, const float* v, const float* gsave) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return (d % 4 == 0) && al(in) && al(out) && in != out && (size_t)h * w * d * 4 < ((size_t)1 << 31);
+    return (d % 4 == 0) && al(in) && al(out) && al(P) && al(m) && al(v) && al(gsave) && in != out && (size_t)h * w * d * 4 < ((size_t)1 << 31);
 }
+bool box3_tile_fwd_supported(const float* in, const float* out, int h, int w, int d) { return out && box3_tile_supported(in, out, h, w, d, nullptr, nullptr, nullptr, nullptr); }
 
 template <int TZ, int TY, int TXQ, int NW, int WPS>
-static int launch_tile_fwd_t(const float* in, float* out, int h, int w, int d, int ns1, int ns2, int ns3, hipStream_t s) {
+static int launch_tile_t(const float* in, float* out, int h, int w, int d, int ns1, int ns2, int ns3, bool backward, float* P, float* m, float* v,
+                         AdamConsts ac, float* gsave, hipStream_t s) {
     const int ntz = cdiv(h, TZ), nty = cdiv(w, TY), ntx = cdiv(d, 4 * TXQ);
     const int ntiles = 3 * ntz * nty * ntx;
     const unsigned nb = (unsigned)((ntiles + 7) / 8 * 8);
     // segments of at least two planes (bt_walk), at most one per two planes
     auto clampns = [](int ns, int planes) { return ns < 1 ? 1 : (ns > planes / 2 ? planes / 2 : ns); };
-    hipLaunchKernelGGL((k_box3_tile_fwd<TZ, TY, TXQ, NW, WPS>), dim3(nb), dim3(64 * NW), 0, s, in, out, h, w, d, ntz, nty, ntx, ntiles,
-                       clampns(ns1, TZ + 4), clampns(ns2, TZ + 2), clampns(ns3, TZ));
-    return check_last("box3_tile_fwd");
+    const int a1 = clampns(ns1, TZ + 4), a2 = clampns(ns2, TZ + 2), a3 = clampns(ns3, TZ);
+#define CVX_BT_LAUNCH(B, A) hipLaunchKernelGGL((k_box3_tile<TZ, TY, TXQ, NW, WPS, B, A>), dim3(nb), dim3(64 * NW), 0, s, in, out, h, w, d, ntz, nty, ntx, ntiles, a1, a2, a3, P, m, v, ac, gsave)
+    if (!backward) CVX_BT_LAUNCH(false, false);
+    else if (!P) CVX_BT_LAUNCH(true, false);
+    else CVX_BT_LAUNCH(true, true);
+#undef CVX_BT_LAUNCH
+    return check_last("box3_tile");
 }
 
-// variant (option box_fwd_tile) = kind * 1000 + NS1 * 100 + NS2 * 10 + NS3 (z segments per row in the three passes; 0 = the kind's default):
+// variant (option box_fwd_tile / box_bwd_tile) = kind * 1000 + NS1 * 100 + NS2 * 10 + NS3 (z segments per row in the three passes; 0 = the kind's default):
 // kind 1 = 12 x 8 x 56 tiles, 8 wavefronts, two workgroups per CU (79.7 KB of LDS each); kind 2 = 12 x 16 x 56, 16 wavefronts, one per CU
 // (137 KB).  Measured on the benchmark grid 80 x 96 x 112 under rocprofv3 (profiles/r05_boxtile_sweep.txt): marching kernel 19.8-20.0 us,
 // kind 2 with 4 / 3 / 4 segments 15.6-16.6 us, kind 1 18.7-19.6 us; both kinds issue the marching kernel's 8.1 M VALU wave-instructions
 // (the 27 additions per output and stage are ATen's) and run at the ~3.3 clocks per instruction of four wavefronts per SIMD -- the LDS
 // footprint of the stage tiles leaves no room for more (a 64-register, 8-wavefront build of kind 1 spills and takes 25 us).
-int launch_box3_tile_fwd(const float* in, float* out, int h, int w, int d, int variant, hipStream_t s) {
+int launch_box3_tile(const float* in, float* out, int h, int w, int d, int variant, bool backward, float* P, float* m, float* v, AdamConsts ac,
+                     float* gsave, hipStream_t s) {
     const int kind = variant / 1000, ns = variant % 1000;
     int ns1 = ns / 100, ns2 = (ns / 10) % 10, ns3 = ns % 10;
     if (kind == 1) {
         if (!ns) { ns1 = 5; ns2 = 3; ns3 = 4; }
-        return launch_tile_fwd_t<12, 8, 14, 8, 4>(in, out, h, w, d, ns1, ns2, ns3, s);
+        return launch_tile_t<12, 8, 14, 8, 4>(in, out, h, w, d, ns1, ns2, ns3, backward, P, m, v, ac, gsave, s);
     }
     if (!ns) { ns1 = 4; ns2 = 3; ns3 = 4; }
-    return launch_tile_fwd_t<12, 16, 14, 16, 4>(in, out, h, w, d, ns1, ns2, ns3, s);
+    return launch_tile_t<12, 16, 14, 16, 4>(in, out, h, w, d, ns1, ns2, ns3, backward, P, m, v, ac, gsave, s);
+}
+int launch_box3_tile_fwd(const float* in, float* out, int h, int w, int d, int variant, hipStream_t s) {
+    return launch_box3_tile(in, out, h, w, d, variant, false, nullptr, nullptr, nullptr, AdamConsts{}, nullptr, s);
 }
 
-// automatic choice (option box_fwd_tile = -1): the large tiles when they fill the chip
+// automatic choice (option box_fwd_tile / box_bwd_tile = -1): the large tiles when they fill the chip
 int box3_tile_fwd_auto(int h, int w, int d) {
     const int n2 = 3 * cdiv(h, 12) * cdiv(w, 16) * cdiv(d, 56);
     return n2 >= 192 ? 2000 : 0;

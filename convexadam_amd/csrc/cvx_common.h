@@ -93,6 +93,7 @@ struct Options {
     long long edt_sequential;      // 1: squared distance transform with the sequential lower-envelope passes (one thread per line) instead of the tiled outward search
     long long warp_octant;         // adam_mode "fast" warp kernel, tile order inside an XCD's share: G >= 2 (default 4) = x fastest, then G z-adjacent tiles, then y (the tiles that share planes follow each other: FETCH_SIZE -13 %, 5.64 -> 5.59 ms per pair); 0 = plain slabs (x, y, z); 1 = one octant of the tile grid per XCD (measured: no gain)
     long long box_fwd_tile;        // forward three-box pass of the Adam loop: -1 = automatic (tiles of boxtile.hip where they fill the chip), 0 = z-marching pipeline (boxmarch.hip), kind * 1000 + segments = a tile kernel variant (boxtile.hip; bit-identical)
+    long long box_bwd_tile;        // adjoint three-box pass (+ Adam update) of the exact Adam loop: as box_fwd_tile (-1 automatic, 0 = z-marching pipeline, kind * 1000 + segments)
     long long box_walk;            // 1 (default): single zero-padded box filters (sweep smoothers, final smoothing) through the z-walking kernel; 0 = one thread per output (bit-identical)
     long long corr_dual;           // 1: the whole-pair pipeline evaluates both directions' cost volumes in ONE launch of the fused correlation kernel (bit-identical; measured: the
                                    //    correlation stage 0.374 -> 0.360 ms for both directions, frac 0.183 -> 0.190, but the plain argmin of the first volume then reads it from HBM instead of the Infinity
@@ -391,6 +392,10 @@ int launch_box3_march(const float* in, float* out, int h, int w, int d, bool bac
 bool box3_tile_fwd_supported(const float* in, const float* out, int h, int w, int d);
 int launch_box3_tile_fwd(const float* in, float* out, int h, int w, int d, int variant, hipStream_t s);
 int box3_tile_fwd_auto(int h, int w, int d);       // variant for this grid, 0 = keep the marching kernel
+// the same tiles for the exact adjoint boxes (ATen's avg_pool3d_backward order), optionally with the Adam update in the last pass
+bool box3_tile_supported(const float* in, const float* out, int h, int w, int d, const float* P, const float* m, const float* v, const float* gsave);
+int launch_box3_tile(const float* in, float* out, int h, int w, int d, int variant, bool backward, float* P, float* m, float* v, AdamConsts ac,
+                     float* gsave, hipStream_t s);
 // warp.hip: [C][V] -> [CP/4][V][4] feature copies and the warp + data-term gradient of one Adam iteration
 // (half: records of four half-precision values -- fp16 storage of the pooled features -- instead of four floats)
 int launch_to_chunked(const float* in, int C, size_t V, float* out, bool half, hipStream_t s);

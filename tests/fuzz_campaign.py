@@ -47,6 +47,7 @@ def _draw_options(rng):
     from convexadam_amd import _lib
     L = _lib.lib()
     L.cvx_set_option(b"box_fwd_tile", int(rng.choice([-1, 0, 1000, 2000, 1834, 2274, 1222])))
+    L.cvx_set_option(b"box_bwd_tile", int(rng.choice([-1, 0, 1000, 2000, 1834, 2274, 1222])))
     L.cvx_set_option(b"box_walk", int(rng.integers(0, 2)))
     L.cvx_set_option(b"corr_dual", int(rng.integers(0, 2)))
 

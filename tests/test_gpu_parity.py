@@ -375,16 +375,17 @@ def test_forward_box_tiles_vs_oracle(U, orc, shape, variant):
     F2 = rng.random((C,) + shape, dtype=np.float32)
     M2 = rng.random((C,) + shape, dtype=np.float32)
     P0 = (0.7 * rng.standard_normal((3,) + shape)).astype(np.float32)
-    old = L.cvx_get_option(b"box_fwd_tile")
-    assert L.cvx_set_option(b"box_fwd_tile", variant) == 0
-    try:
+    old = L.cvx_get_option(b"box_fwd_tile"), L.cvx_get_option(b"box_bwd_tile")
+    assert L.cvx_set_option(b"box_fwd_tile", variant) == 0 and L.cvx_set_option(b"box_bwd_tile", variant) == 0
+    try:                                                           # (the same tiles run the exact adjoint boxes + Adam update: box_bwd_tile)
         Ud, st = U.adam_run(dev(F2)[None], dev(M2)[None], dev(P0)[None], 1.25, 3, return_state=True)
     finally:
-        L.cvx_set_option(b"box_fwd_tile", old)
+        L.cvx_set_option(b"box_fwd_tile", old[0]); L.cvx_set_option(b"box_bwd_tile", old[1])
     r = orc.adam_run(F2, M2, P0, 1.25, 3, want_grad=True)
     assert np.array_equal(host(Ud)[0], r["U"])
     assert np.array_equal(host(st["G"])[0], r["G"])
     assert np.array_equal(host(st["P"])[0], r["P"])
+    assert np.array_equal(host(st["m"])[0], r["m"]) and np.array_equal(host(st["v"])[0], r["v"])
 
 
 @pytest.mark.parametrize("xsplit", [-1, 0, 2, 3])
@@ -1229,7 +1230,7 @@ def test_full_size_sweep_extreme_settings(M):
 
 # ---- (9) every selectable kernel variant -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opt,val", [("mind_tiled", 1), ("mm_tx", 32), ("mm_tx", 64), ("mm_slots", 64), ("box_tiled", 1), ("no_prune", 1),
-                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("cf_prio", 0x9d), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0), ("box_cpt", 2), ("box_uneven", 100), ("box_prio", 1), ("mind_overlap", 1), ("corr_fused_all", 1), ("box_fwd_tile", 0), ("box_fwd_tile", 1000), ("box_fwd_tile", 2000), ("corr_dual", 1), ("box_walk", 0)])
+                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("cf_prio", 0x9d), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0), ("box_cpt", 2), ("box_uneven", 100), ("box_prio", 1), ("mind_overlap", 1), ("corr_fused_all", 1), ("box_fwd_tile", 0), ("box_fwd_tile", 1000), ("box_fwd_tile", 2000), ("corr_dual", 1), ("box_walk", 0), ("box_bwd_tile", 0), ("box_bwd_tile", 1000), ("box_bwd_tile", 2000)])
 def test_kernel_variants_agree(M, U, orc, golden, opt, val):
     """The library's run-time switches (cvx_set_option / CVX_* environment variables) select alternative kernels for the same
     operators; every one of them is bit-identical to the oracle: marching vs tiled MIND stencil and its tile shapes, marching vs tiled
