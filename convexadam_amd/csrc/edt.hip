@@ -229,7 +229,11 @@ __global__ __launch_bounds__(128) void k_edt_envelope(int* __restrict__ vol, int
 // ---- Hausdorff-95 building blocks (reference: cupy_hd95, self_configuring/convexAdam_hyper_util.py:32-51) ----------
 // inside = (nearest-resampled label map == label), outside = 1 - inside; nearest index as in ATen's upsample_nearest3d with a given
 // scale factor (nearest_idx, UpSample.h): identity when the extent is unchanged, dst >> 1 when it doubles, else
-// src = min(floor(dst * sc), in - 1) in float32 with sc = float32(1 / scale_factor) (:33-34); (Ho, Wo, Do) = the resampled extent
+// src = min(floor(dst * sc), in - 1) in float32 with sc = float32(1 / scale_factor) (:33-34); (Ho, Wo, Do) = the resampled extent.
+// The identity and >> 1 shortcuts are ATen's CPU kernel (UpSampleKernel.cpp nearest_idx): that is the path the golden vectors were
+// captured on (tests/golden/hd95.npz: the reference's cupy_hd95 with torch on the CPU).  ATen's CUDA kernel has no shortcut and
+// evaluates floor(dst * sc) always; the two agree for every integer `precision` and can differ only for a non-integer scale whose
+// resampled extent happens to equal n_in or 2 n_in -- this library follows the CPU convention there, like its goldens.
 __device__ __forceinline__ int nearest_src(int dst, int n_in, int n_out, float sc) {
     return n_out == n_in ? dst : n_out == 2 * n_in ? dst >> 1 : min((int)floorf((float)dst * sc), n_in - 1);
 }

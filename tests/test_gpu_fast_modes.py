@@ -271,6 +271,35 @@ def test_drop_in_api_packs_the_field_on_the_device(M, dtype):
     assert len(many) == 3 and all(np.array_equal(a, b) for a, b in zip(many, outs))
 
 
+def test_drop_in_api_from_several_threads_never_shares_a_pinned_buffer(M):
+    """the pooled pinned result buffers are handed out under a lock with a BUSY mark -- four threads calling
+    convex_adam_pt at once (synchronize() releases the GIL between take() and the weak reference to the result) each get their own
+    array, equal to the single-threaded result for their pair."""
+    import threading
+    from convexadam_amd.phantom import phantom
+    shape = (32, 28, 36)
+    fix = phantom(shape, 2, 20)
+    movs = [torch.roll(phantom(shape, 2, 21 + i), (1 + i % 2, -1, i % 3), (0, 1, 2)) for i in range(4)]
+    kw = dict(mind_r=1, mind_d=2, lambda_weight=1.25, grid_sp=4, disp_hw=2, selected_niter=3, grid_sp_adam=2, ic=True, adam_mode="exact")
+    want = [M.convex_adam_pt(fix, mv, dtype=torch.float32, device=torch.device(DEV), **kw).copy() for mv in movs]
+    got, errs = [[None] * 6 for _ in range(4)], []
+
+    def work(i):
+        try:
+            for r in range(6):
+                got[i][r] = M.convex_adam_pt(fix, movs[i], dtype=torch.float32, device=torch.device(DEV), **kw)
+        except Exception as e:                                           # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    for i in range(4):
+        for r in range(6):
+            assert np.array_equal(got[i][r], want[i]), (i, r)
+    ptrs = [a.__array_interface__["data"][0] for row in got for a in row]
+    assert len(set(ptrs)) == len(ptrs)                                   # 24 live results, 24 distinct buffers
+
+
 def test_sweep_scores_are_the_same_in_both_adam_modes():
     """VERDICT round 3, acceptance of the fast Adam mode: the evaluation scalars of a registration (Dice, Dice of the hard labels, TRE,
     HD95, log-Jacobian std) agree to three digits between adam_mode "exact" and "fast"."""

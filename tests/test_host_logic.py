@@ -420,3 +420,35 @@ def test_torch_full_sum_restatement():
                 assert float(torch.from_numpy(x).sum()) == orc.torch_sum(x, T), (T, n)
     finally:
         torch.set_num_threads(old)
+
+
+def test_pinned_pool_marks_entries_busy_under_a_lock():
+    """ADVICE round 4 (convex_adam_MIND._PinnedPool): take() marks an entry BUSY inside the lock, give() installs the weak reference to the
+    array handed out (or frees the entry); a second take() while the first caller still holds the entry gets another one.  The pool logic
+    is exercised here with ordinary host tensors (pinning needs a device)."""
+    import gc
+    import numpy as np
+    import torch
+    from convexadam_amd import convex_adam_MIND as M
+    pool = M._PinnedPool()
+    real_empty = torch.empty
+    try:
+        torch.empty = lambda *a, pin_memory=False, **k: real_empty(*a, **k)        # no device here: the pool's bookkeeping is what is tested
+        e1, b1 = pool.take((4, 5), torch.float64)
+        e2, b2 = pool.take((4, 5), torch.float64)                                 # e1 is BUSY: a different entry
+        assert e1 is not e2 and b1.data_ptr() != b2.data_ptr() and e1[1] is M._BUSY and e2[1] is M._BUSY
+        a1 = b1.numpy()
+        pool.give(e1, a1)
+        e3, b3 = pool.take((4, 5), torch.float64)                                 # a1 is alive, e2 busy: a third entry
+        assert e3 is not e1 and e3 is not e2
+        pool.give(e2, None)                                                       # freed without a result (an exception path)
+        e4, _ = pool.take((2, 5), torch.float64)
+        assert e4 is e2                                                           # the free entry is reused (a smaller request fits)
+        del a1
+        gc.collect()
+        e5, _ = pool.take((4, 5), torch.float64)
+        assert e5 is e1                                                           # the result was garbage-collected: its buffer returns
+        pool.clear()
+        assert all(e[1] is M._BUSY for e in pool._entries)                        # busy entries survive a clear()
+    finally:
+        torch.empty = real_empty
