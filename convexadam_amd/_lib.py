@@ -187,17 +187,25 @@ def stream_ptr(device=None):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-_workspaces = {}
+_tls = threading.local()
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per (device, stream): the library never allocates."""
+    """Grow-only scratch buffer per (thread, device, stream): the library never allocates.  Per THREAD as well (round 5): two Python
+    threads calling the drop-in API on the same stream interleave their launches (ctypes releases the GIL inside the C call); with a
+    shared scratch buffer one pair's kernels would run between the other's on the same memory.  Every other piece of a call's data --
+    inputs, outputs, optimiser state -- already belongs to the call; the buffers of a thread are freed with the thread."""
+    ws = getattr(_tls, "workspaces", None)
+    if ws is None:
+        ws = _tls.workspaces = {}
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    buf = _workspaces.get(key)
+    buf = ws.get(key)
     if buf is None or buf.numel() < nbytes:
-        _workspaces[key] = buf = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=device)
+        ws[key] = buf = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=device)
     return buf
 
 
 def release_workspaces():
-    _workspaces.clear()
+    """Drops the calling thread's scratch buffers."""
+    if getattr(_tls, "workspaces", None):
+        _tls.workspaces.clear()
