@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void k_box_walk(const float* __restrict__ in, 
     constexpr int K = 2 * R + 1, WC = CPT + 2 * R;
     const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;         // (c, y, q)
     if (item >= (size_t)C * W * nq) return;
+    const int lane = threadIdx.x & 63;
     const int q = (int)(item % nq), y = (int)((item / nq) % W), c = (int)(item / ((size_t)nq * W));
     const int x0 = q * CPT, z0 = (int)blockIdx.y * L, zend = min(z0 + L, H);
     const size_t plane = (size_t)W * D;
@@ -150,10 +151,26 @@ __global__ __launch_bounds__(256) void k_box_walk(const float* __restrict__ in, 
                     const float2 a = rok[i] ? *reinterpret_cast<const float2*>(rp) : make_float2(0.f, 0.f);
                     w[i][R] = a.x; w[i][R + 1] = a.y;
                 }
+                if (R <= CPT) {
+                    // the halo columns are the neighbour lanes' own columns (items are (c, y, q) with q fastest: lane - 1 holds the quad to the left
+                    // unless this lane starts a row): DPP wave shifts instead of 2 R scalar loads per row; the first / last lane of a wavefront
+                    // has no neighbour lane and loads (a one-lane load costs the texture path a lane, not a wavefront)
 #pragma unroll
-                for (int t = 0; t < R; ++t) {
-                    w[i][t] = (rok[i] && cl[t]) ? rp[t - R] : 0.0f;
-                    w[i][R + CPT + t] = (rok[i] && cr[t]) ? rp[CPT + t] : 0.0f;
+                    for (int t = 0; t < R; ++t) {
+                        const float fromL = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w[i][CPT + t]), 0x138, 0xf, 0xf, true));      // wave_shr:1: lane - 1's column CPT - R + t
+                        const float fromR = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w[i][R + t]), 0x130, 0xf, 0xf, true));        // wave_shl:1: lane + 1's column t
+                        float hl = fromL, hr = fromR;
+                        if (lane == 0 && rok[i] && cl[t]) hl = rp[t - R];
+                        if (lane == 63 && rok[i] && cr[t]) hr = rp[CPT + t];
+                        w[i][t] = cl[t] ? hl : 0.0f;
+                        w[i][R + CPT + t] = cr[t] ? hr : 0.0f;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < R; ++t) {
+                        w[i][t] = (rok[i] && cl[t]) ? rp[t - R] : 0.0f;
+                        w[i][R + CPT + t] = (rok[i] && cr[t]) ? rp[CPT + t] : 0.0f;
+                    }
                 }
             }
 #pragma unroll
