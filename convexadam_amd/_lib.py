@@ -63,6 +63,8 @@ SIGNATURES = {
     "cvx_get_option": (C.c_longlong, [C.c_char_p]),
     "cvx_affine_base_host": (None, [_i, _vp]),
     "cvx_disp_mesh_host": (None, [_i, _vp]),
+    "cvx_disp_mesh_f32": (_i, [_i, _vp, _vp]),
+    "cvx_affine_base_f32": (_i, [_i, _vp, _vp]),
     "cvx_mindssc_workspace_bytes": (_sz, [_i] * 5),
     "cvx_mindssc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "cvx_avgpool_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -202,6 +202,19 @@ static int validate(const cvx_pair_params* p) {
 
 using namespace cvx;
 
+extern "C" int cvx_disp_mesh_f32(int disp_hw, float* out_device, void* stream) {
+    CVX_REQUIRE(out_device && disp_hw >= 0 && disp_hw <= CVX_MAX_DISP_HW, "cvx_disp_mesh_f32: bad arguments (disp_hw 0 .. %d)", CVX_MAX_DISP_HW);
+    const int n = 2 * disp_hw + 1, K = n * n * n;
+    hipLaunchKernelGGL(k_disp_mesh, dim3(cdiv(K, 256)), dim3(256), 0, as_stream(stream), disp_hw, out_device);
+    return check_last("disp_mesh");
+}
+extern "C" int cvx_affine_base_f32(int S, float* out_device, void* stream) {
+    CVX_REQUIRE(out_device && S >= 1, "cvx_affine_base_f32: bad arguments");
+    BaseTables t = {{S, 0, 0, 0, 0, 0}, {out_device, nullptr, nullptr, nullptr, nullptr, nullptr}};
+    hipLaunchKernelGGL(k_affine_bases, dim3(cdiv(S, 64) > 4 ? cdiv(S, 64) : 4, 6), dim3(64), 0, as_stream(stream), t);
+    return check_last("affine_base");
+}
+
 extern "C" void cvx_set_profiling(int enabled) {
     g_profiling = enabled < 0 ? 0 : (enabled > 3 ? 3 : enabled);
     g_marks.clear();

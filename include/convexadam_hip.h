@@ -106,6 +106,10 @@ void cvx_affine_base_host(int S, float* out_host);
 /* search mesh of convex_adam_MIND.py:127: out_host[3][n^3], n = 2*disp_hw+1,
  * flat k = (dD+hw)*n*n + (dW+hw)*n + (dH+hw), channel a = displacement along axis a. */
 void cvx_disp_mesh_host(int disp_hw, float* out_host);
+/* the same two tables as the whole-pair pipeline builds them ON THE DEVICE (same float operations as the host helpers: the tables are
+ * never uploaded): out_device[3][n^3] resp. out_device[S] */
+int cvx_disp_mesh_f32(int disp_hw, float* out_device, void* stream);
+int cvx_affine_base_f32(int S, float* out_device, void* stream);
 
 /* MIND-SSC descriptors ---------------------------------------------------------------------------
  * replaces MINDSSC(img, radius, dilation, device)          convex_adam_utils.py:24-68

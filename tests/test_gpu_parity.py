@@ -1228,6 +1228,29 @@ def test_full_size_sweep_extreme_settings(M):
     assert sweep.item_cost(dict(grid_sp=4, disp_hw=6), shape) > sweep.item_cost(dict(grid_sp=8, disp_hw=3), shape)
 
 
+def test_device_tables_equal_the_host_helpers_and_torch():
+    """SURVEY 8(a) row F and the affine identity tables AS THE PIPELINE BUILDS THEM (on the device, never uploaded): cvx_disp_mesh_f32 /
+    cvx_affine_base_f32 equal the host helpers bit for bit, which equal torch's affine_grid (tests/test_host_logic.py)."""
+    import torch.nn.functional as Fn
+    from convexadam_amd import _lib
+    from convexadam_amd.convex_adam_utils import affine_base, disp_mesh
+    L = _lib.lib()
+    sp = _lib.stream_ptr(torch.device(DEV))
+    for hw in (0, 1, 2, 3, 6, 8, 11, 15):
+        n = 2 * hw + 1
+        out = torch.empty((3, n ** 3), dtype=torch.float32, device=DEV)
+        assert L.cvx_disp_mesh_f32(hw, _lib.ptr(out), sp) == 0
+        assert np.array_equal(host(out), disp_mesh(hw)), hw
+        if hw:
+            m = Fn.affine_grid(hw * torch.eye(3, 4)[None], (1, 1, n, n, n), align_corners=True).permute(0, 4, 1, 2, 3).reshape(3, -1)
+            assert np.array_equal(host(out), m.numpy()), hw
+    for S in (1, 2, 3, 26, 37, 80, 112, 224, 1000):
+        out = torch.empty((S,), dtype=torch.float32, device=DEV)
+        assert L.cvx_affine_base_f32(S, _lib.ptr(out), sp) == 0
+        assert np.array_equal(host(out), affine_base(S)), S
+    assert L.cvx_disp_mesh_f32(99, _lib.ptr(out), sp) != 0 and L.cvx_affine_base_f32(0, _lib.ptr(out), sp) != 0
+
+
 # ---- (9) every selectable kernel variant -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opt,val", [("mind_tiled", 1), ("mm_tx", 32), ("mm_tx", 64), ("mm_slots", 64), ("box_tiled", 1), ("no_prune", 1),
                                      ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("cf_prio", 0x9d), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0), ("box_cpt", 2), ("box_uneven", 100), ("box_prio", 1), ("mind_overlap", 1), ("corr_fused_all", 1), ("box_fwd_tile", 0), ("box_fwd_tile", 1000), ("box_fwd_tile", 2000), ("corr_dual", 1), ("box_walk", 0), ("box_bwd_tile", 0), ("box_bwd_tile", 1000), ("box_bwd_tile", 2000)])
