@@ -167,9 +167,15 @@ struct CandBox {
     bool degenerate;
 };
 // kp = previous winner of the voxel (low 32 bits of its key), ssd_kp = ssd[kp, x], sm_x = smin[x]: fetched by the caller, who can
-// issue these loads before the smoothing step instead of after it (one memory round trip less on the critical path)
+// issue these loads before the smoothing step instead of after it (one memory round trip less on the critical path).
+// col = ssd + x (the voxel's column, stride v).  A box of more than `refine_above` displacements is tried again with the cost of the
+// lattice point NEAREST to u as the bound (any displacement's cost is a valid bound): where many displacements tie at the minimum --
+// zero background: every in-volume displacement of a background voxel costs 0 -- the previous winner is the FIRST of them and may lie
+// far from u, while the nearest one costs the same and closes the ball to a few displacements.  One more load, only for boxes that
+// would otherwise go to the list; both kernels evaluate the same function, so they see the same box.
+template <typename ST>
 __device__ __forceinline__ CandBox cand_box(const float* __restrict__ mesh, float uc, float ub, float ua, float coef, int K, int n,
-                                            int kp, float ssd_kp, float sm_x) {
+                                            int kp, float ssd_kp, float sm_x, const ST* __restrict__ col, size_t v, int refine_above) {
     CandBox c;
     c.uc = uc; c.ub = ub; c.ua = ua; c.sm = sm_x;
     c.kp = kp;
@@ -179,13 +185,27 @@ __device__ __forceinline__ CandBox cand_box(const float* __restrict__ mesh, floa
     q += e2 * e2;
     c.bound = ssd_kp + coef * q;                                        // the reference cost of the previous winner
     const float hwf = (float)((n - 1) / 2);
-    const float qmax = fdiv((c.bound - c.sm) + fabsf(c.bound) * 2.384185791015625e-07f, coef) * 1.00001f;
-    const float R = fsqrt(fmaxf(qmax, 0.0f)) * 1.00001f + 1.0e-4f;
-    c.c_lo = max((int)ceilf(c.uc - R + hwf), 0); c.c_hi = min((int)floorf(c.uc + R + hwf), n - 1);
-    c.b_lo = max((int)ceilf(c.ub - R + hwf), 0); c.b_hi = min((int)floorf(c.ub + R + hwf), n - 1);
-    c.a_lo = max((int)ceilf(c.ua - R + hwf), 0); c.a_hi = min((int)floorf(c.ua + R + hwf), n - 1);
-    c.vol = (long long)max(c.c_hi - c.c_lo + 1, 0) * max(c.b_hi - c.b_lo + 1, 0) * max(c.a_hi - c.a_lo + 1, 0);
-    c.degenerate = !(coef > 0.0f) || !(R == R) || c.vol <= 0;           // no usable bound: scan the whole window
+    auto close_box = [&]() {
+        const float qmax = fdiv((c.bound - c.sm) + fabsf(c.bound) * 2.384185791015625e-07f, coef) * 1.00001f;
+        const float R = fsqrt(fmaxf(qmax, 0.0f)) * 1.00001f + 1.0e-4f;
+        c.c_lo = max((int)ceilf(c.uc - R + hwf), 0); c.c_hi = min((int)floorf(c.uc + R + hwf), n - 1);
+        c.b_lo = max((int)ceilf(c.ub - R + hwf), 0); c.b_hi = min((int)floorf(c.ub + R + hwf), n - 1);
+        c.a_lo = max((int)ceilf(c.ua - R + hwf), 0); c.a_hi = min((int)floorf(c.ua + R + hwf), n - 1);
+        c.vol = (long long)max(c.c_hi - c.c_lo + 1, 0) * max(c.b_hi - c.b_lo + 1, 0) * max(c.a_hi - c.a_lo + 1, 0);
+        c.degenerate = !(coef > 0.0f) || !(R == R) || c.vol <= 0;       // no usable bound: scan the whole window
+    };
+    close_box();
+    if (!c.degenerate && c.vol > refine_above && uc == uc && ub == ub && ua == ua) {
+        const int kn = (min(max((int)rintf(ua + hwf), 0), n - 1) * n + min(max((int)rintf(ub + hwf), 0), n - 1)) * n + min(max((int)rintf(uc + hwf), 0), n - 1);
+        if (kn != kp) {
+            const float f0 = mesh[kn] - c.uc, f1 = mesh[K + kn] - c.ub, f2 = mesh[2 * K + kn] - c.ua;
+            float qn = f0 * f0;
+            qn += f1 * f1;
+            qn += f2 * f2;
+            const float near_cost = SsdIO<ST>::ld(col + (size_t)kn * v) + coef * qn;          // the reference cost of the nearest displacement
+            if (near_cost < c.bound) { c.bound = near_cost; c.kp = kn; close_box(); }
+        }
+    }
     if (c.degenerate) { c.c_lo = c.b_lo = c.a_lo = 0; c.c_hi = c.b_hi = c.a_hi = n - 1; c.vol = (long long)n * n * n; }
     return c;
 }
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const ST* __restrict__ ssd,
                                                      const float* __restrict__ smin, const PrevT* __restrict__ kprev, int limit,
                                                      unsigned long long* __restrict__ list, int* __restrict__ list_count,
                                                      int* __restrict__ next_count, unsigned long long* __restrict__ keys,
-                                                     const unsigned long long* __restrict__ minkeys, Prob2 o) {
+                                                     const unsigned long long* __restrict__ minkeys, int refine, Prob2 o) {
     if (blockIdx.y) {
         ssd = shifted(ssd, o.ssd); u = shifted(u, o.out); smin = shifted(smin, o.ws); kprev = shifted(kprev, o.ws);
         list = shifted(list, o.ws); list_count = shifted(list_count, o.ws); next_count = shifted(next_count, o.ws);
@@ -228,7 +248,7 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const ST* __restrict__ ssd,
     // argmin's winner, and stays it.  minkeys = the (cost, index) keys of the library's own minimum pass: on the public entry points the
     // caller's `argmin` only seeds the first smoothing step and need not be the first NaN
     if (sm_x != sm_x) { keys[x] = pack_min_key(sm_x, minkeys ? (unsigned)(minkeys[x] & 0xffffffffull) : (unsigned)kp); return; }
-    const CandBox c = cand_box(mesh, uc, ub, ua, coef, K, n, kp, ssd_kp, sm_x);
+    const CandBox c = cand_box(mesh, uc, ub, ua, coef, K, n, kp, ssd_kp, sm_x, ssd + x, v, refine);
     if (c.vol > limit) {                // hand the box over in chunks of 256 displacements: (voxel << 8 | chunk) work items
         const int nchunks = (int)((c.vol + 255) >> 8);
         const int at = atomicAdd(list_count, nchunks);
@@ -265,7 +285,7 @@ __global__ __launch_bounds__(256) void k_argmin_wave(const ST* __restrict__ ssd,
                                                      const float* __restrict__ u, float coef, int K, int n, size_t v,
                                                      const float* __restrict__ smin, const PrevT* __restrict__ kprev,
                                                      const unsigned long long* __restrict__ list, const int* __restrict__ list_count,
-                                                     unsigned long long* __restrict__ keys, int stream_above, int vec, Prob2 o) {
+                                                     unsigned long long* __restrict__ keys, int stream_above, int vec, int refine, Prob2 o) {
     if (blockIdx.y) {
         ssd = shifted(ssd, o.ssd); u = shifted(u, o.out); smin = shifted(smin, o.ws); kprev = shifted(kprev, o.ws);
         list = shifted(list, o.ws); list_count = shifted(list_count, o.ws); keys = shifted(keys, o.ws);
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(256) void k_argmin_wave(const ST* __restrict__ ssd,
         const size_t x = (size_t)(item >> 8);
         const long long first = (long long)(item & 255) << 8;              // 256 displacements of the box: 4 per lane
         const int kp = (int)(unsigned)kprev[x];
-        const CandBox c = cand_box(mesh, u[x], u[v + x], u[2 * v + x], coef, K, n, kp, SsdIO<ST>::ld(ssd + (size_t)kp * v + x), smin[x]);
+        const CandBox c = cand_box(mesh, u[x], u[v + x], u[2 * v + x], coef, K, n, kp, SsdIO<ST>::ld(ssd + (size_t)kp * v + x), smin[x], ssd + x, v, refine);
         const int nc = c.c_hi - c.c_lo + 1, nb = c.b_hi - c.b_lo + 1;
         int kk[4];
         float pen[4];
@@ -455,15 +475,16 @@ static int argmin_pass_pruned(const ST* ssd, const float* mesh, float* u, float 
                               const float* smin, const PrevT* kprev, unsigned long long* list, int* list_count, int* next_count,
                               unsigned long long* keys, const unsigned long long* minkeys, const Prob2& o, int nprob, hipStream_t s) {
     const size_t v = (size_t)h * w * d;
+    const int refine = options().prune_refine != 0 ? 8 : 0x7fffffff;     // boxes above the per-thread limit get the second bound
     hipLaunchKernelGGL((k_argmin_voxel<PrevT, ST>), dim3((unsigned)cdiv64((int64_t)v, 64), nprob), dim3(64), 0, s, ssd, mesh, u, coef, K, n, h,
-                       w, d, smin, kprev, 8, list, list_count, next_count, keys, minkeys, o);
+                       w, d, smin, kprev, 8, list, list_count, next_count, keys, minkeys, refine, o);
     // worst case bounded by one coalesced scan per pass: a chunk of 256 scattered reads moves about 8 KB, the scan K * v * 4 bytes
     const long long above = options().prune_stream_above >= 0 ? options().prune_stream_above : (long long)((double)K * (double)v / 2048.0);
     const int stream_above = (int)(above > 0x7fffffff ? 0x7fffffff : above);
     const int vec = (v % 4 == 0) && ((reinterpret_cast<uintptr_t>(ssd) | (uintptr_t)(o.ssd < 0 ? -o.ssd : o.ssd)) & 15) == 0;
     // voxels whose key the voxel kernel stored plainly keep it under the scan (it finds the same winner); listed voxels were armed to ~0
     hipLaunchKernelGGL((k_argmin_wave<PrevT, ST>), dim3(512, nprob), dim3(256), 0, s, ssd, mesh, u, coef, K, n, v, smin, kprev, list,
-                       list_count, keys, stream_above, vec, o);
+                       list_count, keys, stream_above, vec, refine, o);
     return check_last("argmin_pruned");
 }
 
@@ -516,6 +537,7 @@ extern "C" size_t cvx_coupled_convex_workspace_bytes(int h, int w, int d, int di
     used = carve_size(used, sizeof(unsigned long long) * ((size_t)((n * n * n + 255) / 256) * v + 8));   // work items of the pruned passes + count
     return used + 256;
 }
+
 
 extern "C" int cvx_coupled_convex_f32(const float* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d,
                                       int disp_hw, float* out, void* workspace, size_t workspace_bytes, void* stream) {

@@ -98,6 +98,8 @@ struct Options {
     long long corr_dual;           // 1: the whole-pair pipeline evaluates both directions' cost volumes in ONE launch of the fused correlation kernel (bit-identical; measured: the
                                    //    correlation stage 0.374 -> 0.360 ms for both directions, frac 0.183 -> 0.190, but the plain argmin of the first volume then reads it from HBM instead of the Infinity
                                    //    Cache -- 0.106 -> 0.157 ms for both -- so the pair is 0.02 ms SLOWER); 0 (default) = one launch per direction
+    long long prune_refine;        // 1 (default): a candidate box too large for one thread is closed again with the cost of the displacement nearest to the smoothed field as the
+                                   //    bound (ties at the minimum -- zero background -- otherwise keep whole windows; bit-identical); 0 = previous winner's cost only
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };

@@ -252,12 +252,14 @@ def test_coupled_convex_vs_oracle(U, orc, shape, hw):
     assert np.array_equal(host(out)[0], orc.coupled_convex(rs, ra, mesh, hw))
 
 
-@pytest.mark.parametrize("kind", ["foreign_argmin", "flat", "plateaus", "hw0"])
+@pytest.mark.parametrize("kind", ["foreign_argmin", "flat", "plateaus", "hw0", "zero_columns", "zero_columns_foreign", "signed_zero_columns"])
 def test_coupled_convex_pruning_edge_cases(U, orc, kind):
     """The pruned (branch-and-bound) passes must return the reference's argmin for inputs that defeat the bound: an `argmin`
     argument that is not the argmin of the volume (the lower bound then comes from a streaming pass), a completely flat
     volume (every displacement ties: lowest index wins, every voxel keeps its whole window), plateaus of equal cost, and the
-    single-displacement window."""
+    single-displacement window.  zero_columns: many displacements tie at the minimum (zero background) -- boxes that the previous winner's
+    cost leaves too large are closed again with the cost of the displacement nearest to the smoothed field (cand_box), also with a
+    foreign `argmin` and with -0.0 entries (which compare equal to +0.0 but order below it in the keys)."""
     rng = np.random.default_rng(7)
     shape, hw = (6, 8, 12), 3
     if kind == "hw0":
@@ -270,8 +272,14 @@ def test_coupled_convex_pruning_edge_cases(U, orc, kind):
         ssd = (rng.integers(0, 3, (K,) + shape) * 0.5).astype(np.float32)
     else:
         ssd = rng.random((K,) + shape, dtype=np.float32)
+    if kind.startswith("zero_columns") or kind == "signed_zero_columns":
+        ssd[:, :, :5, :] = 0.0                                              # a zero background beside structured columns
+        ssd[:, 2:4, 5:, 3:7] = 0.0                                          # and an island inside them
+        ssd[K // 3, 1, 2, :] = 1e-30                                        # all-zero but for one tiny entry: an ordinary column
+        if kind == "signed_zero_columns":
+            ssd[::7, :, 1, :] = -0.0                                        # -0.0 entries: compare equal, yet the column is not "all +0.0"
     am = ssd.reshape(K, -1).argmin(0).reshape(shape).astype(np.int64)
-    if kind == "foreign_argmin":
+    if kind in ("foreign_argmin", "zero_columns_foreign"):
         am = rng.integers(0, K, shape).astype(np.int64)
     mesh = orc.disp_mesh(hw)
     out = U.coupled_convex(dev(ssd), dev(am), dev(mesh)[:, :, None], 1, shape)
@@ -1253,7 +1261,7 @@ def test_device_tables_equal_the_host_helpers_and_torch():
 
 # ---- (9) every selectable kernel variant -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opt,val", [("mind_tiled", 1), ("mm_tx", 32), ("mm_tx", 64), ("mm_slots", 64), ("box_tiled", 1), ("no_prune", 1),
-                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("cf_prio", 0x9d), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0), ("box_cpt", 2), ("box_uneven", 100), ("box_prio", 1), ("mind_overlap", 1), ("corr_fused_all", 1), ("box_fwd_tile", 0), ("box_fwd_tile", 1000), ("box_fwd_tile", 2000), ("corr_dual", 1), ("box_walk", 0), ("box_bwd_tile", 0), ("box_bwd_tile", 1000), ("box_bwd_tile", 2000)])
+                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("cf_prio", 0x9d), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0), ("box_cpt", 2), ("box_uneven", 100), ("box_prio", 1), ("mind_overlap", 1), ("corr_fused_all", 1), ("box_fwd_tile", 0), ("box_fwd_tile", 1000), ("box_fwd_tile", 2000), ("corr_dual", 1), ("prune_refine", 0), ("box_walk", 0), ("box_bwd_tile", 0), ("box_bwd_tile", 1000), ("box_bwd_tile", 2000)])
 def test_kernel_variants_agree(M, U, orc, golden, opt, val):
     """The library's run-time switches (cvx_set_option / CVX_* environment variables) select alternative kernels for the same
     operators; every one of them is bit-identical to the oracle: marching vs tiled MIND stencil and its tile shapes, marching vs tiled
