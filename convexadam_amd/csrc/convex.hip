@@ -249,29 +249,47 @@ __global__ __launch_bounds__(64) void k_argmin_voxel(const ST* __restrict__ ssd,
     // caller's `argmin` only seeds the first smoothing step and need not be the first NaN
     if (sm_x != sm_x) { keys[x] = pack_min_key(sm_x, minkeys ? (unsigned)(minkeys[x] & 0xffffffffull) : (unsigned)kp); return; }
     const CandBox c = cand_box(mesh, uc, ub, ua, coef, K, n, kp, ssd_kp, sm_x, ssd + x, v, refine);
-    if (c.vol > limit) {                // hand the box over in chunks of 256 displacements: (voxel << 8 | chunk) work items
+    if (c.vol > min(limit, 8)) {        // (8 = NB below) hand the box over in chunks of 256 displacements: (voxel << 8 | chunk) work items
         const int nchunks = (int)((c.vol + 255) >> 8);
         const int at = atomicAdd(list_count, nchunks);
         for (int i = 0; i < nchunks; ++i) list[at + i] = ((unsigned long long)x << 8) | (unsigned)i;
         keys[x] = ~0ull;                // merged by the wavefronts with atomicMin
         return;
     }
-    float best = 0.0f;                  // the previous winner lies inside the box and is simply visited again in index order,
-    int bi = -1;                        // which keeps the reference's first-minimum rule
-    for (int ia = c.a_lo; ia <= c.a_hi; ++ia)
-        for (int ib = c.b_lo; ib <= c.b_hi; ++ib)
-            for (int ic = c.c_lo; ic <= c.c_hi; ++ic) {
-                const int k = (ia * n + ib) * n + ic;
-                const float e0 = mesh[k] - c.uc, e1 = mesh[K + k] - c.ub, e2 = mesh[2 * K + k] - c.ua;
-                float q = e0 * e0;      // (..).pow(2).sum(0): sequential over the 3 components
-                q += e1 * e1;
-                q += e2 * e2;
-                const float pen = coef * q;                            // coeffs[j]*(...)                     (:104)
-                const float lower = c.sm + pen;                        // <= cost_k
-                if (lower > c.bound || (bi >= 0 && lower >= best)) continue;
-                const float cost = SsdIO<ST>::ld(ssd + (size_t)k * v + x) + pen;       // ssd + coeffs[j]*(...)
-                if ((bi < 0) | argmin_better(cost, best)) { best = cost; bi = k; }
+    // The previous winner (or the nearest displacement, see cand_box) lies inside the box and is simply visited again in index order,
+    // which keeps the reference's first-minimum rule.  The box holds at most `limit` <= 8 displacements: their penalties are evaluated
+    // first and ALL admissible cost-volume entries are requested together -- one memory round trip for the box instead of one per visited
+    // displacement (the serial scan skipped an entry once a better one was known; those few extra loads are cheaper than the waiting).
+    constexpr int NB = 8;
+    int kk[NB];
+    float pen[NB], val[NB];
+    bool need[NB];
+    {
+        int ic = c.c_lo, ib = c.b_lo, ia = c.a_lo;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const bool in = j < (int)c.vol;
+            kk[j] = (ia * n + ib) * n + ic;                                // j-th displacement of the box in index order
+            const float e0 = mesh[kk[j]] - c.uc, e1 = mesh[K + kk[j]] - c.ub, e2 = mesh[2 * K + kk[j]] - c.ua;
+            float q = e0 * e0;          // (..).pow(2).sum(0): sequential over the 3 components
+            q += e1 * e1;
+            q += e2 * e2;
+            pen[j] = coef * q;                                             // coeffs[j]*(...)                     (:104)
+            need[j] = in && !(c.sm + pen[j] > c.bound);                    // c.sm + pen <= cost_k
+            if (j + 1 < (int)c.vol) {                                      // advance (c fastest); stays on a valid displacement past the end
+                if (++ic > c.c_hi) { ic = c.c_lo; if (++ib > c.b_hi) { ib = c.b_lo; ++ia; } }
             }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) val[j] = need[j] ? SsdIO<ST>::ld(ssd + (size_t)kk[j] * v + x) : 0.0f;
+    float best = 0.0f;
+    int bi = -1;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const float cost = val[j] + pen[j];                                // ssd + coeffs[j]*(...)
+        if (need[j] && ((bi < 0) | argmin_better(cost, best))) { best = cost; bi = kk[j]; }
+    }
     if (bi < 0) { best = c.bound; bi = c.kp; }   // cannot happen (kp passes its own test); keeps the output defined
     keys[x] = pack_min_key(best, (unsigned)bi);
 }
@@ -477,7 +495,7 @@ static int argmin_pass_pruned(const ST* ssd, const float* mesh, float* u, float 
     const size_t v = (size_t)h * w * d;
     const int refine = options().prune_refine != 0 ? 8 : 0x7fffffff;     // boxes above the per-thread limit get the second bound
     hipLaunchKernelGGL((k_argmin_voxel<PrevT, ST>), dim3((unsigned)cdiv64((int64_t)v, 64), nprob), dim3(64), 0, s, ssd, mesh, u, coef, K, n, h,
-                       w, d, smin, kprev, 8, list, list_count, next_count, keys, minkeys, refine, o);
+                       w, d, smin, kprev, 8, list, list_count, next_count, keys, minkeys, refine, o);   // limit 8 = NB of the voxel kernel
     // worst case bounded by one coalesced scan per pass: a chunk of 256 scattered reads moves about 8 KB, the scan K * v * 4 bytes
     const long long above = options().prune_stream_above >= 0 ? options().prune_stream_above : (long long)((double)K * (double)v / 2048.0);
     const int stream_above = (int)(above > 0x7fffffff ? 0x7fffffff : above);
