@@ -257,7 +257,7 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
                        float lambda_weight, int niter, int step0, float cost_scale, const float* base_h, const float* base_w,
                        const float* base_d, float* U, float* grad_out, const int* snapshot_iters_host, int n_snap,
                        float* snapshots, const cvx_smoother* sm, bool keep_state, bool f16_features, int fast, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+                       size_t workspace_bytes, void* stream, bool features_are_records) {
     CVX_REQUIRE(F2 && M2 && P && m && v && U && base_h && base_w && base_d, "cvx_adam_run_f32: null pointer");
     CVX_REQUIRE(C > 0 && h > 1 && w > 1 && d > 1, "cvx_adam_run_f32: bad extent C=%d %dx%dx%d", C, h, w, d);
     CVX_REQUIRE(niter >= 0 && step0 >= 0, "cvx_adam_run_f32: negative iteration count");
@@ -284,7 +284,8 @@ int cvx::adam_run_impl(const float* F2, const float* M2, int C, int h, int w, in
     const int CP = (C + 3) / 4 * 4;
     float* Fcl = cv.take<float>((size_t)CP * (V + 1));
     float* Mcl = cv.take<float>((size_t)CP * (V + 1));
-    if (niter > 0) {
+    if (features_are_records) { Fcl = const_cast<float*>(F2); Mcl = const_cast<float*>(M2); }       // built by the producer (mind.hip::k_mind_finish_pool)
+    else if (niter > 0) {
         int rc;
         if ((rc = launch_to_chunked(F2, C, V, Fcl, f16_features, s)) || (rc = launch_to_chunked(M2, C, V, Mcl, f16_features, s))) return rc;
     }

@@ -507,9 +507,19 @@ static int argmin_pass_pruned(const ST* ssd, const float* mesh, float* u, float 
 }
 
 // plain argmin pass that leaves its (cost, index) keys in `keys` (first key buffer of a coupled-convex workspace)
-int launch_argmin_keys(const void* ssd, bool f16, int K, size_t v, unsigned long long* keys, hipStream_t s) {
-    if (f16) return argmin_pass(static_cast<const __half*>(ssd), nullptr, nullptr, 0.0f, false, K, v, keys, true, s);
-    return argmin_pass(static_cast<const float*>(ssd), nullptr, nullptr, 0.0f, false, K, v, keys, true, s);
+int launch_argmin_keys(const void* ssd, bool f16, int K, size_t v, unsigned long long* keys, bool arm, hipStream_t s) {
+    if (f16) return argmin_pass(static_cast<const __half*>(ssd), nullptr, nullptr, 0.0f, false, K, v, keys, arm, s);
+    return argmin_pass(static_cast<const float*>(ssd), nullptr, nullptr, 0.0f, false, K, v, keys, arm, s);
+}
+int* coupled_ws_counts(void* workspace, size_t workspace_bytes, int h, int w, int d, int disp_hw) {
+    const int n = 2 * disp_hw + 1, K = n * n * n;
+    const size_t v = (size_t)h * w * d;
+    Carver cv(workspace, workspace_bytes);
+    for (int i = 0; i < 3; ++i) (void)cv.take<unsigned long long>(v);
+    (void)cv.take<int>(v);
+    (void)cv.take<float>(v);
+    const size_t list_cap = (size_t)((K + 255) / 256) * v;
+    return reinterpret_cast<int*>(cv.take<unsigned long long>(list_cap + 8) + list_cap);
 }
 
 int launch_argmin(const void* ssd, bool f16, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
@@ -574,7 +584,8 @@ extern "C" int cvx_coupled_convex_f16(const void* ssd_half, const int64_t* argmi
 // nprob = 2: a second, independent problem (displaced by `o`, see Prob2) is solved by the same launches.
 template <typename ST>
 static int coupled_core(const ST* ssd, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
-                        bool argmin_is_exact, void* workspace, size_t workspace_bytes, const Prob2& o, int nprob, void* stream) {
+                        bool argmin_is_exact, void* workspace, size_t workspace_bytes, const Prob2& o, int nprob, void* stream,
+                        bool counts_zeroed = false) {
     // argmin == nullptr: the (cost, index) keys of the plain argmin pass sit in the first key buffer of the workspace
     const bool from_keys = argmin == nullptr;
     CVX_REQUIRE(ssd && mesh && out && workspace, "cvx_coupled_convex_f32: null pointer");
@@ -602,7 +613,7 @@ static int coupled_core(const ST* ssd, const int64_t* argmin, const float* mesh,
     const bool prune = !no_prune;
     if (prune) {
         int* counts = list_count;                                       // two alternating list lengths
-        for (int q = 0; q < nprob; ++q)
+        for (int q = 0; q < nprob && !counts_zeroed; ++q)
             if (hipMemsetAsync(reinterpret_cast<char*>(counts) + (q ? o.ws : 0), 0, 2 * sizeof(int), s) != hipSuccess)
                 return fail(CVX_ERR_LAUNCH, "coupled_convex: memset failed");
         if (from_keys) hipLaunchKernelGGL(k_keys_to_idx_min, gv, dim3(256), 0, s, keys[0], v, idx, smin, o);
@@ -653,25 +664,25 @@ int cvx::coupled_convex_impl(const void* ssd, bool f16, const int64_t* argmin, c
 template <typename ST>
 static int coupled_dual_t(const ST* ssdA, const int64_t* argminA, float* outA, void* wsA, const ST* ssdB,
                           const int64_t* argminB, float* outB, void* wsB, const float* mesh, int h, int w, int d, int disp_hw,
-                          size_t workspace_bytes, void* stream) {
+                          size_t workspace_bytes, void* stream, bool counts_zeroed) {
     const bool no_prune = options().no_prune != 0;
     if (no_prune || !ssdB || !outB || !wsB) {
-        int rc = coupled_core(ssdA, argminA, mesh, h, w, d, disp_hw, outA, true, wsA, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);
+        int rc = coupled_core(ssdA, argminA, mesh, h, w, d, disp_hw, outA, true, wsA, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream, counts_zeroed);
         if (rc || !ssdB) return rc;
-        return coupled_core(ssdB, argminB, mesh, h, w, d, disp_hw, outB, true, wsB, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream);
+        return coupled_core(ssdB, argminB, mesh, h, w, d, disp_hw, outB, true, wsB, workspace_bytes, Prob2{0, 0, 0, 0}, 1, stream, counts_zeroed);
     }
     auto diff = [](const void* b, const void* a) { return (ptrdiff_t)(reinterpret_cast<uintptr_t>(b) - reinterpret_cast<uintptr_t>(a)); };
     // the carve-up of a workspace depends on its alignment modulo 256: equal residues give equal layouts
     if (((reinterpret_cast<uintptr_t>(wsA) ^ reinterpret_cast<uintptr_t>(wsB)) & 255) != 0)
         return fail(CVX_ERR_INVALID_ARG, "coupled_convex_dual: workspaces must share their alignment modulo 256");
     const Prob2 o{diff(ssdB, ssdA), diff(argminB, argminA), diff(outB, outA), diff(wsB, wsA)};
-    return coupled_core(ssdA, argminA, mesh, h, w, d, disp_hw, outA, true, wsA, workspace_bytes, o, 2, stream);
+    return coupled_core(ssdA, argminA, mesh, h, w, d, disp_hw, outA, true, wsA, workspace_bytes, o, 2, stream, counts_zeroed);
 }
 int cvx::coupled_convex_dual_impl(const void* ssdA, const int64_t* argminA, float* outA, void* wsA, const void* ssdB, bool f16,
                                   const int64_t* argminB, float* outB, void* wsB, const float* mesh, int h, int w, int d, int disp_hw,
-                                  size_t workspace_bytes, void* stream) {
-    if (f16) return coupled_dual_t(static_cast<const __half*>(ssdA), argminA, outA, wsA, static_cast<const __half*>(ssdB), argminB, outB, wsB, mesh, h, w, d, disp_hw, workspace_bytes, stream);
-    return coupled_dual_t(static_cast<const float*>(ssdA), argminA, outA, wsA, static_cast<const float*>(ssdB), argminB, outB, wsB, mesh, h, w, d, disp_hw, workspace_bytes, stream);
+                                  size_t workspace_bytes, void* stream, bool counts_zeroed) {
+    if (f16) return coupled_dual_t(static_cast<const __half*>(ssdA), argminA, outA, wsA, static_cast<const __half*>(ssdB), argminB, outB, wsB, mesh, h, w, d, disp_hw, workspace_bytes, stream, counts_zeroed);
+    return coupled_dual_t(static_cast<const float*>(ssdA), argminA, outA, wsA, static_cast<const float*>(ssdB), argminB, outB, wsB, mesh, h, w, d, disp_hw, workspace_bytes, stream, counts_zeroed);
 }
 
 extern "C" size_t cvx_inverse_consistency_workspace_bytes(int h, int w, int d) {

@@ -100,6 +100,8 @@ struct Options {
                                    //    Cache -- 0.106 -> 0.157 ms for both -- so the pair is 0.02 ms SLOWER); 0 (default) = one launch per direction
     long long prune_refine;        // 1 (default): a candidate box too large for one thread is closed again with the cost of the displacement nearest to the smoothed field as the
                                    //    bound (ties at the minimum -- zero background -- otherwise keep whole windows; bit-identical); 0 = previous winner's cost only
+    long long mind_records;        // 1 (default): the whole-pair pipeline's MIND pass writes the Adam-grid pooling directly as the loop's feature records (no planar copy, no
+                                   //    k_to_chunked pass: -31 us per pair); 0 = planar pooled features + re-packing (bit-identical)
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };
@@ -319,7 +321,9 @@ int launch_box_zero(const float* in, float* out, int C, int H, int W, int D, int
 int launch_smoother(const float* in, float* out, float* tmp, int C, int H, int W, int D, const cvx_smoother& sm, bool backward,
                     hipStream_t s);
 // (ssd: float32 cost volume, or half precision when f16 -- fp16 storage)
-int launch_argmin_keys(const void* ssd, bool f16, int K, size_t v, unsigned long long* keys, hipStream_t s);
+int launch_argmin_keys(const void* ssd, bool f16, int K, size_t v, unsigned long long* keys, bool arm, hipStream_t s);   // arm = false: the caller set the keys to all ones
+// the two alternating list lengths of the pruned passes inside a coupled-convex workspace (same carve-up as coupled_core)
+int* coupled_ws_counts(void* workspace, size_t workspace_bytes, int h, int w, int d, int disp_hw);
 int launch_argmin(const void* ssd, bool f16, const float* mesh, const float* u, float coef, bool coupled, int K, size_t v,
                   unsigned long long* keys, int64_t* argmin_out, hipStream_t s);
 // out = interp(in * pre_mul) / post_div   (pre_mul, post_div = 1 -> plain F.interpolate)
@@ -362,17 +366,19 @@ __device__ __forceinline__ void adam_update(float g, float& P, float& m, float& 
 int adam_run_impl(const float* F2, const float* M2, int C, int h, int w, int d, float* P, float* m, float* v, float lambda_weight,
                   int niter, int step0, float cost_scale, const float* base_h, const float* base_w, const float* base_d, float* U,
                   float* grad_out, const int* snapshot_iters_host, int n_snap, float* snapshots, const cvx_smoother* sm,
-                  bool keep_state, bool f16_features, int fast, void* workspace, size_t workspace_bytes, void* stream);   // fast: 0 exact, 1 fast, 2 fast_all
+                  bool keep_state, bool f16_features, int fast, void* workspace, size_t workspace_bytes, void* stream,
+                  bool features_are_records = false);   // fast: 0 exact, 1 fast, 2 fast_all; features_are_records: F2 / M2 already hold the chunked records
 // convex.hip: coupled convex regularisation behind cvx_coupled_convex_f32 (argmin_is_exact: see there)
 int coupled_convex_impl(const void* ssd, bool f16, const int64_t* argmin, const float* mesh, int h, int w, int d, int disp_hw, float* out,
                         bool argmin_is_exact, void* workspace, size_t workspace_bytes, void* stream);
 int coupled_convex_dual_impl(const void* ssdA, const int64_t* argminA, float* outA, void* wsA, const void* ssdB, bool f16, const int64_t* argminB,
                              float* outB, void* wsB, const float* mesh, int h, int w, int d, int disp_hw, size_t workspace_bytes,
-                             void* stream);
+                             void* stream, bool counts_zeroed = false);   // counts_zeroed: the caller cleared coupled_ws_counts of both workspaces
 // mind.hip: MIND-SSC delivered only through its stride poolings (pipeline path, no full-resolution descriptor)
 bool mind_pooled_supported(int H, int W, int D, int g1, int g2);
 int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int dilation, int g1, float* out1, int g2, float* out2,
-                       float* raw, void* workspace, size_t workspace_bytes, hipStream_t s);
+                       float* raw, void* workspace, size_t workspace_bytes, hipStream_t s, int records = 0);   // records 1 / 2: out2 = float32 / half feature records
+bool mind_pooled_records_supported(int H, int W, int D, int g1, int g2);
 // corrbox.hip: the two box filters of the SSD volume (z-marching pipeline); raw [K][h][w][px] -> ssd [K][h][w][d]
 bool corr_box2_supported(int h, int w, int d, int px);
 int launch_corr_box2(const float* raw, int K, int h, int w, int d, int px, float* ssd, hipStream_t s);

@@ -475,11 +475,7 @@ constexpr int MP_TX = 24, MP_NT = 512;
 
 // raster-order window sum of G^3 taps from the LDS tile and its store; (c, wz, wy, wx) = window inside the tile
 template <int T, int G>
-__device__ __forceinline__ void mp_window(const float* __restrict__ E, int c, int wz, int wy, int wx, int z0, int y0, int x0, int H,
-                                          int W, int D, float* __restrict__ out) {
-    const int Ho = H / G, Wo = W / G, Do = D / G;
-    const int oz = z0 / G + wz, oy = y0 / G + wy, ox = x0 / G + wx;
-    if (oz >= Ho || oy >= Wo || ox >= Do) return;
+__device__ __forceinline__ float mp_window_mean(const float* __restrict__ E, int c, int wz, int wy, int wx) {
     const float* base = E + ((c * T + wz * G) * T + wy * G) * MP_TX + wx * G;
     float s = 0.0f;
 #pragma unroll
@@ -507,16 +503,27 @@ __device__ __forceinline__ void mp_window(const float* __restrict__ E, int c, in
                 for (int x = 0; x < G; ++x) s += v[y][x];
         }
     }
-    out[(size_t)c * Ho * Wo * Do + ((size_t)oz * Wo + oy) * Do + ox] = fdiv(s, (float)(G * G * G));
+    return fdiv(s, (float)(G * G * G));
+}
+template <int T, int G>
+__device__ __forceinline__ void mp_window(const float* __restrict__ E, int c, int wz, int wy, int wx, int z0, int y0, int x0, int H,
+                                          int W, int D, float* __restrict__ out) {
+    const int Ho = H / G, Wo = W / G, Do = D / G;
+    const int oz = z0 / G + wz, oy = y0 / G + wy, ox = x0 / G + wx;
+    if (oz >= Ho || oy >= Wo || ox >= Do) return;
+    out[(size_t)c * Ho * Wo * Do + ((size_t)oz * Wo + oy) * Do + ox] = mp_window_mean<T, G>(E, c, wz, wy, wx);
 }
 
 // T = GA >= GB, GB divides GA; out2 may be null (single pooling).  512 threads: phase 1 gives every thread 2 adjacent voxels
 // (12 x 8-byte loads, normalise, 12 x 8-byte LDS stores); in phase 2 the first wavefronts evaluate the few large windows
 // (one long sequential sum each) while the others sweep the many small ones.
+// rec2 (optional, replaces out2): the small-window output as the Adam loop's feature RECORDS (warp.hip::k_to_chunked layout:
+// [3][V2 + 1][4 channels], record V2 of a chunk all zero; rec_half: four half-precision values per record, rounded to nearest even as
+// k_to_chunked_h does) -- the planar pooled copy and the re-packing pass over it disappear from the pipeline.
 template <int GA, int GB>
 __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restrict__ raw, int H, int W, int D,
                                                             const MindStats* __restrict__ st, float* __restrict__ out1,
-                                                            float* __restrict__ out2, ExpTable et) {
+                                                            float* __restrict__ out2, void* __restrict__ rec2, int rec_half, ExpTable et) {
     constexpr int T = GA;
     __shared__ __attribute__((aligned(16))) float E[12 * T * T * MP_TX];          // [c][z][y][x], final channel order
     const int tid = threadIdx.x;
@@ -550,6 +557,29 @@ __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restr
     constexpr int WA = (NA + 63) / 64 * 64;                                        // threads reserved for them (whole wavefronts)
     if (tid < WA) {
         if (tid < NA) mp_window<T, GA>(E, tid / (MP_TX / GA), 0, 0, tid % (MP_TX / GA), z0, y0, x0, H, W, D, out1);
+    } else if (rec2) {
+        constexpr int nb = T / GB, nx = MP_TX / GB;
+        const int Ho = H / GB, Wo = W / GB, Do = D / GB;
+        const size_t V2 = (size_t)Ho * Wo * Do;
+        for (int i = tid - WA; i < 3 * nb * nb * nx; i += MP_NT - WA) {
+            const int wx = i % nx, wy = (i / nx) % nb, wz = (i / (nx * nb)) % nb, cq = i / (nx * nb * nb);
+            const int oz = z0 / GB + wz, oy = y0 / GB + wy, ox = x0 / GB + wx;
+            if (oz >= Ho || oy >= Wo || ox >= Do) continue;
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = mp_window_mean<T, GB>(E, 4 * cq + j, wz, wy, wx);
+            const size_t at = (size_t)cq * (V2 + 1) + ((size_t)oz * Wo + oy) * Do + ox;
+            if (rec_half) {
+                typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                const h16x4 o = {(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};          // round to nearest even
+                static_cast<uint2*>(rec2)[at] = __builtin_bit_cast(uint2, o);
+            } else static_cast<float4*>(rec2)[at] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid >= WA && tid < WA + 3) {       // the zero record of every chunk
+            const size_t at = (size_t)(tid - WA) * (V2 + 1) + V2;
+            if (rec_half) static_cast<uint2*>(rec2)[at] = make_uint2(0u, 0u);
+            else static_cast<float4*>(rec2)[at] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     } else if (out2) {
         constexpr int nb = T / GB, nx = MP_TX / GB;
         for (int i = tid - WA; i < 12 * nb * nb * nx; i += MP_NT - WA) {
@@ -664,8 +694,11 @@ bool mind_pooled_supported(int H, int W, int D, int g1, int g2) { return mind_po
 
 // MIND-SSC of `img` delivered only as avg_pool3d(., g1, stride g1) -> out1 and (g2 > 0) avg_pool3d(., g2, stride g2) -> out2;
 // `raw` is a 12*V float scratch (the raw patch SSDs).  Same values as cvx_mindssc_f32 followed by cvx_avgpool_f32.
+// records (with out2): out2 receives the g2-pooled descriptor as feature records instead of planar channels (needs g2 <= g1); see
+// mind_pooled_records_supported
+bool mind_pooled_records_supported(int H, int W, int D, int g1, int g2) { return g2 > 0 && g2 <= g1 && mind_pool_tile(H, W, D, g1, g2) != 0; }
 int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int dilation, int g1, float* out1, int g2, float* out2,
-                       float* raw, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                       float* raw, void* workspace, size_t workspace_bytes, hipStream_t s, int records) {
     int rc = mind_check(img, raw, workspace, H, W, D, radius, dilation, workspace_bytes);
     if (rc) return rc;
     const int T = mind_pool_tile(H, W, D, g1, g2 > 0 ? g2 : g1);
@@ -678,7 +711,10 @@ int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int di
     const int ga = swap ? g2 : g1, gb = g2 > 0 ? (swap ? g1 : g2) : g1;
     float* oa = swap ? out2 : out1;
     float* ob = g2 > 0 ? (swap ? out1 : out2) : nullptr;
-#define CVX_MP(GA, GB) hipLaunchKernelGGL((k_mind_finish_pool<GA, GB>), grid, dim3(MP_NT), 0, s, raw, H, W, D, st, oa, ob, mind_exp_table())
+    if (records && (swap || !out2)) return fail(CVX_ERR_UNSUPPORTED, "mind_pooled: feature records need 0 < g2 <= g1");
+    void* rec = records ? out2 : nullptr;             // records: 1 = float32, 2 = half precision
+    if (records) ob = nullptr;
+#define CVX_MP(GA, GB) hipLaunchKernelGGL((k_mind_finish_pool<GA, GB>), grid, dim3(MP_NT), 0, s, raw, H, W, D, st, oa, ob, rec, records == 2 ? 1 : 0, mind_exp_table())
     if (ga == 6 && gb == 2) CVX_MP(6, 2);
     else if (ga == 6 && gb == 3) CVX_MP(6, 3);
     else if (ga == 6 && gb == 6) CVX_MP(6, 6);

@@ -36,6 +36,40 @@ __global__ void k_disp_mesh(int hw, float* out) {
     out[2 * K + k] = la * (float)hw;
 }
 
+// Everything of a pair that depends on nothing but its geometry, in ONE launch instead of seven (two table kernels, the two all-ones fills
+// of the plain argmins' key buffers, the list counters of both coupled-convex solves, the zero Adam state): the identity tables, the
+// search mesh, keys = ~0, counts = 0, m = v = 0.
+struct PairSetup {
+    BaseTables t;
+    int hw; float* mesh;
+    unsigned long long* keys[2]; size_t v;
+    int* counts[2];
+    float4* zero[2]; size_t nzero4;
+};
+__global__ __launch_bounds__(256) void k_pair_setup(PairSetup a) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int S = a.t.S[t];
+        float* out = a.t.out[t];
+        for (size_t i = gid; out && i < (size_t)S; i += gsz) out[i] = fdiv(linspace_pm1_at(S, (int)i) * (float)(S - 1), (float)S);
+    }
+    const int n = 2 * a.hw + 1, K = n * n * n;
+    for (size_t k = gid; k < (size_t)K; k += gsz) {
+        const int c = (int)k % n, b = ((int)k / n) % n, aa = (int)k / (n * n);
+        const float la = n == 1 ? 0.f : linspace_pm1_at(n, aa), lb = n == 1 ? 0.f : linspace_pm1_at(n, b), lc = n == 1 ? 0.f : linspace_pm1_at(n, c);
+        a.mesh[k] = lc * (float)a.hw;
+        a.mesh[K + k] = lb * (float)a.hw;
+        a.mesh[2 * K + k] = la * (float)a.hw;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (a.keys[q]) for (size_t x = gid; x < a.v; x += gsz) a.keys[q][x] = ~0ull;
+        if (a.counts[q] && gid < 2) a.counts[q][gid] = 0;
+        if (a.zero[q]) for (size_t i = gid; i < a.nzero4; i += gsz) a.zero[q][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // (disp_soft / scale).flip(1)                                             convex_adam_MIND.py:134,139
 __global__ __launch_bounds__(256) void k_ic_prepare(const float* __restrict__ soft, int h, int w, int d, float* __restrict__ out) {
     const size_t v = (size_t)h * w * d;
@@ -112,8 +146,10 @@ static PairLayout pair_layout(const cvx_pair_params& p, int n_snap = 0, int max_
         L.disp_hr = take(u, f * 3 * L.V);
     }
     if (p.lambda_weight > 0) {
-        L.F2 = take(u, f * L.C * L.V2);
-        L.M2 = take(u, f * L.C * L.V2);
+        // planar pooled features, or (MIND path, option mind_records) the Adam loop's records: [CP/4][V2 + 1][4]
+        const size_t f2_bytes = f * (size_t)((L.C + 3) / 4 * 4) * (L.V2 + 1);
+        L.F2 = take(u, f2_bytes);
+        L.M2 = take(u, f2_bytes);
         L.P = take(u, f * 3 * L.V2); L.m = take(u, f * 3 * L.V2); L.v_ = take(u, f * 3 * L.V2); L.U = take(u, f * 3 * L.V2);
         L.adam_ws = take(u, cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2));
         L.bh2 = take(u, f * L.h2); L.bw2 = take(u, f * L.w2); L.bd2 = take(u, f * L.d2);
@@ -308,6 +344,9 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     // written at full resolution (launch_mind_pooled: raw patch SSDs -> normalise + exp + both poolings in one pass)
     const bool adam = p->lambda_weight > 0;
     const bool pooled_mind = p->n_feat == 0 && mind_pooled_supported(p->H, p->W, p->D, p->grid_sp, adam ? p->grid_sp_adam : 0);
+    // the Adam-grid pooling of the descriptor written as the loop's feature records (no planar copy, no re-packing pass)
+    const bool mind_records = pooled_mind && adam && options().mind_records != 0 && mind_pooled_records_supported(p->H, p->W, p->D, p->grid_sp, p->grid_sp_adam);
+    const int rec_kind = mind_records ? (p->fp16_storage ? 2 : 1) : 0;
     if (p->n_feat == 0) {
         const size_t mws = cvx_mindssc_workspace_bytes(p->H, p->W, p->D, p->mind_r, p->mind_d);
         if (pooled_mind) {
@@ -321,9 +360,9 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
             if (overlap) { (void)hipEventRecord(ev_fork, s); (void)hipStreamWaitEvent(side, ev_fork, 0); }
             else side = s;
             if ((rc = launch_mind_pooled(img_fixed, p->H, p->W, p->D, p->mind_r, p->mind_d, p->grid_sp, F(L.fs), g2, adam ? F(L.F2) : nullptr,
-                                         F(L.featF), ws + L.mind_ws, mws, s))) return rc;
+                                         F(L.featF), ws + L.mind_ws, mws, s, rec_kind))) return rc;
             rc = launch_mind_pooled(img_moving, p->H, p->W, p->D, p->mind_r, p->mind_d, p->grid_sp, F(L.ms), g2, adam ? F(L.M2) : nullptr,
-                                    F(L.featM), ws + (overlap ? L.mind_ws2 : L.mind_ws), mws, side);
+                                    F(L.featM), ws + (overlap ? L.mind_ws2 : L.mind_ws), mws, side, rec_kind);
             if (overlap) { (void)hipEventRecord(ev_join, side); (void)hipStreamWaitEvent(s, ev_join, 0); }      // (joined even after an error)
             if (rc) return rc;
         } else {
@@ -338,20 +377,31 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
         if ((rc = cvx_avgpool_f32(featF, L.C, p->H, p->W, p->D, p->grid_sp, F(L.fs), stream))) return rc;
         if ((rc = cvx_avgpool_f32(featM, L.C, p->H, p->W, p->D, p->grid_sp, F(L.ms), stream))) return rc;
     }
-    hipLaunchKernelGGL(k_disp_mesh, dim3(cdiv(L.K, 256)), dim3(256), 0, s, p->disp_hw, F(L.mesh));
+    const size_t vws = cvx_coupled_convex_workspace_bytes(L.h, L.w, L.d, p->disp_hw);
+    // first key buffer of the coupled-convex workspace (carved exactly as coupled_core does): the plain argmin leaves its keys there
+    unsigned long long* keys = Carver(ws + L.conv_ws, vws).take<unsigned long long>(L.v);
+    unsigned long long* keys2 = p->ic ? Carver(ws + L.conv_ws2, vws).take<unsigned long long>(L.v) : nullptr;
+    const bool no_prune = options().no_prune != 0;        // streaming coupled passes need int64 winners
     {
         const bool adam_tables = p->lambda_weight > 0;
-        BaseTables t = {{L.h, L.w, L.d, L.h2, L.w2, L.d2},
-                        {F(L.bh), F(L.bw), F(L.bd), adam_tables ? F(L.bh2) : nullptr, adam_tables ? F(L.bw2) : nullptr, adam_tables ? F(L.bd2) : nullptr}};
-        hipLaunchKernelGGL(k_affine_bases, dim3(4, 6), dim3(64), 0, s, t);
+        // (m, v zeroed here only if 16-byte stores fit: 3 * V2 floats from a 256-byte aligned offset)
+        const bool zero_state = adam_tables && (3 * L.V2) % 4 == 0;
+        PairSetup a = {{{L.h, L.w, L.d, L.h2, L.w2, L.d2},
+                        {F(L.bh), F(L.bw), F(L.bd), adam_tables ? F(L.bh2) : nullptr, adam_tables ? F(L.bw2) : nullptr, adam_tables ? F(L.bd2) : nullptr}},
+                       p->disp_hw, F(L.mesh), {keys, keys2}, L.v,
+                       {no_prune ? nullptr : coupled_ws_counts(ws + L.conv_ws, vws, L.h, L.w, L.d, p->disp_hw),
+                        (no_prune || !p->ic) ? nullptr : coupled_ws_counts(ws + L.conv_ws2, vws, L.h, L.w, L.d, p->disp_hw)},
+                       {zero_state ? reinterpret_cast<float4*>(ws + L.m) : nullptr, zero_state ? reinterpret_cast<float4*>(ws + L.v_) : nullptr}, 3 * L.V2 / 4};
+        hipLaunchKernelGGL(k_pair_setup, dim3(zero_state ? 1024 : 64), dim3(256), 0, s, a);
+        if (adam_tables && !zero_state) {
+            (void)hipMemsetAsync(F(L.m), 0, sizeof(float) * 3 * L.V2, s);
+            (void)hipMemsetAsync(F(L.v_), 0, sizeof(float) * 3 * L.V2, s);
+        }
     }
     mark("pool", s);
     // 3. forward correlation + coupled convex                                  (:124-130)
     const size_t cws = cvx_correlate_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);
-    const size_t vws = cvx_coupled_convex_workspace_bytes(L.h, L.w, L.d, p->disp_hw);
     int64_t* am = reinterpret_cast<int64_t*>(ws + L.argmin);
-    // first key buffer of the coupled-convex workspace (carved exactly as coupled_core does): the plain argmin leaves its keys there
-    unsigned long long* keys = Carver(ws + L.conv_ws, vws).take<unsigned long long>(L.v);
     const bool f16 = p->fp16_storage != 0;
     const cvx_corr_opts copt = {p->cost, p->n_box == 1 ? 1 : 2, p->corr_fast, f16 ? 2 : 0};
     const bool variant = copt.cost || copt.n_box == 1 || copt.fast || copt.f16;
@@ -361,34 +411,32 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     // Both directions' cost volumes in ONE launch of the fused kernel when the pair is inverse consistent (option corr_dual): the stage
     // interval "correlate" then covers both directions and "correlate_rev" is not recorded.
     const bool dual = p->ic && options().corr_dual != 0 && !corr_use_unfused(L.C, L.h, L.w, L.d, p->disp_hw, variant) && p->disp_hw <= CVX_MAX_DISP_HW;
-    const bool no_prune = options().no_prune != 0;        // streaming coupled passes need int64 winners
     int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
-    unsigned long long* keys2 = p->ic ? Carver(ws + L.conv_ws2, vws).take<unsigned long long>(L.v) : nullptr;
     if (dual) {
         const size_t fws = corr_fused_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);
         if ((rc = launch_corr_fused_dual(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, copt.cost, copt.n_box, copt.fast, copt.f16, F(L.ssd), F(L.ssd2),
                                          ws + L.corr_ws, fws, ws + L.corr_ws2, s))) return rc;
         mark("correlate", s);
         if (no_prune) rc = launch_argmin(F(L.ssd), f16, nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s);
-        else rc = launch_argmin_keys(F(L.ssd), f16, L.K, L.v, keys, s);
+        else rc = launch_argmin_keys(F(L.ssd), f16, L.K, L.v, keys, /*arm=*/false, s);
         if (rc) return rc;
         mark("argmin", s);
         if (no_prune) rc = launch_argmin(F(L.ssd2), f16, nullptr, nullptr, 0.0f, false, L.K, L.v, keys2, am2, s);
-        else rc = launch_argmin_keys(F(L.ssd2), f16, L.K, L.v, keys2, s);
+        else rc = launch_argmin_keys(F(L.ssd2), f16, L.K, L.v, keys2, /*arm=*/false, s);
         if (rc) return rc;
         mark("argmin_rev", s);
     } else {
     if ((rc = cvx_correlate_ex_f32(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, variant ? &copt : nullptr, F(L.ssd), nullptr, ws + L.corr_ws, cws, stream))) return rc;
     mark("correlate", s);
     if (no_prune) rc = launch_argmin(F(L.ssd), f16, nullptr, nullptr, 0.0f, false, L.K, L.v, keys, am, s);
-    else rc = launch_argmin_keys(F(L.ssd), f16, L.K, L.v, keys, s);            // keys stay in the coupled workspace's first buffer
+    else rc = launch_argmin_keys(F(L.ssd), f16, L.K, L.v, keys, /*arm=*/false, s);            // keys stay in the coupled workspace's first buffer
     if (rc) return rc;
     mark("argmin", s);
     if (p->ic) {                                // reverse direction (:136-138): same operators with the roles swapped
         if ((rc = cvx_correlate_ex_f32(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, variant ? &copt : nullptr, F(L.ssd2), nullptr, ws + L.corr_ws, cws, stream))) return rc;
         mark("correlate_rev", s);
         if (no_prune) rc = launch_argmin(F(L.ssd2), f16, nullptr, nullptr, 0.0f, false, L.K, L.v, keys2, am2, s);
-        else rc = launch_argmin_keys(F(L.ssd2), f16, L.K, L.v, keys2, s);
+        else rc = launch_argmin_keys(F(L.ssd2), f16, L.K, L.v, keys2, /*arm=*/false, s);
         if (rc) return rc;
         mark("argmin_rev", s);
     }
@@ -396,7 +444,7 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     // both coupled-convex solves in the same launches (ic) or the forward one alone
     if ((rc = coupled_convex_dual_impl(F(L.ssd), no_prune ? am : nullptr, F(L.soft), ws + L.conv_ws, p->ic ? F(L.ssd2) : nullptr, f16, no_prune ? am2 : nullptr,
                                        p->ic ? F(L.soft2) : nullptr, p->ic ? ws + L.conv_ws2 : nullptr, F(L.mesh), L.h, L.w, L.d,
-                                       p->disp_hw, vws, stream))) return rc;
+                                       p->disp_hw, vws, stream, /*counts_zeroed=*/!no_prune))) return rc;
     mark("coupled_convex", s);
 
     const float* disp_hr = F(L.soft);          // ic=False: coarse field, coarse units (:143-144)
@@ -429,15 +477,14 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
         if (coarse_src) {
             if ((rc = launch_resize2(coarse_src, 3, L.h, L.w, L.d, hh, hw_, hd, F(L.disp_hr), F(L.P), L.h2, L.w2, L.d2, (float)p->grid_sp_adam, s))) return rc;
         } else if ((rc = launch_resize(disp_hr, 3, hh, hw_, hd, F(L.P), L.h2, L.w2, L.d2, 1.0f, (float)p->grid_sp_adam, s))) return rc;
-        (void)hipMemsetAsync(F(L.m), 0, sizeof(float) * 3 * L.V2, s);
-        (void)hipMemsetAsync(F(L.v_), 0, sizeof(float) * 3 * L.V2, s);
+        // (m = v = 0: k_pair_setup)
         // (fp16 storage: the Adam loop keeps its feature records in half precision -- rounded when the records are built)
         mark("adam_setup", s);
         const cvx_smoother two_pools = {0, 2, {3, 3, 0, 0}, {0.f, 0.f, 0.f, 0.f, 0.f}};            // task3_docker.py:191
         if ((rc = adam_run_impl(F(L.F2), F(L.M2), L.C, L.h2, L.w2, L.d2, F(L.P), F(L.m), F(L.v_), p->lambda_weight,
                                 p->selected_niter, 0, p->cost_scale, F(L.bh2), F(L.bw2), F(L.bd2), F(L.U), nullptr, snap_iters_host, n_snap,
                                 n_snap ? F(L.snaps) : nullptr, p->n_spline_pools == 2 ? &two_pools : nullptr, /*keep_state=*/false, f16, p->adam_fast, ws + L.adam_ws,
-                                cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2), stream))) return rc;
+                                cvx_adam_workspace_bytes(L.C, L.h2, L.w2, L.d2), stream, mind_records))) return rc;
         mark("adam", s);
         // disp_hr = interpolate(fitted_grid * grid_sp_adam, (H,W,D))                            (:182)
         if (n_snap > 0) {                       // self_configuring/convex_adam_MIND.py:115-139: every snapshot x every final smoothing
