@@ -102,6 +102,8 @@ struct Options {
                                    //    bound (ties at the minimum -- zero background -- otherwise keep whole windows; bit-identical); 0 = previous winner's cost only
     long long mind_records;        // 1 (default): the whole-pair pipeline's MIND pass writes the Adam-grid pooling directly as the loop's feature records (no planar copy, no
                                    //    k_to_chunked pass: -31 us per pair); 0 = planar pooled features + re-packing (bit-identical)
+    long long resize_up2;          // 1 (default): exact factor-2 up-sampling of a 3-channel field through k_resize_up2 (2 x 2 x 2 outputs per thread from one 27-tap
+                                   //    neighbourhood; bit-identical); 0 = one thread per output
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };

@@ -71,10 +71,13 @@ __global__ __launch_bounds__(256) void k_pair_setup(PairSetup a) {
 }
 
 // (disp_soft / scale).flip(1)                                             convex_adam_MIND.py:134,139
-__global__ __launch_bounds__(256) void k_ic_prepare(const float* __restrict__ soft, int h, int w, int d, float* __restrict__ out) {
+// (both directions of a pair in one launch: blockIdx.y selects the field)
+__global__ __launch_bounds__(256) void k_ic_prepare(const float* __restrict__ soft, const float* __restrict__ soft_rev, int h, int w, int d,
+                                                    float* __restrict__ out, float* __restrict__ out_rev) {
     const size_t v = (size_t)h * w * d;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= v) return;
+    if (blockIdx.y) { soft = soft_rev; out = out_rev; }
     const float sc[3] = {(float)(h - 1) / 2.0f, (float)(w - 1) / 2.0f, (float)(d - 1) / 2.0f};
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[(size_t)c * v + p] = fdiv(soft[(size_t)(2 - c) * v + p], sc[2 - c]);
@@ -452,8 +455,7 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     int hh = L.h, hw_ = L.w, hd = L.d;
     if (p->ic) {                                // (:133-141)
         const dim3 gv((unsigned)cdiv64((int64_t)L.v, 256));
-        hipLaunchKernelGGL(k_ic_prepare, gv, dim3(256), 0, s, F(L.soft), L.h, L.w, L.d, F(L.in1));
-        hipLaunchKernelGGL(k_ic_prepare, gv, dim3(256), 0, s, F(L.soft2), L.h, L.w, L.d, F(L.in2));
+        hipLaunchKernelGGL(k_ic_prepare, dim3(gv.x, 2), dim3(256), 0, s, F(L.soft), F(L.soft2), L.h, L.w, L.d, F(L.in1), F(L.in2));
         if ((rc = cvx_inverse_consistency_f32(F(L.in1), F(L.in2), L.h, L.w, L.d, 15, F(L.bh), F(L.bw), F(L.bd), F(L.ic1), F(L.ic2),
                                               ws + L.ic_ws, cvx_inverse_consistency_workspace_bytes(L.h, L.w, L.d), stream))) return rc;
         hipLaunchKernelGGL(k_ic_finish, gv, dim3(256), 0, s, F(L.ic1), L.h, L.w, L.d, (float)p->grid_sp, F(L.upin));

@@ -387,9 +387,86 @@ __global__ __launch_bounds__(256) void k_resize(const float* __restrict__ in, in
         }
     }
 }
+// Exact factor-2 up-sampling (the final up-sampling of the Adam grid, convex_adam_MIND.py:182): one thread per SOURCE voxel k = (kz, ky, kx)
+// produces the 2 x 2 x 2 outputs (2k .. 2k+1).  Their corners all lie in the 3 x 3 x 3 neighbourhood of k (clamped), which is loaded once
+// (27 instead of 64 taps per channel), and ATen's chain of three 1-D interpolations is shared level by level: 18 x-level values, 12
+// y-level values, 8 results -- every output goes through exactly the operations k_resize performs for it (lin_coef per output index decides
+// which two of the three taps it blends, so the clamped borders and a one-voxel axis are covered by the same code).
+template <int CT>
+__global__ __launch_bounds__(256) void k_resize_up2(const float* __restrict__ in, int h, int w, int d, float* __restrict__ out, float pre_mul,
+                                                    float post_div) {
+    const int kx = (int)(blockIdx.x * blockDim.x + threadIdx.x), ky = (int)blockIdx.y, kz = (int)blockIdx.z;
+    if (kx >= d) return;
+    const int H = 2 * h, W = 2 * w, D = 2 * d;
+    struct Ax { int p0[2], p1[2]; float l0[2], l1[2]; };
+    auto axis = [](int k, int n_in, Ax& a) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int i0, i1;
+            lin_coef(2 * k + t, n_in, 2 * n_in, i0, i1, a.l0[t], a.l1[t]);
+            a.p0[t] = i0 - k + 1;           // position inside the triple (k-1, k, k+1): 0, 1 or 2
+            a.p1[t] = i1 - k + 1;
+        }
+    };
+    Ax az, ay, ax;
+    axis(kz, h, az); axis(ky, w, ay); axis(kx, d, ax);
+    const int zi[3] = {kz > 0 ? kz - 1 : 0, kz, kz < h - 1 ? kz + 1 : h - 1}, yi[3] = {ky > 0 ? ky - 1 : 0, ky, ky < w - 1 ? ky + 1 : w - 1},
+              xi[3] = {kx > 0 ? kx - 1 : 0, kx, kx < d - 1 ? kx + 1 : d - 1};
+    auto sel = [](float v0, float v1, float v2, int p) { return p == 0 ? v0 : (p == 1 ? v1 : v2); };
+    const size_t cs = (size_t)h * w * d, n = (size_t)H * W * D;
+    float v[CT][3][3][3];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) v[c][a][b][e] = in[(size_t)c * cs + ((size_t)zi[a] * w + yi[b]) * d + xi[e]];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        float X[3][3][2], Y[3][2][2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float u0 = sel(v[c][a][b][0], v[c][a][b][1], v[c][a][b][2], ax.p0[t]), u1 = sel(v[c][a][b][0], v[c][a][b][1], v[c][a][b][2], ax.p1[t]);
+                    X[a][b][t] = __builtin_fmaf(u0 * pre_mul, ax.l0[t], (u1 * pre_mul) * ax.l1[t]);
+                }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float u0 = sel(X[a][0][t], X[a][1][t], X[a][2][t], ay.p0[ty]), u1 = sel(X[a][0][t], X[a][1][t], X[a][2][t], ay.p1[ty]);
+                    Y[a][ty][t] = __builtin_fmaf(u0, ay.l0[ty], u1 * ay.l1[ty]);
+                }
+#pragma unroll
+        for (int tz = 0; tz < 2; ++tz)
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty) {
+                float r[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float u0 = sel(Y[0][ty][t], Y[1][ty][t], Y[2][ty][t], az.p0[tz]), u1 = sel(Y[0][ty][t], Y[1][ty][t], Y[2][ty][t], az.p1[tz]);
+                    r[t] = __builtin_fmaf(u0, az.l0[tz], u1 * az.l1[tz]);
+                    if (post_div != 1.0f) r[t] = fdiv(r[t], post_div);
+                }
+                *reinterpret_cast<float2*>(out + (size_t)c * n + ((size_t)(2 * kz + tz) * W + (2 * ky + ty)) * D + 2 * kx) = make_float2(r[0], r[1]);
+            }
+    }
+}
 int launch_resize(const float* in, int C, int h, int w, int d, float* out, int H, int W, int D, float pre_mul,
                   float post_div, hipStream_t s) {
     if (H > 65535 || W > 65535) return fail(CVX_ERR_UNSUPPORTED, "resize_trilinear: output extent %dx%d exceeds the grid limits", H, W);
+    if (C == 3 && H == 2 * h && W == 2 * w && D == 2 * d && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && options().resize_up2 != 0) {
+        const int bx = d > 128 ? 256 : (d > 64 ? 128 : 64);
+        hipLaunchKernelGGL(k_resize_up2<3>, dim3((unsigned)cdiv(d, bx), (unsigned)w, (unsigned)h), dim3(bx), 0, s, in, h, w, d, out, pre_mul, post_div);
+        return check_last("resize_trilinear");
+    }
     const int bx = D > 128 ? 256 : (D > 64 ? 128 : 64);              // short rows: do not pad them to 256 lanes
     const dim3 grid((unsigned)cdiv(D, bx), (unsigned)W, (unsigned)H), block(bx);
     if (C == 3) hipLaunchKernelGGL(k_resize<3>, grid, block, 0, s, in, C, h, w, d, out, H, W, D, pre_mul, post_div);

@@ -316,6 +316,32 @@ def test_resize_vs_oracle(U, orc, src, dst):
     assert np.array_equal(host(U.resize_trilinear(dev(x)[None], dst))[0], orc.resize_trilinear(x, dst))
 
 
+@pytest.mark.parametrize("src", [(9, 11, 13), (1, 3, 2), (2, 1, 1), (5, 6, 130), (80, 96, 112)])
+def test_resize_factor_two_kernel(U, orc, src):
+    """Exact factor-2 up-sampling of a 3-channel field takes k_resize_up2 (2 x 2 x 2 outputs per thread from one 27-tap neighbourhood):
+    bit-identical to the oracle and to the one-thread-per-output kernel, including non-finite taps (a tap that the reference multiplies
+    by a zero weight must be the SAME tap: 0 * inf is NaN) and one-voxel axes."""
+    from convexadam_amd import _lib
+    rng = np.random.default_rng(sum(src))
+    x = rng.standard_normal((3,) + src).astype(np.float32)
+    flat = x.reshape(-1)
+    flat[rng.integers(0, flat.size, max(2, flat.size // 50))] = np.inf          # scattered non-finite taps, some on the borders
+    x[:, 0, 0, 0] = -np.inf
+    x[:, -1, -1, -1] = np.nan
+    dst = tuple(2 * s for s in src)
+    got = host(U.resize_trilinear(dev(x)[None], dst))[0]
+    _lib.lib().cvx_set_option(b"resize_up2", 0)
+    try:
+        plain = host(U.resize_trilinear(dev(x)[None], dst))[0]
+    finally:
+        _lib.lib().cvx_set_option(b"resize_up2", 1)
+    ref = orc.resize_trilinear(x, dst)
+    assert np.array_equal(got, plain, equal_nan=True) and np.array_equal(np.isnan(got), np.isnan(plain))
+    assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(np.isnan(got), np.isnan(ref))
+    y = rng.standard_normal((3,) + src).astype(np.float32)
+    assert np.array_equal(host(U.resize_trilinear(dev(y)[None], dst))[0], orc.resize_trilinear(y, dst))
+
+
 @pytest.mark.parametrize("C,src,dst", [(1, (7, 9, 40), (14, 9, 300)), (5, (6, 5, 9), (11, 13, 70)), (2, (4, 4, 4), (4, 4, 4))])
 def test_resize_channel_counts_and_long_rows(U, orc, C, src, dst):
     """The kernels specialise C = 1 and C = 3; other counts take the generic channel loop; rows longer than a workgroup."""
@@ -1261,7 +1287,7 @@ def test_device_tables_equal_the_host_helpers_and_torch():
 
 # ---- (9) every selectable kernel variant -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opt,val", [("mind_tiled", 1), ("mm_tx", 32), ("mm_tx", 64), ("mm_slots", 64), ("box_tiled", 1), ("no_prune", 1),
-                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("cf_prio", 0x9d), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0), ("box_cpt", 2), ("box_uneven", 100), ("box_prio", 1), ("mind_overlap", 1), ("corr_fused_all", 1), ("box_fwd_tile", 0), ("box_fwd_tile", 1000), ("box_fwd_tile", 2000), ("corr_dual", 1), ("prune_refine", 0), ("mind_records", 0), ("box_walk", 0), ("box_bwd_tile", 0), ("box_bwd_tile", 1000), ("box_bwd_tile", 2000)])
+                                     ("corr_unfused", 1), ("prune_stream_above", 0), ("cf_census", 1), ("cf_prio", 0x9d), ("warp_flat", 1), ("box_yt", 4), ("box_wg_target", 700), ("box_xsplit", 0), ("box_cpt", 2), ("box_uneven", 100), ("box_prio", 1), ("mind_overlap", 1), ("corr_fused_all", 1), ("box_fwd_tile", 0), ("box_fwd_tile", 1000), ("box_fwd_tile", 2000), ("corr_dual", 1), ("prune_refine", 0), ("mind_records", 0), ("resize_up2", 0), ("box_walk", 0), ("box_bwd_tile", 0), ("box_bwd_tile", 1000), ("box_bwd_tile", 2000)])
 def test_kernel_variants_agree(M, U, orc, golden, opt, val):
     """The library's run-time switches (cvx_set_option / CVX_* environment variables) select alternative kernels for the same
     operators; every one of them is bit-identical to the oracle: marching vs tiled MIND stencil and its tile shapes, marching vs tiled

@@ -5,5 +5,5 @@ for i in $(seq $N); do for x in $A $B; do
   env $V=$x python bench.py --no-cpu-baseline --no-batched 2>/dev/null | python -c "
 import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); st=d['stages_ms']
-print('$V=$x value %.1f ms %.4f mind %.3f adam_setup %.3f adam %.4f' % (d['value'], d['ms_per_step'], st['mind'], st['adam_setup'], st['adam']))"
+print('$V=$x value %.1f ms %.4f' % (d['value'], d['ms_per_step']), ' '.join('%s %.4f' % (k[:10], v) for k, v in st.items()))"
 done; done
