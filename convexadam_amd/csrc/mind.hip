@@ -533,10 +533,8 @@ __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restr
     mind_bounds(st, (double)V, lo, hi);
     const size_t tail_from = (V / 32) * 32;
     constexpr int NP = MP_TX / 2;
-    for (int i = tid; i < T * T * NP; i += MP_NT) {
-        const int xp = i % NP, y = (i / NP) % T, z = i / (NP * T);
+    auto voxel_pair = [&](int z, int y, int xp) {
         const int gz = z0 + z, gy = y0 + y, gx = x0 + 2 * xp;
-        if (gz >= H || gy >= W || gx + 1 >= D) continue;                           // (D is even) no complete window reaches these voxels
         const size_t lin = ((size_t)gz * W + gy) * D + gx;
         float r[2][12];
 #pragma unroll
@@ -551,6 +549,15 @@ __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restr
             const f32x2 v = {r[0][c], r[1][c]};
             lds_store2(E + ((MIND_INV[c] * T + z) * T + y) * MP_TX + 2 * xp, v);
         }
+    };
+    // voxels of the tile inside the volume (D is even); a tile that overhangs the volume numbers only those, so that its idle lanes
+    // fill whole wavefronts that skip the pass (the last x tile of a 224-voxel row holds 8 of 24 columns) -- no complete window reaches
+    // the others and the windows that do exist never read them
+    const int nz = min(T, H - z0), ny = min(T, W - y0), ncol = min(MP_TX, D - x0) / 2;
+    if (nz == T && ny == T && ncol == NP) {
+        for (int i = tid; i < T * T * NP; i += MP_NT) voxel_pair(i / (NP * T), (i / NP) % T, i % NP);
+    } else {
+        for (int i = tid; i < nz * ny * ncol; i += MP_NT) voxel_pair(i / (ncol * ny), (i / ncol) % ny, i % ncol);
     }
     cvx_barrier();
     constexpr int NA = 12 * (MP_TX / GA);                                          // large windows of the tile (T / GA = 1)
