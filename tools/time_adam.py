@@ -25,20 +25,21 @@ P0 = Fn.interpolate(torch.randn(1, 3, 5, 6, 7, generator=g) * 2.0, size=(h, w, d
 ref = None
 reps = int(os.environ.get("ADAM_REPS", "3"))
 mode = os.environ.get("ADAM_MODE", "fast")            # the bench's timed mode
+storage = os.environ.get("ADAM_STORAGE", "fp32")
 for spec in sys.argv[1:] or [""]:
     opts = dict(kv.split("=") for kv in spec.split(",") if kv)
     old = {k: L.cvx_get_option(k.encode()) for k in opts}
     for k, v in opts.items():
         assert L.cvx_set_option(k.encode(), int(v)) == 0, k
     try:
-        out, st = U.adam_run(F2, M2, P0, 1.25, 5, return_state=True, mode=mode)
+        out, st = U.adam_run(F2, M2, P0, 1.25, 5, return_state=True, mode=mode, storage=storage)
         torch.cuda.synchronize()
         hsh = hashlib.md5(out.cpu().numpy().tobytes()).hexdigest() + hashlib.md5(st["P"].cpu().numpy().tobytes()).hexdigest()
         ref = ref or hsh
         best = 1e9
         for _ in range(reps):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(); U.adam_run(F2, M2, P0, 1.25, 80, return_state=True, mode=mode); e1.record(); torch.cuda.synchronize()
+            e0.record(); U.adam_run(F2, M2, P0, 1.25, 80, return_state=True, mode=mode, storage=storage); e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / 80 * 1e3)
         print("%-50s %7.1f us / iteration   same bits: %s" % (spec or "(default)", best, hsh == ref), flush=True)
     finally:
