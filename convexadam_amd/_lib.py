@@ -135,6 +135,8 @@ SIGNATURES = {
     "cvx_label_bits_bytes": (_sz, [_i, _i, _i, _i]),
     "cvx_label_bits_u64": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cvx_surface_distance_hist_i64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i, _i, _vp]),
+    "cvx_surface_distance_hist_bits_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "cvx_surface_distance_hist_bits_i64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i, _i, _vp, _sz, _vp]),
 }
 
 _lib = None

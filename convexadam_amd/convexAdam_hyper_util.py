@@ -20,6 +20,7 @@ convex_run_paired_mind.py:167-173): warp_labels_nearest, jacobian_log_std_and_fo
 cupy_hd95(fixed, moving, num_labels, precision=1)    :32-51   (device feature transforms + histogram percentile)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -258,6 +259,7 @@ def edt_squared(obj):
 # cupy_hd95(method="surface"): rows searched around a surface voxel before the call falls back to the distance transforms (the cost of a
 # voxel grows with the square of its distance to the other surface; the transforms' cost does not depend on it)
 HD95_SURFACE_MAX_RADIUS = 48
+HD95_SURFACE_KERNEL = os.environ.get("CONVEXADAM_HD95_KERNEL", "bits")      # "bits" | "voxels" (csrc/surfdist.hip)
 
 
 def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=None, counts=None):
@@ -363,10 +365,19 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=N
                     act[lab >> 6] |= 1 << (lab & 63)
                 act4 = (C.c_uint64 * 4)(*act)
                 # k = 0: dist1[surf2] (surface of the moving map against the fixed planes), k = 1: dist2[surf1] (:48)
-                for k, (seg_b, bits_a) in enumerate(((mv, bits_f), (fx, bits_m))):
-                    check(L.cvx_surface_distance_hist_i64(ptr(seg_b), ptr(bits_a), H, W, D, nl, C.cast(act4, C.c_void_p), nbins,
-                                                          C.c_void_p(hist.data_ptr() + 8 * k * nbins), 2 * nbins,
-                                                          C.c_void_p(flag.data_ptr() + 4 * k), 2, int(HD95_SURFACE_MAX_RADIUS), sp))
+                # (HD95_SURFACE_KERNEL = "bits", the default: both maps as bit planes, 64 voxels per thread; "voxels": one lane per voxel of
+                # the label map -- the round-4 kernel, same counts)
+                nws = int(L.cvx_surface_distance_hist_bits_workspace_bytes(H, W, D, nl)) if HD95_SURFACE_KERNEL == "bits" else 0
+                ws = workspace(nws, dev) if nws else None
+                for k, (seg_b, bits_b, bits_a) in enumerate(((mv, bits_m, bits_f), (fx, bits_f, bits_m))):
+                    if HD95_SURFACE_KERNEL == "bits":
+                        check(L.cvx_surface_distance_hist_bits_i64(ptr(bits_b), ptr(bits_a), H, W, D, nl, C.cast(act4, C.c_void_p), nbins,
+                                                                   C.c_void_p(hist.data_ptr() + 8 * k * nbins), 2 * nbins,
+                                                                   C.c_void_p(flag.data_ptr() + 4 * k), 2, int(HD95_SURFACE_MAX_RADIUS), ptr(ws), nws, sp))
+                    else:
+                        check(L.cvx_surface_distance_hist_i64(ptr(seg_b), ptr(bits_a), H, W, D, nl, C.cast(act4, C.c_void_p), nbins,
+                                                              C.c_void_p(hist.data_ptr() + 8 * k * nbins), 2 * nbins,
+                                                              C.c_void_p(flag.data_ptr() + 4 * k), 2, int(HD95_SURFACE_MAX_RADIUS), sp))
                 quant = float(np.true_divide(95, np.float32(100)))               # numpy: q / float32(100) for float32 data
                 check(L.cvx_hist_percentile_neighbours_batch_i64(ptr(hist), nbins, 2 * nl, quant, ptr(out3), sp))
                 host = tail.cpu().numpy()

@@ -210,6 +210,306 @@ __global__ __launch_bounds__(256) void k_surface_dist_hist(const float* __restri
     }
 }
 
+
+// ---- the same histogram from the bit planes of BOTH maps, 64 voxels per thread (round 5) ----------------------------------------------
+// k_surface_dist_hist spends one lane per voxel on window extraction and, beyond squared distance 8, one wavefront per voxel on a ring
+// search: 275 us on a well registered 160x192x224 pair of 17 labels, 1.07 ms at an HD95 of 6 (30 % of the two-stage sweep).  With the
+// planes of map b at hand as well (cupy_hd95 builds both for the two directions anyway) the whole thing is word arithmetic:
+//   k_surf_words   one thread per word of b's planes: surface = S & ~(the six in-bounds neighbours are all in S); the non-zero words of the
+//                  active labels go to a compact list (a few per cent of the 2 M words)
+//   k_surf_levels  one thread per listed word.  The 64 surface bits split into those outside the label in map a (target: a's set bits)
+//                  and inside (target: the zero bits of a that are voxels).  Stage A: the 3 x 3 rows around the word's row, shifts by
+//                  0 .. 1 along D -> one mask per squared distance 1, 2, 3 ("some target lies exactly there"); the bits are counted at the
+//                  FIRST level that covers them.  Stage B (only while bits are left): the offsets (dh, dw, dz) of the cube of radius 7 in
+//                  order of their squared distance 4 .. 63 (a table), one level mask per distance.  A cube of radius R holds every voxel
+//                  at squared distance < (R + 1)^2, so every level is exact.  What is left after level 63 goes to a list of far voxels.
+//   k_surf_far     one wavefront per far voxel: the ring search of k_surface_dist_hist (64 rows per step, exact, stops at r^2 >= best).
+// Same counts as k_surface_dist_hist bit for bit (tests/test_gpu_parity.py::test_hd95_*: equal to the transform method).
+struct SurfWord { unsigned long long surf; unsigned at; unsigned q; };          // at = row * nseg + sg, q = label
+// Both work lists are SURF_NL sub-lists with a counter each: appends to ONE counter serialise in the L2 (measured: ~10 ns per returning
+// atomic on the same address -- 19 000 wavefront appends took 207 us), 256 counters on different lines do not
+constexpr int SURF_NL = 256;
+struct SurfLists { SurfWord* words[3]; unsigned long long* far; unsigned* n_words[3]; unsigned* n_far; unsigned cap_words, cap_far; };   // n_*: [SURF_NL], cap_*: per sub-list; words[s] = input of stage s
+
+__global__ __launch_bounds__(256) void k_surf_words(const unsigned long long* __restrict__ bits_b, int H, int W, int D, int nseg, int nl,
+                                                    ActiveLabels act, SurfLists L) {
+    const size_t per = (size_t)H * W * nseg;              // (< 2^31: checked by the caller)
+    const int q = (int)blockIdx.y + 1;                    // grid.y = label plane
+    if (!((act.m[q >> 6] >> (q & 63)) & 1ull)) return;
+    const unsigned at = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long surf = 0ull;
+    if (at < per) {
+        const int row = (int)(at / (unsigned)nseg), sg = (int)(at - (unsigned)row * nseg), h = row / W, w = row - h * W;
+        const unsigned long long* B = bits_b + (size_t)(q - 1) * per;
+        const unsigned long long S = B[at];
+        if (S) {
+            // bit z of a neighbour mask: the neighbour of voxel z in that direction carries the label too -- or does not exist (the
+            // reference compares with in-bounds neighbours only)
+            const unsigned long long zm = (S << 1) | (sg > 0 ? B[at - 1] >> 63 : 1ull);
+            unsigned long long zp = (S >> 1) | (sg + 1 < nseg ? B[at + 1] << 63 : 0ull);
+            if (sg == nseg - 1) zp |= 1ull << ((D - 1) & 63);
+            const unsigned long long wm = w > 0 ? B[at - nseg] : ~0ull, wp = w + 1 < W ? B[at + nseg] : ~0ull;
+            const unsigned long long hm = h > 0 ? B[at - (size_t)W * nseg] : ~0ull, hp = h + 1 < H ? B[at + (size_t)W * nseg] : ~0ull;
+            surf = S & ~(zm & zp & wm & wp & hm & hp);
+        }
+    }
+    // one counter update per wavefront; its entries stay together and in word order (the lanes of k_surf_levels then read neighbouring words)
+    const unsigned long long has = __ballot(surf != 0ull);
+    if (!has) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0u;
+    const unsigned sub = (blockIdx.x * 4u + (threadIdx.x >> 6)) % (unsigned)SURF_NL;
+    if (lane == __builtin_ctzll(has)) base = atomicAdd(&L.n_words[0][sub], (unsigned)__builtin_popcountll(has));
+    base = __shfl(base, __builtin_ctzll(has));
+    if (surf) {
+        const unsigned slot = base + (unsigned)__builtin_popcountll(has & ((1ull << lane) - 1ull));
+        if (slot < L.cap_words) L.words[0][(size_t)sub * L.cap_words + slot] = SurfWord{surf, at, (unsigned)q};
+        // (a full sub-list: k_surf_levels sees the counter above the capacity and flags every active label)
+    }
+}
+
+// target words (previous, own, next segment of one row) shifted by dz in both directions: bit z set <=> a target at z - dz or z + dz
+__device__ __forceinline__ unsigned long long surf_hit(unsigned long long tp, unsigned long long t, unsigned long long tn, int dz) {
+    if (dz == 0) return t;
+    return (t << dz) | (tp >> (64 - dz)) | (t >> dz) | (tn << (64 - dz));
+}
+
+// stages B and C as a table: the (dh, dw, dz >= 0) inside the cube of radius SURF_R with SURF_K0 <= dh^2 + dw^2 + dz^2 < (SURF_R + 1)^2, ordered by
+// squared distance (counting sort at compile time) -- a rolled loop that ends as soon as the word has no bits left
+constexpr int SURF_MIN_LANES = 12;
+constexpr int SURF_R = 7, SURF_K0 = 4, SURF_K1 = (SURF_R + 1) * (SURF_R + 1) - 1, SURF_TMAX = 1280;
+struct SurfTable { unsigned e[SURF_TMAX]; int n; };      // entry = k << 24 | dz << 16 | (dw + 8) << 8 | (dh + 8): one scalar load per entry
+constexpr SurfTable surf_make_table() {
+    SurfTable t{};
+    int first[SURF_K1 + 2] = {};
+    for (int dh = -SURF_R; dh <= SURF_R; ++dh)
+        for (int dw = -SURF_R; dw <= SURF_R; ++dw)
+            for (int dz = 0; dz <= SURF_R; ++dz) {
+                const int k = dh * dh + dw * dw + dz * dz;
+                if (k >= SURF_K0 && k <= SURF_K1) ++first[k + 1];
+            }
+    for (int k = 1; k <= SURF_K1 + 1; ++k) first[k] += first[k - 1];
+    t.n = first[SURF_K1 + 1];
+    for (int dh = -SURF_R; dh <= SURF_R; ++dh)
+        for (int dw = -SURF_R; dw <= SURF_R; ++dw)
+            for (int dz = 0; dz <= SURF_R; ++dz) {
+                const int k = dh * dh + dw * dw + dz * dz;
+                if (k >= SURF_K0 && k <= SURF_K1) {
+                    const int at = first[k]++;
+                    t.e[at] = ((unsigned)k << 24) | ((unsigned)dz << 16) | ((unsigned)(dw + 8) << 8) | (unsigned)(dh + 8);
+                }
+            }
+    return t;
+}
+static_assert(surf_make_table().n <= SURF_TMAX, "table size");
+constexpr int surf_first_ge(int k) { const SurfTable t = surf_make_table(); int i = 0; while (i < t.n && (int)(t.e[i] >> 24) < k) ++i; return i; }
+constexpr int SURF_T9 = surf_first_ge(9);          // entries [0, SURF_T9): squared distances 4 .. 8 (the cube of radius 2)
+__constant__ SurfTable SURF_T = surf_make_table();
+
+// level masks of one cube: rows |dh|, |dw| <= R, shifts 0 .. R, squared distances KLO .. KHI (all loops unrolled: the level index of a
+// (row, shift) is a compile-time constant, combinations outside KLO .. KHI vanish).  LO: targets = set bits, LI: targets = zero bits.
+template <int R, int KLO, int KHI>
+__device__ __forceinline__ void surf_cube(const unsigned long long* __restrict__ PA, int H, int W, int nseg, int h, int w, int sg,
+                                          unsigned long long vmp, unsigned long long vm, unsigned long long vmn,
+                                          unsigned long long (&LO)[KHI - KLO + 1], unsigned long long (&LI)[KHI - KLO + 1]) {
+#pragma unroll
+    for (int dh = -R; dh <= R; ++dh)
+#pragma unroll
+        for (int dw = -R; dw <= R; ++dw) {
+            const int base2 = dh * dh + dw * dw;
+            if (base2 > KHI) continue;
+            // (a row that contributed every shift it can to the levels below KLO in an earlier stage still has larger shifts to give)
+            if (base2 + R * R < KLO) continue;
+            const int hh = h + dh, ww = w + dw;
+            const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const unsigned long long* rb = PA + ((size_t)(ok ? hh : h) * W + (ok ? ww : w)) * nseg + sg;
+            unsigned long long m = rb[0], mp = sg > 0 ? rb[-1] : 0ull, mn = sg + 1 < nseg ? rb[1] : 0ull;
+            const unsigned long long okm = ok ? ~0ull : 0ull;
+            const unsigned long long c = ~m & vm & okm, cp = ~mp & vmp & okm, cn = ~mn & vmn & okm;
+            m &= okm; mp &= okm; mn &= okm;
+#pragma unroll
+            for (int dz = 0; dz <= R; ++dz) {
+                const int k = base2 + dz * dz;
+                if (k < KLO || k > KHI) continue;
+                LO[k - KLO] |= surf_hit(mp, m, mn, dz);
+                LI[k - KLO] |= surf_hit(cp, c, cn, dz);
+            }
+        }
+}
+
+// STAGE 0: levels 1 .. 3 (unrolled 3 x 3 cube) of every surface word; 1: levels 4 .. 8 of the words that still hold bits; 2: levels 9 .. 63 of
+// what is left after that, then the far list.  Three launches with a compaction in between: a wavefront waits for its slowest word, so the
+// few words that need the long tail of the table must not sit in wavefronts of finished ones.
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_surf_levels(const unsigned long long* __restrict__ bits_a, int H, int W, int D, int nseg, int nl,
+                                                     int nbins, unsigned long long* __restrict__ hist_all, size_t hist_stride,
+                                                     int* __restrict__ overflow_all, int overflow_stride, SurfLists L) {
+    constexpr int LL = 64, LB = 64;
+    __shared__ unsigned int low[LL * LB];
+    for (int i = threadIdx.x; i < LL * LB; i += blockDim.x) low[i] = 0;
+    cvx_barrier();
+    const size_t per = (size_t)H * W * nseg;
+    // workgroup (sub-list, part): grid = SURF_NL x parts
+    const unsigned sub = blockIdx.x % (unsigned)SURF_NL, part = blockIdx.x / (unsigned)SURF_NL, parts = gridDim.x / (unsigned)SURF_NL;
+    const unsigned n_all = L.n_words[STAGE][sub], n = min(n_all, L.cap_words);
+    if (n_all > L.cap_words && part == 0 && threadIdx.x < (unsigned)nl) atomicMax(&overflow_all[(size_t)threadIdx.x * overflow_stride], 2);   // lost words: hand over
+    const unsigned long long tail = (D & 63) ? (1ull << (D & 63)) - 1ull : ~0ull;
+    for (unsigned e0 = part * blockDim.x; e0 < n; e0 += parts * blockDim.x) {          // (uniform trip count: the body holds wavefront-wide ballots)
+        const unsigned e = e0 + threadIdx.x;
+        const bool live = e < n;
+        const SurfWord wd = live ? L.words[STAGE][(size_t)sub * L.cap_words + e] : SurfWord{0ull, 0u, 1u};
+        const int q = (int)wd.q, row = (int)(wd.at / (unsigned)nseg), sg = (int)(wd.at - (unsigned)row * nseg), h = row / W, w = row - h * W;
+        const unsigned long long* PA = bits_a + (size_t)(q - 1) * per;
+        const unsigned long long A0 = PA[wd.at];
+        unsigned long long rem_o = wd.surf & ~A0, rem_i = wd.surf & A0;         // outside l in map a: nearest set bit; inside: nearest zero bit
+        // which bit positions of the three segments are voxels
+        const unsigned long long vm = sg == nseg - 1 ? tail : ~0ull, vmp = sg > 0 ? ~0ull : 0ull,
+                                 vmn = sg + 1 < nseg ? (sg + 1 == nseg - 1 ? tail : ~0ull) : 0ull;
+        auto settle = [&](int k, unsigned long long lo, unsigned long long li) {
+            const unsigned c = (unsigned)(__builtin_popcountll(rem_o & lo) + __builtin_popcountll(rem_i & li));
+            rem_o &= ~lo; rem_i &= ~li;
+            if (!c) return;
+            if (k >= nbins) atomicMax(&overflow_all[(size_t)(q - 1) * overflow_stride], 1);
+            else if (q <= LL && k < LB) atomicAdd(&low[(q - 1) * LB + k], c);
+            else atomicAdd(&hist_all[(size_t)(q - 1) * hist_stride + k], (unsigned long long)c);
+        };
+        if (STAGE == 0) {
+            unsigned long long LO[3] = {0, 0, 0}, LI[3] = {0, 0, 0};
+            surf_cube<1, 1, 3>(PA, H, W, nseg, h, w, sg, vmp, vm, vmn, LO, LI);
+#pragma unroll
+            for (int k = 1; k <= 3; ++k) settle(k, LO[k - 1], LI[k - 1]);
+        } else {
+            // batches of NB table entries: their 3 NB loads are in flight together (one entry at a time the loop ran at one memory round
+            // trip per entry: ~100 us for a word that goes through the whole table)
+            constexpr int NB = 8;
+            const int nt = STAGE == 1 ? SURF_T9 : SURF_T.n;
+            int cur_k = STAGE == 1 ? SURF_K0 : 9;
+            unsigned long long lo = 0ull, li = 0ull;
+            for (int t0 = STAGE == 1 ? 0 : SURF_T9; t0 < nt && (rem_o | rem_i); t0 += NB) {
+                // the table pays per wavefront (every lane waits for the slowest word), the ring search per voxel: beyond the cube of
+                // radius 2 the table goes on only while a fair share of the wavefront still has bits left
+                if (STAGE == 2 && __builtin_popcountll(__ballot((rem_o | rem_i) != 0ull)) < SURF_MIN_LANES) break;
+                unsigned long long m[NB], mp[NB], mn[NB];
+                unsigned ent[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    ent[j] = SURF_T.e[min(t0 + j, nt - 1)];
+                    const int hh = h + (int)(ent[j] & 255u) - 8, ww = w + (int)((ent[j] >> 8) & 255u) - 8;
+                    const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;           // (a row outside the volume is skipped below: any valid address will do)
+                    const unsigned long long* rb = PA + ((size_t)(ok ? hh : h) * W + (ok ? ww : w)) * nseg + sg;
+                    m[j] = rb[0];
+                    mp[j] = sg > 0 ? rb[-1] : 0ull;
+                    mn[j] = sg + 1 < nseg ? rb[1] : 0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (t0 + j >= nt) break;
+                    const int k = (int)(ent[j] >> 24), dz = (int)((ent[j] >> 16) & 255u);
+                    const int hh = h + (int)(ent[j] & 255u) - 8, ww = w + (int)((ent[j] >> 8) & 255u) - 8;
+                    const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                    if (k != cur_k) { settle(cur_k, lo, li); lo = 0ull; li = 0ull; cur_k = k; }
+                    if (!ok) continue;
+                    lo |= surf_hit(mp[j], m[j], mn[j], dz);
+                    li |= surf_hit(~mp[j] & vmp, ~m[j] & vm, ~mn[j] & vmn, dz);
+                }
+            }
+            settle(cur_k, lo, li);
+        }
+        unsigned long long rest = rem_o | rem_i;
+        if (STAGE < 2) {                     // words with bits left: input of the next stage (one counter update per wavefront)
+            const unsigned long long has = __ballot(rest != 0ull);
+            if (has) {
+                const int lane = threadIdx.x & 63, leader = __builtin_ctzll(has);
+                unsigned base = 0u;
+                if (lane == leader) base = atomicAdd(&L.n_words[STAGE < 2 ? STAGE + 1 : 0][sub], (unsigned)__builtin_popcountll(has));
+                base = __shfl(base, leader);
+                if (rest) {
+                    const unsigned slot = base + (unsigned)__builtin_popcountll(has & ((1ull << lane) - 1ull));
+                    if (slot < L.cap_words) L.words[STAGE < 2 ? STAGE + 1 : 0][(size_t)sub * L.cap_words + slot] = SurfWord{rest, wd.at, wd.q};
+                }
+            }
+        } else if (rest) {                   // far voxels: (label, row, z) for the ring search
+            const unsigned fsub = (sub * 7u + (threadIdx.x >> 4)) % (unsigned)SURF_NL;
+            unsigned slot = atomicAdd(&L.n_far[fsub], (unsigned)__builtin_popcountll(rest));
+            while (rest) {
+                const int b = __builtin_ctzll(rest);
+                rest &= rest - 1ull;
+                if (slot < L.cap_far) L.far[(size_t)fsub * L.cap_far + slot] = ((unsigned long long)q << 56) | ((unsigned long long)(sg * 64 + b) << 32) | (unsigned)row;
+                else atomicMax(&overflow_all[(size_t)(q - 1) * overflow_stride], 2);             // list full: the label is handed to the transforms
+                ++slot;
+            }
+        }
+    }
+    cvx_barrier();
+    for (int i = threadIdx.x; i < LL * LB; i += blockDim.x) {
+        const int q = i / LB, bin = i - q * LB;
+        if (low[i] && q < nl && bin < nbins) atomicAdd(&hist_all[(size_t)q * hist_stride + bin], (unsigned long long)low[i]);
+    }
+}
+
+// one wavefront per far voxel (squared distance >= 64): rows in square rings around its row, 64 rows per step
+__global__ __launch_bounds__(256) void k_surf_far(const unsigned long long* __restrict__ bits_a, int H, int W, int D, int nseg, int nbins,
+                                                  unsigned long long* __restrict__ hist_all, size_t hist_stride, int* __restrict__ overflow_all,
+                                                  int overflow_stride, int max_radius, SurfLists L) {
+    constexpr int LL = 64, LB = 128;
+    __shared__ unsigned int low[LL * LB];
+    const int nrows = H * W, lane = threadIdx.x & 63;
+    const unsigned sub = blockIdx.x % (unsigned)SURF_NL, part = blockIdx.x / (unsigned)SURF_NL, parts = gridDim.x / (unsigned)SURF_NL;
+    const unsigned n = min(L.n_far[sub], L.cap_far);
+    if (part * (blockDim.x >> 6) >= n) return;             // nothing for this workgroup (before the 32 KB of LDS are cleared and flushed)
+    for (int i = threadIdx.x; i < LL * LB; i += blockDim.x) low[i] = 0;
+    cvx_barrier();
+    const unsigned wave0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(part * (blockDim.x >> 6) + (threadIdx.x >> 6))), nw = parts * (blockDim.x >> 6);
+    for (unsigned e = wave0; e < n; e += nw) {
+        const unsigned long long it = L.far[(size_t)sub * L.cap_far + e];
+        const int ql = (int)(it >> 56), z = (int)((it >> 32) & 0xffffffu), row = (int)(unsigned)(it & 0xffffffffull);
+        const int h = row / W, w = row - h * W;
+        // a label that has already exceeded the radius is void for the caller (flag 2): its other far voxels are skipped.  A plain load: a stale
+        // value only costs the searches it would have saved (the agent-scope atomic load here was a memory round trip per voxel)
+        if (max_radius > 0 && overflow_all[(size_t)(ql - 1) * overflow_stride] == 2) continue;
+        const unsigned long long* plane = bits_a + (size_t)(ql - 1) * nrows * nseg;
+        const bool inside = (plane[(size_t)row * nseg + (z >> 6)] >> (z & 63)) & 1ull;
+        const int rmax = max(max(h, H - 1 - h), max(w, W - 1 - w));
+        int best = INT_MAX;
+        bool gave_up = false;
+        for (int i0 = 0;; i0 += 64) {
+            const int idx = i0 + lane;
+            int s = (int)sqrtf((float)idx);                                       // floor(sqrt(idx)); idx < 2^24
+            if (s * s > idx) --s;
+            if ((s + 1) * (s + 1) <= idx) ++s;
+            const int r = (s + 1) >> 1;                                           // ring of cell idx: smallest r with (2r+1)^2 > idx
+            const int r0 = __shfl(r, 0);
+            if (r0 > rmax || (long long)r0 * r0 >= best) break;
+            if (max_radius > 0 && r0 > max_radius) { gave_up = true; break; }
+            int dh = 0, dw = 0;
+            if (r > 0) {
+                const int t = idx - (2 * r - 1) * (2 * r - 1), side = t / (2 * r), pos = t - side * 2 * r;
+                dh = side == 0 ? -r + pos : side == 1 ? r : side == 2 ? r - pos : -r;
+                dw = side == 0 ? -r : side == 1 ? -r + pos : side == 2 ? r : r - pos;
+            }
+            const int hh = h + dh, ww = w + dw, base2 = dh * dh + dw * dw;
+            int cand = INT_MAX;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W && base2 < best) {
+                const int g = nearest_in_row(plane + ((size_t)hh * W + ww) * nseg, nseg, D, z, inside);
+                if (g != INT_MAX) cand = base2 + g * g;
+            }
+            for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+            best = min(best, cand);
+        }
+        if (lane == 0) {
+            if (gave_up) atomicMax(&overflow_all[(size_t)(ql - 1) * overflow_stride], 2);
+            else if (best < 0 || best >= nbins) atomicMax(&overflow_all[(size_t)(ql - 1) * overflow_stride], 1);   // no voxel of the wanted kind in map a
+            else if (ql <= LL && best < LB) atomicAdd(&low[(ql - 1) * LB + best], 1u);
+            else atomicAdd(&hist_all[(size_t)(ql - 1) * hist_stride + best], 1ull);
+        }
+    }
+    cvx_barrier();
+    for (int i = threadIdx.x; i < LL * LB; i += blockDim.x) {
+        const int q = i / LB, bin = i - q * LB;
+        if (low[i] && bin < nbins) atomicAdd(&hist_all[(size_t)q * hist_stride + bin], (unsigned long long)low[i]);
+    }
+}
+
 }  // namespace cvx
 
 using namespace cvx;
@@ -245,3 +545,48 @@ extern "C" int cvx_surface_distance_hist_i64(const float* seg_b, const uint64_t*
                        reinterpret_cast<unsigned long long*>(hist), (size_t)hist_stride, overflow, overflow_stride, max_radius);
     return check_last("surface_distance_hist");
 }
+
+// bits_b / bits_a = cvx_label_bits_u64 of the two maps; otherwise as cvx_surface_distance_hist_i64 (same counts, same flags)
+extern "C" size_t cvx_surface_distance_hist_bits_workspace_bytes(int H, int W, int D, int num_labels) {
+    if (H <= 0 || W <= 0 || D <= 0 || num_labels <= 0) return 0;
+    const size_t words = (size_t)num_labels * H * W * ((D + 63) / 64);
+    (void)words;
+    const size_t cap_words = (size_t)1 << 14, cap_far = (size_t)1 << 14;       // per sub-list: 4 M surface words / far voxels in all; beyond that the call reports flag 2
+    return 256 + sizeof(unsigned) * 4 * SURF_NL + 3 * (256 + sizeof(SurfWord) * cap_words * SURF_NL) + 256 + sizeof(unsigned long long) * cap_far * SURF_NL + 256;
+}
+
+extern "C" int cvx_surface_distance_hist_bits_i64(const uint64_t* bits_b, const uint64_t* bits_a, int H, int W, int D, int num_labels,
+                                                  const uint64_t* active4, int nbins, int64_t* hist, int64_t hist_stride, int* overflow,
+                                                  int overflow_stride, int max_radius, void* workspace, size_t workspace_bytes, void* stream) {
+    CVX_REQUIRE(bits_b && bits_a && hist && overflow && active4 && workspace && H > 0 && W > 0 && D > 0 && num_labels > 0 && num_labels <= 255 &&
+                    nbins > 0 && hist_stride >= nbins && overflow_stride >= 1 && max_radius >= 0,
+                "cvx_surface_distance_hist_bits_i64: bad arguments (1 .. 255 labels)");
+    CVX_REQUIRE(H <= 2047 && W <= 2047 && D <= 32768, "cvx_surface_distance_hist_bits_i64: extent too large (H, W <= 2047, D <= 32768)");
+    if (workspace_bytes < cvx_surface_distance_hist_bits_workspace_bytes(H, W, D, num_labels))
+        return fail(CVX_ERR_WORKSPACE, "cvx_surface_distance_hist_bits_i64: workspace too small");
+    ActiveLabels act;
+    for (int i = 0; i < 4; ++i) act.m[i] = active4[i];
+    const int nseg = (D + 63) / 64;
+    const size_t words = (size_t)num_labels * H * W * nseg;
+    CVX_REQUIRE((int64_t)H * W * nseg <= INT_MAX - 65536 && words < ((size_t)1 << 32), "cvx_surface_distance_hist_bits_i64: volume too large");
+    hipStream_t s = as_stream(stream);
+    Carver cv(workspace, workspace_bytes);
+    unsigned* counters = cv.take<unsigned>(4 * SURF_NL);
+    SurfLists L;
+    L.cap_words = 1u << 14;
+    L.cap_far = 1u << 14;
+    for (int i = 0; i < 3; ++i) { L.words[i] = cv.take<SurfWord>((size_t)L.cap_words * SURF_NL); L.n_words[i] = counters + i * SURF_NL; }
+    L.far = cv.take<unsigned long long>((size_t)L.cap_far * SURF_NL);
+    L.n_far = counters + 3 * SURF_NL;
+    if (hipMemsetAsync(counters, 0, 4 * SURF_NL * sizeof(unsigned), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "surface_distance_hist_bits: memset failed");
+    const unsigned long long* Bb = reinterpret_cast<const unsigned long long*>(bits_b);
+    const unsigned long long* Ba = reinterpret_cast<const unsigned long long*>(bits_a);
+    unsigned long long* hh = reinterpret_cast<unsigned long long*>(hist);
+    hipLaunchKernelGGL(k_surf_words, dim3((unsigned)cdiv64((int64_t)H * W * nseg, 256), (unsigned)num_labels), dim3(256), 0, s, Bb, H, W, D, nseg, num_labels, act, L);
+    hipLaunchKernelGGL(k_surf_levels<0>, dim3(SURF_NL * 4), dim3(256), 0, s, Ba, H, W, D, nseg, num_labels, nbins, hh, (size_t)hist_stride, overflow, overflow_stride, L);
+    hipLaunchKernelGGL(k_surf_levels<1>, dim3(SURF_NL * 4), dim3(256), 0, s, Ba, H, W, D, nseg, num_labels, nbins, hh, (size_t)hist_stride, overflow, overflow_stride, L);
+    hipLaunchKernelGGL(k_surf_levels<2>, dim3(SURF_NL * 4), dim3(256), 0, s, Ba, H, W, D, nseg, num_labels, nbins, hh, (size_t)hist_stride, overflow, overflow_stride, L);
+    hipLaunchKernelGGL(k_surf_far, dim3(SURF_NL * 8), dim3(256), 0, s, Ba, H, W, D, nseg, nbins, hh, (size_t)hist_stride, overflow, overflow_stride, max_radius, L);
+    return check_last("surface_distance_hist_bits");
+}
+

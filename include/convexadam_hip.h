@@ -473,6 +473,13 @@ size_t cvx_label_bits_bytes(int H, int W, int D, int num_labels);
 int cvx_label_bits_u64(const float* seg, int H, int W, int D, int num_labels, uint64_t* bits, void* stream);
 int cvx_surface_distance_hist_i64(const float* seg_b, const uint64_t* bits_a, int H, int W, int D, int num_labels, const uint64_t* active4,
                                   int nbins, int64_t* hist, int64_t hist_stride, int* overflow, int overflow_stride, int max_radius, void* stream);
+/* the same histogram from the bit planes of BOTH maps (bits_b = cvx_label_bits_u64 of the map whose surface is walked): 64 voxels per
+ * thread, squared distances up to 24 by word arithmetic on the planes, a ring search per voxel only beyond (csrc/surfdist.hip).  Counts
+ * and flags as cvx_surface_distance_hist_i64 (flag 2 also when the internal work lists overflow) */
+size_t cvx_surface_distance_hist_bits_workspace_bytes(int H, int W, int D, int num_labels);
+int cvx_surface_distance_hist_bits_i64(const uint64_t* bits_b, const uint64_t* bits_a, int H, int W, int D, int num_labels,
+                                       const uint64_t* active4, int nbins, int64_t* hist, int64_t hist_stride, int* overflow,
+                                       int overflow_stride, int max_radius, void* workspace, size_t workspace_bytes, void* stream);
 
 #pragma GCC visibility pop
 
