@@ -389,8 +389,9 @@ def main(argv=None):
                          "gradient and the adjoint smoother, forward smoother / regulariser / update in the reference's order; fast_all = separable forward "
                          "smoother too (fastest; further from the reference's fields -- offered because the sweep grades by overlap scores, which agreed to "
                          "three digits between the modes on the synthetic label maps, not the default since round 5)")
-    ap.add_argument("--workers", type=int, default=0, help="items in flight per rank, each on its own thread and HIP stream (0 = automatic = 1: since round 4 "
-                    "the evaluation kernels fill the GPU on their own -- 2.67 s with one worker, 2.96 s with two on the 48-item example)")
+    ap.add_argument("--workers", type=int, default=0, help="items in flight per rank, each on its own thread and HIP stream (0 = automatic = 3: the host side of "
+                    "an item -- two synchronisations per evaluation, Python between the launches -- is a fifth of its time since the evaluation kernels "
+                    "got short; measured on the 192-item example, alternating runs: 38-42 items/s with one worker, 43-44 with two, 45-55 with three or four)")
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", 0))
@@ -403,7 +404,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     two_stage = a.stage1 > 0
-    n_workers = a.workers if a.workers > 0 else 1
+    n_workers = a.workers if a.workers > 0 else (3 if use_gpu else 1)
     queue = WorkQueue(rank, world)
     run_id = dict(shape=list(a.shape), pairs=a.pairs, stage1=a.stage1, stage2=a.stage2, settings=a.settings, niter=a.niter, evaluate=bool(a.evaluate),
                   dry_run=bool(a.dry_run), adam_mode=a.adam_mode)

@@ -1225,7 +1225,7 @@ def test_two_stage_sweep_on_the_device(tmp_path):
     s = json.loads(out.read_text())
     assert s["stage1"]["n_items"] == 3 and s["stage2"]["n_items"] == 2 and s["stage2"]["evaluations"] == 32
     lines = [json.loads(l) for l in open(str(out) + ".rank0.jsonl")]
-    assert "header" in lines[0] and s["workers_per_rank"] == 1          # one worker per GPU by default since round 4 (the evaluation kernels fill the chip)
+    assert "header" in lines[0] and s["workers_per_rank"] == 3          # three items in flight per GPU by default since round 5 (they hide each other's host side)
     lines = lines[1:]
     assert len(lines) == 5 and all("ms" in l or "evals" in l for l in lines)
     conv = [l for l in lines if l["stage"] == "convex"]
