@@ -63,7 +63,10 @@ def surface_hist_numpy(seg_b, seg_a, nl, active, nbins):
     return hist, over
 
 
-def run_surface_hist(seg_b, seg_a, nl, active, max_radius=0):
+KERNELS = ("voxels", "bits")            # cvx_surface_distance_hist_i64 (one lane per voxel of map b) / _bits_i64 (word arithmetic on both maps' planes, round 5)
+
+
+def run_surface_hist(seg_b, seg_a, nl, active, max_radius=0, kernel="voxels"):
     from convexadam_amd._lib import check, lib, ptr, stream_ptr
     L = lib()
     H, W, D = seg_a.shape
@@ -78,12 +81,21 @@ def run_surface_hist(seg_b, seg_a, nl, active, max_radius=0):
     for lab in active:
         act[lab >> 6] |= 1 << (lab & 63)
     act4 = (C.c_uint64 * 4)(*act)
-    check(L.cvx_surface_distance_hist_i64(ptr(b), ptr(bits), H, W, D, nl, C.cast(act4, C.c_void_p), nbins, ptr(hist), nbins, ptr(over), 1, max_radius, sp))
+    if kernel == "bits":
+        bits_b = torch.empty_like(bits)
+        check(L.cvx_label_bits_u64(ptr(b), H, W, D, nl, ptr(bits_b), sp))
+        nws = int(L.cvx_surface_distance_hist_bits_workspace_bytes(H, W, D, nl))
+        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+        check(L.cvx_surface_distance_hist_bits_i64(ptr(bits_b), ptr(bits), H, W, D, nl, C.cast(act4, C.c_void_p), nbins, ptr(hist), nbins, ptr(over), 1,
+                                                   max_radius, ptr(ws), nws, sp))
+    else:
+        check(L.cvx_surface_distance_hist_i64(ptr(b), ptr(bits), H, W, D, nl, C.cast(act4, C.c_void_p), nbins, ptr(hist), nbins, ptr(over), 1, max_radius, sp))
     return host(bits), host(hist), host(over), nbins
 
 
-@pytest.mark.parametrize("shape", [(9, 7, 12), (12, 10, 64), (6, 9, 65), (5, 4, 200), (30, 26, 70), (3, 40, 129)])
-def test_label_bits_and_surface_distances_vs_scipy(shape):
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("shape", [(9, 7, 12), (12, 10, 64), (6, 9, 65), (5, 4, 200), (30, 26, 70), (3, 40, 129), (4, 5, 330)])
+def test_label_bits_and_surface_distances_vs_scipy(shape, kernel):
     """cvx_label_bits_u64 == numpy's packed masks, and cvx_surface_distance_hist_i64 == the histogram of (edt(a==l) + edt(a!=l))**2 over
     the voxels of b whose inside distance is 1: rows of less / exactly / more than one 64-voxel word, labels touching the border, a
     label missing from one map (inactive: skipped), one-voxel labels, non-integer and out-of-range values (no label)."""
@@ -97,7 +109,7 @@ def test_label_bits_and_surface_distances_vs_scipy(shape):
     b[H // 2, W // 2, min(D - 1, D // 2 + 1)] = 5
     active = [lab for lab in range(1, nl + 1) if (a == lab).any() and (b == lab).any()]
     assert 4 not in active and len(active) >= 3
-    bits, hist, over, nbins = run_surface_hist(b, a, nl, active)
+    bits, hist, over, nbins = run_surface_hist(b, a, nl, active, kernel=kernel)
     nseg = (D + 63) // 64
     want_bits = np.zeros((nl, H * W, nseg * 64), np.uint8)
     for lab in range(1, nl + 1):
@@ -111,7 +123,7 @@ def test_label_bits_and_surface_distances_vs_scipy(shape):
     # values that are no label: fractional and out of range (bit planes and surface test both ignore them)
     af, bf = a.astype(np.float32), b.astype(np.float32)
     af[1, 1, 1], bf[2, 2, 2] = 1.5, 77.0
-    bits2, hist2, over2, _ = run_surface_hist(bf, af, nl, active)
+    bits2, hist2, over2, _ = run_surface_hist(bf, af, nl, active, kernel=kernel)
     a2, b2 = a.copy(), b.copy()
     a2[1, 1, 1], b2[2, 2, 2] = 0, 0
     # the voxel of b holding 77 differs from every neighbour (it makes ITS neighbours surface voxels, like any other foreign value)
@@ -119,7 +131,8 @@ def test_label_bits_and_surface_distances_vs_scipy(shape):
     assert np.array_equal(hist2, want2)
 
 
-def test_surface_distance_far_targets_and_missing_targets():
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_surface_distance_far_targets_and_missing_targets(kernel):
     """The ring search runs to the far corner when the only voxel of the label in map a is there (exact at any distance), and reports
     overflow when map a holds no voxel of the wanted kind (the label fills all of a: its outside transform has no zero voxel)."""
     shape = (20, 33, 70)
@@ -127,19 +140,40 @@ def test_surface_distance_far_targets_and_missing_targets():
     a[19, 32, 69] = 1
     b = np.zeros(shape, np.int64)
     b[0:2, 0:2, 0:3] = 1
-    bits, hist, over, nbins = run_surface_hist(b, a, 2, [1])
+    bits, hist, over, nbins = run_surface_hist(b, a, 2, [1], kernel=kernel)
     want, wover = surface_hist_numpy(b, a, 2, [1], nbins)
     assert np.array_equal(hist, want) and not over.any() and hist[0].sum() > 0
     assert hist[0, 19 ** 2 + 32 ** 2 + 67 ** 2] == 1                                    # from the surface voxel (0, 0, 2)
     # a bounded search gives up on those voxels (flag 2: the caller switches to the transforms) but still counts what it reaches
-    bits, hist, over, nbins = run_surface_hist(b, a, 2, [1], max_radius=5)
+    bits, hist, over, nbins = run_surface_hist(b, a, 2, [1], max_radius=5, kernel=kernel)
     assert over[0] == 2 and hist.sum() == 0
     a[1, 3, 0] = 1
-    bits, hist, over, nbins = run_surface_hist(b, a, 2, [1], max_radius=5)
+    bits, hist, over, nbins = run_surface_hist(b, a, 2, [1], max_radius=5, kernel=kernel)
     assert over[0] == 0 and np.array_equal(hist, surface_hist_numpy(b, a, 2, [1], nbins)[0])
     a[:] = 1
-    bits, hist, over, nbins = run_surface_hist(b, a, 2, [1])
+    bits, hist, over, nbins = run_surface_hist(b, a, 2, [1], kernel=kernel)
     assert over[0] == 1 and over[1] == 0 and hist.sum() == 0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_surface_distance_kernels_agree_on_mid_range_distances_and_many_labels(seed):
+    """The two kernels count the same squared distances where the word arithmetic's stages hand over to each other: a label map against
+    itself shifted by 3 .. 9 voxels (squared distances around 8, 24 and 63: the table's levels, the early hand-over of sparse wavefronts, the
+    ring search), 70 labels (labels above 64 count through global atomics), rows of two words with a ragged tail."""
+    rng = np.random.default_rng(seed)
+    shape, nl = (26, 30, 100), 70
+    base = blobs(shape, 12, 100 + seed)
+    a = np.where(base > 0, base * 5 + 8, 0)                 # labels 13, 18, .. 68: some beyond the 64 that count in LDS
+    shift = tuple(int(v) for v in rng.integers(2, 7, 3))
+    b = np.roll(a, shift, (0, 1, 2))
+    active = [lab for lab in range(1, nl + 1) if (a == lab).any() and (b == lab).any()]
+    assert len(active) >= 6 and max(active) > 64
+    r0 = run_surface_hist(b, a, nl, active, kernel="voxels")
+    r1 = run_surface_hist(b, a, nl, active, kernel="bits")
+    assert np.array_equal(r0[1], r1[1]) and np.array_equal(r0[2], r1[2]) and r1[1].sum() > 0
+    assert r1[1][:, 9:64].sum() > 0 and r1[1][:, 64:].sum() > 0, "the example must reach the table's upper levels and the ring search"
+    want, _ = surface_hist_numpy(b, a, nl, active, r1[3])
+    assert np.array_equal(r1[1], want)
 
 
 @pytest.mark.parametrize("shape,nl", [((24, 30, 40), 6), ((40, 36, 70), 13), ((17, 21, 130), 3)])
