@@ -447,6 +447,15 @@ __global__ __launch_bounds__(256) void k_surf_levels(const unsigned long long* _
     }
 }
 
+// minimum over the 64 lanes (in every lane): four DPP steps inside the rows of 16 lanes, then the four row results through readlane
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));     // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));     // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 // one wavefront per far voxel (squared distance >= 64): rows in square rings around its row, 64 rows per step
 __global__ __launch_bounds__(256) void k_surf_far(const unsigned long long* __restrict__ bits_a, int H, int W, int D, int nseg, int nbins,
                                                   unsigned long long* __restrict__ hist_all, size_t hist_stride, int* __restrict__ overflow_all,
@@ -493,8 +502,7 @@ __global__ __launch_bounds__(256) void k_surf_far(const unsigned long long* __re
                 const int g = nearest_in_row(plane + ((size_t)hh * W + ww) * nseg, nseg, D, z, inside);
                 if (g != INT_MAX) cand = base2 + g * g;
             }
-            for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
-            best = min(best, cand);
+            best = min(best, wave_min_i32(cand));
         }
         if (lane == 0) {
             if (gave_up) atomicMax(&overflow_all[(size_t)(ql - 1) * overflow_stride], 2);
