@@ -521,9 +521,22 @@ __global__ __launch_bounds__(256) void k_resize2(const float* __restrict__ T, in
 #pragma unroll
     for (int a = 0; a < 2; ++a) lin_coef(Z[a], h, H, cz[a][0], cz[a][1], wz[a][0], wz[a][1]);
     const size_t plane = (size_t)W * D;
+    // (wave-uniform: every lane's two x taps adjacent and 8-byte aligned; T is the 256-byte aligned scratch of launch_resize2)
+    const bool pairs = (D & 1) == 0 && (reinterpret_cast<uintptr_t>(T) & 7) == 0 && __all(X[1] == X[0] + 1 && (X[0] & 1) == 0);
     auto one = [&](int c) {
         const float* Tc = T + (size_t)c * h * plane;
         float v[2][2][2][2];                                        // [a][level-1 plane][b][e]: all 16 taps in flight
+        if (pairs) {                                                // the two x taps are one aligned 8-byte piece (factor-2 reduction: X = 2x, 2x + 1)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float2 q = *reinterpret_cast<const float2*>(Tc + (size_t)cz[a][p] * plane + (size_t)Y[b] * D + X[0]);
+                        v[a][p][b][0] = q.x; v[a][p][b][1] = q.y;
+                    }
+        } else {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -532,6 +545,7 @@ __global__ __launch_bounds__(256) void k_resize2(const float* __restrict__ T, in
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) v[a][p][b][e] = Tc[(size_t)cz[a][p] * plane + (size_t)Y[b] * D + X[e]];
+        }
         float lev1[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {

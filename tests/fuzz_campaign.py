@@ -269,13 +269,26 @@ def trial_hd95(rng, t):
                 res.append(call()); errs.append(False)
             except (RuntimeError, ValueError):           # a label filling a whole map: no outside voxel (scipy: undefined feature transform)
                 res.append(None); errs.append(True)
+        # a label that fills a whole map has no outside voxel: scipy's (and cupyx's) transform of a volume without background is undefined,
+        # so the restatement is no witness there (seed 20260929, trial 6071: label 1 fills BOTH 17 x 5 x 3 maps -- no surface voxel at all,
+        # both device paths return the percentile of an empty set, NaN, the scipy form 1.0); the two device paths must still agree
+        full = any((a == q).all() or (b == q).all() for q in range(1, nl + 1))
         if any(errs[:2]):
             ok = errs[0] == errs[1]
         else:
-            ok = np.array_equal(res[0], res[1]) and (errs[2] or np.array_equal(res[0], res[2]))
+            ok = np.array_equal(res[0], res[1], equal_nan=True) and (errs[2] or full or np.array_equal(res[0], res[2], equal_nan=True))
+        radius = HU.HD95_SURFACE_MAX_RADIUS
+        if not ok:                                           # keep the case (gpurun_out/ travels back from the GPU box)
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_hd95_fail_%d.npz" % t), a=a, b=b, nl=nl, radius=radius,
+                                    surface=np.asarray(res[0] if res[0] is not None else []), edt=np.asarray(res[1] if res[1] is not None else []),
+                                    scipy=np.asarray(res[2] if res[2] is not None else []), errs=np.asarray(errs))
+            except Exception:
+                pass
     finally:
         HU.HD95_SURFACE_MAX_RADIUS = old
-    return ok, ("hd95", sh, nl)
+    return ok, ("hd95", sh, nl, radius)
 
 
 def main():
