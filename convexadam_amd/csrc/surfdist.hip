@@ -229,7 +229,12 @@ struct SurfWord { unsigned long long surf; unsigned at; unsigned q; };          
 // Both work lists are SURF_NL sub-lists with a counter each: appends to ONE counter serialise in the L2 (measured: ~10 ns per returning
 // atomic on the same address -- 19 000 wavefront appends took 207 us), 256 counters on different lines do not
 constexpr int SURF_NL = 256;
-struct SurfLists { SurfWord* words[3]; unsigned long long* far; unsigned* n_words[3]; unsigned* n_far; unsigned cap_words, cap_far; };   // n_*: [SURF_NL], cap_*: per sub-list; words[s] = input of stage s
+struct SurfLists {            // n_*: [SURF_NL] counters, cap_*: per sub-list
+    SurfWord* words[2]; unsigned* n_words[2];          // words[s] = input of k_surf_levels<s>
+    unsigned long long* vox[2]; unsigned* n_vox[2];     // voxels left after level 8: input of the two rounds of k_surf_voxels   (label << 56 | z << 32 | row)
+    unsigned long long* far; unsigned* n_far;           // voxels left after that: input of k_surf_far
+    unsigned cap_words, cap_vox, cap_far;
+};
 
 __global__ __launch_bounds__(256) void k_surf_words(const unsigned long long* __restrict__ bits_b, int H, int W, int D, int nseg, int nl,
                                                     ActiveLabels act, SurfLists L) {
@@ -276,8 +281,7 @@ __device__ __forceinline__ unsigned long long surf_hit(unsigned long long tp, un
 
 // stages B and C as a table: the (dh, dw, dz >= 0) inside the cube of radius SURF_R with SURF_K0 <= dh^2 + dw^2 + dz^2 < (SURF_R + 1)^2, ordered by
 // squared distance (counting sort at compile time) -- a rolled loop that ends as soon as the word has no bits left
-constexpr int SURF_MIN_LANES = 12;
-constexpr int SURF_R = 7, SURF_K0 = 4, SURF_K1 = (SURF_R + 1) * (SURF_R + 1) - 1, SURF_TMAX = 1280;
+constexpr int SURF_R = 2, SURF_K0 = 4, SURF_K1 = (SURF_R + 1) * (SURF_R + 1) - 1, SURF_TMAX = 1280;
 struct SurfTable { unsigned e[SURF_TMAX]; int n; };      // entry = k << 24 | dz << 16 | (dw + 8) << 8 | (dh + 8): one scalar load per entry
 constexpr SurfTable surf_make_table() {
     SurfTable t{};
@@ -382,13 +386,10 @@ __global__ __launch_bounds__(256) void k_surf_levels(const unsigned long long* _
             // batches of NB table entries: their 3 NB loads are in flight together (one entry at a time the loop ran at one memory round
             // trip per entry: ~100 us for a word that goes through the whole table)
             constexpr int NB = 8;
-            const int nt = STAGE == 1 ? SURF_T9 : SURF_T.n;
-            int cur_k = STAGE == 1 ? SURF_K0 : 9;
+            const int nt = SURF_T9;
+            int cur_k = SURF_K0;
             unsigned long long lo = 0ull, li = 0ull;
-            for (int t0 = STAGE == 1 ? 0 : SURF_T9; t0 < nt && (rem_o | rem_i); t0 += NB) {
-                // the table pays per wavefront (every lane waits for the slowest word), the ring search per voxel: beyond the cube of
-                // radius 2 the table goes on only while a fair share of the wavefront still has bits left
-                if (STAGE == 2 && __builtin_popcountll(__ballot((rem_o | rem_i) != 0ull)) < SURF_MIN_LANES) break;
+            for (int t0 = 0; t0 < nt && (rem_o | rem_i); t0 += NB) {
                 unsigned long long m[NB], mp[NB], mn[NB];
                 unsigned ent[NB];
 #pragma unroll
@@ -416,27 +417,36 @@ __global__ __launch_bounds__(256) void k_surf_levels(const unsigned long long* _
             settle(cur_k, lo, li);
         }
         unsigned long long rest = rem_o | rem_i;
-        if (STAGE < 2) {                     // words with bits left: input of the next stage (one counter update per wavefront)
+        if (STAGE == 0) {                    // words with bits left: input of the next stage (one counter update per wavefront)
             const unsigned long long has = __ballot(rest != 0ull);
             if (has) {
                 const int lane = threadIdx.x & 63, leader = __builtin_ctzll(has);
                 unsigned base = 0u;
-                if (lane == leader) base = atomicAdd(&L.n_words[STAGE < 2 ? STAGE + 1 : 0][sub], (unsigned)__builtin_popcountll(has));
+                if (lane == leader) base = atomicAdd(&L.n_words[1][sub], (unsigned)__builtin_popcountll(has));
                 base = __shfl(base, leader);
                 if (rest) {
                     const unsigned slot = base + (unsigned)__builtin_popcountll(has & ((1ull << lane) - 1ull));
-                    if (slot < L.cap_words) L.words[STAGE < 2 ? STAGE + 1 : 0][(size_t)sub * L.cap_words + slot] = SurfWord{rest, wd.at, wd.q};
+                    if (slot < L.cap_words) L.words[1][(size_t)sub * L.cap_words + slot] = SurfWord{rest, wd.at, wd.q};
                 }
             }
-        } else if (rest) {                   // far voxels: (label, row, z) for the ring search
-            const unsigned fsub = (sub * 7u + (threadIdx.x >> 4)) % (unsigned)SURF_NL;
-            unsigned slot = atomicAdd(&L.n_far[fsub], (unsigned)__builtin_popcountll(rest));
-            while (rest) {
-                const int b = __builtin_ctzll(rest);
-                rest &= rest - 1ull;
-                if (slot < L.cap_far) L.far[(size_t)fsub * L.cap_far + slot] = ((unsigned long long)q << 56) | ((unsigned long long)(sg * 64 + b) << 32) | (unsigned)row;
-                else atomicMax(&overflow_all[(size_t)(q - 1) * overflow_stride], 2);             // list full: the label is handed to the transforms
-                ++slot;
+        } else {                             // voxels beyond squared distance 8: one list entry each (label, row, z); one counter update per wavefront
+            const int lane = threadIdx.x & 63;
+            const unsigned mine = (unsigned)__builtin_popcountll(rest);
+            unsigned incl = mine;                                              // inclusive prefix sum over the lanes
+            for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            const unsigned total = __shfl(incl, 63);
+            if (total) {
+                const unsigned vsub = (sub * 7u + (threadIdx.x >> 6) + (e0 >> 8)) % (unsigned)SURF_NL;
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(&L.n_vox[0][vsub], total);
+                unsigned slot = __shfl(base, 0) + incl - mine;
+                while (rest) {
+                    const int b = __builtin_ctzll(rest);
+                    rest &= rest - 1ull;
+                    if (slot < L.cap_vox) L.vox[0][(size_t)vsub * L.cap_vox + slot] = ((unsigned long long)q << 56) | ((unsigned long long)(sg * 64 + b) << 32) | (unsigned)row;
+                    else atomicMax(&overflow_all[(size_t)(q - 1) * overflow_stride], 2);         // list full: the label is handed to the transforms
+                    ++slot;
+                }
             }
         }
     }
@@ -444,6 +454,137 @@ __global__ __launch_bounds__(256) void k_surf_levels(const unsigned long long* _
     for (int i = threadIdx.x; i < LL * LB; i += blockDim.x) {
         const int q = i / LB, bin = i - q * LB;
         if (low[i] && q < nl && bin < nbins) atomicAdd(&hist_all[(size_t)q * hist_stride + bin], (unsigned long long)low[i]);
+    }
+}
+
+// rows (dh, dw) of the square of radius SURF_VR around a voxel's row, ordered by dh^2 + dw^2 (counting sort at compile time)
+constexpr int SURF_VR = 31, SURF_VROWS = (2 * SURF_VR + 1) * (2 * SURF_VR + 1);
+struct SurfRows { unsigned e[SURF_VROWS]; };             // entry = base2 << 16 | (dw + 32) << 8 | (dh + 32)
+constexpr SurfRows surf_make_rows() {
+    SurfRows t{};
+    int first[2 * SURF_VR * SURF_VR + 2] = {};
+    for (int dh = -SURF_VR; dh <= SURF_VR; ++dh)
+        for (int dw = -SURF_VR; dw <= SURF_VR; ++dw) ++first[dh * dh + dw * dw + 1];
+    for (int k = 1; k <= 2 * SURF_VR * SURF_VR + 1; ++k) first[k] += first[k - 1];
+    for (int dh = -SURF_VR; dh <= SURF_VR; ++dh)
+        for (int dw = -SURF_VR; dw <= SURF_VR; ++dw) {
+            const int k = dh * dh + dw * dw;
+            t.e[first[k]++] = ((unsigned)k << 16) | ((unsigned)(dw + 32) << 8) | (unsigned)(dh + 32);
+        }
+    return t;
+}
+__constant__ SurfRows SURF_ROWS = surf_make_rows();
+// round 0 of k_surf_voxels scans the SURF_VROWS0 nearest rows: every other row is at least sqrt(SURF_FINAL0) away
+constexpr int SURF_VROWS0 = 256, SURF_FINAL0 = (int)(surf_make_rows().e[SURF_VROWS0] >> 16);
+static_assert(SURF_FINAL0 <= (SURF_VR + 1) * (SURF_VR + 1), "round 0 is bounded by its rows, not by the window");
+
+// One LANE per voxel that is farther than squared distance 8 from its target (the compacted leftovers of k_surf_levels<1>): the rows around
+// it in order of dh^2 + dw^2; of each row the 63 bits z-31 .. z+31 (own word and a neighbour), nearest target bit by count-leading /
+// trailing-zeros.  A lane is done when the next row is at least sqrt(best) away; the cube of radius 31 holds every voxel at squared
+// distance < 1024, so a minimum below that is final.  What is left (or has no target inside the cube) goes to the ring search.
+// (The same loop inside k_surface_dist_hist, round 5, was SLOWER than its wavefront-per-voxel search: there a few far lanes kept whole
+// wavefronts of settled voxels waiting.  Here every lane is a far voxel.  The search radius option does not apply: it bounds the ring search.)
+// Two rounds with a compaction in between (a wavefront waits for its slowest lane): ROUND 0 -- the 256 nearest rows, final below the squared
+// distance of the first row it does not scan; ROUND 1 -- what is left, all 3 969 rows from the start, final below 1 024; once fewer than
+// SURF_MIN_LANES lanes of a wavefront are still searching beyond the first 256 rows they are handed to the ring search (one wavefront per
+// voxel, better for the few).
+constexpr int SURF_MIN_LANES = 8;
+template <int ROUND>
+__global__ __launch_bounds__(256) void k_surf_voxels(const unsigned long long* __restrict__ bits_a, int H, int W, int D, int nseg, int nbins,
+                                                     unsigned long long* __restrict__ hist_all, size_t hist_stride, int* __restrict__ overflow_all,
+                                                     int overflow_stride, SurfLists L) {
+    constexpr int NROWS = ROUND == 0 ? SURF_VROWS0 : SURF_VROWS, FINAL_BELOW = ROUND == 0 ? SURF_FINAL0 : (SURF_VR + 1) * (SURF_VR + 1);
+    unsigned long long* const out_list = ROUND == 0 ? L.vox[1] : L.far;
+    unsigned* const out_n = ROUND == 0 ? L.n_vox[1] : L.n_far;
+    const unsigned out_cap = ROUND == 0 ? L.cap_vox : L.cap_far;
+    // a QUAD of lanes per voxel: lane s of the quad takes rows t0 + 4 j + s of a step (32 rows per step and voxel), the quad shares its best
+    // value after every step -- four times fewer dependent steps per voxel than one lane each (a step is a memory round trip), and a
+    // wavefront waits for the slowest of 16 voxels instead of 64
+    constexpr int LL = 64, LB = 128, R = SURF_VR, NB = 8, LPV = 4, VPW = 256 / LPV;
+    __shared__ unsigned int low[LL * LB];
+    __shared__ unsigned rows[NROWS];                   // the row table in LDS: the lanes of a quad read different entries (from constant memory: one more memory round trip per step)
+    const unsigned sub = blockIdx.x % (unsigned)SURF_NL, part = blockIdx.x / (unsigned)SURF_NL, parts = gridDim.x / (unsigned)SURF_NL;
+    const unsigned n_all = L.n_vox[ROUND][sub], n = min(n_all, L.cap_vox);
+    if (part * VPW >= n) return;
+    for (int i = threadIdx.x; i < LL * LB; i += blockDim.x) low[i] = 0;
+    for (int i = threadIdx.x; i < NROWS; i += blockDim.x) rows[i] = SURF_ROWS.e[i];
+    cvx_barrier();
+    const size_t per = (size_t)H * W * nseg;
+    const int sl = threadIdx.x & (LPV - 1);
+    for (unsigned e0 = part * VPW; e0 < n; e0 += parts * VPW) {
+        const unsigned e = e0 + (threadIdx.x >> 2);
+        const bool live = e < n;
+        const unsigned long long it = live ? L.vox[ROUND][(size_t)sub * L.cap_vox + e] : (1ull << 56);
+        const int q = (int)(it >> 56), z = (int)((it >> 32) & 0xffffffu), row = (int)(unsigned)(it & 0xffffffffull);
+        const int h = row / W, w = row - h * W, sg = z >> 6, zb = z & 63;
+        const unsigned long long* PA = bits_a + (size_t)(q - 1) * per;
+        const bool inside = live && ((PA[(size_t)row * nseg + sg] >> zb) & 1ull);       // inside the label in map a: the target is the nearest voxel outside
+        // window bit j <-> voxel z - R + j; valid voxels only (the complement of a row must not count positions outside the volume)
+        const int jlo = max(0, R - z), jhi = min(2 * R + 1, D - z + R);              // valid window bits [jlo, jhi)
+        const unsigned long long vwin = ((jhi >= 64 ? ~0ull : (1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull)) & ((1ull << (2 * R + 1)) - 1ull);
+        int best = live ? INT_MAX : 0;
+        bool handed = false;
+        for (int t0 = 0; t0 < NROWS; t0 += NB * LPV) {
+            const int base2_0 = (int)(rows[t0] >> 16);
+            const unsigned long long busy = __ballot(base2_0 < best);
+            if (!busy) break;                                                      // every voxel done (rows are ordered: nothing closer can follow)
+            if (ROUND == 1 && t0 >= SURF_VROWS0 && __builtin_popcountll(busy) < SURF_MIN_LANES * LPV) { handed = base2_0 < best; break; }
+            unsigned long long m[NB], mp[NB], mn[NB];
+            unsigned ent[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                ent[j] = rows[min(t0 + LPV * j + sl, NROWS - 1)];
+                const int hh = h + (int)(ent[j] & 255u) - 32, ww = w + (int)((ent[j] >> 8) & 255u) - 32;
+                const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                const unsigned long long* rb = PA + ((size_t)(ok ? hh : h) * W + (ok ? ww : w)) * nseg + sg;
+                m[j] = rb[0];
+                mp[j] = (zb < R && sg > 0) ? rb[-1] : 0ull;
+                mn[j] = (zb > 63 - R && sg + 1 < nseg) ? rb[1] : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int base2 = (int)(ent[j] >> 16);
+                const int hh = h + (int)(ent[j] & 255u) - 32, ww = w + (int)((ent[j] >> 8) & 255u) - 32;
+                if (t0 + LPV * j + sl >= NROWS || base2 >= best || hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+                unsigned long long win = zb >= R ? m[j] >> (zb - R) : m[j] << (R - zb);
+                if (zb < R) win |= mp[j] >> (64 - R + zb);
+                if (zb > 63 - R) win |= mn[j] << (64 + R - zb);
+                win = (inside ? ~win : win) & vwin;
+                if (!win) continue;
+                const unsigned long long left = win & ((2ull << R) - 1ull), right = win >> R;
+                const int dl = left ? R - (63 - __builtin_clzll(left)) : INT_MAX, dr = right ? __builtin_ctzll(right) : INT_MAX;
+                const int g = min(dl, dr);
+                best = min(best, base2 + g * g);
+            }
+            best = min(best, __builtin_amdgcn_update_dpp(best, best, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+            best = min(best, __builtin_amdgcn_update_dpp(best, best, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]: the quad agrees
+        }
+        const bool mine = live && sl == 0;                                          // one lane of the quad reports
+        const bool settled = mine && !handed && best < FINAL_BELOW;
+        if (settled) {
+            if (best >= nbins) atomicMax(&overflow_all[(size_t)(q - 1) * overflow_stride], 1);
+            else if (q <= LL && best < LB) atomicAdd(&low[(q - 1) * LB + best], 1u);
+            else atomicAdd(&hist_all[(size_t)(q - 1) * hist_stride + best], 1ull);
+        }
+        // the others (beyond the cube, no target in it, or handed over): next list, one counter update per wavefront
+        const unsigned long long pass = __ballot(mine && !settled);
+        if (pass) {
+            const int lane = threadIdx.x & 63, leader = __builtin_ctzll(pass);
+            const unsigned osub = (sub * 7u + (threadIdx.x >> 6) + (e0 >> 6)) % (unsigned)SURF_NL;
+            unsigned base = 0u;
+            if (lane == leader) base = atomicAdd(&out_n[osub], (unsigned)__builtin_popcountll(pass));
+            base = __shfl(base, leader);
+            if (mine && !settled) {
+                const unsigned slot = base + (unsigned)__builtin_popcountll(pass & ((1ull << lane) - 1ull));
+                if (slot < out_cap) out_list[(size_t)osub * out_cap + slot] = it;
+                else atomicMax(&overflow_all[(size_t)(q - 1) * overflow_stride], 2);
+            }
+        }
+    }
+    cvx_barrier();
+    for (int i = threadIdx.x; i < LL * LB; i += blockDim.x) {
+        const int q = i / LB, bin = i - q * LB;
+        if (low[i] && bin < nbins) atomicAdd(&hist_all[(size_t)q * hist_stride + bin], (unsigned long long)low[i]);
     }
 }
 
@@ -560,7 +701,7 @@ extern "C" size_t cvx_surface_distance_hist_bits_workspace_bytes(int H, int W, i
     const size_t words = (size_t)num_labels * H * W * ((D + 63) / 64);
     (void)words;
     const size_t cap_words = (size_t)1 << 14, cap_far = (size_t)1 << 14;       // per sub-list: 4 M surface words / far voxels in all; beyond that the call reports flag 2
-    return 256 + sizeof(unsigned) * 4 * SURF_NL + 3 * (256 + sizeof(SurfWord) * cap_words * SURF_NL) + 256 + sizeof(unsigned long long) * cap_far * SURF_NL + 256;
+    return 256 + sizeof(unsigned) * 5 * SURF_NL + 2 * (256 + sizeof(SurfWord) * cap_words * SURF_NL) + 3 * (256 + sizeof(unsigned long long) * cap_far * SURF_NL) + 256;
 }
 
 extern "C" int cvx_surface_distance_hist_bits_i64(const uint64_t* bits_b, const uint64_t* bits_a, int H, int W, int D, int num_labels,
@@ -579,21 +720,24 @@ extern "C" int cvx_surface_distance_hist_bits_i64(const uint64_t* bits_b, const 
     CVX_REQUIRE((int64_t)H * W * nseg <= INT_MAX - 65536 && words < ((size_t)1 << 32), "cvx_surface_distance_hist_bits_i64: volume too large");
     hipStream_t s = as_stream(stream);
     Carver cv(workspace, workspace_bytes);
-    unsigned* counters = cv.take<unsigned>(4 * SURF_NL);
+    unsigned* counters = cv.take<unsigned>(5 * SURF_NL);
     SurfLists L;
     L.cap_words = 1u << 14;
     L.cap_far = 1u << 14;
-    for (int i = 0; i < 3; ++i) { L.words[i] = cv.take<SurfWord>((size_t)L.cap_words * SURF_NL); L.n_words[i] = counters + i * SURF_NL; }
+    L.cap_vox = L.cap_far;
+    for (int i = 0; i < 2; ++i) { L.words[i] = cv.take<SurfWord>((size_t)L.cap_words * SURF_NL); L.n_words[i] = counters + i * SURF_NL; }
+    for (int i = 0; i < 2; ++i) { L.vox[i] = cv.take<unsigned long long>((size_t)L.cap_vox * SURF_NL); L.n_vox[i] = counters + (2 + i) * SURF_NL; }
     L.far = cv.take<unsigned long long>((size_t)L.cap_far * SURF_NL);
-    L.n_far = counters + 3 * SURF_NL;
-    if (hipMemsetAsync(counters, 0, 4 * SURF_NL * sizeof(unsigned), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "surface_distance_hist_bits: memset failed");
+    L.n_far = counters + 4 * SURF_NL;
+    if (hipMemsetAsync(counters, 0, 5 * SURF_NL * sizeof(unsigned), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "surface_distance_hist_bits: memset failed");
     const unsigned long long* Bb = reinterpret_cast<const unsigned long long*>(bits_b);
     const unsigned long long* Ba = reinterpret_cast<const unsigned long long*>(bits_a);
     unsigned long long* hh = reinterpret_cast<unsigned long long*>(hist);
     hipLaunchKernelGGL(k_surf_words, dim3((unsigned)cdiv64((int64_t)H * W * nseg, 256), (unsigned)num_labels), dim3(256), 0, s, Bb, H, W, D, nseg, num_labels, act, L);
     hipLaunchKernelGGL(k_surf_levels<0>, dim3(SURF_NL * 4), dim3(256), 0, s, Ba, H, W, D, nseg, num_labels, nbins, hh, (size_t)hist_stride, overflow, overflow_stride, L);
     hipLaunchKernelGGL(k_surf_levels<1>, dim3(SURF_NL * 4), dim3(256), 0, s, Ba, H, W, D, nseg, num_labels, nbins, hh, (size_t)hist_stride, overflow, overflow_stride, L);
-    hipLaunchKernelGGL(k_surf_levels<2>, dim3(SURF_NL * 4), dim3(256), 0, s, Ba, H, W, D, nseg, num_labels, nbins, hh, (size_t)hist_stride, overflow, overflow_stride, L);
+    hipLaunchKernelGGL(k_surf_voxels<0>, dim3(SURF_NL * 8), dim3(256), 0, s, Ba, H, W, D, nseg, nbins, hh, (size_t)hist_stride, overflow, overflow_stride, L);
+    hipLaunchKernelGGL(k_surf_voxels<1>, dim3(SURF_NL * 8), dim3(256), 0, s, Ba, H, W, D, nseg, nbins, hh, (size_t)hist_stride, overflow, overflow_stride, L);
     hipLaunchKernelGGL(k_surf_far, dim3(SURF_NL * 8), dim3(256), 0, s, Ba, H, W, D, nseg, nbins, hh, (size_t)hist_stride, overflow, overflow_stride, max_radius, L);
     return check_last("surface_distance_hist_bits");
 }
