@@ -220,10 +220,13 @@ __global__ __launch_bounds__(256) void k_surface_dist_hist(const float* __restri
 //   k_surf_levels  one thread per listed word.  The 64 surface bits split into those outside the label in map a (target: a's set bits)
 //                  and inside (target: the zero bits of a that are voxels).  Stage A: the 3 x 3 rows around the word's row, shifts by
 //                  0 .. 1 along D -> one mask per squared distance 1, 2, 3 ("some target lies exactly there"); the bits are counted at the
-//                  FIRST level that covers them.  Stage B (only while bits are left): the offsets (dh, dw, dz) of the cube of radius 7 in
-//                  order of their squared distance 4 .. 63 (a table), one level mask per distance.  A cube of radius R holds every voxel
-//                  at squared distance < (R + 1)^2, so every level is exact.  What is left after level 63 goes to a list of far voxels.
-//   k_surf_far     one wavefront per far voxel: the ring search of k_surface_dist_hist (64 rows per step, exact, stops at r^2 >= best).
+//                  FIRST level that covers them.  Stage B (compacted: only the words with bits left): the offsets (dh, dw, dz) with squared
+//                  distance 4 .. 8 (a table), one level mask per distance.  A cube of radius R holds every voxel at squared distance
+//                  < (R + 1)^2, so every level is exact.  The bits left after level 8 become one list entry per voxel.
+//   k_surf_voxels  a quad of lanes per such voxel: rows in order of their distance, the 63 bits around z of each; two compacted rounds
+//                  (256 rows, then all 3 969 of the square of radius 31); exact below squared distance 1 024.
+//   k_surf_far     one wavefront per voxel that is farther (or was handed over): the ring search of k_surface_dist_hist (64 rows per step,
+//                  exact, stops at r^2 >= best).
 // Same counts as k_surface_dist_hist bit for bit (tests/test_gpu_parity.py::test_hd95_*: equal to the transform method).
 struct SurfWord { unsigned long long surf; unsigned at; unsigned q; };          // at = row * nseg + sg, q = label
 // Both work lists are SURF_NL sub-lists with a counter each: appends to ONE counter serialise in the L2 (measured: ~10 ns per returning
@@ -341,9 +344,8 @@ __device__ __forceinline__ void surf_cube(const unsigned long long* __restrict__
         }
 }
 
-// STAGE 0: levels 1 .. 3 (unrolled 3 x 3 cube) of every surface word; 1: levels 4 .. 8 of the words that still hold bits; 2: levels 9 .. 63 of
-// what is left after that, then the far list.  Three launches with a compaction in between: a wavefront waits for its slowest word, so the
-// few words that need the long tail of the table must not sit in wavefronts of finished ones.
+// STAGE 0: levels 1 .. 3 (unrolled 3 x 3 cube) of every surface word; 1: levels 4 .. 8 of the words that still hold bits, then one list entry
+// per voxel that is left.  Two launches with a compaction in between: a wavefront waits for its slowest word.
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_surf_levels(const unsigned long long* __restrict__ bits_a, int H, int W, int D, int nseg, int nl,
                                                      int nbins, unsigned long long* __restrict__ hist_all, size_t hist_stride,
