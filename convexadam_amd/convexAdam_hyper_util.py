@@ -367,10 +367,11 @@ def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=N
                 # k = 0: dist1[surf2] (surface of the moving map against the fixed planes), k = 1: dist2[surf1] (:48)
                 # (HD95_SURFACE_KERNEL = "bits", the default: both maps as bit planes, 64 voxels per thread; "voxels": one lane per voxel of
                 # the label map -- the round-4 kernel, same counts)
-                nws = int(L.cvx_surface_distance_hist_bits_workspace_bytes(H, W, D, nl)) if HD95_SURFACE_KERNEL == "bits" else 0
+                use_bits = HD95_SURFACE_KERNEL == "bits" and nl * H * W * ((D + 63) // 64) < (1 << 32)       # (the word lists index 32 bits)
+                nws = int(L.cvx_surface_distance_hist_bits_workspace_bytes(H, W, D, nl)) if use_bits else 0
                 ws = workspace(nws, dev) if nws else None
                 for k, (seg_b, bits_b, bits_a) in enumerate(((mv, bits_m, bits_f), (fx, bits_f, bits_m))):
-                    if HD95_SURFACE_KERNEL == "bits":
+                    if use_bits:
                         check(L.cvx_surface_distance_hist_bits_i64(ptr(bits_b), ptr(bits_a), H, W, D, nl, C.cast(act4, C.c_void_p), nbins,
                                                                    C.c_void_p(hist.data_ptr() + 8 * k * nbins), 2 * nbins,
                                                                    C.c_void_p(flag.data_ptr() + 4 * k), 2, int(HD95_SURFACE_MAX_RADIUS), ptr(ws), nws, sp))
