@@ -104,6 +104,8 @@ struct Options {
                                    //    k_to_chunked pass: -31 us per pair); 0 = planar pooled features + re-packing (bit-identical)
     long long resize_up2;          // 1 (default): exact factor-2 up-sampling of a 3-channel field through k_resize_up2 (2 x 2 x 2 outputs per thread from one 27-tap
                                    //    neighbourhood; bit-identical); 0 = one thread per output
+    long long mind_blocked;        // 1 (default): the pipeline's MIND stencil writes its raw patch SSDs blocked by the tiles of the normalise + pool pass (contiguous reads there:
+                                   //    half as many L1-miss requests for the same bytes); 0 = planar (bit-identical)
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };
@@ -381,6 +383,7 @@ bool mind_pooled_supported(int H, int W, int D, int g1, int g2);
 int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int dilation, int g1, float* out1, int g2, float* out2,
                        float* raw, void* workspace, size_t workspace_bytes, hipStream_t s, int records = 0);   // records 1 / 2: out2 = float32 / half feature records
 bool mind_pooled_records_supported(int H, int W, int D, int g1, int g2);
+size_t mind_pooled_raw_floats(int H, int W, int D, int g1, int g2);      // floats of launch_mind_pooled's `raw` scratch (>= 12 H W D: blocked tiles overhang)
 // corrbox.hip: the two box filters of the SSD volume (z-marching pipeline); raw [K][h][w][px] -> ssd [K][h][w][d]
 bool corr_box2_supported(int h, int w, int d, int px);
 int launch_corr_box2(const float* raw, int K, int h, int w, int d, int px, float* ssd, hipStream_t s);

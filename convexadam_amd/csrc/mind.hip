@@ -523,7 +523,7 @@ __device__ __forceinline__ void mp_window(const float* __restrict__ E, int c, in
 template <int GA, int GB>
 __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restrict__ raw, int H, int W, int D,
                                                             const MindStats* __restrict__ st, float* __restrict__ out1,
-                                                            float* __restrict__ out2, void* __restrict__ rec2, int rec_half, ExpTable et) {
+                                                            float* __restrict__ out2, void* __restrict__ rec2, int rec_half, ExpTable et, MindRawLayout lay) {
     constexpr int T = GA;
     __shared__ __attribute__((aligned(16))) float E[12 * T * T * MP_TX];          // [c][z][y][x], final channel order
     const int tid = threadIdx.x;
@@ -533,13 +533,16 @@ __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restr
     mind_bounds(st, (double)V, lo, hi);
     const size_t tail_from = (V / 32) * 32;
     constexpr int NP = MP_TX / 2;
+    // blocked raw SSDs (MindRawLayout): this workgroup's tile is one contiguous piece
+    const float* tile_raw = lay.T ? raw + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * lay.tile_floats : raw;
     auto voxel_pair = [&](int z, int y, int xp) {
         const int gz = z0 + z, gy = y0 + y, gx = x0 + 2 * xp;
         const size_t lin = ((size_t)gz * W + gy) * D + gx;
+        const size_t at = lay.T ? (size_t)((z * T + y) * MP_TX + 2 * xp) : lin, cs = lay.T ? lay.chan_floats : V;
         float r[2][12];
 #pragma unroll
         for (int c = 0; c < 12; ++c) {
-            const float2 q = *reinterpret_cast<const float2*>(raw + (size_t)MIND_INV[c] * V + lin);
+            const float2 q = *reinterpret_cast<const float2*>(tile_raw + (size_t)MIND_INV[c] * cs + at);
             r[0][c] = q.x; r[1][c] = q.y;
         }
         mind_normalise(r[0], lo, hi, lin >= tail_from, et);
@@ -604,12 +607,13 @@ static size_t mind_lds_bytes(int R, int dil, int nbuf, int TX) {
 }
 
 template <int R>
-static int mind_launch_r(const float* img, int H, int W, int D, int dil, MindStats* st, float* out, hipStream_t s) {
+static int mind_launch_r(const float* img, int H, int W, int D, int dil, MindStats* st, float* out, hipStream_t s, const MindRawLayout& lay) {
     const bool tiled_only = options().mind_tiled != 0;
     if (!tiled_only && mind_march_supported(img, out, H, W, D, R, dil)) {
-        launch_mind_march(img, H, W, D, st, out, s);
+        launch_mind_march(img, H, W, D, st, out, s, lay);
         return check_last("mindssc");
     }
+    if (lay.T) return fail(CVX_ERR_UNSUPPORTED, "mindssc: the blocked layout needs the marching stencil");
     if (mind_lds_bytes(R, dil, 1, 64) <= 160 * 1024) {
         const dim3 grid(cdiv(D, 64), cdiv(W, TY), cdiv(H, TZ));
         const int nbuf = mind_lds_bytes(R, dil, 2, 64) <= 160 * 1024 ? 2 : 1;
@@ -630,7 +634,7 @@ static int mind_launch_r(const float* img, int H, int W, int D, int dil, MindSta
 
 // min/max -> split grids -> stencil pass: raw patch SSDs in `raw` [12][V] (final channel order), statistics in *st
 static int mind_stencil(const float* img, int H, int W, int D, int radius, int dilation, float* raw, void* workspace,
-                        size_t workspace_bytes, MindStats** st_out, hipStream_t s) {
+                        size_t workspace_bytes, MindStats** st_out, hipStream_t s, const MindRawLayout& lay = MindRawLayout{0, 0, 0, 0, 0}) {
     Carver cv(workspace, workspace_bytes);
     float* part = cv.take<float>(2 * 1024);
     MindStats* st = cv.take<MindStats>(1);
@@ -641,9 +645,9 @@ static int mind_stencil(const float* img, int H, int W, int D, int radius, int d
     hipLaunchKernelGGL(k_mind_stats_init, dim3(1), dim3(256), 0, s, part, nb, (double)V, st);
     int rc;
     switch (radius) {
-        case 1: rc = mind_launch_r<1>(img, H, W, D, dilation, st, raw, s); break;
-        case 2: rc = mind_launch_r<2>(img, H, W, D, dilation, st, raw, s); break;
-        default: rc = mind_launch_r<3>(img, H, W, D, dilation, st, raw, s); break;
+        case 1: rc = mind_launch_r<1>(img, H, W, D, dilation, st, raw, s, lay); break;
+        case 2: rc = mind_launch_r<2>(img, H, W, D, dilation, st, raw, s, lay); break;
+        default: rc = mind_launch_r<3>(img, H, W, D, dilation, st, raw, s, lay); break;
     }
     const long long T = options().mind_mean_threads;
     if (rc || T <= 0) return rc;
@@ -701,6 +705,20 @@ bool mind_pooled_supported(int H, int W, int D, int g1, int g2) { return mind_po
 
 // MIND-SSC of `img` delivered only as avg_pool3d(., g1, stride g1) -> out1 and (g2 > 0) avg_pool3d(., g2, stride g2) -> out2;
 // `raw` is a 12*V float scratch (the raw patch SSDs).  Same values as cvx_mindssc_f32 followed by cvx_avgpool_f32.
+// The stencil pass of the pooled path writes its raw SSDs blocked by the second pass's tiles (MindRawLayout) when the marching kernel runs it,
+// the global mean is the exactly rounded one (the reference-bits mean walks the planar volume) and option mind_blocked is on.
+// mind_pooled_raw_floats: size of the `raw` scratch the caller must provide (the tiles overhang the volume).
+static bool mind_pooled_blocked(const float* img, const float* raw, int H, int W, int D, int radius, int dilation, int g1, int g2) {
+    return options().mind_blocked != 0 && options().mind_tiled == 0 && options().mind_mean_threads <= 0 && mind_pool_tile(H, W, D, g1, g2 > 0 ? g2 : g1) != 0 &&
+           mind_march_supported(img, raw, H, W, D, radius, dilation);
+}
+size_t mind_pooled_raw_floats(int H, int W, int D, int g1, int g2) {
+    const int T = mind_pool_tile(H, W, D, g1, g2 > 0 ? g2 : g1);
+    const size_t planar = (size_t)12 * H * W * D;
+    if (T == 0) return planar;
+    const size_t blocked = (size_t)cdiv(D, MP_TX) * cdiv(W, T) * cdiv(H, T) * 12 * T * T * MP_TX;
+    return blocked > planar ? blocked : planar;
+}
 // records (with out2): out2 receives the g2-pooled descriptor as feature records instead of planar channels (needs g2 <= g1); see
 // mind_pooled_records_supported
 bool mind_pooled_records_supported(int H, int W, int D, int g1, int g2) { return g2 > 0 && g2 <= g1 && mind_pool_tile(H, W, D, g1, g2) != 0; }
@@ -711,8 +729,10 @@ int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int di
     const int T = mind_pool_tile(H, W, D, g1, g2 > 0 ? g2 : g1);
     if (T == 0 || !out1) return fail(CVX_ERR_UNSUPPORTED, "mind_pooled: window sizes %d, %d do not tile", g1, g2);
     MindStats* st = nullptr;
-    if ((rc = mind_stencil(img, H, W, D, radius, dilation, raw, workspace, workspace_bytes, &st, s))) return rc;
     const dim3 grid(cdiv(D, MP_TX), cdiv(W, T), cdiv(H, T));
+    const MindRawLayout lay = mind_pooled_blocked(img, raw, H, W, D, radius, dilation, g1, g2)
+                                  ? MindRawLayout{T, (int)grid.x, (int)grid.y, (size_t)12 * T * T * MP_TX, (size_t)T * T * MP_TX} : MindRawLayout{0, 0, 0, 0, 0};
+    if ((rc = mind_stencil(img, H, W, D, radius, dilation, raw, workspace, workspace_bytes, &st, s, lay))) return rc;
     // (ga, gb) = (larger, smaller) window; the larger one goes to the matching output
     const bool swap = g2 > g1;
     const int ga = swap ? g2 : g1, gb = g2 > 0 ? (swap ? g1 : g2) : g1;
@@ -721,7 +741,7 @@ int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int di
     if (records && (swap || !out2)) return fail(CVX_ERR_UNSUPPORTED, "mind_pooled: feature records need 0 < g2 <= g1");
     void* rec = records ? out2 : nullptr;             // records: 1 = float32, 2 = half precision
     if (records) ob = nullptr;
-#define CVX_MP(GA, GB) hipLaunchKernelGGL((k_mind_finish_pool<GA, GB>), grid, dim3(MP_NT), 0, s, raw, H, W, D, st, oa, ob, rec, records == 2 ? 1 : 0, mind_exp_table())
+#define CVX_MP(GA, GB) hipLaunchKernelGGL((k_mind_finish_pool<GA, GB>), grid, dim3(MP_NT), 0, s, raw, H, W, D, st, oa, ob, rec, records == 2 ? 1 : 0, mind_exp_table(), lay)
     if (ga == 6 && gb == 2) CVX_MP(6, 2);
     else if (ga == 6 && gb == 3) CVX_MP(6, 3);
     else if (ga == 6 && gb == 6) CVX_MP(6, 6);

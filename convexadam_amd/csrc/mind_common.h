@@ -25,6 +25,14 @@ struct MindStats {
 
 // z-marching stencil (mindmarch.hip): radius 1, dilation 2, rows of a multiple of 4 voxels, 16-byte aligned pointers
 bool mind_march_supported(const float* img, const float* out, int H, int W, int D, int radius, int dilation);
-void launch_mind_march(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s);
+// Where the stencil pass puts the raw patch SSDs.  T == 0: planar [12][H][W][D].  T > 0 (pipeline, mind.hip::launch_mind_pooled): blocked by the
+// tiles of k_mind_finish_pool -- [tile (z, y, x)][12][T][T][24] -- so that a tile is 12 T^2 24 contiguous floats: the second pass then reads whole
+// 128-byte lines in order instead of 96-byte row pieces shared with the neighbouring tile (it runs at the depth of the L1 miss queue: half as many
+// requests for the same bytes)
+struct MindRawLayout {
+    int T, ntx, nty;                 // tile edge (z, y), tiles along x (of 24 voxels) and y
+    size_t tile_floats, chan_floats; // 12 T T 24 and T T 24 (planar: unused / H W D)
+};
+void launch_mind_march(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s, MindRawLayout lay = MindRawLayout{0, 0, 0, 0, 0});
 
 }  // namespace cvx

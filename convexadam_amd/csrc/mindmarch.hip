@@ -68,7 +68,7 @@ __device__ __forceinline__ void mm_publish(const MMLoader& L, float* ring, int l
 
 // one plane of one wave group: taps of squared-difference plane zc -> running sums; EMIT: output plane gz is due
 template <typename G, int SET, bool EMIT>
-__device__ __forceinline__ void mm_box_step(const float* __restrict__ ring, float* __restrict__ X, float* __restrict__ out, size_t V,
+__device__ __forceinline__ void mm_box_step(const float* __restrict__ ring, float* __restrict__ X, float* __restrict__ out, size_t V /* channel stride of `out` */,
                                             size_t lin, bool store_ok, int zc, const int (&rowoff)[3], int colbase, bool left,
                                             bool right, int row, int q, float (&A)[MM_CPS][4], float (&P)[MM_CPS][4]) {
     constexpr MindOffsets MO{};
@@ -121,11 +121,15 @@ __device__ __forceinline__ void mm_box_step(const float* __restrict__ ring, floa
 template <typename G, int SET>
 __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __restrict__ out, MindStats* __restrict__ st, float* ring,
                                        float* X, double (*red)[MM_NT / 64], int H, int W, int D, int z0, int z1, int y0, int x0,
-                                       MMLoader& L) {
+                                       MMLoader& L, const MindRawLayout& lay) {
     const int tid = threadIdx.x, t128 = tid & 127;
     const int row = t128 / G::TXQ, q = t128 % G::TXQ;
     const int gy = y0 + row, gx0 = x0 + 4 * q;
     const size_t V = (size_t)H * W * D;
+    // blocked output (see MindRawLayout): the part of the index that does not depend on the plane
+    const int gyc = gy < W ? gy : 0, gxc = gx0 < D ? gx0 : 0;
+    const size_t out_a = lay.T ? ((size_t)(gyc / lay.T) * lay.ntx + (size_t)(gxc / 24)) * lay.tile_floats + (size_t)(gyc % lay.T) * 24 + (size_t)(gxc % 24) : 0;
+    const size_t out_cs = lay.T ? lay.chan_floats : V;
     int rowoff[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) rowoff[i] = (clampi(gy + i - 1, 0, W - 1) - y0 + 3) * G::RP;
@@ -183,10 +187,12 @@ __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __r
         zc_prev = zc;
         cvx_barrier();
         const int gz = z0 + s - 2;
-        const size_t lin = ((size_t)(gz < 0 ? 0 : gz) * W + (gy < W ? gy : 0)) * D + (gx0 < D ? gx0 : 0);
+        const int gzc = gz < 0 ? 0 : gz;
+        const size_t lin = lay.T ? out_a + ((size_t)(gzc / lay.T) * lay.nty * lay.ntx * lay.tile_floats + (size_t)(gzc % lay.T) * lay.T * 24)
+                                 : ((size_t)gzc * W + (gy < W ? gy : 0)) * D + (gx0 < D ? gx0 : 0);
         float* Xs = X + (s & 1) * XSZ;
-        if (s >= 2) mm_box_step<G, SET, true>(ring, Xs, out, V, lin, store_ok, zc, rowoff, colbase, left, right, row, q, A, P);
-        else mm_box_step<G, SET, false>(ring, Xs, out, V, lin, store_ok, zc, rowoff, colbase, left, right, row, q, A, P);
+        if (s >= 2) mm_box_step<G, SET, true>(ring, Xs, out, out_cs, lin, store_ok, zc, rowoff, colbase, left, right, row, q, A, P);
+        else mm_box_step<G, SET, false>(ring, Xs, out, out_cs, lin, store_ok, zc, rowoff, colbase, left, right, row, q, A, P);
         if (s >= 3) stats(X + ((s - 1) & 1) * XSZ, gz - 1);
     }
     cvx_barrier();
@@ -203,7 +209,7 @@ __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __r
 
 template <typename G>
 __global__ __launch_bounds__(MM_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mind_march(const float* __restrict__ img, int H, int W, int D, int zc_len, int nzc, int nyt,
-                                                      int nxt, MindStats* __restrict__ st, float* __restrict__ out) {
+                                                      int nxt, MindStats* __restrict__ st, float* __restrict__ out, MindRawLayout lay) {
     __shared__ __attribute__((aligned(16))) float ring[6 * G::PLANE];      // 5 live planes + the one being replaced
     __shared__ __attribute__((aligned(16))) float X[2 * 12 * G::TY * G::TX];   // double buffered
     __shared__ double red[3][MM_NT / 64];
@@ -234,10 +240,10 @@ __global__ __launch_bounds__(MM_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     }
     // (the first barrier of the march makes the ring visible)
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 7);
-    if (grp == 0) mm_run<G, 0>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
-    else if (grp == 1) mm_run<G, 1>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
-    else if (grp == 2) mm_run<G, 2>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
-    else mm_run<G, 3>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L);
+    if (grp == 0) mm_run<G, 0>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L, lay);
+    else if (grp == 1) mm_run<G, 1>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L, lay);
+    else if (grp == 2) mm_run<G, 2>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L, lay);
+    else mm_run<G, 3>(img, out, st, ring, X, red, H, W, D, z0, z1, y0, x0, L, lay);
 }
 
 bool mind_march_supported(const float* img, const float* out, int H, int W, int D, int radius, int dilation) {
@@ -247,7 +253,7 @@ bool mind_march_supported(const float* img, const float* out, int H, int W, int 
 }
 
 template <typename G>
-static void launch_mind_march_g(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s) {
+static void launch_mind_march_g(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s, const MindRawLayout& lay) {
     const int nyt = cdiv(W, G::TY), nxt = cdiv(D, G::TX);
     // two workgroups per CU (register bound): at most 512 workgroups so that all of them are resident at once -- a second,
     // partly filled round costs more than the longer chunks; chunks of at least 8 planes keep the 2-plane fill below 25 %
@@ -258,15 +264,15 @@ static void launch_mind_march_g(const float* img, int H, int W, int D, MindStats
     if (zc_len < 8) zc_len = 8;
     nzc = cdiv(H, zc_len);
     const unsigned grid = (unsigned)((nzc * nyt * nxt + 7) / 8 * 8);
-    hipLaunchKernelGGL(k_mind_march<G>, dim3(grid), dim3(MM_NT), 0, s, img, H, W, D, zc_len, nzc, nyt, nxt, st, out);
+    hipLaunchKernelGGL(k_mind_march<G>, dim3(grid), dim3(MM_NT), 0, s, img, H, W, D, zc_len, nzc, nyt, nxt, st, out, lay);
 }
 
-void launch_mind_march(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s) {
+void launch_mind_march(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s, MindRawLayout lay) {
     const int force = (int)options().mm_tx;
     const int rem = D % 64;
     const bool narrow = force ? force == 32 : (rem != 0 && rem <= 32);
-    if (narrow) launch_mind_march_g<MMGeo<16, 32>>(img, H, W, D, st, out, s);
-    else launch_mind_march_g<MMGeo<8, 64>>(img, H, W, D, st, out, s);
+    if (narrow) launch_mind_march_g<MMGeo<16, 32>>(img, H, W, D, st, out, s, lay);
+    else launch_mind_march_g<MMGeo<8, 64>>(img, H, W, D, st, out, s, lay);
 }
 
 }  // namespace cvx

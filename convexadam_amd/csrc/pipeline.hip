@@ -119,8 +119,10 @@ static PairLayout pair_layout(const cvx_pair_params& p, int n_snap = 0, int max_
     size_t u = 256;      // offset 0 is reserved as "unused"
     const size_t f = sizeof(float);
     if (p.n_feat == 0) {
-        L.featF = take(u, f * 12 * L.V);
-        L.featM = take(u, f * 12 * L.V);
+        // (the pooled path's raw patch SSDs may be blocked by tiles that overhang the volume: mind_pooled_raw_floats >= 12 V)
+        const size_t raw_floats = mind_pooled_raw_floats(p.H, p.W, p.D, p.grid_sp, p.lambda_weight > 0 ? p.grid_sp_adam : 0);
+        L.featF = take(u, f * raw_floats);
+        L.featM = take(u, f * raw_floats);
         L.mind_ws = take(u, cvx_mindssc_workspace_bytes(p.H, p.W, p.D, p.mind_r, p.mind_d));
         L.mind_ws2 = take(u, cvx_mindssc_workspace_bytes(p.H, p.W, p.D, p.mind_r, p.mind_d));      // the moving image's pass runs beside the fixed one's
     }

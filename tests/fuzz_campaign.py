@@ -52,6 +52,7 @@ def _draw_options(rng):
     L.cvx_set_option(b"corr_dual", int(rng.integers(0, 2)))
     L.cvx_set_option(b"prune_refine", int(rng.integers(0, 4) > 0))
     L.cvx_set_option(b"mind_records", int(rng.integers(0, 4) > 0))
+    L.cvx_set_option(b"mind_blocked", int(rng.integers(0, 4) > 0))
     L.cvx_set_option(b"resize_up2", int(rng.integers(0, 4) > 0))
 
 
