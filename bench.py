@@ -609,6 +609,11 @@ def main():
                                "note": "median interval between consecutive hipEvents on the launch stream (cvx_set_profiling(3): one event behind every kernel of the "
                                        "loop, 3 pairs x 79 iterations, outside the timed region; an interval = the kernel + its boundary); SURVEY 8(d) bytes: 185.8 MB per iteration"}
             rk["iteration"]["frac"] = rk["iteration"]["algorithmic_bytes"] / (rk["iteration"]["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            if "adam.warp_gradient" in rk:
+                rk["adam.warp_gradient"]["bound"] = ("L1 miss queue: 2.0 M read requests per launch at 323 clocks mean latency = 55 of 64 in flight per CU "
+                                                     "(profiles/r05_adam_loop_memory_counters_fp32.txt, DESIGN.md 11.8)")
+            if "adam.forward_boxes" in rk:
+                rk["adam.forward_boxes"]["bound"] = "instruction issue: 3 x 27 additions per output in ATen's order (DESIGN.md 11.1)"
             res["roofline_by_kernel"] = rk
         if batched is not None:
             res["batched_2streams"] = batched
