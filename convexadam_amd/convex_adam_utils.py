@@ -96,9 +96,11 @@ def correlate(mind_fix, mind_mov, disp_hw, grid_sp, shape, ch=12, cost="ssd", n_
     am = torch.empty((h, w, d), dtype=torch.int64, device=f.device)
     nws = lib().cvx_correlate_workspace_bytes(ch, h, w, d, int(disp_hw))
     ws = workspace(nws, f.device)
-    if cost not in ("ssd", "sad") or n_box not in (1, 2) or mode not in ("exact", "fast"):
-        raise ValueError("correlate: cost must be 'ssd' or 'sad', n_box 1 or 2, mode 'exact' or 'fast'")
-    opts = CorrOpts(1 if cost == "sad" else 0, int(n_box), 1 if mode == "fast" else 0, 2 if half else 0)
+    if cost not in ("ssd", "sad") or n_box not in (1, 2) or mode not in ("exact", "fast", "certified"):
+        raise ValueError("correlate: cost must be 'ssd' or 'sad', n_box 1 or 2, mode 'exact', 'fast' or 'certified'")
+    # mode="certified": the pipeline's internal arithmetic (cvx_corr_opts.fast = 2) -- `ssd` holds the UNSCALED sums (729 x the mean to
+    # within 2^-16 relative) and `argmin` is nevertheless the reference's argmin of the EXACT volume (certified, resolved exactly where needed)
+    opts = CorrOpts(1 if cost == "sad" else 0, int(n_box), {"exact": 0, "fast": 1, "certified": 2}[mode], 2 if half else 0)
     with torch.cuda.device(f.device):
         check(lib().cvx_correlate_ex_f32(ptr(f), ptr(m), ch, h, w, d, int(disp_hw), C.byref(opts), ptr(ssd), ptr(am), ptr(ws), nws,
                                          stream_ptr(f.device)))

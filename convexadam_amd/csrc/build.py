@@ -11,8 +11,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["api.hip", "mind.hip", "mindmarch.hip", "pool.hip", "correlate.hip", "corrbox.hip", "corrfused.hip", "convex.hip", "adam.hip", "adamfast.hip", "warp.hip", "boxmarch.hip", "boxtile.hip", "metrics.hip", "edt.hip", "surfdist.hip", "pipeline.hip"]
-PER_FILE_FLAGS = {"warp.hip": ["-fno-slp-vectorize"], "adamfast.hip": ["-fno-slp-vectorize"], "boxmarch.hip": ["-fno-slp-vectorize"], "boxtile.hip": ["-fno-slp-vectorize"], "corrbox.hip": ["-fno-slp-vectorize"], "corrfused.hip": ["-fno-slp-vectorize"], "mindmarch.hip": ["-fno-slp-vectorize"]}     # see the header of warp.hip
+SOURCES = ["api.hip", "mind.hip", "mindmarch.hip", "pool.hip", "correlate.hip", "corrbox.hip", "corrfused.hip", "corrcert.hip", "certify.hip", "convex.hip", "adam.hip", "adamfast.hip", "warp.hip", "boxmarch.hip", "boxtile.hip", "metrics.hip", "edt.hip", "surfdist.hip", "pipeline.hip"]
+PER_FILE_FLAGS = {"warp.hip": ["-fno-slp-vectorize"], "adamfast.hip": ["-fno-slp-vectorize"], "boxmarch.hip": ["-fno-slp-vectorize"], "boxtile.hip": ["-fno-slp-vectorize"], "corrbox.hip": ["-fno-slp-vectorize"], "corrfused.hip": ["-fno-slp-vectorize"], "corrcert.hip": ["-fno-slp-vectorize"], "mindmarch.hip": ["-fno-slp-vectorize"]}     # see the header of warp.hip
 LIB = os.path.join(HERE, "libconvexadam_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-fvisibility=hidden",

@@ -1,0 +1,560 @@
+// certify.hip -- the reference's argmin decisions (torch.argmin(ssd, 0) convex_adam_utils.py:87; the six coupled passes :98-107) taken
+// on the CERTIFIED-FAST cost volume of corrcert.hip, bit for bit the decisions the exact volume gives.
+//
+// ssdu[k,x] is the unscaled fast volume: the exact entry ssd[k,x] lies in the interval
+//     [ max(ssdu * CLO - TINY, 0),  ssdu * CHI + min(ssdu, TINY) ]        CLO / CHI = (1 -/+ 3 * 2^-16) / 729
+// (relative part: DESIGN 12.1; TINY covers the denormal range, where ATen's divisions may round to zero; ssdu == 0 <=> ssd == 0).
+// Rounding is monotonic, so the exact cost fl(ssd + pen) of a displacement lies in [lo, hi] = [fl(lower + pen), fl(upper + pen)].
+// A decision is CERTAIN when the second smallest lo exceeds the smallest hi (then every other displacement costs strictly more than
+// the one with the smallest lo); otherwise the candidates {k : lo_k <= min hi} are evaluated EXACTLY -- one wavefront restates
+// ATen's arithmetic for that entry: 125 channel sums in `.sum(0)`'s order (cascade for C >= 16, the interleaved order of the tensor's
+// last < 32 elements), 27 raster-order box sums / 27, one more -- and the first minimum of the exact costs wins.  Zero backgrounds
+// stay certain: their entries are exact zeros on both sides, the penalties decide.  On the benchmark pair 0..3 voxels of 30 784 need the
+// evaluator per pass.
+//
+// Pruning is the branch and bound of convex.hip with the bounds widened to what is known: the lower bound of every cost is
+// fl(lower(min_k ssdu) + pen_k), the upper bound of the minimum is hi of any displacement (the previous winner, or the lattice point
+// nearest to u).  Same launches per pass as the exact path (a voxel kernel, a wavefront kernel), both directions of a pair in each.
+#include <hip/hip_runtime.h>
+
+#include "cvx_common.h"
+
+namespace cvx {
+
+// interval of the exact entry (see the header); the constants are rounded outwards by construction (3 instead of 2 units of 2^-16)
+#define CERT_CLO ((float)((1.0 - 3.0 / 65536.0) / 729.0))
+#define CERT_CHI ((float)((1.0 + 3.0 / 65536.0) / 729.0))
+#define CERT_TINY 1.0e-40f
+__device__ __forceinline__ float cert_lower(float s) { return fmaxf(__builtin_fmaf(s, CERT_CLO, -CERT_TINY), 0.0f); }
+__device__ __forceinline__ float cert_upper(float s) { return __builtin_fmaf(s, CERT_CHI, fminf(s, CERT_TINY)); }
+
+__device__ __forceinline__ unsigned ordered_bits(float v) {              // the value part of pack_min_key
+    unsigned b = __float_as_uint(v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    if (v != v) b = 0u;
+    return b;
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned b) { return __uint_as_float((b & 0x80000000u) ? (b & 0x7fffffffu) : ~b); }
+
+struct CertProb {
+    const float* ssdu; const float* fix; const float* mov; const float* tail;
+    unsigned long long* key; unsigned* sec;       // plain pass: (min, index) and the runner-up value
+    int* idx0; int* idxA; int* idxB;              // winners: plain pass, coupled passes (ping-pong)
+    float* smin;                                  // min_k ssdu[k,x] (NaN: the column holds a NaN)
+    unsigned* list; int* counts;                  // work lists (one counter per pass: [0] plain, [1..6] coupled)
+    float* u;                                     // [3][v] running smoothed field = the result
+    int64_t* argmin_out;                          // optional int64 copy of the plain winners
+};
+struct CertGeo { int C, h, w, d, hw, n, K, ntail; long long tail_from; };
+struct CertArgs { CertProb p[2]; CertGeo g; const float* mesh; float coef; int pass; };
+
+// ---- exact evaluation of ONE entry by one wavefront (blocks of 64 threads; sm = 160 floats of LDS) ------------------------------
+__device__ float cert_exact_entry(const CertGeo& G, const CertProb& P, int k, int xlin, float* sm, int lane) {
+    const int n = G.n, nn = n * n, h = G.h, w = G.w, d = G.d, hw = G.hw;
+    const int iH = k % n, iW = (k / n) % n, iD = k / nn;
+    const int x = xlin % d, y = (xlin / d) % w, z = xlin / (d * w);
+    const size_t v = (size_t)h * w * d;
+    for (int t = lane; t < 125; t += 64) {
+        const int a = t / 25 - 2, b = (t / 5) % 5 - 2, c = t % 5 - 2;
+        const int pz = z + a, py = y + b, px = x + c;
+        float val = 0.0f;
+        if (pz >= 0 && pz < h && py >= 0 && py < w && px >= 0 && px < d) {
+            const long long flat = (((long long)pz * nn + iW * n + iD) * w + py) * d + px;   // position in the reference's (h, n^2, w, d) tensor
+            if (G.ntail > 0 && flat >= G.tail_from) val = P.tail[iH * 32 + (int)(flat - G.tail_from)];
+            else {
+                const int mz = pz + iH - hw, my = py + iW - hw, mx = px + iD - hw;
+                const bool inb = mz >= 0 && mz < h && my >= 0 && my < w && mx >= 0 && mx < d;
+                const float* fp = P.fix + ((size_t)pz * w + py) * d + px;
+                const float* mp = P.mov + ((size_t)(inb ? mz : 0) * w + (inb ? my : 0)) * d + (inb ? mx : 0);
+                float a0 = 0.0f, a1 = 0.0f;
+                for (int ch = 0; ch < G.C; ++ch) {
+                    const float df = fp[(size_t)ch * v] - (inb ? mp[(size_t)ch * v] : 0.0f);
+                    a0 += df * df;                                        // .pow(2).sum(0)
+                    if ((ch & 15) == 15) { a1 += a0; a0 = 0.0f; }         // ATen's cascade (two levels below 256 channels)
+                }
+                val = G.C >= 16 ? a0 + a1 : a0;
+            }
+        }
+        sm[t] = val;
+    }
+    __syncthreads();
+    if (lane < 27) {
+        const int a = lane / 9 - 1, b = (lane / 3) % 3 - 1, c = lane % 3 - 1;
+        const int pz = z + a, py = y + b, px = x + c;
+        float s = 0.0f;
+        const bool in = pz >= 0 && pz < h && py >= 0 && py < w && px >= 0 && px < d;
+        if (in) {
+            for (int aa = -1; aa <= 1; ++aa)
+                for (int bb = -1; bb <= 1; ++bb)
+                    for (int cc = -1; cc <= 1; ++cc) {
+                        const int qz = pz + aa, qy = py + bb, qx = px + cc;
+                        if (qz >= 0 && qz < h && qy >= 0 && qy < w && qx >= 0 && qx < d) s += sm[((a + aa + 2) * 5 + (b + bb + 2)) * 5 + (c + cc + 2)];
+                    }
+            s = div_exact<27>(s);
+        }
+        sm[128 + lane] = in ? s : -1.0f;           // (-1 marks a tap outside the volume; box sums are never negative)
+    }
+    __syncthreads();
+    float s = 0.0f;
+    for (int t = 0; t < 27; ++t) {
+        const float b = sm[128 + t];
+        if (b >= 0.0f || b != b) s += b;
+    }
+    __syncthreads();                                // sm is reused by the next entry
+    return div_exact<27>(s);
+}
+
+// ---- plain argmin: one streaming pass, (min, index) through a 64-bit atomicMin, the runner-up through what that atomic displaces --
+__global__ __launch_bounds__(256) void k_cert_plain_stream(CertArgs A, int kslice, int vec4) {
+    const CertProb& P = A.p[blockIdx.z];
+    const size_t v = (size_t)A.g.h * A.g.w * A.g.d;
+    const int K = A.g.K;
+    const size_t x0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int k0 = blockIdx.y * kslice, k1 = min(k0 + kslice, K);
+    if (x0 >= v) return;
+    const int nv = (int)min((size_t)4, v - x0);
+    const float INF = __uint_as_float(0x7f800000u);
+    // branch-free scan: (best, index) with torch.argmin's comparison, the runner-up as a plain minimum (+inf = none), and a flag for
+    // entries in the denormal zone (ATen's divisions may have rounded those to zero)
+    float best[4], second[4];
+    int bi[4];
+    bool tiny[4] = {false, false, false, false};
+    const float* p = P.ssdu + (size_t)k0 * v + x0;
+    auto load4 = [&](const float* q, float (&c4)[4]) {
+        if (vec4) { const float4 t = *reinterpret_cast<const float4*>(q); c4[0] = t.x; c4[1] = t.y; c4[2] = t.z; c4[3] = t.w; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c4[j] = j < nv ? q[j] : 0.0f;
+        }
+    };
+    {
+        float c4[4];
+        load4(p, c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { best[j] = c4[j]; bi[j] = k0; second[j] = INF; tiny[j] = (c4[j] > 0.0f) & (c4[j] < 1.0e-36f); }
+        p += v;
+    }
+#pragma unroll 4
+    for (int k = k0 + 1; k < k1; ++k, p += v) {
+        float c4[4];
+        load4(p, c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float c = c4[j];
+            tiny[j] = tiny[j] | ((c > 0.0f) & (c < 1.0e-36f));
+            const bool lt = argmin_better(c, best[j]);
+            second[j] = fminf(second[j], lt ? best[j] : c);       // (fminf drops a NaN: a column with a NaN is decided by its first NaN anyway)
+            best[j] = lt ? c : best[j];
+            bi[j] = lt ? k : bi[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j >= nv) continue;
+        const unsigned long long mine = pack_min_key(best[j], (unsigned)bi[j]);
+        const unsigned long long old = atomicMin(&P.key[x0 + j], mine);
+        unsigned cand = second[j] == INF ? 0xffffffffu : ordered_bits(second[j]);
+        if (old != ~0ull) {
+            const unsigned loser = (unsigned)((old < mine ? mine : old) >> 32);
+            cand = loser < cand ? loser : cand;
+        }
+        if (tiny[j]) cand = 0u;                     // sends the voxel to the exact evaluator
+        if (cand != 0xffffffffu) atomicMin(&P.sec[x0 + j], cand);
+    }
+}
+
+// certain winners -> idx0 / smin; the rest -> list
+__global__ __launch_bounds__(256) void k_cert_plain_finalize(CertArgs A) {
+    const CertProb& P = A.p[blockIdx.y];
+    const size_t v = (size_t)A.g.h * A.g.w * A.g.d;
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= v) return;
+    const unsigned long long key = P.key[x];
+    const unsigned b1 = (unsigned)(key >> 32), b2 = P.sec[x];
+    const int k1 = (int)(unsigned)(key & 0xffffffffull);
+    const float s1 = b1 == 0u ? __uint_as_float(0x7fc00000u) : from_ordered_bits(b1);
+    P.smin[x] = s1;
+    P.idx0[x] = k1;
+    if (P.argmin_out) P.argmin_out[x] = k1;
+    // first NaN / single displacement / exact zero (the first of the zeros; no entry of the column in the denormal zone) / a clear runner-up
+    bool certain = b1 == 0u || b2 == 0xffffffffu;
+    if (!certain && b2 != 0u) certain = s1 == 0.0f || cert_lower(from_ordered_bits(b2)) > cert_upper(s1);
+    if (!certain) P.list[atomicAdd(&P.counts[0], 1)] = (unsigned)x;
+}
+
+// flagged voxels of the plain pass: one wavefront per voxel scans the column, evaluates the candidates exactly
+__global__ __launch_bounds__(64) void k_cert_plain_resolve(CertArgs A) {
+    __shared__ float sm[160];
+    const CertProb& P = A.p[blockIdx.y];
+    const size_t v = (size_t)A.g.h * A.g.w * A.g.d;
+    const int K = A.g.K, lane = threadIdx.x;
+    const int cnt = P.counts[0];
+    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const unsigned x = P.list[e];
+        const float* col = P.ssdu + x;
+        float U = __uint_as_float(0x7f800000u);
+        for (int k = lane; k < K; k += 64) U = fminf(U, cert_upper(col[(size_t)k * v]));
+        for (int o = 32; o > 0; o >>= 1) U = fminf(U, __shfl_xor(U, o));
+        unsigned long long bestkey = ~0ull;
+        for (int kb = 0; kb < K; kb += 64) {
+            const int k = kb + lane;
+            const float s = k < K ? col[(size_t)k * v] : 0.0f;
+            const bool cand = k < K && cert_lower(s) <= U;
+            unsigned long long m = __ballot(cand);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int kk = kb + l;
+                const float sk = __shfl(s, l);
+                const float ex = sk == 0.0f ? 0.0f : cert_exact_entry(A.g, P, kk, (int)x, sm, lane);
+                const unsigned long long key = pack_min_key(ex, (unsigned)kk);
+                bestkey = key < bestkey ? key : bestkey;
+            }
+        }
+        if (lane == 0) {
+            const int kw = (int)(unsigned)(bestkey & 0xffffffffull);
+            P.idx0[x] = kw;
+            if (P.argmin_out) P.argmin_out[x] = kw;
+        }
+    }
+}
+
+// ---- coupled passes --------------------------------------------------------------------------------------------------------------
+// u_a(x) = avg_pool3d(mesh[a, idx], 3, padding=1)(x): raster-order sum of the in-range taps, / 27  (convex_adam_utils.py:96,107)
+__device__ __forceinline__ void cert_smooth_winner(const int* __restrict__ idx, const float* __restrict__ mesh, int K, int h, int w, int d, size_t i,
+                                                   float& o0, float& o1, float& o2) {
+    const int x = (int)(i % d), y = (int)((i / d) % w), z = (int)(i / ((size_t)d * w));
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int a = -1; a <= 1; ++a) {
+        const int za = z + a;
+        const bool zok = za >= 0 && za < h;
+        const int zc = zok ? za : z;
+        int kk[9];
+        bool ok[9];
+#pragma unroll
+        for (int b = -1; b <= 1; ++b)
+#pragma unroll
+            for (int c = -1; c <= 1; ++c) {
+                const int yb = y + b, xc = x + c;
+                const bool in = zok && yb >= 0 && yb < w && xc >= 0 && xc < d;
+                const int t = (b + 1) * 3 + (c + 1);
+                ok[t] = in;
+                kk[t] = idx[((size_t)zc * w + (in ? yb : y)) * d + (in ? xc : x)];
+            }
+        float m0[9], m1[9], m2[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { m0[t] = mesh[kk[t]]; m1[t] = mesh[K + kk[t]]; m2[t] = mesh[2 * K + kk[t]]; }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            s0 += ok[t] ? m0[t] : 0.0f;
+            s1 += ok[t] ? m1[t] : 0.0f;
+            s2 += ok[t] ? m2[t] : 0.0f;
+        }
+    }
+    o0 = fdiv(s0, 27.0f);
+    o1 = fdiv(s1, 27.0f);
+    o2 = fdiv(s2, 27.0f);
+}
+
+__device__ __forceinline__ float cert_pen(const float* __restrict__ mesh, int K, int k, float uc, float ub, float ua, float coef) {
+    const float e0 = mesh[k] - uc, e1 = mesh[K + k] - ub, e2 = mesh[2 * K + k] - ua;
+    float q = e0 * e0;          // (..).pow(2).sum(0): sequential over the 3 components
+    q += e1 * e1;
+    q += e2 * e2;
+    return coef * q;            // coeffs[j]*(...)                                                      (:104)
+}
+
+struct CertBox {
+    float uc, ub, ua, slo, bound;
+    int c_lo, c_hi, b_lo, b_hi, a_lo, a_hi;
+    long long vol;
+    bool degenerate;
+};
+// the admissible box: every displacement whose lower cost bound fl(slo + pen) does not exceed `bound` (an upper bound of the minimum)
+__device__ __forceinline__ CertBox cert_box(const float* __restrict__ mesh, float uc, float ub, float ua, float coef, int K, int n, int kp,
+                                            float ssdu_kp, float smin_u, const float* __restrict__ col, size_t v, int refine_above) {
+    CertBox c;
+    c.uc = uc; c.ub = ub; c.ua = ua;
+    c.slo = cert_lower(smin_u);
+    c.bound = cert_upper(ssdu_kp) + cert_pen(mesh, K, kp, uc, ub, ua, coef);
+    const float hwf = (float)((n - 1) / 2);
+    auto close_box = [&]() {
+        const float qmax = fdiv((c.bound - c.slo) + fabsf(c.bound) * 2.384185791015625e-07f, coef) * 1.00001f;
+        const float R = fsqrt(fmaxf(qmax, 0.0f)) * 1.00001f + 1.0e-4f;
+        c.c_lo = max((int)ceilf(c.uc - R + hwf), 0); c.c_hi = min((int)floorf(c.uc + R + hwf), n - 1);
+        c.b_lo = max((int)ceilf(c.ub - R + hwf), 0); c.b_hi = min((int)floorf(c.ub + R + hwf), n - 1);
+        c.a_lo = max((int)ceilf(c.ua - R + hwf), 0); c.a_hi = min((int)floorf(c.ua + R + hwf), n - 1);
+        c.vol = (long long)max(c.c_hi - c.c_lo + 1, 0) * max(c.b_hi - c.b_lo + 1, 0) * max(c.a_hi - c.a_lo + 1, 0);
+        c.degenerate = !(coef > 0.0f) || !(R == R) || c.vol <= 0;
+    };
+    close_box();
+    if (!c.degenerate && c.vol > refine_above && uc == uc && ub == ub && ua == ua) {
+        const int kn = (min(max((int)rintf(ua + hwf), 0), n - 1) * n + min(max((int)rintf(ub + hwf), 0), n - 1)) * n + min(max((int)rintf(uc + hwf), 0), n - 1);
+        if (kn != kp) {
+            const float near_hi = cert_upper(col[(size_t)kn * v]) + cert_pen(mesh, K, kn, uc, ub, ua, coef);
+            if (near_hi < c.bound) { c.bound = near_hi; close_box(); }
+        }
+    }
+    if (c.degenerate) { c.c_lo = c.b_lo = c.a_lo = 0; c.c_hi = c.b_hi = c.a_hi = n - 1; c.vol = (long long)n * n * n; }
+    return c;
+}
+
+// one thread per voxel: smoothing of the previous winners, the admissible box, boxes of at most 8 displacements decided here
+__global__ __launch_bounds__(64) void k_cert_voxel(CertArgs A, int refine) {
+    const CertProb& P = A.p[blockIdx.y];
+    const int h = A.g.h, w = A.g.w, d = A.g.d, K = A.g.K, n = A.g.n;
+    const size_t v = (size_t)h * w * d;
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= v) return;
+    const int* prev = A.pass == 1 ? P.idx0 : ((A.pass & 1) ? P.idxB : P.idxA);
+    int* next = (A.pass & 1) ? P.idxA : P.idxB;
+    const int kp = prev[x];
+    const float s_kp = P.ssdu[(size_t)kp * v + x];
+    const float sm_x = P.smin[x];
+    float uc, ub, ua;
+    cert_smooth_winner(prev, A.mesh, K, h, w, d, x, uc, ub, ua);
+    P.u[x] = uc; P.u[v + x] = ub; P.u[2 * v + x] = ua;
+    // a column with a NaN: torch.argmin returns the first NaN in every pass (the penalty is finite) = the plain pass's winner
+    if (sm_x != sm_x) { next[x] = P.idx0[x]; return; }
+    const CertBox c = cert_box(A.mesh, uc, ub, ua, A.coef, K, n, kp, s_kp, sm_x, P.ssdu + x, v, refine);
+    constexpr int NB = 8;
+    if (c.vol > NB) { P.list[atomicAdd(&P.counts[A.pass], 1)] = (unsigned)x; return; }
+    int kk[NB];
+    float pen[NB], val[NB];
+    bool need[NB];
+    {
+        int ic = c.c_lo, ib = c.b_lo, ia = c.a_lo;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const bool in = j < (int)c.vol;
+            kk[j] = (ia * n + ib) * n + ic;
+            pen[j] = cert_pen(A.mesh, K, kk[j], c.uc, c.ub, c.ua, A.coef);
+            need[j] = in && !(c.slo + pen[j] > c.bound);
+            if (j + 1 < (int)c.vol) {
+                if (++ic > c.c_hi) { ic = c.c_lo; if (++ib > c.b_hi) { ib = c.b_lo; ++ia; } }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) val[j] = need[j] ? P.ssdu[(size_t)kk[j] * v + x] : 0.0f;
+    float lo1 = 0.f, lo2 = 0.f, U = __uint_as_float(0x7f800000u);
+    int k1 = -1, cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (!need[j]) continue;
+        const float lo = cert_lower(val[j]) + pen[j], hi = cert_upper(val[j]) + pen[j];
+        U = fminf(U, hi);
+        if (cnt == 0) { lo1 = lo; k1 = kk[j]; }
+        else if (lo < lo1) { lo2 = lo1; lo1 = lo; k1 = kk[j]; }
+        else if (cnt == 1 || lo < lo2) lo2 = lo;
+        ++cnt;
+    }
+    if (cnt == 0) { next[x] = kp; return; }         // cannot happen (kp passes its own test); keeps the output defined
+    if (cnt == 1 || lo2 > U) { next[x] = k1; return; }
+    P.list[atomicAdd(&P.counts[A.pass], 1)] = (unsigned)x;
+}
+
+// one wavefront per listed voxel: scan of the admissible box, exact evaluation of what the intervals leave open
+__global__ __launch_bounds__(64) void k_cert_wave(CertArgs A, int refine) {
+    __shared__ float sm[160];
+    const CertProb& P = A.p[blockIdx.y];
+    const int h = A.g.h, w = A.g.w, d = A.g.d, K = A.g.K, n = A.g.n;
+    const size_t v = (size_t)h * w * d;
+    const int lane = threadIdx.x;
+    const int* prev = A.pass == 1 ? P.idx0 : ((A.pass & 1) ? P.idxB : P.idxA);
+    int* next = (A.pass & 1) ? P.idxA : P.idxB;
+    const int cnt = P.counts[A.pass];
+    const float INF = __uint_as_float(0x7f800000u);
+    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const size_t x = P.list[e];
+        const int kp = prev[x];
+        const float* col = P.ssdu + x;
+        const CertBox c = cert_box(A.mesh, P.u[x], P.u[v + x], P.u[2 * v + x], A.coef, K, n, kp, col[(size_t)kp * v], P.smin[x], col, v, refine);
+        const int nc = c.c_hi - c.c_lo + 1, nb = c.b_hi - c.b_lo + 1;
+        // pass 1 over the box: smallest lo (first index among equals), runner-up lo, smallest hi
+        unsigned long long key = ~0ull;
+        float lo2 = INF, U = INF;
+        for (long long i0 = 0; i0 < c.vol; i0 += 64) {
+            const long long i = i0 + lane;
+            if (i < c.vol) {
+                const int ic = c.c_lo + (int)(i % nc), ib = c.b_lo + (int)((i / nc) % nb), ia = c.a_lo + (int)(i / ((long long)nc * nb));
+                const int k = (ia * n + ib) * n + ic;
+                const float pen = cert_pen(A.mesh, K, k, c.uc, c.ub, c.ua, A.coef);
+                if (c.degenerate || !(c.slo + pen > c.bound)) {
+                    const float s = col[(size_t)k * v];
+                    const float lo = cert_lower(s) + pen, hi = cert_upper(s) + pen;
+                    U = fminf(U, hi);
+                    const unsigned long long kk = pack_min_key(lo, (unsigned)k);
+                    if (kk < key) { if (key != ~0ull) lo2 = fminf(lo2, from_ordered_bits((unsigned)(key >> 32))); key = kk; }
+                    else lo2 = fminf(lo2, lo);
+                }
+            }
+        }
+        unsigned long long gkey = key;
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(gkey, o); gkey = t < gkey ? t : gkey; }
+        float mine2 = key == gkey ? lo2 : fminf(lo2, key != ~0ull ? from_ordered_bits((unsigned)(key >> 32)) : INF);
+        for (int o = 32; o > 0; o >>= 1) { mine2 = fminf(mine2, __shfl_xor(mine2, o)); U = fminf(U, __shfl_xor(U, o)); }
+        if (gkey == ~0ull) { if (lane == 0) next[x] = kp; continue; }             // (cannot happen)
+        if (mine2 > U) { if (lane == 0) next[x] = (int)(unsigned)(gkey & 0xffffffffull); continue; }
+        // pass 2: the candidates lo <= U, exactly
+        unsigned long long bestkey = ~0ull;
+        for (long long i0 = 0; i0 < c.vol; i0 += 64) {
+            const long long i = i0 + lane;
+            bool cand = false;
+            int k = 0;
+            float s = 0.0f, pen = 0.0f;
+            if (i < c.vol) {
+                const int ic = c.c_lo + (int)(i % nc), ib = c.b_lo + (int)((i / nc) % nb), ia = c.a_lo + (int)(i / ((long long)nc * nb));
+                k = (ia * n + ib) * n + ic;
+                pen = cert_pen(A.mesh, K, k, c.uc, c.ub, c.ua, A.coef);
+                if (c.degenerate || !(c.slo + pen > c.bound)) {
+                    s = col[(size_t)k * v];
+                    cand = cert_lower(s) + pen <= U;
+                }
+            }
+            unsigned long long m = __ballot(cand);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int kk = __shfl(k, l);
+                const float sk = __shfl(s, l), pk = __shfl(pen, l);
+                const float ex = sk == 0.0f ? 0.0f : cert_exact_entry(A.g, P, kk, (int)x, sm, lane);
+                const unsigned long long kx = pack_min_key(ex + pk, (unsigned)kk);      // ssd + coeffs[j]*(...)
+                bestkey = kx < bestkey ? kx : bestkey;
+            }
+        }
+        if (lane == 0) next[x] = (int)(unsigned)(bestkey & 0xffffffffull);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cert_gather(CertArgs A) {
+    const CertProb& P = A.p[blockIdx.y];
+    const size_t v = (size_t)A.g.h * A.g.w * A.g.d;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    const int* prev = A.pass == 1 ? P.idx0 : ((A.pass & 1) ? P.idxB : P.idxA);
+    float o0, o1, o2;
+    cert_smooth_winner(prev, A.mesh, A.g.K, A.g.h, A.g.w, A.g.d, i, o0, o1, o2);
+    P.u[i] = o0; P.u[v + i] = o1; P.u[2 * v + i] = o2;
+}
+
+__global__ __launch_bounds__(256) void k_cert_arm(CertArgs A, int nprob) {
+    const size_t v = (size_t)A.g.h * A.g.w * A.g.d;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int q = 0; q < nprob; ++q) {
+        if (i < v) { A.p[q].key[i] = ~0ull; A.p[q].sec[i] = 0xffffffffu; }
+        if (i < 8) A.p[q].counts[i] = 0;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int sad, float* tail, hipStream_t s);
+
+size_t corr_certify_workspace_bytes(int C, int h, int w, int d, int hw) {
+    (void)C;
+    const size_t v = (size_t)h * w * d;
+    const int n = 2 * hw + 1;
+    size_t used = 0;
+    used = carve_size(used, sizeof(unsigned long long) * v);      // key
+    used = carve_size(used, sizeof(unsigned) * v);                // sec
+    for (int i = 0; i < 3; ++i) used = carve_size(used, sizeof(int) * v);   // idx0, idxA, idxB
+    used = carve_size(used, sizeof(float) * v);                   // smin
+    used = carve_size(used, sizeof(unsigned) * v);                // list
+    used = carve_size(used, sizeof(int) * 8);                     // counts
+    used = carve_size(used, sizeof(float) * 32 * n);              // tail
+    return used + 256;
+}
+
+struct CertCarve { unsigned long long* key; unsigned* sec; int* idx0; int* idxA; int* idxB; float* smin; unsigned* list; int* counts; float* tail; };
+static CertCarve cert_carve(void* workspace, size_t workspace_bytes, int h, int w, int d, int hw) {
+    const size_t v = (size_t)h * w * d;
+    const int n = 2 * hw + 1;
+    Carver cv(workspace, workspace_bytes);
+    CertCarve c;
+    c.key = cv.take<unsigned long long>(v);
+    c.sec = cv.take<unsigned>(v);
+    c.idx0 = cv.take<int>(v); c.idxA = cv.take<int>(v); c.idxB = cv.take<int>(v);
+    c.smin = cv.take<float>(v);
+    c.list = cv.take<unsigned>(v);
+    c.counts = cv.take<int>(8);
+    c.tail = cv.take<float>((size_t)32 * n);
+    return c;
+}
+static CertGeo cert_geo(int C, int h, int w, int d, int hw) {
+    CertGeo g;
+    g.C = C; g.h = h; g.w = w; g.d = d; g.hw = hw; g.n = 2 * hw + 1; g.K = g.n * g.n * g.n;
+    const long long ncols = (long long)h * g.n * g.n * w * d;
+    g.tail_from = (ncols / 32) * 32;
+    g.ntail = (int)(ncols - g.tail_from);
+    return g;
+}
+static CertProb cert_prob(const float* ssdu, const float* fix, const float* mov, const CertCarve& c, float* u, int64_t* argmin_out) {
+    return CertProb{ssdu, fix, mov, c.tail, c.key, c.sec, c.idx0, c.idxA, c.idxB, c.smin, c.list, c.counts, u, argmin_out};
+}
+
+// plain argmin of one or two problems (nprob = 2: the two directions of a pair); leaves idx0 / smin in the workspaces
+static int cert_plain(CertArgs& A, int nprob, bool arm, hipStream_t s) {
+    const CertGeo& g = A.g;
+    const size_t v = (size_t)g.h * g.w * g.d;
+    const int K = g.K;
+    if (arm) hipLaunchKernelGGL(k_cert_arm, dim3((unsigned)cdiv64((int64_t)(v > 8 ? v : 8), 256)), dim3(256), 0, s, A, nprob);
+    for (int q = 0; q < nprob; ++q)
+        if (g.ntail > 0) launch_corr_tail_compact(A.p[q].fix, A.p[q].mov, g.C, g.h, g.w, g.d, g.hw, 0, const_cast<float*>(A.p[q].tail), s);
+    bool vec4 = v % 4 == 0;
+    for (int q = 0; q < nprob; ++q) vec4 = vec4 && (reinterpret_cast<uintptr_t>(A.p[q].ssdu) & 15) == 0;
+    const int xb = (int)cdiv64((int64_t)cdiv64((int64_t)v, 4), 256);
+    int nslices = cdiv(512, xb);
+    if (nslices > K) nslices = K;
+    if (nslices < 1) nslices = 1;
+    const int kslice = cdiv(K, nslices);
+    nslices = cdiv(K, kslice);
+    hipLaunchKernelGGL(k_cert_plain_stream, dim3(xb, nslices, nprob), dim3(256), 0, s, A, kslice, vec4 ? 1 : 0);
+    hipLaunchKernelGGL(k_cert_plain_finalize, dim3((unsigned)cdiv64((int64_t)v, 256), nprob), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_cert_plain_resolve, dim3(256, nprob), dim3(64), 0, s, A);
+    return check_last("certified argmin");
+}
+
+int corr_certified_argmin(const float* ssdu, const float* fix, const float* mov, int C, int h, int w, int d, int hw, int64_t* argmin,
+                          void* workspace, size_t workspace_bytes, hipStream_t s) {
+    if (workspace_bytes < corr_certify_workspace_bytes(C, h, w, d, hw)) return fail(CVX_ERR_WORKSPACE, "certified argmin: workspace too small");
+    const CertCarve c = cert_carve(workspace, workspace_bytes, h, w, d, hw);
+    CertArgs A{};
+    A.g = cert_geo(C, h, w, d, hw);
+    A.p[0] = cert_prob(ssdu, fix, mov, c, nullptr, argmin);
+    A.p[1] = A.p[0];
+    return cert_plain(A, 1, true, s);
+}
+
+// both directions (ssduB == nullptr: one) from the certified-fast volumes to the smoothed fields: plain argmin + six coupled passes
+// stage: 0 = everything, 1 = the plain argmin only, 2 = the coupled passes only (after a call with stage 1 on the same workspaces)
+int coupled_convex_cert_impl(const float* ssduA, const float* fixA, const float* movA, float* outA, void* wsA, const float* ssduB, const float* fixB,
+                             const float* movB, float* outB, void* wsB, const float* mesh, int C, int h, int w, int d, int hw, size_t workspace_bytes,
+                             hipStream_t s, int stage) {
+    if (workspace_bytes < corr_certify_workspace_bytes(C, h, w, d, hw)) return fail(CVX_ERR_WORKSPACE, "certified coupled convex: workspace too small");
+    const int nprob = ssduB ? 2 : 1;
+    CertArgs A{};
+    A.g = cert_geo(C, h, w, d, hw);
+    A.mesh = mesh;
+    const CertCarve ca = cert_carve(wsA, workspace_bytes, h, w, d, hw);
+    A.p[0] = cert_prob(ssduA, fixA, movA, ca, outA, nullptr);
+    A.p[1] = A.p[0];
+    if (ssduB) { const CertCarve cb = cert_carve(wsB, workspace_bytes, h, w, d, hw); A.p[1] = cert_prob(ssduB, fixB, movB, cb, outB, nullptr); }
+    if (stage != 2) {
+        const int rc = cert_plain(A, nprob, true, s);
+        if (rc || stage == 1) return rc;
+    }
+    const size_t v = (size_t)h * w * d;
+    const int refine = options().prune_refine != 0 ? 8 : 0x7fffffff;
+    static const float coeffs[6] = {0.003f, 0.01f, 0.03f, 0.1f, 0.3f, 1.0f};      // torch.tensor([...]) float32 (:98)
+    for (int it = 0; it < 6; ++it) {
+        A.coef = coeffs[it]; A.pass = it + 1;
+        hipLaunchKernelGGL(k_cert_voxel, dim3((unsigned)cdiv64((int64_t)v, 64), nprob), dim3(64), 0, s, A, refine);
+        hipLaunchKernelGGL(k_cert_wave, dim3(1024, nprob), dim3(64), 0, s, A, refine);
+    }
+    A.pass = 7;
+    hipLaunchKernelGGL(k_cert_gather, dim3((unsigned)cdiv64((int64_t)v, 256), nprob), dim3(256), 0, s, A);
+    return check_last("certified coupled convex");
+}
+
+}  // namespace cvx

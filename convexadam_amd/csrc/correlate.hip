@@ -236,6 +236,27 @@ static void corr_raw_dispatch(const float* Fp, const float* Mp, const CorrGeom& 
     else hipLaunchKernelGGL((k_corr_raw<HW, false>), grid, dim3(256), 0, s, Fp, Mp, g, raw);
 }
 
+// ---- the certified-fast volume: which kernel produces it (option corr_cert: 1 = the role kernel of corrfused.hip in its fast arithmetic
+// without the final scaling -- the faster one as measured --, 2 = the staged kernel of corrcert.hip; 0 in the pipeline = exact volumes) -------
+static bool certfast_use_staged(int C, int h, int w, int d, int hw) {
+    const bool staged_ok = corr_cert_supported(C, h, w, d, hw), fused_ok = corr_fused_supported(C, h, w, d, hw) && C < 16;
+    if (options().corr_cert == 2) return staged_ok;
+    return staged_ok && !fused_ok;
+}
+bool corr_certfast_supported(int C, int h, int w, int d, int hw) {
+    return corr_cert_supported(C, h, w, d, hw) || (corr_fused_supported(C, h, w, d, hw) && C < 16);
+}
+size_t corr_certfast_workspace_bytes(int C, int h, int w, int d, int hw) {
+    const size_t a = corr_cert_supported(C, h, w, d, hw) ? corr_cert_workspace_bytes(C, h, w, d, hw) : 0;
+    const size_t b = corr_fused_supported(C, h, w, d, hw) ? corr_fused_workspace_bytes(C, h, w, d, hw) : 0;
+    return align_up(a > b ? a : b, 256);
+}
+int launch_corr_certfast(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* ssdu, void* workspace, size_t workspace_bytes,
+                         hipStream_t s) {
+    if (certfast_use_staged(C, h, w, d, hw)) return launch_corr_cert(fix, mov, C, h, w, d, hw, ssdu, workspace, workspace_bytes, s);
+    return launch_corr_fused(fix, mov, C, h, w, d, hw, 0, 2, /*fast=*/2, 0, ssdu, workspace, workspace_bytes, s);
+}
+
 }  // namespace cvx
 
 using namespace cvx;
@@ -251,7 +272,14 @@ bool cvx::corr_use_unfused(int C, int h, int w, int d, int hw, bool variant) {
     return corr_box2_supported(h, w, d, g.px) && (size_t)g.n * g.n * g.n * h * w * g.px * sizeof(float) <= ((size_t)2 << 30);
 }
 
+static size_t correlate_workspace_exact(int C, int h, int w, int d, int disp_hw);
 extern "C" size_t cvx_correlate_workspace_bytes(int C, int h, int w, int d, int disp_hw) {
+    // (the certified-fast variant, cvx_corr_opts.fast = 2, stages its own padded copies)
+    const size_t exact = correlate_workspace_exact(C, h, w, d, disp_hw);
+    const size_t cert = corr_certfast_supported(C, h, w, d, disp_hw) ? corr_certfast_workspace_bytes(C, h, w, d, disp_hw) + corr_certify_workspace_bytes(C, h, w, d, disp_hw) + 512 : 0;
+    return exact > cert ? exact : cert;
+}
+static size_t correlate_workspace_exact(int C, int h, int w, int d, int disp_hw) {
     const size_t fused = corr_fused_supported(C, h, w, d, disp_hw)
                              ? carve_size(corr_fused_workspace_bytes(C, h, w, d, disp_hw), sizeof(unsigned long long) * (size_t)h * w * d) + 256 : 0;
     if (fused && !corr_use_unfused(C, h, w, d, disp_hw, false)) return fused;         // fused kernel: no raw intermediate
@@ -273,7 +301,7 @@ extern "C" int cvx_correlate_f32(const float* fix, const float* mov, int C, int 
 extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, int h, int w, int d, int disp_hw, const cvx_corr_opts* opts,
                                     float* ssd, int64_t* argmin, void* workspace, size_t workspace_bytes, void* stream) {
     const int cost = opts ? opts->cost : 0, n_box = opts ? opts->n_box : 2, fast = opts ? opts->fast : 0, f16 = opts ? opts->f16 : 0;
-    CVX_REQUIRE((cost == 0 || cost == 1) && (n_box == 1 || n_box == 2) && (fast == 0 || fast == 1) && f16 >= 0 && f16 <= 2, "cvx_correlate_ex_f32: bad options");
+    CVX_REQUIRE((cost == 0 || cost == 1) && (n_box == 1 || n_box == 2) && (fast == 0 || fast == 1 || fast == 2) && f16 >= 0 && f16 <= 2, "cvx_correlate_ex_f32: bad options");
     CVX_REQUIRE(!(f16 && (cost != 0 || n_box != 2)), "cvx_correlate_ex_f32: fp16 storage exists for the SSD cost with two boxes only");
     CVX_REQUIRE(!(fast && (cost != 0 || n_box != 2)), "cvx_correlate_ex_f32: the fast mode exists for the SSD cost with two boxes only");
     CVX_REQUIRE(fix && mov && ssd && workspace, "cvx_correlate_f32: null pointer");
@@ -285,6 +313,17 @@ extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, i
     hipStream_t s = as_stream(stream);
     const CorrGeom g = corr_geom(C, h, w, d, disp_hw);
     const size_t K = (size_t)g.n * g.n * g.n;
+    if (fast == 2) {
+        // certified-fast arithmetic: `ssd` receives the UNSCALED sums (729 x the mean, to within 2^-16 relative); `argmin` -- if asked for --
+        // is the reference's argmin (first minimum of the EXACT volume), certified from the fast one and resolved exactly where it cannot be
+        if (f16) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_ex_f32: the certified-fast volume is float32");
+        if (!corr_certfast_supported(C, h, w, d, disp_hw)) return fail(CVX_ERR_UNSUPPORTED, "cvx_correlate_ex_f32: certified-fast correlation not built for this geometry");
+        const size_t cws = corr_certfast_workspace_bytes(C, h, w, d, disp_hw);
+        int rc = launch_corr_certfast(fix, mov, C, h, w, d, disp_hw, ssd, workspace, cws, s);
+        if (rc || !argmin) return rc;
+        return corr_certified_argmin(ssd, fix, mov, C, h, w, d, disp_hw, argmin, static_cast<char*>(workspace) + align_up(cws, 256),
+                                     corr_certify_workspace_bytes(C, h, w, d, disp_hw), s);
+    }
     const bool variant = cost != 0 || n_box != 2 || fast || f16;
     if (!corr_use_unfused(C, h, w, d, disp_hw, variant)) {
         const size_t fws = corr_fused_workspace_bytes(C, h, w, d, disp_hw);

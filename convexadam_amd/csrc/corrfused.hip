@@ -274,7 +274,7 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
 typedef _Float16 h16x4u __attribute__((ext_vector_type(4), aligned(2)));   // four half-precision values at 2-byte alignment
 
 // OT = element type of the cost volume: float, or __half (fp16 STORAGE: half the bytes written here and read by the argmin passes)
-template <int G, bool FIRST, bool LAST, bool FAST, bool ONEBOX, bool F16, typename OT, bool TILED>
+template <int G, bool FIRST, bool LAST, bool FAST, bool ONEBOX, bool F16, typename OT, bool TILED, bool UNSCALED = false>
 __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const float* Sin, float* S1, const float* zero, OT* __restrict__ ssd) {
     constexpr int R = G + 2, NSUB = (G + 1) / 2;
     const int n = g.n, nn = n * n, q = it.q, RS = g.RS, PF = g.PF;
@@ -327,7 +327,7 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
                         if (FAST) {
                             cf_box_item_fast(sb + sp * pf, rs, mid[k], pre[k], fin);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) o[j] = LAST ? fin[j] * SCALE : fin[j];
+                            for (int j = 0; j < 4; ++j) o[j] = (LAST && !UNSCALED) ? fin[j] * SCALE : fin[j];     // UNSCALED: the certified pipeline's volume (no multiplication that could underflow)
                         } else {
                             cf_box_item(sb + sp * pf, rs, mid[k], pre[k], fin);
 #pragma unroll
@@ -379,11 +379,12 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
 }
 
 // MODE bits: 1 = FAST (FMA + separable sums, not bit-compatible), 2 = SAD cost, 4 = single box, 8 = cost volume rounded to fp16 (values in a
-// float32 buffer), 16 = cost volume STORED as fp16 (the buffer holds __half: same values as 8, half the bytes)
+// float32 buffer), 16 = cost volume STORED as fp16 (the buffer holds __half: same values as 8, half the bytes), 32 = FAST without the
+// final multiplication by 1 / 729 (the unscaled volume certify.hip takes its decisions on)
 template <int G, int MODE, bool CASC, bool TILED>
 __device__ __forceinline__ void cf_roles(int role, const float* Fp, const float* Mp, const float* tail, const CFGeom& g, const CFItem& it,
                                          float* lds, float* S0, float* S1, void* ssd_any) {
-    constexpr bool FAST = (MODE & 1) != 0, SAD = (MODE & 2) != 0, ONEBOX = (MODE & 4) != 0, F16 = (MODE & 8) != 0, HALF = (MODE & 16) != 0;
+    constexpr bool FAST = (MODE & 1) != 0, SAD = (MODE & 2) != 0, ONEBOX = (MODE & 4) != 0, F16 = (MODE & 8) != 0, HALF = (MODE & 16) != 0, UNS = (MODE & 32) != 0;
     using OT = typename std::conditional<HALF, __half, float>::type;
     OT* ssd = static_cast<OT*>(ssd_any);
     if (role == 0) {
@@ -392,7 +393,7 @@ __device__ __forceinline__ void cf_roles(int role, const float* Fp, const float*
         else cf_raw<G, 0, FAST, SAD, false, TILED>(Fp, Mp, tail, g, it, S0, ONEBOX ? g.h + 2 : g.h + 4);
     } else if (ONEBOX) cf_box<G, true, true, FAST, true, F16, OT, TILED>(g, it, S0, S1, lds, ssd);
     else if (role == 1) cf_box<G, true, false, FAST, false, F16, OT, TILED>(g, it, S0, S1, lds, ssd);
-    else cf_box<G, false, true, FAST, false, F16, OT, TILED>(g, it, S1, S1, lds, ssd);
+    else cf_box<G, false, true, FAST, false, F16, OT, TILED, UNS>(g, it, S1, S1, lds, ssd);
 }
 
 // A launch may carry a SECOND problem of the same geometry (the reverse direction of a pair, pipeline.hip): blocks items1 .. 2 items1 - 1
@@ -551,6 +552,7 @@ int launch_corr_fused_dual(const float* fix, const float* mov, int C, int h, int
     // every argument check comes before the first launch: a refused call leaves nothing on the stream
     if (workspace_bytes < corr_fused_workspace_bytes(C, h, w, d, hw)) return fail(CVX_ERR_WORKSPACE, "correlate (fused): workspace too small");
     if (fast && (cost != 0 || n_box != 2)) return fail(CVX_ERR_UNSUPPORTED, "correlate: the fast mode exists for the SSD cost with two boxes only");
+    if (fast == 2 && f16) return fail(CVX_ERR_UNSUPPORTED, "correlate: the unscaled fast volume is float32");
     if (f16 && (cost != 0 || n_box != 2)) return fail(CVX_ERR_UNSUPPORTED, "correlate: fp16 storage exists for the SSD cost with two boxes only");
     if (f16 < 0 || f16 > 2) return fail(CVX_ERR_INVALID_ARG, "correlate: f16 must be 0, 1 or 2");
     Carver cv(workspace, workspace_bytes);
@@ -575,7 +577,8 @@ int launch_corr_fused_dual(const float* fix, const float* mov, int C, int h, int
     CFGeom gl = g;
     gl.prio = (int)options().cf_prio;
     gl.dbg = (options().cf_census && !ssd_rev) ? census_buf : nullptr;      // debugging aid: per-workgroup start / end / placement in the workspace
-    if (fast && f16 == 2) cf_launch<1 + 8 + 16>(gl, Fp, Mp, tail, ssd, s, sec);
+    if (fast == 2) cf_launch<1 + 32>(gl, Fp, Mp, tail, ssd, s, sec);
+    else if (fast && f16 == 2) cf_launch<1 + 8 + 16>(gl, Fp, Mp, tail, ssd, s, sec);
     else if (fast && f16) cf_launch<9>(gl, Fp, Mp, tail, ssd, s, sec);
     else if (fast) cf_launch<1>(gl, Fp, Mp, tail, ssd, s, sec);
     else if (f16 == 2) cf_launch<8 + 16>(gl, Fp, Mp, tail, ssd, s, sec);

@@ -106,6 +106,11 @@ struct Options {
                                    //    neighbourhood; bit-identical); 0 = one thread per output
     long long mind_blocked;        // 1 (default): the pipeline's MIND stencil writes its raw patch SSDs blocked by the tiles of the normalise + pool pass (contiguous reads there:
                                    //    half as many L1-miss requests for the same bytes); 0 = planar (bit-identical)
+    long long corr_cert;           // 1 (default) / 2: the whole-pair pipeline evaluates its cost volumes in the certified-fast arithmetic and takes the argmin decisions with
+                                   //    certification (certify.hip) where the geometry allows: SAME winners, SAME field bits as the exact kernels; 1 = the role kernel of
+                                   //    corrfused.hip (fast arithmetic, unscaled), 2 = the staged kernel of corrcert.hip; 0 = exact volumes
+    long long cc_debug;            // timing experiments on the certified-fast correlation kernel (bits: 1 no stores, 2 no staging after the first chunk, 4 no channel
+                                   //    sums, 8 no y pass, 16 no x / z pass): WRONG results, never set outside tools/experiments
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };
@@ -395,6 +400,24 @@ int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, i
 // both directions of a pair in ONE launch (ssd_rev = correlate(mov, fix); workspace_rev: a second workspace of the same size)
 int launch_corr_fused_dual(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
                            void* ssd, void* ssd_rev, void* workspace, size_t workspace_bytes, void* workspace_rev, hipStream_t s);
+// corrcert.hip: the cost volume in the certified-fast arithmetic -- UNSCALED sums over the 729 taps, |ssdu / 729 - ssd| <= 2^-16 ssd
+bool corr_cert_supported(int C, int h, int w, int d, int hw);
+size_t corr_cert_workspace_bytes(int C, int h, int w, int d, int hw);
+int launch_corr_cert(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* ssdu, void* workspace, size_t workspace_bytes,
+                     hipStream_t s);
+// correlate.hip: the certified-fast volume from whichever kernel option corr_cert selects
+bool corr_certfast_supported(int C, int h, int w, int d, int hw);
+size_t corr_certfast_workspace_bytes(int C, int h, int w, int d, int hw);
+int launch_corr_certfast(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* ssdu, void* workspace, size_t workspace_bytes,
+                         hipStream_t s);
+// certify.hip: decisions on the certified-fast volume that equal the reference's on the exact one
+size_t corr_certify_workspace_bytes(int C, int h, int w, int d, int hw);
+int corr_certified_argmin(const float* ssdu, const float* fix, const float* mov, int C, int h, int w, int d, int hw, int64_t* argmin,
+                          void* workspace, size_t workspace_bytes, hipStream_t s);
+// both directions (ssduB == nullptr: one) from the certified-fast volumes to the smoothed fields: plain argmin + six coupled passes
+int coupled_convex_cert_impl(const float* ssduA, const float* fixA, const float* movA, float* outA, void* wsA, const float* ssduB, const float* fixB,
+                             const float* movB, float* outB, void* wsB, const float* mesh, int C, int h, int w, int d, int hw, size_t workspace_bytes,
+                             hipStream_t s, int stage = 0);      // stage 1: plain argmin only, 2: the coupled passes only
 // correlate.hip: would cvx_correlate_ex_f32 take the unfused round-1 kernels for this problem?
 bool corr_use_unfused(int C, int h, int w, int d, int hw, bool variant);
 // boxmarch.hip: three chained 3^3 boxes (forward / adjoint / adjoint + Adam) for rows of at most 126 voxels

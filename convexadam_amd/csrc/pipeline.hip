@@ -97,7 +97,7 @@ struct PairLayout {
     int H, W, D, h, w, d, h2, w2, d2, C, K;
     size_t V, v, V2;
     // byte offsets into the workspace (0 = not used)
-    size_t featF, featM, mind_ws, mind_ws2, fs, ms, corr_ws, corr_ws2, ssd, argmin, mesh, conv_ws, ssd2, argmin2, conv_ws2, soft, soft2, in1, in2, ic1, ic2, ic_ws,
+    size_t featF, featM, mind_ws, mind_ws2, fs, ms, corr_ws, corr_ws2, ssd, argmin, mesh, conv_ws, ssd2, argmin2, conv_ws2, cert_ws, cert_ws2, soft, soft2, in1, in2, ic1, ic2, ic_ws,
         upin, disp_hr, F2, M2, P, m, v_, U, adam_ws, smooth_ws, snaps, bh, bw, bd, bh2, bw2, bd2, total;
 };
 
@@ -136,6 +136,9 @@ static PairLayout pair_layout(const cvx_pair_params& p, int n_snap = 0, int max_
     L.argmin = take(u, sizeof(int64_t) * L.v);
     L.mesh = take(u, f * 3 * (size_t)L.K);
     L.conv_ws = take(u, cvx_coupled_convex_workspace_bytes(L.h, L.w, L.d, p.disp_hw));
+    // certified decisions on the fast cost volume (certify.hip): one small workspace per direction
+    L.cert_ws = take(u, corr_certify_workspace_bytes(L.C, L.h, L.w, L.d, p.disp_hw));
+    if (p.ic) L.cert_ws2 = take(u, corr_certify_workspace_bytes(L.C, L.h, L.w, L.d, p.disp_hw));
     L.soft = take(u, f * 3 * L.v);
     L.bh = take(u, f * L.h); L.bw = take(u, f * L.w); L.bd = take(u, f * L.d);
     if (p.ic) {
@@ -413,10 +416,28 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     if (p->fp16_storage) {                      // features are stored in half precision by the reference's GPU default (MIND:79)
         if ((rc = cvx_round_f16_f32(F(L.fs), (int64_t)L.C * L.v, stream)) || (rc = cvx_round_f16_f32(F(L.ms), (int64_t)L.C * L.v, stream))) return rc;
     }
+    // Certified-fast path (option corr_cert, default): the cost volumes in the fast arithmetic (unscaled, 2^-16 relative to ATen's), every
+    // argmin decision certified against the exact arithmetic or evaluated exactly (certify.hip) -- the SAME winners, hence the same field bits,
+    // as the exact kernels below; packaged operator only (SSD, two boxes, float32, pruned passes).
+    const bool cert = options().corr_cert != 0 && !variant && !no_prune && corr_certfast_supported(L.C, L.h, L.w, L.d, p->disp_hw);
+    int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
+    if (cert) {
+        const size_t fws = corr_certfast_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw), qws = corr_certify_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);
+        if ((rc = launch_corr_certfast(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd), ws + L.corr_ws, fws, s))) return rc;
+        mark("correlate", s);
+        if (p->ic) {
+            if ((rc = launch_corr_certfast(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd2), ws + L.corr_ws, fws, s))) return rc;
+            mark("correlate_rev", s);
+        }
+        if ((rc = coupled_convex_cert_impl(F(L.ssd), F(L.fs), F(L.ms), F(L.soft), ws + L.cert_ws, p->ic ? F(L.ssd2) : nullptr, F(L.ms), F(L.fs),
+                                           p->ic ? F(L.soft2) : nullptr, p->ic ? ws + L.cert_ws2 : nullptr, F(L.mesh), L.C, L.h, L.w, L.d, p->disp_hw, qws, s, 1))) return rc;
+        mark("argmin", s);
+        if ((rc = coupled_convex_cert_impl(F(L.ssd), F(L.fs), F(L.ms), F(L.soft), ws + L.cert_ws, p->ic ? F(L.ssd2) : nullptr, F(L.ms), F(L.fs),
+                                           p->ic ? F(L.soft2) : nullptr, p->ic ? ws + L.cert_ws2 : nullptr, F(L.mesh), L.C, L.h, L.w, L.d, p->disp_hw, qws, s, 2))) return rc;
+    } else {
     // Both directions' cost volumes in ONE launch of the fused kernel when the pair is inverse consistent (option corr_dual): the stage
     // interval "correlate" then covers both directions and "correlate_rev" is not recorded.
     const bool dual = p->ic && options().corr_dual != 0 && !corr_use_unfused(L.C, L.h, L.w, L.d, p->disp_hw, variant) && p->disp_hw <= CVX_MAX_DISP_HW;
-    int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
     if (dual) {
         const size_t fws = corr_fused_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);
         if ((rc = launch_corr_fused_dual(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, copt.cost, copt.n_box, copt.fast, copt.f16, F(L.ssd), F(L.ssd2),
@@ -450,6 +471,7 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     if ((rc = coupled_convex_dual_impl(F(L.ssd), no_prune ? am : nullptr, F(L.soft), ws + L.conv_ws, p->ic ? F(L.ssd2) : nullptr, f16, no_prune ? am2 : nullptr,
                                        p->ic ? F(L.soft2) : nullptr, p->ic ? ws + L.conv_ws2 : nullptr, F(L.mesh), L.h, L.w, L.d,
                                        p->disp_hw, vws, stream, /*counts_zeroed=*/!no_prune))) return rc;
+    }
     mark("coupled_convex", s);
 
     const float* disp_hr = F(L.soft);          // ic=False: coarse field, coarse units (:143-144)
