@@ -2,7 +2,7 @@
 // on the CERTIFIED-FAST cost volume of corrcert.hip, bit for bit the decisions the exact volume gives.
 //
 // ssdu[k,x] is the unscaled fast volume: the exact entry ssd[k,x] lies in the interval
-//     [ max(ssdu * CLO - TINY, 0),  ssdu * CHI + min(ssdu, TINY) ]        CLO / CHI = (1 -/+ 3 * 2^-16) / 729
+//     [ max(ssdu * CLO - TINY, 0),  ssdu * CHI + min(ssdu, TINY) ]        CLO / CHI = (1 -/+ 2^-16) / 729
 // (relative part: DESIGN 12.1; TINY covers the denormal range, where ATen's divisions may round to zero; ssdu == 0 <=> ssd == 0).
 // Rounding is monotonic, so the exact cost fl(ssd + pen) of a displacement lies in [lo, hi] = [fl(lower + pen), fl(upper + pen)].
 // A decision is CERTAIN when the second smallest lo exceeds the smallest hi (then every other displacement costs strictly more than
@@ -16,14 +16,17 @@
 // fl(lower(min_k ssdu) + pen_k), the upper bound of the minimum is hi of any displacement (the previous winner, or the lattice point
 // nearest to u).  Same launches per pass as the exact path (a voxel kernel, a wavefront kernel), both directions of a pair in each.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "cvx_common.h"
 
 namespace cvx {
 
-// interval of the exact entry (see the header); the constants are rounded outwards by construction (3 instead of 2 units of 2^-16)
-#define CERT_CLO ((float)((1.0 - 3.0 / 65536.0) / 729.0))
-#define CERT_CHI ((float)((1.0 + 3.0 / 65536.0) / 729.0))
+// interval of the exact entry (see the header): ATen's path rounds at most 67 times between an input and an output (1 product, 12 channel
+// additions, 2 x (26 additions + 1 division)), the fast kernels at most 25-30 (with the factor 2 of the two subtracted edge terms): together
+// below 7.6e-6 = 2^-17 relative; the constants use 2^-16 (measured distance: 5.8e-7)
+#define CERT_CLO ((float)((1.0 - 1.0 / 65536.0) / 729.0))
+#define CERT_CHI ((float)((1.0 + 1.0 / 65536.0) / 729.0))
 #define CERT_TINY 1.0e-40f
 __device__ __forceinline__ float cert_lower(float s) { return fmaxf(__builtin_fmaf(s, CERT_CLO, -CERT_TINY), 0.0f); }
 __device__ __forceinline__ float cert_upper(float s) { return __builtin_fmaf(s, CERT_CHI, fminf(s, CERT_TINY)); }
@@ -36,20 +39,33 @@ __device__ __forceinline__ unsigned ordered_bits(float v) {              // the 
 }
 __device__ __forceinline__ float from_ordered_bits(unsigned b) { return __uint_as_float((b & 0x80000000u) ? (b & 0x7fffffffu) : ~b); }
 
+// a voxel the voxel kernel leaves to the wavefront kernel, with everything it already knows (the wavefront kernel then starts its scan one
+// memory round trip after its launch instead of four)
+struct CertRec { unsigned x, box; int kp; float bound, slo, uc, ub, ua; };
+
 struct CertProb {
     const float* ssdu; const float* fix; const float* mov; const float* tail;
     unsigned long long* key; unsigned* sec;       // plain pass: (min, index) and the runner-up value
     int* idx0; int* idxA; int* idxB;              // winners: plain pass, coupled passes (ping-pong)
     float* smin;                                  // min_k ssdu[k,x] (NaN: the column holds a NaN)
-    unsigned* list; int* counts;                  // work lists (one counter per pass: [0] plain, [1..6] coupled)
+    unsigned* list; int* counts;                  // flagged voxels of the plain pass; one counter per pass: [0] plain, [1..6] coupled
+    struct CertRec* rec;                          // work records of the coupled passes (the voxel kernel hands its box to the wavefront kernel)
     float* u;                                     // [3][v] running smoothed field = the result
     int64_t* argmin_out;                          // optional int64 copy of the plain winners
 };
 struct CertGeo { int C, h, w, d, hw, n, K, ntail; long long tail_from; };
 struct CertArgs { CertProb p[2]; CertGeo g; const float* mesh; float coef; int pass; };
 
-// ---- exact evaluation of ONE entry by one wavefront (blocks of 64 threads; sm = 160 floats of LDS) ------------------------------
-__device__ float cert_exact_entry(const CertGeo& G, const CertProb& P, int k, int xlin, float* sm, int lane) {
+// ---- exact evaluation of ONE entry by one wavefront (sm = 160 floats of LDS that belong to the calling wavefront) ----------------
+// WAVE: the workgroup holds several wavefronts -- LDS accesses of ONE wavefront complete in order, so a wavefront-level fence replaces the
+// workgroup barrier
+template <bool WAVE>
+__device__ __forceinline__ void cert_sync() {
+    if (WAVE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    else __syncthreads();
+}
+template <bool WAVE>
+__device__ float cert_exact_entry_t(const CertGeo& G, const CertProb& P, int k, int xlin, float* sm, int lane) {
     const int n = G.n, nn = n * n, h = G.h, w = G.w, d = G.d, hw = G.hw;
     const int iH = k % n, iW = (k / n) % n, iD = k / nn;
     const int x = xlin % d, y = (xlin / d) % w, z = xlin / (d * w);
@@ -67,17 +83,30 @@ __device__ float cert_exact_entry(const CertGeo& G, const CertProb& P, int k, in
                 const float* fp = P.fix + ((size_t)pz * w + py) * d + px;
                 const float* mp = P.mov + ((size_t)(inb ? mz : 0) * w + (inb ? my : 0)) * d + (inb ? mx : 0);
                 float a0 = 0.0f, a1 = 0.0f;
-                for (int ch = 0; ch < G.C; ++ch) {
-                    const float df = fp[(size_t)ch * v] - (inb ? mp[(size_t)ch * v] : 0.0f);
-                    a0 += df * df;                                        // .pow(2).sum(0)
-                    if ((ch & 15) == 15) { a1 += a0; a0 = 0.0f; }         // ATen's cascade (two levels below 256 channels)
+                // (16 channels at a time: all their loads are in flight together, the sum then runs in ATen's order)
+                for (int c0 = 0; c0 < G.C; c0 += 16) {
+                    float fv[16], mv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const bool on = c0 + i < G.C;
+                        fv[i] = on ? fp[(size_t)(c0 + i) * v] : 0.0f;
+                        mv[i] = (on && inb) ? mp[(size_t)(c0 + i) * v] : 0.0f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (c0 + i < G.C) {
+                            const float df = fv[i] - mv[i];
+                            a0 += df * df;                                    // .pow(2).sum(0)
+                        }
+                    }
+                    if (c0 + 16 <= G.C) { a1 += a0; a0 = 0.0f; }              // ATen's cascade (two levels below 256 channels): a full block of 16 is folded
                 }
                 val = G.C >= 16 ? a0 + a1 : a0;
             }
         }
         sm[t] = val;
     }
-    __syncthreads();
+    cert_sync<WAVE>();
     if (lane < 27) {
         const int a = lane / 9 - 1, b = (lane / 3) % 3 - 1, c = lane % 3 - 1;
         const int pz = z + a, py = y + b, px = x + c;
@@ -94,15 +123,18 @@ __device__ float cert_exact_entry(const CertGeo& G, const CertProb& P, int k, in
         }
         sm[128 + lane] = in ? s : -1.0f;           // (-1 marks a tap outside the volume; box sums are never negative)
     }
-    __syncthreads();
+    cert_sync<WAVE>();
     float s = 0.0f;
     for (int t = 0; t < 27; ++t) {
         const float b = sm[128 + t];
         if (b >= 0.0f || b != b) s += b;
     }
-    __syncthreads();                                // sm is reused by the next entry
+    cert_sync<WAVE>();                                // sm is reused by the next entry
     return div_exact<27>(s);
 }
+
+__device__ float cert_exact_entry(const CertGeo& G, const CertProb& P, int k, int xlin, float* sm, int lane) { return cert_exact_entry_t<false>(G, P, k, xlin, sm, lane); }
+__device__ float cert_exact_entry_wave(const CertGeo& G, const CertProb& P, int k, int xlin, float* sm, int lane) { return cert_exact_entry_t<true>(G, P, k, xlin, sm, lane); }
 
 // ---- plain argmin: one streaming pass, (min, index) through a 64-bit atomicMin, the runner-up through what that atomic displaces --
 __global__ __launch_bounds__(256) void k_cert_plain_stream(CertArgs A, int kslice, int vec4) {
@@ -182,7 +214,8 @@ __global__ __launch_bounds__(256) void k_cert_plain_finalize(CertArgs A) {
     if (!certain) P.list[atomicAdd(&P.counts[0], 1)] = (unsigned)x;
 }
 
-// flagged voxels of the plain pass: one wavefront per voxel scans the column, evaluates the candidates exactly
+// flagged voxels of the plain pass: one wavefront per voxel; the smallest upper bound is the one of the minimum (the key), the column is
+// scanned 1 024 entries at a time with 16 loads per lane in flight, the candidates are evaluated exactly
 __global__ __launch_bounds__(64) void k_cert_plain_resolve(CertArgs A) {
     __shared__ float sm[160];
     const CertProb& P = A.p[blockIdx.y];
@@ -192,23 +225,29 @@ __global__ __launch_bounds__(64) void k_cert_plain_resolve(CertArgs A) {
     for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
         const unsigned x = P.list[e];
         const float* col = P.ssdu + x;
-        float U = __uint_as_float(0x7f800000u);
-        for (int k = lane; k < K; k += 64) U = fminf(U, cert_upper(col[(size_t)k * v]));
-        for (int o = 32; o > 0; o >>= 1) U = fminf(U, __shfl_xor(U, o));
+        const float U = cert_upper(P.smin[x]);
         unsigned long long bestkey = ~0ull;
-        for (int kb = 0; kb < K; kb += 64) {
-            const int k = kb + lane;
-            const float s = k < K ? col[(size_t)k * v] : 0.0f;
-            const bool cand = k < K && cert_lower(s) <= U;
-            unsigned long long m = __ballot(cand);
-            while (m) {
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int kk = kb + l;
-                const float sk = __shfl(s, l);
-                const float ex = sk == 0.0f ? 0.0f : cert_exact_entry(A.g, P, kk, (int)x, sm, lane);
-                const unsigned long long key = pack_min_key(ex, (unsigned)kk);
-                bestkey = key < bestkey ? key : bestkey;
+        for (int kb = 0; kb < K; kb += 1024) {
+            float s[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int k = kb + 64 * i + lane; s[i] = k < K ? col[(size_t)k * v] : __uint_as_float(0x7f800000u); }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                // exact zeros: only the first of them can win (they all cost 0) -- no loop over a zero background's thousands of entries
+                const unsigned long long mz = __ballot(s[i] == 0.0f);
+                if (mz) {
+                    const unsigned long long key = pack_min_key(0.0f, (unsigned)(kb + 64 * i + __ffsll((long long)mz) - 1));
+                    bestkey = key < bestkey ? key : bestkey;
+                }
+                unsigned long long m = __ballot(s[i] != 0.0f && cert_lower(s[i]) <= U);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int kk = kb + 64 * i + l;
+                    const float ex = cert_exact_entry(A.g, P, kk, (int)x, sm, lane);
+                    const unsigned long long key = pack_min_key(ex, (unsigned)kk);
+                    bestkey = key < bestkey ? key : bestkey;
+                }
             }
         }
         if (lane == 0) {
@@ -319,7 +358,9 @@ __global__ __launch_bounds__(64) void k_cert_voxel(CertArgs A, int refine) {
     if (sm_x != sm_x) { next[x] = P.idx0[x]; return; }
     const CertBox c = cert_box(A.mesh, uc, ub, ua, A.coef, K, n, kp, s_kp, sm_x, P.ssdu + x, v, refine);
     constexpr int NB = 8;
-    if (c.vol > NB) { P.list[atomicAdd(&P.counts[A.pass], 1)] = (unsigned)x; return; }
+    const unsigned boxpack = (unsigned)c.c_lo | ((unsigned)c.c_hi << 5) | ((unsigned)c.b_lo << 10) | ((unsigned)c.b_hi << 15) | ((unsigned)c.a_lo << 20) | ((unsigned)c.a_hi << 25) | (c.degenerate ? 1u << 30 : 0u);
+    const CertRec rec = {(unsigned)x, boxpack, kp, c.bound, c.slo, c.uc, c.ub, c.ua};
+    if (c.vol > NB) { P.rec[atomicAdd(&P.counts[A.pass], 1)] = rec; return; }
     int kk[NB];
     float pen[NB], val[NB];
     bool need[NB];
@@ -352,43 +393,69 @@ __global__ __launch_bounds__(64) void k_cert_voxel(CertArgs A, int refine) {
     }
     if (cnt == 0) { next[x] = kp; return; }         // cannot happen (kp passes its own test); keeps the output defined
     if (cnt == 1 || lo2 > U) { next[x] = k1; return; }
-    P.list[atomicAdd(&P.counts[A.pass], 1)] = (unsigned)x;
+    P.rec[atomicAdd(&P.counts[A.pass], 1)] = rec;
 }
 
-// one wavefront per listed voxel: scan of the admissible box, exact evaluation of what the intervals leave open
-__global__ __launch_bounds__(64) void k_cert_wave(CertArgs A, int refine) {
-    __shared__ float sm[160];
+// one wavefront per listed voxel: scan of the admissible box (512 displacements per round, 8 loads per lane in flight), exact
+// evaluation of what the intervals leave open
+__global__ __launch_bounds__(256) void k_cert_wave(CertArgs A) {
+    __shared__ float smem[4][160];
     const CertProb& P = A.p[blockIdx.y];
     const int h = A.g.h, w = A.g.w, d = A.g.d, K = A.g.K, n = A.g.n;
     const size_t v = (size_t)h * w * d;
-    const int lane = threadIdx.x;
-    const int* prev = A.pass == 1 ? P.idx0 : ((A.pass & 1) ? P.idxB : P.idxA);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* sm = smem[wv];
     int* next = (A.pass & 1) ? P.idxA : P.idxB;
     const int cnt = P.counts[A.pass];
     const float INF = __uint_as_float(0x7f800000u);
-    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
-        const size_t x = P.list[e];
-        const int kp = prev[x];
+    for (int e = blockIdx.x * 4 + wv; e < cnt; e += gridDim.x * 4) {
+        const CertRec r = P.rec[e];
+        const size_t x = r.x;
+        const int kp = r.kp;
         const float* col = P.ssdu + x;
-        const CertBox c = cert_box(A.mesh, P.u[x], P.u[v + x], P.u[2 * v + x], A.coef, K, n, kp, col[(size_t)kp * v], P.smin[x], col, v, refine);
-        const int nc = c.c_hi - c.c_lo + 1, nb = c.b_hi - c.b_lo + 1;
-        // pass 1 over the box: smallest lo (first index among equals), runner-up lo, smallest hi
+        CertBox c;
+        c.uc = r.uc; c.ub = r.ub; c.ua = r.ua; c.slo = r.slo; c.bound = r.bound;
+        c.c_lo = r.box & 31; c.c_hi = (r.box >> 5) & 31; c.b_lo = (r.box >> 10) & 31; c.b_hi = (r.box >> 15) & 31; c.a_lo = (r.box >> 20) & 31; c.a_hi = (r.box >> 25) & 31;
+        c.degenerate = ((r.box >> 30) & 1u) != 0;
+        c.vol = (long long)(c.c_hi - c.c_lo + 1) * (c.b_hi - c.b_lo + 1) * (c.a_hi - c.a_lo + 1);
+        const int nc = c.c_hi - c.c_lo + 1, nb = c.b_hi - c.b_lo + 1, ncb = nc * nb;
+        const float rc = 1.0f / (float)nc, rab = 1.0f / (float)ncb;
+        // round 1 over the box: smallest lo (first index among equals), runner-up lo, smallest hi.  All loads of a round
+        // -- of 768 per round -- are in flight together (slots beyond the box are skipped wave-uniformly)
         unsigned long long key = ~0ull;
         float lo2 = INF, U = INF;
-        for (long long i0 = 0; i0 < c.vol; i0 += 64) {
-            const long long i = i0 + lane;
-            if (i < c.vol) {
-                const int ic = c.c_lo + (int)(i % nc), ib = c.b_lo + (int)((i / nc) % nb), ia = c.a_lo + (int)(i / ((long long)nc * nb));
-                const int k = (ia * n + ib) * n + ic;
-                const float pen = cert_pen(A.mesh, K, k, c.uc, c.ub, c.ua, A.coef);
-                if (c.degenerate || !(c.slo + pen > c.bound)) {
-                    const float s = col[(size_t)k * v];
-                    const float lo = cert_lower(s) + pen, hi = cert_upper(s) + pen;
-                    U = fminf(U, hi);
-                    const unsigned long long kk = pack_min_key(lo, (unsigned)k);
-                    if (kk < key) { if (key != ~0ull) lo2 = fminf(lo2, from_ordered_bits((unsigned)(key >> 32))); key = kk; }
-                    else lo2 = fminf(lo2, lo);
+        constexpr int NL = 12;
+        for (long long i0 = 0; i0 < c.vol; i0 += 64 * NL) {
+            int kk[NL];
+            float pen[NL], val[NL];
+            bool need[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                need[j] = false; kk[j] = 0; pen[j] = 0.0f;
+                if (i0 + 64 * j < c.vol) {                                     // (uniform)
+                    const int i = (int)i0 + lane + 64 * j;
+                    need[j] = i < (int)c.vol;
+                    const int ii = need[j] ? i : 0;
+                    // box position of flat index ii without integer division: ii < 2^15 and the divisors are below 2^10, so (ii + 0.5) / divisor
+                    // stays 0.5 / divisor away from every integer -- far more than the rounding of the float product
+                    const int qa = (int)(((float)ii + 0.5f) * rab), ra = ii - qa * ncb;
+                    const int qb = (int)(((float)ra + 0.5f) * rc);
+                    const int ic = c.c_lo + ra - qb * nc, ib = c.b_lo + qb, ia = c.a_lo + qa;
+                    kk[j] = (ia * n + ib) * n + ic;
+                    pen[j] = cert_pen(A.mesh, K, kk[j], c.uc, c.ub, c.ua, A.coef);
+                    need[j] = need[j] && (c.degenerate || !(c.slo + pen[j] > c.bound));
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < NL; ++j) val[j] = need[j] ? col[(size_t)kk[j] * v] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                if (!need[j]) continue;
+                const float lo = cert_lower(val[j]) + pen[j], hi = cert_upper(val[j]) + pen[j];
+                U = fminf(U, hi);
+                const unsigned long long kx = pack_min_key(lo, (unsigned)kk[j]);
+                if (kx < key) { if (key != ~0ull) lo2 = fminf(lo2, from_ordered_bits((unsigned)(key >> 32))); key = kx; }
+                else lo2 = fminf(lo2, lo);
             }
         }
         unsigned long long gkey = key;
@@ -397,31 +464,42 @@ __global__ __launch_bounds__(64) void k_cert_wave(CertArgs A, int refine) {
         for (int o = 32; o > 0; o >>= 1) { mine2 = fminf(mine2, __shfl_xor(mine2, o)); U = fminf(U, __shfl_xor(U, o)); }
         if (gkey == ~0ull) { if (lane == 0) next[x] = kp; continue; }             // (cannot happen)
         if (mine2 > U) { if (lane == 0) next[x] = (int)(unsigned)(gkey & 0xffffffffull); continue; }
-        // pass 2: the candidates lo <= U, exactly
+        // round 2: the candidates lo <= U, exactly
+        if (lane == 0) atomicAdd(&P.counts[7], 1);                               // (statistics: decisions that needed the exact evaluator)
         unsigned long long bestkey = ~0ull;
-        for (long long i0 = 0; i0 < c.vol; i0 += 64) {
-            const long long i = i0 + lane;
-            bool cand = false;
-            int k = 0;
-            float s = 0.0f, pen = 0.0f;
-            if (i < c.vol) {
-                const int ic = c.c_lo + (int)(i % nc), ib = c.b_lo + (int)((i / nc) % nb), ia = c.a_lo + (int)(i / ((long long)nc * nb));
-                k = (ia * n + ib) * n + ic;
-                pen = cert_pen(A.mesh, K, k, c.uc, c.ub, c.ua, A.coef);
-                if (c.degenerate || !(c.slo + pen > c.bound)) {
-                    s = col[(size_t)k * v];
-                    cand = cert_lower(s) + pen <= U;
+        for (long long i0 = 0; i0 < c.vol; i0 += 64 * NL) {
+            int kk[NL];
+            float pen[NL], val[NL];
+            bool need[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                need[j] = false; kk[j] = 0; pen[j] = 0.0f;
+                if (i0 + 64 * j < c.vol) {
+                    const int i = (int)i0 + lane + 64 * j;
+                    need[j] = i < (int)c.vol;
+                    const int ii = need[j] ? i : 0;
+                    const int qa = (int)(((float)ii + 0.5f) * rab), ra = ii - qa * ncb;
+                    const int qb = (int)(((float)ra + 0.5f) * rc);
+                    kk[j] = ((c.a_lo + qa) * n + c.b_lo + qb) * n + c.c_lo + ra - qb * nc;
+                    pen[j] = cert_pen(A.mesh, K, kk[j], c.uc, c.ub, c.ua, A.coef);
+                    need[j] = need[j] && (c.degenerate || !(c.slo + pen[j] > c.bound));
                 }
             }
-            unsigned long long m = __ballot(cand);
-            while (m) {
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int kk = __shfl(k, l);
-                const float sk = __shfl(s, l), pk = __shfl(pen, l);
-                const float ex = sk == 0.0f ? 0.0f : cert_exact_entry(A.g, P, kk, (int)x, sm, lane);
-                const unsigned long long kx = pack_min_key(ex + pk, (unsigned)kk);      // ssd + coeffs[j]*(...)
-                bestkey = kx < bestkey ? kx : bestkey;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) val[j] = need[j] ? col[(size_t)kk[j] * v] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                if (!(i0 + 64 * j < c.vol)) continue;
+                unsigned long long m = __ballot(need[j] && cert_lower(val[j]) + pen[j] <= U);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int k2 = __shfl(kk[j], l);
+                    const float sk = __shfl(val[j], l), pk = __shfl(pen[j], l);
+                    const float ex = sk == 0.0f ? 0.0f : cert_exact_entry_wave(A.g, P, k2, (int)x, sm, lane);
+                    const unsigned long long kx = pack_min_key(ex + pk, (unsigned)k2);      // ssd + coeffs[j]*(...)
+                    bestkey = kx < bestkey ? kx : bestkey;
+                }
             }
         }
         if (lane == 0) next[x] = (int)(unsigned)(bestkey & 0xffffffffull);
@@ -461,12 +539,13 @@ size_t corr_certify_workspace_bytes(int C, int h, int w, int d, int hw) {
     for (int i = 0; i < 3; ++i) used = carve_size(used, sizeof(int) * v);   // idx0, idxA, idxB
     used = carve_size(used, sizeof(float) * v);                   // smin
     used = carve_size(used, sizeof(unsigned) * v);                // list
+    used = carve_size(used, sizeof(CertRec) * v);                 // records
     used = carve_size(used, sizeof(int) * 8);                     // counts
     used = carve_size(used, sizeof(float) * 32 * n);              // tail
     return used + 256;
 }
 
-struct CertCarve { unsigned long long* key; unsigned* sec; int* idx0; int* idxA; int* idxB; float* smin; unsigned* list; int* counts; float* tail; };
+struct CertCarve { unsigned long long* key; unsigned* sec; int* idx0; int* idxA; int* idxB; float* smin; unsigned* list; CertRec* rec; int* counts; float* tail; };
 static CertCarve cert_carve(void* workspace, size_t workspace_bytes, int h, int w, int d, int hw) {
     const size_t v = (size_t)h * w * d;
     const int n = 2 * hw + 1;
@@ -477,6 +556,7 @@ static CertCarve cert_carve(void* workspace, size_t workspace_bytes, int h, int 
     c.idx0 = cv.take<int>(v); c.idxA = cv.take<int>(v); c.idxB = cv.take<int>(v);
     c.smin = cv.take<float>(v);
     c.list = cv.take<unsigned>(v);
+    c.rec = cv.take<CertRec>(v);
     c.counts = cv.take<int>(8);
     c.tail = cv.take<float>((size_t)32 * n);
     return c;
@@ -490,29 +570,44 @@ static CertGeo cert_geo(int C, int h, int w, int d, int hw) {
     return g;
 }
 static CertProb cert_prob(const float* ssdu, const float* fix, const float* mov, const CertCarve& c, float* u, int64_t* argmin_out) {
-    return CertProb{ssdu, fix, mov, c.tail, c.key, c.sec, c.idx0, c.idxA, c.idxB, c.smin, c.list, c.counts, u, argmin_out};
+    return CertProb{ssdu, fix, mov, c.tail, c.key, c.sec, c.idx0, c.idxA, c.idxB, c.smin, c.list, c.counts, c.rec, u, argmin_out};
 }
 
-// plain argmin of one or two problems (nprob = 2: the two directions of a pair); leaves idx0 / smin in the workspaces
-static int cert_plain(CertArgs& A, int nprob, bool arm, hipStream_t s) {
+// the plain argmin in three parts so that a caller can stream each volume while it is still in the Infinity Cache (right behind its
+// correlation kernel): arm (keys, counters, the interleaved-order tail values), stream (one problem), finish (certify + resolve)
+static void cert_arm(CertArgs& A, int nprob, hipStream_t s) {
+    const CertGeo& g = A.g;
+    const size_t v = (size_t)g.h * g.w * g.d;
+    hipLaunchKernelGGL(k_cert_arm, dim3((unsigned)cdiv64((int64_t)(v > 8 ? v : 8), 256)), dim3(256), 0, s, A, nprob);
+    for (int q = 0; q < nprob; ++q)
+        if (g.ntail > 0) launch_corr_tail_compact(A.p[q].fix, A.p[q].mov, g.C, g.h, g.w, g.d, g.hw, 0, const_cast<float*>(A.p[q].tail), s);
+}
+// problems [q0, q0 + nq)
+static void cert_stream(CertArgs A, int q0, int nq, hipStream_t s) {
     const CertGeo& g = A.g;
     const size_t v = (size_t)g.h * g.w * g.d;
     const int K = g.K;
-    if (arm) hipLaunchKernelGGL(k_cert_arm, dim3((unsigned)cdiv64((int64_t)(v > 8 ? v : 8), 256)), dim3(256), 0, s, A, nprob);
-    for (int q = 0; q < nprob; ++q)
-        if (g.ntail > 0) launch_corr_tail_compact(A.p[q].fix, A.p[q].mov, g.C, g.h, g.w, g.d, g.hw, 0, const_cast<float*>(A.p[q].tail), s);
+    if (q0) { A.p[0] = A.p[q0]; }
     bool vec4 = v % 4 == 0;
-    for (int q = 0; q < nprob; ++q) vec4 = vec4 && (reinterpret_cast<uintptr_t>(A.p[q].ssdu) & 15) == 0;
+    for (int q = 0; q < nq; ++q) vec4 = vec4 && (reinterpret_cast<uintptr_t>(A.p[q].ssdu) & 15) == 0;
     const int xb = (int)cdiv64((int64_t)cdiv64((int64_t)v, 4), 256);
     int nslices = cdiv(512, xb);
     if (nslices > K) nslices = K;
     if (nslices < 1) nslices = 1;
     const int kslice = cdiv(K, nslices);
     nslices = cdiv(K, kslice);
-    hipLaunchKernelGGL(k_cert_plain_stream, dim3(xb, nslices, nprob), dim3(256), 0, s, A, kslice, vec4 ? 1 : 0);
+    hipLaunchKernelGGL(k_cert_plain_stream, dim3(xb, nslices, nq), dim3(256), 0, s, A, kslice, vec4 ? 1 : 0);
+}
+static int cert_finish(CertArgs& A, int nprob, hipStream_t s) {
+    const size_t v = (size_t)A.g.h * A.g.w * A.g.d;
     hipLaunchKernelGGL(k_cert_plain_finalize, dim3((unsigned)cdiv64((int64_t)v, 256), nprob), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_cert_plain_resolve, dim3(256, nprob), dim3(64), 0, s, A);
     return check_last("certified argmin");
+}
+static int cert_plain(CertArgs& A, int nprob, bool arm, hipStream_t s) {
+    if (arm) cert_arm(A, nprob, s);
+    cert_stream(A, 0, nprob, s);
+    return cert_finish(A, nprob, s);
 }
 
 int corr_certified_argmin(const float* ssdu, const float* fix, const float* mov, int C, int h, int w, int d, int hw, int64_t* argmin,
@@ -527,7 +622,8 @@ int corr_certified_argmin(const float* ssdu, const float* fix, const float* mov,
 }
 
 // both directions (ssduB == nullptr: one) from the certified-fast volumes to the smoothed fields: plain argmin + six coupled passes
-// stage: 0 = everything, 1 = the plain argmin only, 2 = the coupled passes only (after a call with stage 1 on the same workspaces)
+// stage: 0 = everything; or in sequence 1 = arm, 2 = stream the first volume, 3 = stream the second, 4 = certify + resolve the plain argmin,
+// 5 = the coupled passes (the pipeline interleaves 2 / 3 with the correlation kernels: each volume is streamed from the Infinity Cache)
 int coupled_convex_cert_impl(const float* ssduA, const float* fixA, const float* movA, float* outA, void* wsA, const float* ssduB, const float* fixB,
                              const float* movB, float* outB, void* wsB, const float* mesh, int C, int h, int w, int d, int hw, size_t workspace_bytes,
                              hipStream_t s, int stage) {
@@ -540,17 +636,26 @@ int coupled_convex_cert_impl(const float* ssduA, const float* fixA, const float*
     A.p[0] = cert_prob(ssduA, fixA, movA, ca, outA, nullptr);
     A.p[1] = A.p[0];
     if (ssduB) { const CertCarve cb = cert_carve(wsB, workspace_bytes, h, w, d, hw); A.p[1] = cert_prob(ssduB, fixB, movB, cb, outB, nullptr); }
-    if (stage != 2) {
-        const int rc = cert_plain(A, nprob, true, s);
-        if (rc || stage == 1) return rc;
-    }
+    if (stage == 1) { cert_arm(A, nprob, s); return check_last("certified argmin"); }
+    if (stage == 2) { cert_stream(A, 0, 1, s); return check_last("certified argmin"); }
+    if (stage == 3) { if (nprob > 1) cert_stream(A, 1, 1, s); return check_last("certified argmin"); }
+    if (stage == 4) return cert_finish(A, nprob, s);
+    if (stage == 0) { const int rc = cert_plain(A, nprob, true, s); if (rc) return rc; }
     const size_t v = (size_t)h * w * d;
     const int refine = options().prune_refine != 0 ? 8 : 0x7fffffff;
     static const float coeffs[6] = {0.003f, 0.01f, 0.03f, 0.1f, 0.3f, 1.0f};      // torch.tensor([...]) float32 (:98)
     for (int it = 0; it < 6; ++it) {
         A.coef = coeffs[it]; A.pass = it + 1;
         hipLaunchKernelGGL(k_cert_voxel, dim3((unsigned)cdiv64((int64_t)v, 64), nprob), dim3(64), 0, s, A, refine);
-        hipLaunchKernelGGL(k_cert_wave, dim3(1024, nprob), dim3(64), 0, s, A, refine);
+        hipLaunchKernelGGL(k_cert_wave, dim3(512, nprob), dim3(256), 0, s, A);
+    }
+    if (getenv("CVX_CERT_TRACE")) {                       // debugging aid (synchronises): how many voxels each pass sent to the wavefront kernel
+        for (int q = 0; q < nprob; ++q) {
+            int cnt[8];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(cnt, A.p[q].counts, sizeof(cnt), hipMemcpyDeviceToHost);
+            fprintf(stderr, "cert trace: problem %d: plain flagged %d; listed per coupled pass %d %d %d %d %d %d, %d of them evaluated exactly (of %zu voxels)\n", q, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7], v);
+        }
     }
     A.pass = 7;
     hipLaunchKernelGGL(k_cert_gather, dim3((unsigned)cdiv64((int64_t)v, 256), nprob), dim3(256), 0, s, A);

@@ -417,7 +417,7 @@ int corr_certified_argmin(const float* ssdu, const float* fix, const float* mov,
 // both directions (ssduB == nullptr: one) from the certified-fast volumes to the smoothed fields: plain argmin + six coupled passes
 int coupled_convex_cert_impl(const float* ssduA, const float* fixA, const float* movA, float* outA, void* wsA, const float* ssduB, const float* fixB,
                              const float* movB, float* outB, void* wsB, const float* mesh, int C, int h, int w, int d, int hw, size_t workspace_bytes,
-                             hipStream_t s, int stage = 0);      // stage 1: plain argmin only, 2: the coupled passes only
+                             hipStream_t s, int stage = 0);      // stage 0 = everything, 1..5 = arm / stream A / stream B / certify the plain argmin / coupled passes
 // correlate.hip: would cvx_correlate_ex_f32 take the unfused round-1 kernels for this problem?
 bool corr_use_unfused(int C, int h, int w, int d, int hw, bool variant);
 // boxmarch.hip: three chained 3^3 boxes (forward / adjoint / adjoint + Adam) for rows of at most 126 voxels

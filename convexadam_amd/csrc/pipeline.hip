@@ -423,17 +423,22 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
     if (cert) {
         const size_t fws = corr_certfast_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw), qws = corr_certify_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);
+        auto cert_stage = [&](int stage) {
+            return coupled_convex_cert_impl(F(L.ssd), F(L.fs), F(L.ms), F(L.soft), ws + L.cert_ws, p->ic ? F(L.ssd2) : nullptr, F(L.ms), F(L.fs),
+                                            p->ic ? F(L.soft2) : nullptr, p->ic ? ws + L.cert_ws2 : nullptr, F(L.mesh), L.C, L.h, L.w, L.d, p->disp_hw, qws, s, stage);
+        };
+        if ((rc = cert_stage(1))) return rc;                                    // keys, counters, tail values
         if ((rc = launch_corr_certfast(F(L.fs), F(L.ms), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd), ws + L.corr_ws, fws, s))) return rc;
         mark("correlate", s);
+        if ((rc = cert_stage(2))) return rc;                                    // the plain argmin streams the volume while the Infinity Cache holds it
+        mark("argmin", s);
         if (p->ic) {
             if ((rc = launch_corr_certfast(F(L.ms), F(L.fs), L.C, L.h, L.w, L.d, p->disp_hw, F(L.ssd2), ws + L.corr_ws, fws, s))) return rc;
             mark("correlate_rev", s);
+            if ((rc = cert_stage(3))) return rc;
+            mark("argmin_rev", s);
         }
-        if ((rc = coupled_convex_cert_impl(F(L.ssd), F(L.fs), F(L.ms), F(L.soft), ws + L.cert_ws, p->ic ? F(L.ssd2) : nullptr, F(L.ms), F(L.fs),
-                                           p->ic ? F(L.soft2) : nullptr, p->ic ? ws + L.cert_ws2 : nullptr, F(L.mesh), L.C, L.h, L.w, L.d, p->disp_hw, qws, s, 1))) return rc;
-        mark("argmin", s);
-        if ((rc = coupled_convex_cert_impl(F(L.ssd), F(L.fs), F(L.ms), F(L.soft), ws + L.cert_ws, p->ic ? F(L.ssd2) : nullptr, F(L.ms), F(L.fs),
-                                           p->ic ? F(L.soft2) : nullptr, p->ic ? ws + L.cert_ws2 : nullptr, F(L.mesh), L.C, L.h, L.w, L.d, p->disp_hw, qws, s, 2))) return rc;
+        if ((rc = cert_stage(4)) || (rc = cert_stage(5))) return rc;
     } else {
     // Both directions' cost volumes in ONE launch of the fused kernel when the pair is inverse consistent (option corr_dual): the stage
     // interval "correlate" then covers both directions and "correlate_rev" is not recorded.
