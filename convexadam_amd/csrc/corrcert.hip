@@ -37,6 +37,10 @@ namespace cvx {
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int CC_CH = 4;          // channels per staged chunk
+// Staging helpers (the wavefronts of a set of <= 4 shifts stage 64 quads each of their tile's run besides the loaders): built and measured --
+// the helpers then wait for their own loads at every chunk barrier (1.45 us under the load of 254 workgroups: the L2s deliver ~10 TB/s of
+// the 0.97 GB a launch stages), 141 -> 169 us for the 9-shift workgroups -- and left off.
+constexpr bool CC_HELPERS = false;
 constexpr int CC_MAXT = 4;        // tile types: pair workgroups per row (n <= 31: 3) + the single set
 
 struct CCGeom {                   // (host side; the kernel receives the CCKern subset)
@@ -166,6 +170,8 @@ struct CCItem {
     int nsets, ntile, chn;
     int B[2], iH[2], iW[2], start[2], rowoff[2], gq[2];
     int type, row0, RM;
+    int hstart[2];                // first quad of the tile run that the set's own wavefronts stage (sets of <= 4 shifts help the loaders; -1: none)
+    int lstart[2];                // per tile: quads the helpers cover = where the loaders' share of the run begins
 };
 // Launch order.  The hardware deals workgroups to the 8 XCDs round-robin (block b -> XCD b % 8), and every XCD has its own 4 MB L2:
 // the staging copies (10 MB) only stay L2-resident if an XCD's workgroups walk the SAME planes at the same time.  So the work list is
@@ -215,6 +221,15 @@ __device__ __forceinline__ CCItem cc_decode(const CCKern& g, int b) {
             else { it.nsets = 1; it.B[1] = 0; }
         }
     }
+    // staging helpers: the wavefronts of a set of at most four shifts have registers to spare and stage wps * 64 quads of their tile's run
+    {
+        const int H = g.wps * 64, nM = it.RM * g.MQ;
+        it.hstart[0] = it.hstart[1] = -1; it.lstart[0] = it.lstart[1] = 0;
+        for (int q = 0; q < it.nsets; ++q) {
+            const int t = it.ntile == 2 ? q : 0;
+            if (CC_HELPERS && it.B[q] <= 4 && it.lstart[t] < nM) { it.hstart[q] = it.lstart[t]; it.lstart[t] = it.lstart[t] + H < nM ? it.lstart[t] + H : nM; }
+        }
+    }
     return it;
 }
 
@@ -228,6 +243,16 @@ __device__ __forceinline__ CCItem cc_decode(const CCKern& g, int b) {
         "v_fmac_f32_dpp %3, %7, %8 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0"                                               \
         : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                                                    \
         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(m))
+#define CC_DPP4M(ctrl)                                                                                                              \
+    asm("s_nop 1\n\t"                                                                                                              \
+        "v_fmac_f32_dpp %0, %4, %8 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                                           \
+        "v_fmac_f32_dpp %1, %5, %9 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                                           \
+        "v_fmac_f32_dpp %2, %6, %10 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                                          \
+        "v_fmac_f32_dpp %3, %7, %11 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0"                                              \
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                                                    \
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]))
+__device__ __forceinline__ void cc_tap_up4(float (&acc)[4], const float (&a)[4], const float (&m)[4]) { CC_DPP4M("wave_shr:1"); }
+__device__ __forceinline__ void cc_tap_dn4(float (&acc)[4], const float (&a)[4], const float (&m)[4]) { CC_DPP4M("wave_shl:1"); }
 __device__ __forceinline__ void cc_tap_up(float (&acc)[4], const float (&a)[4], float m) { CC_DPP4("wave_shr:1"); }
 __device__ __forceinline__ void cc_tap_dn(float (&acc)[4], const float (&a)[4], float m) { CC_DPP4("wave_shl:1"); }
 
@@ -247,6 +272,8 @@ struct CCCtx {
     float* exch;                   // exchange planes of THIS set (plane k at k * exq * 4)
     int nF, nM;                    // quads per channel of the F plane / of one M tile
     int chn, nch;                  // channels per chunk, chunks per plane
+    __amdgpu_buffer_rsrc_t rsrc;   // the staging copies
+    unsigned uM_step, chanM;
 };
 
 // ---- staging: two LOADER wavefronts per workgroup ---------------------------------------------------------------------------------
@@ -264,7 +291,8 @@ __device__ __forceinline__ f32x4 cc_ld16(__amdgpu_buffer_rsrc_t rsrc, unsigned l
 struct CCLoad {
     __amdgpu_buffer_rsrc_t rsrc;
     int lt;                        // loader thread 0 .. 127
-    int rF, rM, ntile;             // pieces per channel of this thread's share: ceil(nF / 128), ceil(nM / 128) per tile
+    int rF, rM, ntile;             // pieces per channel of this thread's share: ceil(nF / 128), ceil(max share of a tile / 128)
+    int lstart[2], lcount[2];      // the loaders' share of a tile's run: quads [lstart, lstart + lcount)
     unsigned uF0, uM0[2], uF_step, uM_step, chanF, chanM;
 };
 // piece r of a channel: r < RF the F run, then RM pieces per tile.  RF / RM / NTILE are compile-time (0 = take the run-time counts: the
@@ -273,7 +301,7 @@ template <int CHN, int RF, int RM, int NTILE, int NPC, bool FETCH>
 __device__ __forceinline__ void cc_loader_pieces(const CCLoad& L, const CCCtx& c, int p, int ci, int buf, f32x4 (&R)[CHN][NPC]) {
     const int rF = RF ? RF : L.rF, rM = RM ? RM : L.rM, ntile = NTILE ? NTILE : L.ntile;
     const unsigned lane_off = 16u * (unsigned)L.lt;
-    const bool tailF = L.lt < c.nF - (rF - 1) * CC_LOADER_THREADS, tailM = L.lt < c.nM - (rM - 1) * CC_LOADER_THREADS;
+    const bool tailF = L.lt < c.nF - (rF - 1) * CC_LOADER_THREADS;
     float* dst = c.lds + buf * c.chunk_floats + 4 * L.lt;
 #pragma unroll
     for (int cl = 0; cl < CHN; ++cl) {
@@ -288,9 +316,11 @@ __device__ __forceinline__ void cc_loader_pieces(const CCLoad& L, const CCCtx& c
                 }
             } else if (r < rF + ntile * rM) {
                 const int t = (r - rF) >= rM ? 1 : 0, rr = r - rF - t * rM;
-                if (rr < rM - 1 || tailM) {
-                    if (FETCH) R[cl][r] = cc_ld16(L.rsrc, lane_off, L.uM0[t] + (unsigned)p * L.uM_step + (unsigned)ch * L.chanM + 2048u * (unsigned)rr);
-                    else lds_store4(dst + (CHN * c.nF + (t * CHN + cl) * c.nM + rr * CC_LOADER_THREADS) * 4, R[cl][r]);
+                const int ls = t ? L.lstart[1] : L.lstart[0], lc = t ? L.lcount[1] : L.lcount[0];
+                const unsigned um = t ? L.uM0[1] : L.uM0[0];
+                if (rr * CC_LOADER_THREADS + L.lt < lc) {
+                    if (FETCH) R[cl][r] = cc_ld16(L.rsrc, lane_off, um + (unsigned)p * L.uM_step + (unsigned)ch * L.chanM + 16u * (unsigned)ls + 2048u * (unsigned)rr);
+                    else lds_store4(dst + (CHN * c.nF + (t * CHN + cl) * c.nM + ls + rr * CC_LOADER_THREADS) * 4, R[cl][r]);
                 }
             }
         }
@@ -324,8 +354,8 @@ __device__ __forceinline__ void cc_loader_run(const CCKern& g, const CCLoad& L, 
     cc_barrier();                                                // (the compute wavefronts' barrier of step h)
 }
 
-struct CCSetSel { int iH, iW, start, rowoff, gq, tile; };
-template <int B, int CT>
+struct CCSetSel { int iH, iW, start, rowoff, gq, tile, hstart; unsigned uM0; };
+template <int B, bool CT, int CHN>
 __device__ __forceinline__ void cc_run(const CCKern& g, const CCCtx& c, const CCItem& it, const CCSetSel st, float* __restrict__ ssd, int lw, int lane) {
     const int h = g.h, w = g.w, d = g.d, lpr = g.lpr;
     // ---- phase-1 identity: lane = cq * w + y
@@ -334,15 +364,19 @@ __device__ __forceinline__ void cc_run(const CCKern& g, const CCCtx& c, const CC
     const bool act1 = cq < g.cpw && q1 < lpr;
     const int q1c = q1 < lpr ? q1 : lpr - 1;
     const int foff = (y1 * g.FQ + q1c) * 4;
-    const int moff = (c.chn * c.nF + st.tile * c.chn * c.nM) * 4 + ((y1 + st.rowoff) * g.MQ + q1c + st.gq) * 4;
+    const int moff = (CHN * c.nF + st.tile * CHN * c.nM) * 4 + ((y1 + st.rowoff) * g.MQ + q1c + st.gq) * 4;
     const int fstep = c.nF * 4, mstep = c.nM * 4;
     const int xw = (1 + y1 * lpr + q1c) * 4;                           // exchange quad of (y1, q1)
     // ---- phase-2 identity: row-major quads
+    // (rows of the FULL quads first, the partial / empty last quads of all rows behind them: only the last wavefront runs the element-wise stores)
     const int t2 = lw * 64 + lane;
     const bool act2 = t2 < g.T;
     const int t2c = t2 < g.T ? t2 : g.T - 1;
-    const int y2 = t2c / lpr, q2 = t2c - y2 * lpr;
-    const int xr = (1 + t2c) * 4;
+    const int qfull = d / 4, nfull = w * qfull;
+    int y2, q2;
+    if (t2c < nfull) { y2 = t2c / qfull; q2 = t2c - y2 * qfull; }
+    else { const int tt = t2c - nfull, npart = lpr - qfull; y2 = tt / npart; q2 = qfull + tt - y2 * npart; }
+    const int xr = (1 + y2 * lpr + q2) * 4;
     const int c0 = 4 * q2;
     const bool full = c0 + 3 < d;
     const int nn = g.n * g.n;
@@ -363,6 +397,35 @@ __device__ __forceinline__ void cc_run(const CCKern& g, const CCCtx& c, const CC
 
     int gc = 0;                                       // chunk counter: buffer = gc & 1
     const int nch = c.nch;
+    // ---- staging helper (sets of at most four shifts): this wavefront's 64 quads of the tile run, one chunk in flight like the loaders'
+    constexpr bool HELP = CC_HELPERS && B <= 4;
+    const int hq = st.hstart + lw * 64 + lane;        // quad of the run
+    const bool hon = HELP && st.hstart >= 0 && hq < c.nM && lw * 64 + lane < g.wps * 64;
+    f32x4 HR[HELP ? CHN : 1];
+    int hp = nch > 1 ? 0 : 1, hci = nch > 1 ? 1 : 0;  // the chunk held in HR
+    auto help_fetch = [&](const int p, const int ci) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cl = 0; cl < CHN; ++cl)
+            if (hon) HR[HELP ? cl : 0] = cc_ld16(c.rsrc, 16u * (unsigned)hq, st.uM0 + (unsigned)p * c.uM_step + (unsigned)(ci * CHN + cl) * c.chanM);
+    };
+    auto help_commit = [&](const int buf) __attribute__((always_inline)) {
+        float* dst = c.lds + buf * c.chunk_floats + (CHN * c.nF + st.tile * CHN * c.nM + hq) * 4;
+#pragma unroll
+        for (int cl = 0; cl < CHN; ++cl)
+            if (hon) lds_store4(dst + cl * c.nM * 4, HR[HELP ? cl : 0]);
+    };
+    // behind the barrier that opens chunk gc: commit the chunk in flight (gc + 1) to the other buffer, request chunk gc + 2
+    auto help_tick = [&]() __attribute__((always_inline)) {
+        if (HELP && st.hstart >= 0 && hp < h) {
+            help_commit((gc + 1) & 1);
+            if (++hci == nch) { hci = 0; ++hp; }
+            if (hp < h) help_fetch(hp, hci);
+        }
+    };
+    if (HELP && st.hstart >= 0) {
+        help_fetch(0, 0); help_commit(0);             // chunk 0 synchronously (the first barrier of the march orders it)
+        if (hp < h) help_fetch(hp, hci);
+    }
     // x / z passes of plane q (the plane the previous step's y pass left in the exchange planes), stores of plane q - 2
     auto phase2 = [&](const int q, float (&Xn)[B][4], const float (&Xo)[B][4], float (&Yn)[B][4], const float (&Yo)[B][4]) __attribute__((always_inline)) {
         const bool feed = q >= 1 && q <= h;          // the first z sum of plane q - 1 lies inside the volume
@@ -428,22 +491,23 @@ __device__ __forceinline__ void cc_run(const CCKern& g, const CCCtx& c, const CC
         // channel sums of one staged chunk (buffer gc & 1) into acc
         auto chunk = [&](const int ci) __attribute__((always_inline)) {
             const float* buf = c.lds + (gc & 1) * c.chunk_floats;
-            const int cn = g.C - ci * c.chn < c.chn ? g.C - ci * c.chn : c.chn;
-            // one channel ahead: the window of channel cl + 1 is requested before channel cl is consumed (running pointers: the
-            // per-channel addresses are not loop invariants the compiler could park in registers)
+            const int cn = CT ? CHN : (g.C - ci * CHN < CHN ? g.C - ci * CHN : CHN);
+            // one channel ahead: the window of channel cl + 1 is requested before channel cl is consumed, into the OTHER of two register sets
+            // (no copies); running pointers: the per-channel addresses are not loop invariants the compiler could park in registers
             const float* pf = buf + cc_opaque(foff);
             const float* pm = buf + cc_opaque(moff);
-            f32x4 fn = lds_load4(pf), mn0 = lds_load4(pm), mn1 = lds_load4(pm + 4);
+            f32x4 fq[2], m0q[2], m1q[2];
+            fq[0] = lds_load4(pf); m0q[0] = lds_load4(pm); m1q[0] = lds_load4(pm + 4);
 #pragma unroll
-            for (int cl = 0; cl < CC_CH; ++cl) {
-                if (cl < cn) {
-                    const f32x4 f4 = fn, m0 = mn0, m1 = mn1;
-                    if (cl + 1 < cn) {
+            for (int cl = 0; cl < CHN; ++cl) {
+                if (CT || cl < cn) {
+                    if (cl + 1 < CHN && (CT || cl + 1 < cn)) {
                         pf += fstep; pm += mstep;
-                        fn = lds_load4(pf);
-                        mn0 = lds_load4(pm);
-                        mn1 = lds_load4(pm + 4);
+                        fq[(cl + 1) & 1] = lds_load4(pf);
+                        m0q[(cl + 1) & 1] = lds_load4(pm);
+                        m1q[(cl + 1) & 1] = lds_load4(pm + 4);
                     }
+                    const f32x4 f4 = fq[cl & 1], m0 = m0q[cl & 1], m1 = m1q[cl & 1];
                     const float f[4] = {f4.x, f4.y, f4.z, f4.w};
                     const float m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
 #pragma unroll
@@ -458,8 +522,9 @@ __device__ __forceinline__ void cc_run(const CCKern& g, const CCCtx& c, const CC
             }
         };
         if (p <= h) {             // p < h: chunk 0 of plane p is staged;  p == h: the last plane's y pass is in the exchange planes
-            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this wavefront's LDS writes (exchange planes) are out
+            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this wavefront's LDS writes (exchange planes, staged pieces) are out
             cc_barrier();
+            if (p < h) help_tick();
         }
         // (p = 0: plane -1 = the zeroed exchange planes, nothing fed, nothing stored -- one call site, executed by every step, so that the
         // arrays it overwrites are dead across the loop edge)
@@ -474,15 +539,18 @@ __device__ __forceinline__ void cc_run(const CCKern& g, const CCCtx& c, const CC
             for (int ci = 1; ci < nch; ++ci) {
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 cc_barrier();
+                help_tick();
                 chunk(ci);
                 ++gc;
             }
             // S.R.S along y; columns >= d become exact zeros (the x pass zero-extends its input)
             const int yo = cc_opaque(y1), qo = cc_opaque(q1), xwo = cc_opaque(xw);
             const float mu = yo > 0 ? 1.0f : 0.0f, md = yo < w - 1 ? 1.0f : 0.0f;
-            float mc[4];
+            // column masks: folded into the second sum's taps where the registers allow it (sets of at most four shifts), else one more product
+            constexpr bool FOLD = B <= 4;
+            float mc[4], muc[FOLD ? 4 : 1], mdc[FOLD ? 4 : 1];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mc[j] = (4 * qo + j < d) ? 1.0f : 0.0f;
+            for (int j = 0; j < 4; ++j) { mc[j] = (4 * qo + j < d) ? 1.0f : 0.0f; if (FOLD) { muc[j] = mu * mc[j]; mdc[j] = md * mc[j]; } }
 #pragma unroll
             for (int k = 0; k < B; ++k) {
                 float t[4], u[4];
@@ -490,11 +558,20 @@ __device__ __forceinline__ void cc_run(const CCKern& g, const CCCtx& c, const CC
                 for (int j = 0; j < 4; ++j) t[j] = acc[k][j];
                 cc_tap_up(t, acc[k], mu);
                 cc_tap_dn(t, acc[k], md);
+                if (FOLD) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) u[j] = t[j];
-                cc_tap_up(u, t, mu);
-                cc_tap_dn(u, t, md);
-                if (act1) lds_store4(c.exch + k * g.exq * 4 + xwo, f32x4{u[0] * mc[0], u[1] * mc[1], u[2] * mc[2], u[3] * mc[3]});
+                    for (int j = 0; j < 4; ++j) u[j] = t[j] * mc[j];
+                    cc_tap_up4(u, t, reinterpret_cast<const float (&)[4]>(muc));
+                    cc_tap_dn4(u, t, reinterpret_cast<const float (&)[4]>(mdc));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = t[j];
+                    cc_tap_up(u, t, mu);
+                    cc_tap_dn(u, t, md);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] *= mc[j];
+                }
+                if (act1) lds_store4(c.exch + k * g.exq * 4 + xwo, f32x4{u[0], u[1], u[2], u[3]});
                 __builtin_amdgcn_sched_barrier(0);          // one shift at a time: the scheduler must not interleave all B (register pressure)
             }
         }
@@ -530,27 +607,32 @@ __global__ __launch_bounds__(MAXT) void k_corr_cert(CCKern g, char* __restrict__
     float* exch0 = lds + 2 * c.chunk_floats;
     c.exch = exch0 + (si == 1 ? it.B[0] : 0) * g.exq * 4;
     const unsigned uM_step = 16u * (unsigned)(g.WQ * g.MQ);
+    c.rsrc = __builtin_amdgcn_make_buffer_rsrc(stage, 0, (int)g.stage_bytes, 0x00020000);
+    c.uM_step = uM_step; c.chanM = g.chanM;
     if (si >= 2) {
         CCLoad L;
-        L.rsrc = __builtin_amdgcn_make_buffer_rsrc(stage, 0, (int)g.stage_bytes, 0x00020000);
+        L.rsrc = c.rsrc;
         L.lt = tid - 2 * g.wps * 64;
         L.rF = (c.nF + CC_LOADER_THREADS - 1) / CC_LOADER_THREADS;
-        L.rM = (c.nM + CC_LOADER_THREADS - 1) / CC_LOADER_THREADS;
         L.ntile = it.ntile;
+        L.lstart[0] = it.lstart[0]; L.lstart[1] = it.lstart[1];
+        L.lcount[0] = c.nM - it.lstart[0]; L.lcount[1] = it.ntile == 2 ? c.nM - it.lstart[1] : 0;
+        L.rM = ((L.lcount[0] > L.lcount[1] ? L.lcount[0] : L.lcount[1]) + CC_LOADER_THREADS - 1) / CC_LOADER_THREADS;
         L.uF_step = 16u * (unsigned)(g.w * g.FQ);
         L.uM_step = uM_step;
         L.uF0 = g.off_F;
         L.uM0[0] = g.off_M[it.type] + (unsigned)it.iH[0] * uM_step + 16u * (unsigned)(it.row0 * g.MQ);
         L.uM0[1] = g.off_M[it.type] + (unsigned)it.iH[1] * uM_step + 16u * (unsigned)(it.row0 * g.MQ);
         L.chanF = g.chanF; L.chanM = g.chanM;
-        // (the benchmark geometry -- planes of 3 x 128 F pieces, 4 x 128 tile pieces -- has straight-line instantiations)
-        if (it.chn == 2) { if (L.rF == 3 && L.rM == 4) cc_loader_run<2, 3, 4, 2, 11>(g, L, c); else cc_loader_run<2, 0, 0, 0, 12>(g, L, c); }
-        else if (L.rF == 3 && L.rM == 4) cc_loader_run<4, 3, 4, 1, 7>(g, L, c);
+        // (the benchmark geometry -- F planes of 3 x 128 pieces, at most one piece left of a tile's run behind the helpers -- has straight-line
+        // instantiations)
+        if (it.chn == 2) {
+            if (L.rF == 3 && L.rM == 4) cc_loader_run<2, 3, 4, 2, 11>(g, L, c);
+            else if (L.rF == 3 && L.rM == 1) cc_loader_run<2, 3, 1, 2, 5>(g, L, c);
+            else cc_loader_run<2, 0, 0, 0, 12>(g, L, c);
+        } else if (L.rF == 3 && L.rM == 4) cc_loader_run<4, 3, 4, 1, 7>(g, L, c);
+        else if (L.rF == 3 && L.rM == 1) cc_loader_run<4, 3, 1, 1, 4>(g, L, c);
         else cc_loader_run<4, 0, 0, 0, 8>(g, L, c);
-        return;
-    }
-    if (g.dbg & 2) {                                     // (timing experiment: the loaders alone, against the same barriers)
-        for (int i = 0; i < g.h * c.nch + 1; ++i) cc_barrier();
         return;
     }
     // zero this set's exchange planes once: the quads before the first and behind the last row are never written
@@ -559,15 +641,22 @@ __global__ __launch_bounds__(MAXT) void k_corr_cert(CCKern g, char* __restrict__
         for (int i = lw * 64 + lane; i < nex; i += g.wps * 64) lds_store4(c.exch + i * 4, f32x4{0.f, 0.f, 0.f, 0.f});
     }
     const int Bs = __builtin_amdgcn_readfirstlane(si ? it.B[1] : it.B[0]);
-    const CCSetSel st = si ? CCSetSel{it.iH[1], it.iW[1], it.start[1], it.rowoff[1], it.gq[1], it.ntile - 1}
-                           : CCSetSel{it.iH[0], it.iW[0], it.start[0], it.rowoff[0], it.gq[0], 0};
+    const unsigned uMt0 = g.off_M[it.type] + 16u * (unsigned)(it.row0 * g.MQ);
+    const CCSetSel st = si ? CCSetSel{it.iH[1], it.iW[1], it.start[1], it.rowoff[1], it.gq[1], it.ntile - 1, it.hstart[1], uMt0 + (unsigned)it.iH[it.ntile - 1] * uM_step}
+                           : CCSetSel{it.iH[0], it.iW[0], it.start[0], it.rowoff[0], it.gq[0], 0, it.hstart[0], uMt0 + (unsigned)it.iH[0] * uM_step};
+    // (the shifts per set and the channels per chunk are compile-time inside the march; CT: every chunk is full)
+#define CC_RUN(BB)                                                                                                    \
+    do {                                                                                                             \
+        if (it.chn == 2) cc_run<BB, CT != 0, 2>(g, c, it, st, ssd, lw, lane); else cc_run<BB, CT != 0, CC_CH>(g, c, it, st, ssd, lw, lane); \
+    } while (0)
     switch (Bs) {
-        case 5: cc_run<5, CT>(g, c, it, st, ssd, lw, lane); break;
-        case 4: cc_run<4, CT>(g, c, it, st, ssd, lw, lane); break;
-        case 3: cc_run<3, CT>(g, c, it, st, ssd, lw, lane); break;
-        case 2: cc_run<2, CT>(g, c, it, st, ssd, lw, lane); break;
-        default: cc_run<1, CT>(g, c, it, st, ssd, lw, lane); break;
+        case 5: CC_RUN(5); break;
+        case 4: CC_RUN(4); break;
+        case 3: CC_RUN(3); break;
+        case 2: CC_RUN(2); break;
+        default: CC_RUN(1); break;
     }
+#undef CC_RUN
     if (g.census && tid == 0) g.census[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -602,7 +691,8 @@ int launch_corr_cert(const float* fix, const float* mov, int C, int h, int w, in
         hipLaunchKernelGGL((k_corr_cert<CT, MAXT>), dim3(k.nwg), block, lds, s, k, stage, ssdu);   \
     } while (0)
     // (768 threads = 3 wavefronts per SIMD: 168 registers per thread)
-    if (block.x <= 768) CC_LAUNCH(1, 768); else CC_LAUNCH(1, 1024);
+    if (C % CC_CH == 0) { if (block.x <= 768) CC_LAUNCH(1, 768); else CC_LAUNCH(1, 1024); }
+    else { if (block.x <= 768) CC_LAUNCH(0, 768); else CC_LAUNCH(0, 1024); }
 #undef CC_LAUNCH
     return check_last("corr_cert");
 }
