@@ -260,6 +260,8 @@ def edt_squared(obj):
 # voxel grows with the square of its distance to the other surface; the transforms' cost does not depend on it)
 HD95_SURFACE_MAX_RADIUS = 48
 HD95_SURFACE_KERNEL = os.environ.get("CONVEXADAM_HD95_KERNEL", "bits")      # "bits" | "voxels" (csrc/surfdist.hip)
+if HD95_SURFACE_KERNEL not in ("bits", "voxels"):
+    raise ValueError("CONVEXADAM_HD95_KERNEL must be 'bits' or 'voxels', got %r" % (HD95_SURFACE_KERNEL,))
 
 
 def cupy_hd95(fixed, moving, num_labels, precision=1, fixed_cache=None, method=None, counts=None):

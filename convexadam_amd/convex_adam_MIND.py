@@ -343,6 +343,7 @@ def _stage_pins():
     image shape changes)."""
     if not hasattr(_tls, "pins"):
         _tls.pins = [None] * 4
+        _tls.pin_free = [None] * 4                       # the event behind the last upload FROM a slot: lives with the slot, not with a generator
     return _tls.pins
 
 
@@ -471,7 +472,10 @@ def convex_adam_pt_many(pairs, dtype: torch.dtype = torch.float16, device: torch
     stage = [None, None]                                 # packed fields on the device
     # pinned staging for two pairs in flight + the events that free them; the buffers outlive the call (per thread: hipHostMalloc of
     # 4 x 27.5 MB cost ~10 ms per generator, 1.2 ms per pair of an 8-pair sweep)
-    pins, pin_free = _stage_pins(), [None] * 4
+    # (the events that free the slots are thread-local like the slots: two generators interleaved on one thread, or a new one started
+    # after an abandoned one, wait for each other's uploads before they overwrite a slot -- ADVICE round 5)
+    pins = _stage_pins()
+    pin_free = _tls.pin_free
 
     def upload(k, img_fixed, img_moving):
         out = []

@@ -529,36 +529,44 @@ __global__ __launch_bounds__(256) void k_cert_arm(CertArgs A, int nprob) {
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int sad, float* tail, hipStream_t s);
 
-size_t corr_certify_workspace_bytes(int C, int h, int w, int d, int hw) {
+// plain = the plain argmin only (cvx_correlate_ex_f32 with fast = 2): keys, runner-up, winners, minimum, list -- 24 bytes per voxel;
+// the coupled passes add the two ping-pong winner arrays and the work records
+size_t corr_certify_workspace_bytes(int C, int h, int w, int d, int hw, bool plain) {
     (void)C;
     const size_t v = (size_t)h * w * d;
     const int n = 2 * hw + 1;
     size_t used = 0;
     used = carve_size(used, sizeof(unsigned long long) * v);      // key
     used = carve_size(used, sizeof(unsigned) * v);                // sec
-    for (int i = 0; i < 3; ++i) used = carve_size(used, sizeof(int) * v);   // idx0, idxA, idxB
+    used = carve_size(used, sizeof(int) * v);                     // idx0
     used = carve_size(used, sizeof(float) * v);                   // smin
     used = carve_size(used, sizeof(unsigned) * v);                // list
-    used = carve_size(used, sizeof(CertRec) * v);                 // records
     used = carve_size(used, sizeof(int) * 8);                     // counts
     used = carve_size(used, sizeof(float) * 32 * n);              // tail
+    if (!plain) {
+        for (int i = 0; i < 2; ++i) used = carve_size(used, sizeof(int) * v);   // idxA, idxB
+        used = carve_size(used, sizeof(CertRec) * v);             // records
+    }
     return used + 256;
 }
 
 struct CertCarve { unsigned long long* key; unsigned* sec; int* idx0; int* idxA; int* idxB; float* smin; unsigned* list; CertRec* rec; int* counts; float* tail; };
-static CertCarve cert_carve(void* workspace, size_t workspace_bytes, int h, int w, int d, int hw) {
+static CertCarve cert_carve(void* workspace, size_t workspace_bytes, int h, int w, int d, int hw, bool plain = false) {
     const size_t v = (size_t)h * w * d;
     const int n = 2 * hw + 1;
     Carver cv(workspace, workspace_bytes);
-    CertCarve c;
+    CertCarve c{};
     c.key = cv.take<unsigned long long>(v);
     c.sec = cv.take<unsigned>(v);
-    c.idx0 = cv.take<int>(v); c.idxA = cv.take<int>(v); c.idxB = cv.take<int>(v);
+    c.idx0 = cv.take<int>(v);
     c.smin = cv.take<float>(v);
     c.list = cv.take<unsigned>(v);
-    c.rec = cv.take<CertRec>(v);
     c.counts = cv.take<int>(8);
     c.tail = cv.take<float>((size_t)32 * n);
+    if (!plain) {
+        c.idxA = cv.take<int>(v); c.idxB = cv.take<int>(v);
+        c.rec = cv.take<CertRec>(v);
+    }
     return c;
 }
 static CertGeo cert_geo(int C, int h, int w, int d, int hw) {
@@ -612,8 +620,8 @@ static int cert_plain(CertArgs& A, int nprob, bool arm, hipStream_t s) {
 
 int corr_certified_argmin(const float* ssdu, const float* fix, const float* mov, int C, int h, int w, int d, int hw, int64_t* argmin,
                           void* workspace, size_t workspace_bytes, hipStream_t s) {
-    if (workspace_bytes < corr_certify_workspace_bytes(C, h, w, d, hw)) return fail(CVX_ERR_WORKSPACE, "certified argmin: workspace too small");
-    const CertCarve c = cert_carve(workspace, workspace_bytes, h, w, d, hw);
+    if (workspace_bytes < corr_certify_workspace_bytes(C, h, w, d, hw, true)) return fail(CVX_ERR_WORKSPACE, "certified argmin: workspace too small");
+    const CertCarve c = cert_carve(workspace, workspace_bytes, h, w, d, hw, true);
     CertArgs A{};
     A.g = cert_geo(C, h, w, d, hw);
     A.p[0] = cert_prob(ssdu, fix, mov, c, nullptr, argmin);
@@ -627,7 +635,7 @@ int corr_certified_argmin(const float* ssdu, const float* fix, const float* mov,
 int coupled_convex_cert_impl(const float* ssduA, const float* fixA, const float* movA, float* outA, void* wsA, const float* ssduB, const float* fixB,
                              const float* movB, float* outB, void* wsB, const float* mesh, int C, int h, int w, int d, int hw, size_t workspace_bytes,
                              hipStream_t s, int stage) {
-    if (workspace_bytes < corr_certify_workspace_bytes(C, h, w, d, hw)) return fail(CVX_ERR_WORKSPACE, "certified coupled convex: workspace too small");
+    if (workspace_bytes < corr_certify_workspace_bytes(C, h, w, d, hw, false)) return fail(CVX_ERR_WORKSPACE, "certified coupled convex: workspace too small");
     const int nprob = ssduB ? 2 : 1;
     CertArgs A{};
     A.g = cert_geo(C, h, w, d, hw);

@@ -276,7 +276,7 @@ static size_t correlate_workspace_exact(int C, int h, int w, int d, int disp_hw)
 extern "C" size_t cvx_correlate_workspace_bytes(int C, int h, int w, int d, int disp_hw) {
     // (the certified-fast variant, cvx_corr_opts.fast = 2, stages its own padded copies)
     const size_t exact = correlate_workspace_exact(C, h, w, d, disp_hw);
-    const size_t cert = corr_certfast_supported(C, h, w, d, disp_hw) ? corr_certfast_workspace_bytes(C, h, w, d, disp_hw) + corr_certify_workspace_bytes(C, h, w, d, disp_hw) + 512 : 0;
+    const size_t cert = corr_certfast_supported(C, h, w, d, disp_hw) ? corr_certfast_workspace_bytes(C, h, w, d, disp_hw) + corr_certify_workspace_bytes(C, h, w, d, disp_hw, true) + 512 : 0;
     return exact > cert ? exact : cert;
 }
 static size_t correlate_workspace_exact(int C, int h, int w, int d, int disp_hw) {
@@ -322,7 +322,7 @@ extern "C" int cvx_correlate_ex_f32(const float* fix, const float* mov, int C, i
         int rc = launch_corr_certfast(fix, mov, C, h, w, d, disp_hw, ssd, workspace, cws, s);
         if (rc || !argmin) return rc;
         return corr_certified_argmin(ssd, fix, mov, C, h, w, d, disp_hw, argmin, static_cast<char*>(workspace) + align_up(cws, 256),
-                                     corr_certify_workspace_bytes(C, h, w, d, disp_hw), s);
+                                     corr_certify_workspace_bytes(C, h, w, d, disp_hw, true), s);
     }
     const bool variant = cost != 0 || n_box != 2 || fast || f16;
     if (!corr_use_unfused(C, h, w, d, disp_hw, variant)) {

@@ -411,7 +411,7 @@ size_t corr_certfast_workspace_bytes(int C, int h, int w, int d, int hw);
 int launch_corr_certfast(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* ssdu, void* workspace, size_t workspace_bytes,
                          hipStream_t s);
 // certify.hip: decisions on the certified-fast volume that equal the reference's on the exact one
-size_t corr_certify_workspace_bytes(int C, int h, int w, int d, int hw);
+size_t corr_certify_workspace_bytes(int C, int h, int w, int d, int hw, bool plain = false);     // plain: the plain argmin only
 int corr_certified_argmin(const float* ssdu, const float* fix, const float* mov, int C, int h, int w, int d, int hw, int64_t* argmin,
                           void* workspace, size_t workspace_bytes, hipStream_t s);
 // both directions (ssduB == nullptr: one) from the certified-fast volumes to the smoothed fields: plain argmin + six coupled passes

@@ -129,7 +129,8 @@ static PairLayout pair_layout(const cvx_pair_params& p, int n_snap = 0, int max_
     L.fs = take(u, f * L.C * L.v);
     L.ms = take(u, f * L.C * L.v);
     L.corr_ws = take(u, cvx_correlate_workspace_bytes(L.C, L.h, L.w, L.d, p.disp_hw));
-    L.corr_ws2 = p.ic ? take(u, corr_fused_workspace_bytes(L.C, L.h, L.w, L.d, p.disp_hw)) : 0;      // the reverse direction's padded copies (both directions in one launch)
+    // the reverse direction's padded copies (both directions in one launch): only where that path can run (option corr_dual, off by default)
+    L.corr_ws2 = (p.ic && options().corr_dual != 0 && corr_fused_supported(L.C, L.h, L.w, L.d, p.disp_hw)) ? take(u, corr_fused_workspace_bytes(L.C, L.h, L.w, L.d, p.disp_hw)) : 0;
     // fp16 storage: the cost volumes hold __half (half the bytes written by the correlation kernel and read by every argmin pass)
     const size_t ssd_elem = p.fp16_storage ? 2 : f;
     L.ssd = take(u, ssd_elem * (size_t)L.K * L.v);

@@ -13,8 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `-m gpu`)")
     # The bit-parity suite compares the pipeline with the oracle's restatement of the REFERENCE's evaluation order: calls that do not
-    # name a mode run adam_mode="exact" here.  The throughput mode (the package default outside the tests) is tested where it is named
-    # explicitly: tests/test_gpu_fast_modes.py, against its own oracle restatement and the reference's capture.
+    # name a mode run adam_mode="exact" here -- which is also the package default since round 5 (this line pins it against an environment
+    # that sets CONVEXADAM_ADAM_MODE).  The opt-in throughput mode is tested where it is named explicitly: tests/test_gpu_fast_modes.py,
+    # against its own oracle restatement and the reference's captures.
     from convexadam_amd import convex_adam_MIND
     convex_adam_MIND.set_default_adam_mode("exact")
 

@@ -43,7 +43,7 @@ LARGE = False          # --large: extents of 96 .. 224 voxels (x tiles, uneven z
 
 
 def _draw_options(rng):
-    """Bit-identical kernel variants added in round 5, drawn per trial (process default context)."""
+    """Bit-identical kernel variants added in rounds 5 and 6, drawn per trial (process default context)."""
     from convexadam_amd import _lib
     L = _lib.lib()
     L.cvx_set_option(b"box_fwd_tile", int(rng.choice([-1, 0, 1000, 2000, 1834, 2274, 1222])))
@@ -54,6 +54,8 @@ def _draw_options(rng):
     L.cvx_set_option(b"mind_records", int(rng.integers(0, 4) > 0))
     L.cvx_set_option(b"mind_blocked", int(rng.integers(0, 4) > 0))
     L.cvx_set_option(b"resize_up2", int(rng.integers(0, 4) > 0))
+    # round 6: the certified-fast correlation path (1 = role kernel in fast arithmetic, 2 = staged kernel) or the exact volumes (0)
+    L.cvx_set_option(b"corr_cert", int(rng.choice([1, 1, 2, 2, 0])))
 
 
 def trial_pipeline(rng, t):

@@ -146,7 +146,8 @@ def test_workspace_queries(L):
     L.cvx_set_option(b"corr_fused_all", 0)
     for gs in (2, 3, 4, 5):                                        # every stage-1 grid of the sweep at 160 x 192 x 224
         h, w, d = 160 // gs, 192 // gs, 224 // gs
-        assert L.cvx_correlate_workspace_bytes(12, h, w, d, 5) < 2 * 12 * (h + 10) * (w + 10) * (d + 32) * 4 + 8 * h * w * d + (1 << 20), gs
+        # (+ 24 bytes per voxel: keys, runner-up, winners, minima and work list of the certified argmin, cvx_corr_opts.fast = 2)
+        assert L.cvx_correlate_workspace_bytes(12, h, w, d, 5) < 2 * 12 * (h + 10) * (w + 10) * (d + 32) * 4 + 24 * h * w * d + (1 << 20), gs
     old = L.cvx_get_option(b"corr_unfused")
     L.cvx_set_option(b"corr_unfused", 1)
     assert L.cvx_correlate_workspace_bytes(20, 26, 32, 37, 6) >= 4 * K * 26 * 32 * 40

@@ -1,0 +1,179 @@
+"""Certified-fast correlation (corrcert.hip / corrfused.hip fast arithmetic, certify.hip): the pipeline's internal cost volume is NOT
+ATen's bit for bit -- it is within a proven relative distance of it -- and every argmin decision taken on it must nevertheless be the
+reference's (torch.argmin(ssd, 0), convex_adam_utils.py:87; the six coupled passes :98-107).  Checked here against the CPU oracle:
+  * the distance itself (|ssdu / 729 - ssd| <= 2^-17 ssd, the bound DESIGN section 12 derives; zero exactly where the oracle is zero);
+  * INDEX EQUALITY of the plain argmin on the 47 shapes of test_correlate_vs_oracle, on volumes built to produce near ties and exact
+    ties (periodic features, shifted copies, constant blocks) and on exact-zero backgrounds, with both kernels (option corr_cert 1 / 2);
+  * the coupled passes through the whole-pair entry point on such volumes (fields array_equal to the oracle's) -- the packaged pipeline
+    tests of test_gpu_parity.py run the certified path as well (it is the default)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+E_REL = 2.0 ** -17
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def U():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from convexadam_amd import convex_adam_utils
+    return convex_adam_utils
+
+
+@pytest.fixture(scope="module")
+def L():
+    from convexadam_amd import _lib
+    return _lib.lib()
+
+
+SHAPES = [(12, (12, 10, 14), 2), (12, (7, 9, 11), 3), (12, (9, 8, 37), 4), (20, (7, 5, 9), 1),
+          (3, (5, 6, 7), 2), (33, (6, 5, 8), 2), (12, (4, 4, 4), 6), (1, (3, 3, 3), 0),
+          (12, (9, 8, 37), 5), (12, (9, 8, 37), 6), (12, (9, 8, 37), 7), (12, (9, 8, 37), 8),
+          (12, (13, 16, 20), 6), (12, (13, 16, 20), 8), (32, (13, 16, 20), 5), (32, (9, 8, 37), 7),
+          (14, (26, 32, 37), 6), (5, (11, 12, 13), 8),
+          (12, (6, 40, 37), 3), (12, (5, 23, 74), 2), (7, (4, 38, 44), 4), (12, (3, 96, 112), 1), (12, (9, 33, 37), 6),
+          (32, (5, 48, 56), 2), (18, (6, 40, 37), 3), (64, (4, 9, 10), 2), (67, (3, 5, 6), 1),
+          (12, (3, 3, 3), 0), (12, (5, 2, 3), 1), (20, (7, 1, 3), 0),
+          (12, (5, 6, 9), 9), (6, (4, 5, 13), 11), (20, (3, 4, 5), 10), (12, (4, 3, 6), 15)]
+
+
+def certified(U, L, f, m, hw, kernel):
+    """(ssdu, argmin) of the certified operator with kernel 1 (role kernel, fast arithmetic) or 2 (staged kernel); None if unsupported"""
+    from convexadam_amd._lib import CvxError, CVX_ERR_UNSUPPORTED
+    C, shape = f.shape[0], f.shape[1:]
+    old = L.cvx_get_option(b"corr_cert")
+    L.cvx_set_option(b"corr_cert", kernel)
+    try:
+        return U.correlate(dev(f)[None], dev(m)[None], hw, 1, shape, C, mode="certified")
+    except CvxError as e:
+        assert e.code == CVX_ERR_UNSUPPORTED, e
+        return None
+    finally:
+        L.cvx_set_option(b"corr_cert", old)
+
+
+def check(U, L, orc, f, m, hw, must_run=False):
+    rs, ra = orc.correlate(f, m, hw)
+    ran = 0
+    for kernel in (1, 2):
+        got = certified(U, L, f, m, hw, kernel)
+        if got is None:
+            continue
+        ran += 1
+        ssdu, am = host(got[0]).astype(np.float64) / 729.0, host(got[1])
+        assert np.array_equal(am, ra), "kernel %d: %d of %d argmins differ from the oracle's" % (kernel, int((am != ra).sum()), ra.size)
+        ref = rs.astype(np.float64)
+        assert np.array_equal(ssdu == 0, ref == 0), "kernel %d: exact zeros differ" % kernel
+        err = np.abs(ssdu - ref)
+        assert bool((err <= E_REL * ref + 1e-38).all()), "kernel %d: distance %g of the proven 2^-17" % (kernel, float((err / np.maximum(ref, 1e-30)).max()))
+    assert ran or not must_run, "no certified kernel took this shape"
+    return ran
+
+
+@pytest.mark.parametrize("C,shape,hw", SHAPES)
+def test_certified_argmin_vs_oracle(U, L, orc, C, shape, hw):
+    rng = np.random.default_rng(C * 100 + hw)
+    f = rng.random((C,) + shape, dtype=np.float32)
+    m = rng.random((C,) + shape, dtype=np.float32)
+    check(U, L, orc, f, m, hw)
+
+
+def test_certified_kernels_cover_the_benchmark_geometries(U, L, orc):
+    """BASELINE configs 1-3 (coarse grids 16^3 hw 4, 26x32x37 hw 6, 37x32x37 hw 8) must take the certified path with both kernels"""
+    from convexadam_amd import _lib
+    for (C, shape, hw) in ((12, (16, 16, 16), 4), (12, (26, 32, 37), 6)):
+        rng = np.random.default_rng(hw)
+        f = rng.random((C,) + shape, dtype=np.float32)
+        m = np.roll(f, (1, -2, 1), (1, 2, 3)) + np.float32(0.05) * rng.random((C,) + shape, dtype=np.float32)
+        assert check(U, L, orc, f, m, hw, must_run=True) == 2
+
+
+@pytest.mark.parametrize("kind", ["periodic", "shifted_copy", "constant", "blocks", "zero_background", "zero_everything", "tiny_values"])
+@pytest.mark.parametrize("C,shape,hw", [(12, (9, 12, 14), 3), (4, (6, 8, 37), 2), (12, (7, 32, 13), 4)])
+def test_certified_argmin_on_near_ties(U, L, orc, kind, C, shape, hw):
+    """Volumes whose cost columns hold exact ties, near ties at rounding level and exact zeros: the certified argmin is the first minimum of
+    the EXACT volume (the evaluator of certify.hip decides what the intervals cannot)."""
+    rng = np.random.default_rng(hw + 7 * C)
+    f = rng.random((C,) + shape, dtype=np.float32)
+    if kind == "periodic":           # period 2 along every axis: displacements that differ by the period cost the same up to rounding
+        base = rng.random((C, 2, 2, 2), dtype=np.float32)
+        f = np.tile(base, (1, shape[0] // 2 + 1, shape[1] // 2 + 1, shape[2] // 2 + 1))[:, :shape[0], :shape[1], :shape[2]].copy()
+        m = f.copy()
+    elif kind == "shifted_copy":
+        m = np.roll(f, (1, 0, -1), (1, 2, 3)).copy()
+    elif kind == "constant":
+        f = np.full((C,) + shape, 0.25, np.float32)
+        m = np.full((C,) + shape, 0.75, np.float32)
+    elif kind == "blocks":           # piecewise constant features: whole plateaus of equal cost
+        f = np.repeat(np.repeat(np.repeat(rng.random((C, 3, 3, 3), dtype=np.float32), shape[0] // 3 + 1, 1), shape[1] // 3 + 1, 2), shape[2] // 3 + 1, 3)
+        f = f[:, :shape[0], :shape[1], :shape[2]].copy()
+        m = np.roll(f, 1, 2).copy()
+    elif kind == "zero_background":
+        m = np.roll(f, (0, 1, 1), (1, 2, 3)).copy()
+        f[:, :, : shape[1] // 2] = 0
+        m[:, :, : shape[1] // 2 + 1] = 0
+    elif kind == "zero_everything":
+        f[:] = 0
+        m = f.copy()
+    else:                            # differences whose squares fall into the denormal range: ATen's divisions round some entries to zero
+        f = (rng.random((C,) + shape, dtype=np.float32) * np.float32(1e-21)).astype(np.float32)
+        m = (rng.random((C,) + shape, dtype=np.float32) * np.float32(1e-21)).astype(np.float32)
+    rs, ra = orc.correlate(f, m, hw)
+    ran = 0
+    for kernel in (1, 2):
+        got = certified(U, L, f, m, hw, kernel)
+        if got is None:
+            continue
+        ran += 1
+        assert np.array_equal(host(got[1]), ra), "%s, kernel %d: %d argmins differ" % (kind, kernel, int((host(got[1]) != ra).sum()))
+    assert ran, "no certified kernel took this shape"
+
+
+@pytest.mark.parametrize("kind", ["periodic", "blocks", "zero_background", "textured"])
+def test_certified_coupled_passes_on_near_ties(L, orc, kind):
+    """The plain argmin AND the six coupled passes through the whole-pair entry point on feature volumes with ties: the convex stage's field
+    is the oracle's bit for bit with the certified path (default) and equals the exact path's (option corr_cert = 0)."""
+    from convexadam_amd.convex_adam_MIND import register_pair_device
+    rng = np.random.default_rng(5)
+    C, shape = 12, (24, 32, 28)
+    f = rng.random((C,) + shape, dtype=np.float32)
+    if kind == "periodic":
+        base = rng.random((C, 4, 4, 4), dtype=np.float32)
+        f = np.tile(base, (1, 6, 8, 7)).copy()
+        m = np.roll(f, (1, 0, 0), (1, 2, 3)).copy()
+    elif kind == "blocks":
+        f = np.repeat(np.repeat(np.repeat(rng.random((C, 6, 8, 7), dtype=np.float32), 4, 1), 4, 2), 4, 3).copy()
+        m = np.roll(f, (2, -1, 1), (1, 2, 3)).copy()
+    elif kind == "zero_background":
+        m = np.roll(f, (1, -1, 2), (1, 2, 3)).copy()
+        f[:, :, :14] = 0
+        m[:, :, :15] = 0
+    else:
+        m = (np.roll(f, (1, -1, 2), (1, 2, 3)) + np.float32(0.1) * rng.random((C,) + shape, dtype=np.float32)).astype(np.float32)
+    kw = dict(lambda_weight=0, grid_sp=2, disp_hw=3, selected_niter=1, grid_sp_adam=2, ic=True)
+    ref = orc.convex_adam_pipeline(None, None, features=(f, m), **kw)
+    outs = []
+    for cert in (1, 2, 0):
+        old = L.cvx_get_option(b"corr_cert")
+        L.cvx_set_option(b"corr_cert", cert)
+        try:
+            outs.append(np.moveaxis(host(register_pair_device(feat_fixed=dev(f), feat_moving=dev(m), **kw)), 0, -1).astype(np.float64))
+        finally:
+            L.cvx_set_option(b"corr_cert", old)
+        assert np.array_equal(outs[-1], ref), "%s, corr_cert = %d: field differs from the oracle's (max %g)" % (kind, cert, np.abs(outs[-1] - ref).max())
+
+
+def test_certified_is_the_pipeline_default_and_saves_nothing_but_time(L):
+    """The option defaults to the certified path; the exact volumes remain one switch away."""
+    assert L.cvx_get_option(b"corr_cert") in (1, 2)
