@@ -60,7 +60,7 @@ def make_pair(device, idx):
     return fix.to(device).contiguous(), mov.to(device).contiguous()
 
 
-CORR_SOURCES = ("corrfused.hip", "correlate.hip", "corrbox.hip")
+CORR_SOURCES = ("corrfused.hip", "correlate.hip", "corrbox.hip", "corrcert.hip", "certify.hip")
 
 
 def corr_sources_sha():
@@ -503,7 +503,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the secondary measurements (batched pairs, other configs, modes)")
+    ap.add_argument("--adam-mode", default="exact", choices=("exact", "fast"), help="mode of the timed loop: exact = the package default (what `value` "
+                    "means); fast = the opt-in throughput arithmetic of the Adam loop (profiling runs; the line then says so in `mode`)")
     a = ap.parse_args()
+    global TIMED, TIMED_MODE_NAME
+    if a.adam_mode == "fast":
+        TIMED, TIMED_MODE_NAME = FAST, "adam_mode=fast (OPT-IN, not the package default; run with --adam-mode fast)"
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -810,6 +815,11 @@ def main():
         if n == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"], res["parity"] = cpu_baseline(fix.cpu().numpy(), mov.cpu().numpy(), field_of_timed_loop)
             oracle_fast = res["parity"].pop("_oracle_fast_field")
+            if a.adam_mode == "fast":                              # profiling runs of the opt-in mode: the checker is the oracle's restatement of THAT mode
+                import numpy as np
+                got = np.moveaxis(field_of_timed_loop, 0, -1).astype(np.float64)
+                res["parity"].update(bit_identical=bool(np.array_equal(got, oracle_fast)), max_abs_diff=float(np.abs(got - oracle_fast).max()),
+                                     epe_vs_oracle=float(np.sqrt(((got - oracle_fast) ** 2).sum(-1)).mean()))
             res["parity"]["tolerance_epe"] = TOLERANCE_EPE
             res["parity"].update(mode_parity(fix, mov, dev, oracle_fast))
             del oracle_fast

@@ -12,8 +12,13 @@ WRITE_SIZE is exact; both are in KiB.  bytes = (factor * FETCH_SIZE + WRITE_SIZE
 (calibrated where the read volume is known, 2.0 -- an upper bound -- elsewhere; the table prints the factor it used and the factor-1 figure)."""
 
 # FETCH_SIZE correction per kernel (substring match): measured = known read bytes / counted bytes on the benchmark configuration
+# (defaults; main() replaces them by the factors calibrated ON THE RUN BEING PROCESSED wherever a kernel of KNOWN_READS was launched)
 FETCH_FACTOR = {"k_mind_finish_pool": 1.0, "k_argmin4": 2.0, "k_to_chunked": 2.0}
 DEFAULT_FACTOR = 2.0
+V_FULL, V_COARSE, K_DISP = 160 * 192 * 224, 26 * 32 * 37, 2197
+# read volume of kernels whose input is streamed exactly once (benchmark configuration), bytes per launch
+KNOWN_READS = {"k_argmin4": K_DISP * V_COARSE * 4, "k_cert_plain_stream": K_DISP * V_COARSE * 4, "k_mind_finish_pool": 12 * V_FULL * 4,
+               "k_to_chunked": 12 * (V_FULL // 8) * 4}
 
 
 def fetch_factor(kernel):
@@ -49,7 +54,7 @@ def corr_sha():
     """sha256 over the correlation-stage sources (bench.py compares it with the tree it runs on -> roofline.traffic_stale)."""
     import hashlib                              # (same recipe as bench.py::corr_sources_sha)
     h = hashlib.sha256()
-    for name in ("corrfused.hip", "correlate.hip", "corrbox.hip"):
+    for name in ("corrfused.hip", "correlate.hip", "corrbox.hip", "corrcert.hip", "certify.hip"):
         with open(os.path.join(ROOT, "convexadam_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -61,9 +66,25 @@ def main(src, tag):
     if db:
         out = subprocess.run([sys.executable, os.path.join(HERE, "rocpd_stats.py"), db[0]], stdout=subprocess.PIPE, text=True).stdout
         with open(os.path.join(prof, tag + "_bench_kernel_stats.txt"), "w") as f:
-            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-batched   (6 pairs)\n" + out)
+            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-batched   (6 pairs, package default mode = exact)\n" + out)
+    db = glob.glob(src + "/stats_fast/**/*_results.db", recursive=True)
+    if db:
+        out = subprocess.run([sys.executable, os.path.join(HERE, "rocpd_stats.py"), db[0]], stdout=subprocess.PIPE, text=True).stdout
+        with open(os.path.join(prof, tag + "_fast_mode_bench_kernel_stats.txt"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-batched --adam-mode fast   (6 pairs, opt-in fast Adam mode)\n" + out)
     fa, fc = pmc(src + "/fetch")
     wa, wc = pmc(src + "/write")
+    # calibrate the FETCH_SIZE factor on this very run: known read bytes / counted bytes, clamped to [1, 2] (the counter tallies a 128-byte
+    # line fetched by a 16-byte-per-lane access as 64 B and shorter pieces 1:1; a ratio outside that range means the kernel did not stream
+    # what KNOWN_READS assumes -- e.g. another configuration -- and the default stays)
+    calibrated = {}
+    for k in fa:
+        for name, nbytes in KNOWN_READS.items():
+            if name in k and fc[k].get("FETCH_SIZE"):
+                counted = fa[k]["FETCH_SIZE"] / fc[k]["FETCH_SIZE"] * 1024
+                if counted > 0 and 0.9 <= nbytes / counted <= 2.2:
+                    calibrated[name] = min(2.0, max(1.0, nbytes / counted))
+    FETCH_FACTOR.update(calibrated)
     rows = []
     for k in sorted(set(fa) | set(wa)):
         n = max(fc[k].get("FETCH_SIZE", 0), wc[k].get("WRITE_SIZE", 0))
@@ -76,15 +97,15 @@ def main(src, tag):
               "#   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched\n"
               "#   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched\n"
               "# Counters are in KiB; WRITE_SIZE is exact, FETCH_SIZE reads 1/2 of a 16-byte-per-lane streamed read on gfx950 and 1/1 of shorter pieces ->\n"
-              "# bytes = (factor*FETCH_SIZE + WRITE_SIZE) * 1024 with the per-kernel factor shown (calibrated: k_mind_finish_pool 1.00, k_argmin4 / k_to_chunked 2.00;\n"
+              "# bytes = (factor*FETCH_SIZE + WRITE_SIZE) * 1024 with the per-kernel factor shown (calibrated on THIS run where the read volume is known: "
+              + ", ".join("%s %.2f" % kv for kv in sorted(calibrated.items())) + ";\n"
               "# 2.00 = upper bound elsewhere; the last column is the factor-1 lower bound).\n")
     buf.write("%-44s %6s %14s %14s %6s %18s %14s\n" % ("kernel", "calls", "FETCH_KiB/call", "WRITE_KiB/call", "factor", "corrected_MB/call", "factor1_MB/call"))
     for k, n, fe, wr, mb in rows:
         buf.write("%-44s %6d %14.1f %14.1f %6.2f %18.1f %14.1f\n" % (k[-44:], n, fe, wr, fetch_factor(k), mb, (fe + wr) * 1024 / 1e6))
     # calibration of the FETCH_SIZE factor on kernels whose read volume is known exactly (benchmark configuration): the guide's x2 holds for
     # accesses that fetch whole 128-byte lines (tallied at 64 B); kernels that read shorter contiguous pieces are counted 1:1
-    V, v, K = 160 * 192 * 224, 26 * 32 * 37, 2197
-    known = {"k_argmin4": K * v * 4, "k_mind_finish_pool": 12 * V * 4, "k_to_chunked": 12 * (V // 8) * 4, "k_resize<3>": None}
+    known = KNOWN_READS
     buf.write("# FETCH_SIZE calibration on this run (known read bytes / counted bytes):\n")
     for k, n, fe, wr, mb in rows:
         for name, nbytes in known.items():
@@ -95,9 +116,11 @@ def main(src, tag):
     # per launch of the fused kernel: since round 5 ONE launch carries both directions of the pair (with two k_corr_prep launches)
     nfused = max([r[1] for r in stage if "k_corr_fused" in r[0] or "k_corr_box" in r[0]] + [1])
     total = sum(r[4] * r[1] for r in stage) * 1e6 / nfused
-    cc = [r for r in rows if any(k in r[0] for k in ("k_argmin_voxel", "k_argmin_wave", "k_gather_box3", "k_keys_to_idx_min"))]
+    cc = [r for r in rows if any(k in r[0] for k in ("k_argmin_voxel", "k_argmin_wave", "k_gather_box3", "k_keys_to_idx_min", "k_cert_voxel", "k_cert_wave", "k_cert_gather",
+                                                       "k_cert_arm", "k_cert_plain_finalize", "k_cert_plain_resolve"))]
     cc_pair = sum(r[4] * r[1] for r in cc) * 1e6              # the PMC passes register ONE pair: calls x bytes per call
     json.dump({"correlate_stage_bytes_per_launch": total, "coupled_convex_bytes_per_pair": cc_pair,
+               "plain_argmin_bytes_per_direction": sum(r[4] * r[1] for r in rows if "k_cert_plain_stream" in r[0] or "k_argmin4" in r[0]) * 1e6 / 2,
                "coupled_convex_kernels": {r[0]: {"calls": r[1], "bytes_per_call": r[4] * 1e6} for r in cc}, "source": "profiles/%s_pmc_hbm_traffic.txt" % tag,
                "kernels": {r[0]: r[4] * 1e6 for r in stage},
                "formula": "(factor*FETCH_SIZE + WRITE_SIZE)*1024 (factor 2: 16-byte streaming reads) summed over k_corr_prep, k_corr_fused (k_corr_tail_compact when the volume has an interleaved-order tail), per launch = per direction", "measured_at_commit": os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip(),
