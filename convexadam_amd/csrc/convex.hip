@@ -12,6 +12,9 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <atomic>
+
 #include "cvx_common.h"
 
 namespace cvx {
@@ -551,6 +554,125 @@ __global__ __launch_bounds__(256) void k_ic_step(const float* __restrict__ a1, c
     for (int c = 0; c < 3; ++c) o2[(size_t)c * v + p] = 0.5f * (a2[(size_t)c * v + p] - tri_sample(t, a1 + (size_t)c * v, h, w, d));
 }
 
+
+// ---- inverse consistency in ONE launch (option ic_fused) ---------------------------------------------------------------------------
+// The 15 steps are dependent and tiny (30 784 voxels, two 370 KB fields): one launch per step costs 5.7 us, of which the kernel boundary is
+// half.  A device-wide barrier costs more than a boundary on this part (4 us for the counter over 256 workgroups, 16 us with the L2
+// write-back / invalidate that makes one XCD's writes visible to another) -- but workgroups of ONE XCD share its L2:
+// between them a barrier could be an L2 atomic and visibility would need no cache maintenance, only accesses that do not stop in the per-CU L1.  The launch has 8 x IC_NWG workgroups, dealt round-robin to the 8 XCDs; the IC_NWG workgroups with
+// blockIdx % 8 == xcd do the work, the others exit at once.  That placement is how the hardware dispatches, not a guarantee: every working
+// workgroup reports its XCC_ID, and if they are not all equal the kernel stops after the first step and k_ic_fallback (always enqueued,
+// normally an empty launch) redoes the whole computation with one workgroup.
+constexpr int IC_NWG = 32, IC_NT = 512;
+struct ICSync { unsigned arrive, xcc_mask, fallback, pad; };
+
+// Field accesses are agent-scope atomics: correct on any placement, but served behind the L2 (~2 us per dependent access).  MEASURED: 19 us per step,
+// 289 us per call against 145 us for 15 launches (tools/experiments/ic_time.py) -- the option is OFF by default.  The cheaper form the idea needs --
+// loads that miss the L1 but hit the XCD's L2 -- does not exist on this part: `sc0` (workgroup scope) loads may hit the L1 (a workgroup owns its CU's
+// L1), so a barrier that polls with them never sees the other workgroups' arrivals (tried: the kernel hangs); `sc1` (agent scope) goes past the L2 for
+// ordinary (non-coherent across XCDs) allocations.  DESIGN.md section 12.10.
+template <bool AG>
+struct ICMem {
+    __device__ __forceinline__ float ld(const float* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void st(float* p, float v) const { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+// tri_sample with loads that are served by the L2 (same arithmetic, same order)
+template <bool AG>
+__device__ __forceinline__ float tri_sample_l2(const ICMem<AG>& M, const Tri& t, const float* vol, int h, int w, int d) {
+    const int x0 = t.x0, y0 = t.y0, z0 = t.z0, x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    const bool zi0 = (unsigned)z0 < (unsigned)h, zi1 = (unsigned)z1 < (unsigned)h, yi0 = (unsigned)y0 < (unsigned)w,
+               yi1 = (unsigned)y1 < (unsigned)w, xi0 = (unsigned)x0 < (unsigned)d, xi1 = (unsigned)x1 < (unsigned)d;
+    const int zc0 = clampi(z0, 0, h - 1), zc1 = clampi(z1, 0, h - 1), yc0 = clampi(y0, 0, w - 1), yc1 = clampi(y1, 0, w - 1),
+              xc0 = clampi(x0, 0, d - 1), xc1 = clampi(x1, 0, d - 1);
+    const int r00 = (zc0 * w + yc0) * d, r01 = (zc0 * w + yc1) * d, r10 = (zc1 * w + yc0) * d, r11 = (zc1 * w + yc1) * d;
+    const float v0 = M.ld(vol + r00 + xc0), v1 = M.ld(vol + r00 + xc1), v2 = M.ld(vol + r01 + xc0), v3 = M.ld(vol + r01 + xc1),
+                v4 = M.ld(vol + r10 + xc0), v5 = M.ld(vol + r10 + xc1), v6 = M.ld(vol + r11 + xc0), v7 = M.ld(vol + r11 + xc1);
+    float o = 0.0f, n;
+    n = o + v0 * t.tnw; o = (zi0 && yi0 && xi0) ? n : o;
+    n = o + v1 * t.tne; o = (zi0 && yi0 && xi1) ? n : o;
+    n = o + v2 * t.tsw; o = (zi0 && yi1 && xi0) ? n : o;
+    n = o + v3 * t.tse; o = (zi0 && yi1 && xi1) ? n : o;
+    n = o + v4 * t.bnw; o = (zi1 && yi0 && xi0) ? n : o;
+    n = o + v5 * t.bne; o = (zi1 && yi0 && xi1) ? n : o;
+    n = o + v6 * t.bsw; o = (zi1 && yi1 && xi0) ? n : o;
+    n = o + v7 * t.bse; o = (zi1 && yi1 && xi1) ? n : o;
+    return o;
+}
+// one step over the voxels p = first, first + stride, ..   (`lo` = lowest address of the four field buffers, `span` = bytes they cover)
+template <bool AG>
+__device__ __forceinline__ void ic_sweep(const float* a1, const float* a2, int h, int w, int d, const float* __restrict__ bh, const float* __restrict__ bw,
+                                         const float* __restrict__ bd, float* o1, float* o2, int first, int stride, const float* lo, unsigned span) {
+    const int v = h * w * d;
+    ICMem<AG> M;
+    (void)lo; (void)span;
+    for (int p = first; p < v; p += stride) {
+        const int x = p % d, y = (p / d) % w, z = p / (d * w);
+        const float a10 = M.ld(a1 + p), a11 = M.ld(a1 + v + p), a12 = M.ld(a1 + 2 * v + p);
+        const float a20 = M.ld(a2 + p), a21 = M.ld(a2 + v + p), a22 = M.ld(a2 + 2 * v + p);
+        Tri t, u;
+        tri_setup(t, bd[x] + a10, bw[y] + a11, bh[z] + a12, h, w, d);
+        tri_setup(u, bd[x] + a20, bw[y] + a21, bh[z] + a22, h, w, d);
+        const float s0 = tri_sample_l2(M, t, a2, h, w, d), s1 = tri_sample_l2(M, t, a2 + v, h, w, d), s2 = tri_sample_l2(M, t, a2 + 2 * v, h, w, d);
+        const float r0 = tri_sample_l2(M, u, a1, h, w, d), r1 = tri_sample_l2(M, u, a1 + v, h, w, d), r2 = tri_sample_l2(M, u, a1 + 2 * v, h, w, d);
+        M.st(o1 + p, 0.5f * (a10 - s0)); M.st(o1 + v + p, 0.5f * (a11 - s1)); M.st(o1 + 2 * v + p, 0.5f * (a12 - s2));
+        M.st(o2 + p, 0.5f * (a20 - r0)); M.st(o2 + v + p, 0.5f * (a21 - r1)); M.st(o2 + 2 * v + p, 0.5f * (a22 - r2));
+    }
+}
+template <bool AG>
+__global__ __launch_bounds__(IC_NT) void k_ic_persistent(const float* f1, const float* f2, int h, int w, int d, int iters, const float* __restrict__ bh,
+                                                         const float* __restrict__ bw, const float* __restrict__ bd, float* t1, float* t2, float* o1,
+                                                         float* o2, ICSync* sync, int xcd, int force_fallback, const float* lo, unsigned span) {
+    if ((int)(blockIdx.x & 7) != xcd) return;
+    const int wg = (int)(blockIdx.x >> 3);
+    constexpr int SCOPE = __HIP_MEMORY_SCOPE_AGENT;
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15u;
+        __hip_atomic_fetch_or(&sync->xcc_mask, force_fallback ? (1u << (wg & 1)) : (1u << xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float *s1 = f1, *s2 = f2;
+    for (int it = 0; it < iters; ++it) {
+        const bool to_out = ((iters - 1 - it) & 1) == 0;
+        float* d1 = to_out ? o1 : t1;
+        float* d2 = to_out ? o2 : t2;
+        ic_sweep<AG>(s1, s2, h, w, d, bh, bw, bd, d1, d2, wg * IC_NT + (int)threadIdx.x, IC_NWG * IC_NT, lo, span);
+        if (it == iters - 1) break;
+        // barrier between the IC_NWG workgroups: every store of this workgroup has reached the L2 (vmcnt(0) of all its wavefronts), then one arrival
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&sync->arrive, 1u, __ATOMIC_RELAXED, SCOPE);
+            const unsigned want = (unsigned)(it + 1) * IC_NWG;
+            while (__hip_atomic_fetch_add(&sync->arrive, 0u, __ATOMIC_RELAXED, SCOPE) < want) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        if (it == 0) {                         // everyone has reported: all on one XCD?
+            const unsigned m = __hip_atomic_load(&sync->xcc_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (m & (m - 1)) {
+                if (wg == 0 && threadIdx.x == 0) __hip_atomic_store(&sync->fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        s1 = d1; s2 = d2;
+    }
+}
+// normally an empty launch; after a failed placement check: the whole computation by one workgroup (its wavefronts share one L1, every access
+// goes to the L2 anyway)
+__global__ __launch_bounds__(1024) void k_ic_fallback(const float* f1, const float* f2, int h, int w, int d, int iters, const float* __restrict__ bh,
+                                                      const float* __restrict__ bw, const float* __restrict__ bd, float* t1, float* t2, float* o1,
+                                                      float* o2, const ICSync* sync) {
+    if (!sync->fallback) return;
+    const float *s1 = f1, *s2 = f2;
+    for (int it = 0; it < iters; ++it) {
+        const bool to_out = ((iters - 1 - it) & 1) == 0;
+        float* d1 = to_out ? o1 : t1;
+        float* d2 = to_out ? o2 : t2;
+        ic_sweep<true>(s1, s2, h, w, d, bh, bw, bd, d1, d2, (int)threadIdx.x, 1024, f1, 0u);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        s1 = d1; s2 = d2;
+    }
+}
+
 }  // namespace cvx
 
 using namespace cvx;
@@ -686,7 +808,7 @@ int cvx::coupled_convex_dual_impl(const void* ssdA, const int64_t* argminA, floa
 }
 
 extern "C" size_t cvx_inverse_consistency_workspace_bytes(int h, int w, int d) {
-    return 2 * (256 + sizeof(float) * 3 * (size_t)h * w * d) + 256;
+    return 2 * (256 + sizeof(float) * 3 * (size_t)h * w * d) + 256 + 256;      // two ping-pong fields + the synchronisation words of k_ic_persistent
 }
 
 extern "C" int cvx_inverse_consistency_f32(const float* f1, const float* f2, int h, int w, int d, int iters,
@@ -705,6 +827,16 @@ extern "C" int cvx_inverse_consistency_f32(const float* f1, const float* f2, int
     if (iters == 0) {
         if (o1 != f1) (void)hipMemcpyAsync(o1, f1, bytes, hipMemcpyDeviceToDevice, s);
         if (o2 != f2) (void)hipMemcpyAsync(o2, f2, bytes, hipMemcpyDeviceToDevice, s);
+        return check_last("inverse_consistency");
+    }
+    if (options().ic_fused && iters >= 2 && v * 3 < ((size_t)1 << 30)) {
+        ICSync* sync = cv.take<ICSync>(1);
+        if (hipMemsetAsync(sync, 0, sizeof(ICSync), s) != hipSuccess) return fail(CVX_ERR_LAUNCH, "inverse_consistency: memset failed");
+        static std::atomic<unsigned> turn{0};
+        const int xcd = (int)(turn.fetch_add(1) & 7u);                     // concurrent pairs (register_pairs streams) take different XCDs
+        hipLaunchKernelGGL(k_ic_persistent<true>, dim3(8 * IC_NWG), dim3(IC_NT), 0, s, f1, f2, h, w, d, iters, base_h, base_w, base_d, t1, t2, o1, o2, sync, xcd,
+                           (int)(options().ic_fused == 2), f1, 0u);
+        hipLaunchKernelGGL(k_ic_fallback, dim3(1), dim3(1024), 0, s, f1, f2, h, w, d, iters, base_h, base_w, base_d, t1, t2, o1, o2, sync);
         return check_last("inverse_consistency");
     }
     // ping-pong (tmp <-> out) arranged so that the last iteration writes o1/o2

@@ -108,7 +108,9 @@ static int cc_nwg(const CCGeom& g) { return g.n * (g.n * g.np + (g.sB ? g.n / 2 
 static size_t cc_lds_bytes(const CCGeom& g) { return 16 * (2 * cc_chunk_quads(g) + (size_t)cc_exch_planes(g) * g.exq); }
 
 bool corr_cert_supported(int C, int h, int w, int d, int hw) {
-    if (C < 1 || C > 255 || hw < 0 || hw > CVX_MAX_DISP_HW || h < 1 || w < 1 || w > 64 || d < 1) return false;
+    // C <= 128: the certification constants (2^-16, certify.hip) cover (C + 18) roundings of the fast chain + (1 + 15 + C/16 + 54) of ATen's
+    // cascade = 224 u at C = 128; beyond that the a-priori distance passes 256 u = 2^-16 and the exact path is taken
+    if (C < 1 || C > 128 || hw < 0 || hw > CVX_MAX_DISP_HW || h < 1 || w < 1 || w > 64 || d < 1) return false;
     const CCGeom g = cc_geom(C, h, w, d, hw);
     if (!g.ok || g.wps < 1 || 2 * g.wps + 2 > 16) return false;
     if (cdiv(w * g.FQ, 128) + cdiv((w + 1) * g.MQ, 128) > 8 || cdiv(w * g.FQ, 128) + 2 * cdiv(w * g.MQ, 128) > 12) return false;      // pieces per channel the loaders hold

@@ -111,6 +111,9 @@ struct Options {
                                    //    corrfused.hip (fast arithmetic, unscaled), 2 = the staged kernel of corrcert.hip; 0 = exact volumes
     long long cc_debug;            // timing experiments on the certified-fast correlation kernel (bits: 1 no stores, 2 no staging after the first chunk, 4 no channel
                                    //    sums, 8 no y pass, 16 no x / z pass): WRONG results, never set outside tools/experiments
+    long long ic_fused;            // inverse consistency: 1 = all iterations in ONE launch by 32 workgroups of one XCD with a barrier between the iterations
+                                   //    (convex.hip::k_ic_persistent; 2 = its device-side fallback forced).  MEASURED SLOWER (289 vs 145 us per call: the field accesses
+                                   //    must be agent-scope and are served behind the L2); 0 (default) = one launch per iteration (bit-identical)
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };

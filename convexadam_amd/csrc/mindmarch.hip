@@ -23,10 +23,15 @@ constexpr int MM_NT = 512, MM_NS = 4, MM_CPS = 3;     // 4 wave groups x 3 chann
 template <int TY_, int TX_>
 struct MMGeo {
     static constexpr int TY = TY_, TX = TX_, TXQ = TX_ / 4;
-    static constexpr int RP = TX_ + 10;           // ring row pitch (floats): 2 (mod 4) -> for TX = 64 the 8-byte reads of two adjacent rows hit disjoint
-                                                  // banks (TX = 32: four rows per 32-lane group, 2-way conflicts; the LDS is not the bound)
+    // ring row pitch (floats).  TX = 64: 74 = 2 (mod 4) -> the 8-byte reads of the two rows of a 32-lane group hit disjoint banks.
+    // TX = 32: a 32-lane group reads FOUR rows (8 quads each); pitch 48 puts consecutive rows 48 = -16 banks apart and odd rows are skewed by
+    // two floats, so the four rows' (4q, 4q+1) pairs tile the 64 banks exactly (round 5: pitch 42, 2-way conflicts on every read, 13.1 M
+    // conflict cycles per launch)
+    static constexpr int RP = TX_ == 32 ? 48 : TX_ + 10;
+    static constexpr int SK = TX_ == 32 ? 2 : 0;
+    __device__ static constexpr int rowbase(int r) { return r * RP + SK * (r & 1); }      // (row + 2k keeps its skew: the stencil's row offsets are even)
     static constexpr int ROWS = TY_ + 6;          // ring row r = volume row clamp(y0 - 3 + r); ring column k = volume column clamp(x0 - 5 + k)
-    static constexpr int PLANE = ROWS * RP;
+    static constexpr int PLANE = ROWS * RP + SK;
     static constexpr int LQ = TXQ + 2;            // loader quads per row: columns x0-4 .. x0+TX+3
     static_assert(TY_ * TXQ == 128 && ROWS * LQ <= MM_NT, "tile shape");
 };
@@ -132,10 +137,8 @@ __device__ __forceinline__ void mm_run(const float* __restrict__ img, float* __r
     const size_t out_cs = lay.T ? lay.chan_floats : V;
     int rowoff[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) rowoff[i] = (clampi(gy + i - 1, 0, W - 1) - y0 + 3) * G::RP;
-    // rows beyond the volume (overhanging tile): clamp keeps the reads inside the ring
-#pragma unroll
-    for (int i = 0; i < 3; ++i) rowoff[i] = min(rowoff[i], (G::ROWS - 3) * G::RP);
+    for (int i = 0; i < 3; ++i) rowoff[i] = G::rowbase(min(clampi(gy + i - 1, 0, W - 1) - y0 + 3, G::ROWS - 3));   // (min: rows beyond the volume of an
+                                                                                                                // overhanging tile stay inside the ring)
     const int colbase = 4 * q + 4;
     const bool left = gx0 == 0, right = gx0 + 4 == D;
     const bool store_ok = gy < W && gx0 < D;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(MM_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     L.gy = clampi(y0 - 3 + lr, 0, W - 1);
     L.gx = x0 - 4 + 4 * lq;
     L.fast = L.gx >= 0 && L.gx + 3 <= D - 1;
-    L.dst = ring + lr * G::RP + 4 * lq + 1;
+    L.dst = ring + G::rowbase(lr) + 4 * lq + 1;
     L.pre = make_float4(0.f, 0.f, 0.f, 0.f);
     // ring around the first centre plane
     const int zc0 = clampi(z0 - 1, 0, H - 1);
