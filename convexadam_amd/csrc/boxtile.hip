@@ -109,8 +109,8 @@ __device__ __forceinline__ void bt_walk(int L, Load load, Prep prep, Emit emit) 
 // the sum; ADAM: the last pass applies torch.optim.Adam's update to P, m, v in place (gsave optionally receives G) instead of storing G.
 template <int TZ, int TY, int TXQ, int NW, int WPS, bool BACKWARD, bool ADAM>
 __global__ __launch_bounds__(64 * NW, WPS) void k_box3_tile(const float* __restrict__ in, float* __restrict__ out, int h, int w, int d,
-                                                           int ntz, int nty, int ntx, int ntiles, int NS1, int NS2, int NS3,
-                                                           float* __restrict__ P, float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
+                                                           int ntz, int nty, int ntx, int ntiles, int NS1, int NS2, int NS3, FastDiv dvz, FastDiv dvx, FastDiv dvy,
+                                                           FastDiv dn1, FastDiv dn2, FastDiv dn3, float* __restrict__ P, float* __restrict__ m, float* __restrict__ v, AdamConsts ac,
                                                            float* __restrict__ gsave) {
     constexpr int TX = 4 * TXQ, RS = TX + 4;                          // LDS row stride (floats): stage 1 holds TX + 4 columns
     constexpr int Z1 = TZ + 4, Y1 = TY + 4, Z2 = TZ + 2, Y2 = TY + 2;
@@ -120,11 +120,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_box3_tile(const float* __restr
     float* S1 = S;
     float* S2 = S + Z1 * Y1 * RS;
     const int per_xcd = (int)(gridDim.x >> 3);
-    int b = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);           // XCD q takes the q-th contiguous run of tiles
+    const int bid = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    const int b = (bid & 7) * per_xcd + (bid >> 3);                             // XCD q takes the q-th contiguous run of tiles
     if (b >= ntiles) return;
-    const int tz = b % ntz; b /= ntz;
-    const int tx = b % ntx; b /= ntx;
-    const int ty = b % nty; const int c = b / nty;
+    // (divisions by launch constants on the scalar unit, cvx_common.h FastDiv)
+    const int b1 = fastdiv(b, dvz), b2 = fastdiv(b1, dvx), c = fastdiv(b2, dvy);
+    const int tz = b - b1 * ntz, tx = b1 - b2 * ntx, ty = b2 - c * nty;
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     const size_t V = (size_t)h * w * d;
     const float* ic = in + (size_t)c * V;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_box3_tile(const float* __restr
     // ---- pass 1: stage 0 (global) -> S1.  Lane q: columns x0 - 4 + 4q .. + 3 (local index i = 4q .. 4q + 3; kept: i = 2 .. TX + 5)
     for (int item = slot; item < Y1 * NS1; item += SLOTS) {
         const int r = item % Y1, sg = item / Y1;
-        const int p0 = sg * Z1 / NS1, L = (sg + 1) * Z1 / NS1 - p0;   // stage-1 planes p0 .. p0 + L - 1  <->  z = z0 - 2 + p
+        const int p0 = fastdiv(sg * Z1, dn1), L = fastdiv((sg + 1) * Z1, dn1) - p0;   // stage-1 planes p0 .. p0 + L - 1  <->  z = z0 - 2 + p
         const int gy = y0 - 2 + r, gx = x0 - 4 + 4 * q;
         const bool qin = gx >= 0 && gx < d && q < TXQ + 2;             // (d % 4 == 0: a quad is inside or outside as a whole)
         unsigned ro[3];
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_box3_tile(const float* __restr
     // ---- pass 2: S1 -> S2.  Lane q < TXQ + 1: stage-2 index j2 = 4q .. 4q + 3  <->  x = x0 - 1 + j2; window = S1 index 4q .. 4q + 5
     for (int item = slot; item < Y2 * NS2; item += SLOTS) {
         const int r = item % Y2, sg = item / Y2;
-        const int p0 = sg * Z2 / NS2, L = (sg + 1) * Z2 / NS2 - p0;   // stage-2 planes p0 ..  <->  z = z0 - 1 + p
+        const int p0 = fastdiv(sg * Z2, dn2), L = fastdiv((sg + 1) * Z2, dn2) - p0;   // stage-2 planes p0 ..  <->  z = z0 - 1 + p
         if (q < TXQ + 1) {
             const float* src = S1 + (p0 * Y1 + r) * RS + 4 * q;
             auto load = [&](int n, BTWin& t) {
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_box3_tile(const float* __restr
     // ---- pass 3: S2 -> U.  Lane q < TXQ: columns x0 + 4q .. + 3; window = S2 index 4q .. 4q + 5
     for (int item = slot; item < TY * NS3; item += SLOTS) {
         const int r = item % TY, sg = item / TY;
-        const int p0 = sg * TZ / NS3, L = (sg + 1) * TZ / NS3 - p0;
+        const int p0 = fastdiv(sg * TZ, dn3), L = fastdiv((sg + 1) * TZ, dn3) - p0;
         const int gy = y0 + r, gx = x0 + 4 * q;
         if (q < TXQ && gy < w && gx < d) {
             const float* src = S2 + (p0 * Y2 + r) * RS + 4 * q;
@@ -280,7 +281,7 @@ static int launch_tile_t(const float* in, float* out, int h, int w, int d, int n
     // segments of at least two planes (bt_walk), at most one per two planes
     auto clampns = [](int ns, int planes) { return ns < 1 ? 1 : (ns > planes / 2 ? planes / 2 : ns); };
     const int a1 = clampns(ns1, TZ + 4), a2 = clampns(ns2, TZ + 2), a3 = clampns(ns3, TZ);
-#define CVX_BT_LAUNCH(B, A) hipLaunchKernelGGL((k_box3_tile<TZ, TY, TXQ, NW, WPS, B, A>), dim3(nb), dim3(64 * NW), 0, s, in, out, h, w, d, ntz, nty, ntx, ntiles, a1, a2, a3, P, m, v, ac, gsave)
+#define CVX_BT_LAUNCH(B, A) hipLaunchKernelGGL((k_box3_tile<TZ, TY, TXQ, NW, WPS, B, A>), dim3(nb), dim3(64 * NW), 0, s, in, out, h, w, d, ntz, nty, ntx, ntiles, a1, a2, a3, fastdiv_make(ntz), fastdiv_make(ntx), fastdiv_make(nty), fastdiv_make(a1), fastdiv_make(a2), fastdiv_make(a3), P, m, v, ac, gsave)
     if (!backward) CVX_BT_LAUNCH(false, false);
     else if (!P) CVX_BT_LAUNCH(true, false);
     else CVX_BT_LAUNCH(true, true);

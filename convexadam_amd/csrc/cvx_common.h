@@ -325,6 +325,13 @@ __device__ __forceinline__ float tri_sample(const Tri& t, const float* __restric
     return o;
 }
 
+// Division of a WAVE-UNIFORM index by a launch constant on the scalar unit: q = mulhi(n, ceil(2^32 / d)) is exact whenever n * d < 2^32
+// (error term n (m d - 2^32) / (d 2^32) < 1 / d).  The compiler's own expansion of `tile / ntx` runs ~25 vector instructions per division
+// in every lane (the scalar unit has no divide) -- three of them opened k_warp_grad.
+struct FastDiv { unsigned d, m; };
+static inline FastDiv fastdiv_make(int d) { FastDiv f; f.d = (unsigned)d; f.m = d <= 1 ? 0u : (unsigned)((((unsigned long long)1 << 32) + (unsigned)d - 1) / (unsigned)d); return f; }
+__device__ __forceinline__ int fastdiv(int n, FastDiv f) { return f.d <= 1 ? n : (int)__umulhi((unsigned)n, f.m); }
+
 // pipeline.hip: event mark behind a kernel of the Adam loop (no-op unless cvx_set_profiling(3))
 void profile_mark_kernel(const char* name, hipStream_t s);
 

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
                                                    int h, int w, int d, const float* __restrict__ U,
                                                    const float* __restrict__ bh, const float* __restrict__ bw,
                                                    const float* __restrict__ bd, float gsc, float cH, float cW, float cD,
-                                                   float* __restrict__ gU, unsigned long long* __restrict__ census) {
+                                                   float* __restrict__ gU, unsigned long long* __restrict__ census, FastDiv dx, FastDiv dy,
+                                                   float sc0, float sc1, float sc2) {
     const size_t V = (size_t)h * w * d;
     if (census && threadIdx.x == 0) {                   // debugging aid (option census_ptr, tools/adam_census.py)
         census[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -69,13 +70,15 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
     // tiles and the overlapping footprints of neighbouring tiles meet in the same 4 MB L2
     const int ntx = (d + 15) / 16, nty = (w + 3) / 4, ntz = (h + 3) / 4;
     const int per_xcd = (int)(gridDim.x >> 3);
-    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int bid = __builtin_amdgcn_readfirstlane((int)blockIdx.x);                 // (the census branch above otherwise drags the index into a vector register)
+    const int tile = (bid & 7) * per_xcd + (bid >> 3);
     if (tile >= ntx * nty * ntz) return;
-    const int tbx = tile % ntx, tby = (tile / ntx) % nty, tbz = tile / (ntx * nty);
+    const int trow = fastdiv(tile, dx), tbz = fastdiv(trow, dy);                     // scalar unit: tile / ntx, (tile / ntx) / nty
+    const int tbx = tile - trow * ntx, tby = trow - tbz * nty;
     const int x = tbx * 16 + (threadIdx.x & 15), y = tby * 4 + ((threadIdx.x >> 4) & 3), z = tbz * 4 + (threadIdx.x >> 6);
     if (x >= d || y >= w || z >= h) return;
     const unsigned p = (unsigned)((z * w + y) * d + x);
-    const float sc0 = (float)((h - 1) / 2.0), sc1 = (float)((w - 1) / 2.0), sc2 = (float)((d - 1) / 2.0);   // (:171)
+    // sc0 = (float)((h - 1) / 2.0), sc1, sc2 likewise: evaluated on the host (launch_warp_grad)                  (:171)
     const float uH = U[p], uW = U[V + p], uD = U[2 * V + p];
     Tri t;
     tri_setup(t, bd[x] + fdiv(uD, sc2), bw[y] + fdiv(uW, sc1), bh[z] + fdiv(uH, sc0), h, w, d);
@@ -148,11 +151,13 @@ __global__ __launch_bounds__(256) void k_warp_grad(const float* __restrict__ F2,
     const unsigned pxp = x < d - 1 ? p + 1 : p, pxm = x > 0 ? p - 1 : p, pzp = z < h - 1 ? p + sH : p, pzm = z > 0 ? p - sH : p,
                    pyp = y < w - 1 ? p + (unsigned)d : p, pym = y > 0 ? p - (unsigned)d : p;
     float nb[3][6];
+    // (buffer loads: 6 per-lane byte offsets + the channel offset in a scalar register instead of 18 64-bit vector address additions)
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, (int)(12u * (unsigned)V), 0x00020000);
+    const unsigned nboff[6] = {4u * pxp, 4u * pxm, 4u * pzp, 4u * pzm, 4u * pyp, 4u * pym};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float* Ua = U + (size_t)a * V;
-        nb[a][0] = Ua[pxp]; nb[a][1] = Ua[pxm]; nb[a][2] = Ua[pzp]; nb[a][3] = Ua[pzm]; nb[a][4] = Ua[pyp]; nb[a][5] = Ua[pym];
-    }
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) nb[a][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ur, (int)nboff[k], (int)(4u * (unsigned)V) * a, 0));
     const float uc3[3] = {uH, uW, uD};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -184,9 +189,11 @@ int launch_warp_grad(const float* Fcl, const float* Mcl, int C, int h, int w, in
     const dim3 gv((unsigned)((cdiv(d, 16) * cdiv(w, 4) * cdiv(h, 4) + 7) / 8 * 8));     // multiple of the 8 XCDs
     unsigned long long* census = reinterpret_cast<unsigned long long*>(options().census_ptr);       // debugging aid: slots [8192, ..)
     if (census) census += 8 * 1024;
-    if (half) hipLaunchKernelGGL((k_warp_grad<true, true>), gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census);
-    else if (options().warp_flat) hipLaunchKernelGGL(k_warp_grad<false>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census);
-    else hipLaunchKernelGGL(k_warp_grad<true>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census);
+    const FastDiv dx = fastdiv_make(cdiv(d, 16)), dy = fastdiv_make(cdiv(w, 4));
+    const float sc0 = (float)((h - 1) / 2.0), sc1 = (float)((w - 1) / 2.0), sc2 = (float)((d - 1) / 2.0);
+    if (half) hipLaunchKernelGGL((k_warp_grad<true, true>), gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census, dx, dy, sc0, sc1, sc2);
+    else if (options().warp_flat) hipLaunchKernelGGL(k_warp_grad<false>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census, dx, dy, sc0, sc1, sc2);
+    else hipLaunchKernelGGL(k_warp_grad<true>, gv, dim3(256), 0, s, Fcl, Mcl, C, CP, h, w, d, U, bh, bw, bd, gsc, cH, cW, cD, gU, census, dx, dy, sc0, sc1, sc2);
     return check_last("warp_grad");
 }
 
