@@ -75,6 +75,10 @@ int cvx_device_count(void);            /* number of visible HIP devices (0 on a 
  *   cf_census           1: the fused correlation kernel records per-workgroup residency in its workspace
  *   label_pow_block     cvx_label_weights_host: elements per vectorised block of the reference host's torch.pow (32 = AVX-512 build, 16 = AVX2)
  *   mind_mean_threads   0: exactly rounded global mean in MINDSSC; T > 0: torch's float32 sum with T threads
+ *   corr_cert           1 (default) / 2: cvx_register_pair(s)_f32 take the argmin decisions of the convex stage on the certified-fast cost volume
+ *                       (cvx_corr_opts.fast = 2; same winners and field bits as the exact volumes; below 16 channels); 1 = the role kernel of
+ *                       corrfused.hip, 2 = the staged kernel of corrcert.hip (every supported channel count); 0 = exact volumes
+ *   ic_fused            1: inverse consistency in one launch (measured slower, off by default; bit-identical)
  * Workspace sizes (cvx_*_workspace_bytes) depend on some switches: query them with the same context / options the call will use.
  *
  * State model.  Switches and the two reference-build tables below live in a CONTEXT.  Every entry point uses the context bound to the
@@ -176,6 +180,10 @@ int cvx_correlate_f32(const float* fix, const float* mov, int C, int h, int w, i
  *   n_box 2: two avg_pool3d       convex_adam_utils.py:84            1: one             l2r_2021_convexAdam_task2_docker.py:60, task3:56
  *   fast  0: ATen's evaluation order, bit-identical to the CPU oracle
  *         1: fused multiply-adds and separable box sums (same real-arithmetic result, last-bit differences; cost 0, n_box 2 only)
+ *         2: CERTIFIED fast (cost 0, n_box 2, float32, C <= 128; CVX_ERR_UNSUPPORTED elsewhere): `ssd` receives the UNSCALED fast volume
+ *            ssdu -- |ssdu / 729 - ssd_exact| <= 2^-17 ssd_exact, ssdu == 0 exactly where ssd_exact == 0 -- and `argmin` the first minimum
+ *            of the EXACT volume (torch.argmin(ssd, 0), convex_adam_utils.py:87), decided from intervals and, for the few columns in doubt,
+ *            by an exact evaluation of the candidates (certify.hip).  What the whole-pair entry points use internally (switch corr_cert)
  *   f16   fp16 STORAGE of the cost volume (the reference's GPU default dtype, convex_adam_MIND.py:79,89-91; float32 accumulation, one
  *         rounding to nearest even on the way out; SSD with two boxes only):
  *         2: `ssd` points to a HALF-PRECISION buffer [n^3][h][w][d] (2-byte elements) -- half the bytes written here and read by
