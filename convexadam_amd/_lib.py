@@ -67,6 +67,8 @@ SIGNATURES = {
     "cvx_affine_base_f32": (_i, [_i, _vp, _vp]),
     "cvx_mindssc_workspace_bytes": (_sz, [_i] * 5),
     "cvx_mindssc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "cvx_mindssc_pooled_scratch_bytes": (_sz, [_i] * 7),
+    "cvx_mindssc_pooled_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "cvx_avgpool_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cvx_round_f16_f32": (_i, [_vp, _i64, _vp]),
     "cvx_pack_field_f64": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -61,6 +61,35 @@ def MINDSSC(img, radius=2, dilation=2, device='cuda'):
     return out if img.dtype == torch.float32 else out.to(img.dtype)
 
 
+def mind_pooled(img, radius, dilation, g1, g2=0, device='cuda', return_repairs=False):
+    """F.avg_pool3d(MINDSSC(img, radius, dilation), g, stride=g) for g = g1 (and g2 > 0) without the full-resolution descriptor: what
+    convex_adam_pt consumes (convex_adam_MIND.py:118-119, 149-150).  img (1,1,H,W,D) -> (1,12,H/g1,W/g1,D/g1) [, (1,12,H/g2,W/g2,D/g2)].
+    return_repairs: also the number of blocks whose pooled cells were recomputed with the clamped variance (single-pass path)."""
+    img = require_device_tensor(img.to(device), "img")
+    if img.dim() != 5 or img.shape[0] != 1 or img.shape[1] != 1:
+        raise ValueError("mind_pooled expects a (1,1,H,W,D) tensor, got %s" % (tuple(img.shape),))
+    H, W, D = [int(s) for s in img.shape[2:]]
+    x = f32c(img)
+    g1, g2 = int(g1), int(g2)
+    o1 = torch.empty((1, 12, H // g1, W // g1, D // g1), dtype=torch.float32, device=x.device)
+    o2 = torch.empty((1, 12, H // g2, W // g2, D // g2), dtype=torch.float32, device=x.device) if g2 > 0 else None
+    nsc = lib().cvx_mindssc_pooled_scratch_bytes(H, W, D, int(radius), int(dilation), g1, g2)
+    if x.data_ptr() % 16:                      # (torch allocations are 256-byte aligned; a view may not be)
+        x = x.clone()
+    sc = torch.empty(max(nsc, 16), dtype=torch.uint8, device=x.device)
+    nws = lib().cvx_mindssc_workspace_bytes(H, W, D, int(radius), int(dilation))
+    ws = workspace(nws, x.device)
+    rep = C.c_int(0)
+    with torch.cuda.device(x.device):
+        check(lib().cvx_mindssc_pooled_f32(ptr(x), H, W, D, int(radius), int(dilation), g1, ptr(o1), g2, ptr(o2) if o2 is not None else None,
+                                           ptr(sc) if nsc else None, nsc, ptr(ws), nws, C.byref(rep) if return_repairs else None, stream_ptr(x.device)))
+    outs = (o1,) if o2 is None else (o1, o2)
+    outs = tuple(o if img.dtype == torch.float32 else o.to(img.dtype) for o in outs)
+    if return_repairs:
+        return outs + (int(rep.value),)
+    return outs if o2 is not None else outs[0]
+
+
 def avg_pool(features, g):
     """F.avg_pool3d(features, g, stride=g) for a (1,C,H,W,D) device tensor.  (convex_adam_MIND.py:118-119)"""
     features = require_device_tensor(features, "features")

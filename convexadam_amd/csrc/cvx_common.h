@@ -114,6 +114,11 @@ struct Options {
     long long ic_fused;            // inverse consistency: 1 = all iterations in ONE launch by 32 workgroups of one XCD with a barrier between the iterations
                                    //    (convex.hip::k_ic_persistent; 2 = its device-side fallback forced).  MEASURED SLOWER (289 vs 145 us per call: the field accesses
                                    //    must be agent-scope and are served behind the L2); 0 (default) = one launch per iteration (bit-identical)
+    long long mind_single;         // 1: the whole-pair pipeline's descriptor in ONE stencil pass (normalisation with the unclamped variance and both poolings inside the
+                                   //    marching kernel, k_mind_repair for the blocks where the variance clamp binds; no raw-SSD round trip: HBM traffic 7.8 x -> ~1.5 x of
+                                   //    the algorithmic bytes; bit-identical).  MEASURED SLOWER (0.546 vs 0.499 ms for both images: both forms are bound by instruction
+                                   //    issue, not by memory); 2 = every block through the repair kernel (test); 0 (default) = two passes
+    long long ms_zlen;             // planes per z chunk of the single-pass kernel (0 = automatic)
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };

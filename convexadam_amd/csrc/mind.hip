@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_mind_stats_init(const float* part, int 
     st->imax = mx;
     st->mean_override = 0.0f;
     st->use_override = 0;
+    st->n_repair = 0u;
 }
 // clamp bounds of the normalisation from the exact partial sums (every consumer evaluates them itself: a handful of scalar
 // operations instead of a one-thread launch between the two passes)
@@ -599,6 +600,114 @@ __global__ __launch_bounds__(MP_NT) void k_mind_finish_pool(const float* __restr
     }
 }
 
+// ---- single-pass pooled path (mindmarch.hip::k_mind_march_pool): the blocks where the variance clamp binds -------------------------------------
+// The marching kernel normalised with the unclamped variance.  That is the reference's value unless var < lo or var > hi (lo, hi = 0.001 x and
+// 1000 x the global mean, convex_adam_utils.py:61) on a voxel whose twelve distances are not all zero (those give exp(-0 / v) = 1 for every
+// v > 0), or lo == 0 (a mean of zero: 0 / 0).  Per T^3 block the march left the smallest such variance, the largest variance and the all-zero mark; this
+// kernel tests every block against the exact bounds -- every workgroup looks at the blocks congruent to its index, 64 per round -- and recomputes the
+// pooled cells of a block that holds a clamped voxel from the image: the 12^3 neighbourhood in LDS, the 27-tap raster-order sums of the stencil
+// (mindmarch.hip::mm_box_step's order), mind_normalise with the clamp, the windows in ATen's order (mp_window_mean).
+__device__ constexpr int MIND_O1[12][3] = {{0,0,-1},{0,-1,0},{0,-1,0},{0,0,1},{0,0,1},{1,0,0},{1,0,0},{1,0,0},{0,1,0},{0,1,0},{0,1,0},{0,1,0}};
+__device__ constexpr int MIND_O2[12][3] = {{-1,0,0},{-1,0,0},{0,0,-1},{-1,0,0},{0,-1,0},{0,0,-1},{0,-1,0},{0,0,1},{-1,0,0},{0,0,-1},{0,0,1},{1,0,0}};
+constexpr int MR_NT = 256;
+
+template <int GA, int GB>
+__global__ __launch_bounds__(MR_NT) void k_mind_repair(const float* __restrict__ img, int H, int W, int D, MindStats* __restrict__ st, const unsigned* __restrict__ blk,
+                                                       float* __restrict__ out1, float* __restrict__ out2, void* __restrict__ rec2, int rec_half, ExpTable et, int force) {
+    constexpr int T = GA, RE = T + 6;                        // region edge: the block and three voxels around it (dilation 2 + box radius 1)
+    __shared__ float R[RE * RE * RE];
+    __shared__ __attribute__((aligned(16))) float E[12 * T * T * MP_TX];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nbz = (H + T - 1) / T, nby = (W + T - 1) / T, nbx = (D + T - 1) / T, nblk = nbz * nby * nbx;
+    const size_t V = (size_t)H * W * D, tail_from = (V / 32) * 32;
+    float lo, hi;
+    mind_bounds(st, (double)V, lo, hi);
+    for (int base = blockIdx.x; base < nblk; base += 64 * gridDim.x) {
+        const int mine = base + lane * gridDim.x;
+        bool bad = false;
+        if (mine < nblk) {
+            const unsigned bmin = blk[mine], bmax = blk[nblk + mine], bz = blk[2 * (size_t)nblk + mine];
+            const float fmin = __uint_as_float(bmin), fmax = __uint_as_float(bmax);
+            // (NaN variances: bits above infinity -- recomputed, whatever the bounds are)
+            bad = force != 0 || fmin < lo || fmax > hi || bmax > 0x7f800000u || (bz != 0u && !(lo > 0.0f));
+        }
+        unsigned long long todo = __ballot(bad);              // the same in every wavefront of the workgroup
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int b = base + l * gridDim.x;
+            const int bx = b % nbx, by = (b / nbx) % nby, bzi = b / (nbx * nby);
+            const int x0 = bx * T, y0 = by * T, z0 = bzi * T;
+            cvx_barrier();                                    // the previous block's windows are done with E, its voxels with R
+            for (int i = tid; i < RE * RE * RE; i += MR_NT) {
+                const int rx = i % RE, ry = (i / RE) % RE, rz = i / (RE * RE);
+                R[i] = img[((size_t)clampi(z0 - 3 + rz, 0, H - 1) * W + clampi(y0 - 3 + ry, 0, W - 1)) * D + clampi(x0 - 3 + rx, 0, D - 1)];
+            }
+            cvx_barrier();
+            if (tid < T * T * T) {
+                const int vx = tid % T, vy = (tid / T) % T, vz = tid / (T * T);
+                const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+                if (gz < H && gy < W && gx < D) {
+                    float r[12];
+                    for (int c = 0; c < 12; ++c) {
+                        float sum = 0.0f;
+                        for (int dz = -1; dz <= 1; ++dz)
+                            for (int dy = -1; dy <= 1; ++dy)
+                                for (int dx = -1; dx <= 1; ++dx) {
+                                    // the box clamps the POSITION first, the shifts clamp again (the reference's two replication pads)
+                                    const int pz = clampi(gz + dz, 0, H - 1), py = clampi(gy + dy, 0, W - 1), px = clampi(gx + dx, 0, D - 1);
+                                    const int az = clampi(pz + 2 * MIND_O1[c][0], 0, H - 1) - z0 + 3, ay = clampi(py + 2 * MIND_O1[c][1], 0, W - 1) - y0 + 3,
+                                              ax = clampi(px + 2 * MIND_O1[c][2], 0, D - 1) - x0 + 3;
+                                    const int bz2 = clampi(pz + 2 * MIND_O2[c][0], 0, H - 1) - z0 + 3, by2 = clampi(py + 2 * MIND_O2[c][1], 0, W - 1) - y0 + 3,
+                                              bx2 = clampi(px + 2 * MIND_O2[c][2], 0, D - 1) - x0 + 3;
+                                    const float d = R[(az * RE + ay) * RE + ax] - R[(bz2 * RE + by2) * RE + bx2];
+                                    sum += d * d;
+                                }
+                        r[c] = div_exact<27>(sum);
+                    }
+                    const size_t lin = ((size_t)gz * W + gy) * D + gx;
+                    mind_normalise(r, lo, hi, lin >= tail_from, et);
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) E[((MIND_INV[c] * T + vz) * T + vy) * MP_TX + vx] = r[c];
+                }
+            }
+            cvx_barrier();
+            if (tid < 12) mp_window<T, GA>(E, tid, 0, 0, 0, z0, y0, x0, H, W, D, out1);
+            constexpr int nb = T / GB;
+            if (rec2) {
+                const int Ho = H / GB, Wo = W / GB, Do = D / GB;
+                const size_t V2 = (size_t)Ho * Wo * Do;
+                for (int i = tid; i < 3 * nb * nb * nb; i += MR_NT) {
+                    const int wx = i % nb, wy = (i / nb) % nb, wz = (i / (nb * nb)) % nb, cq = i / (nb * nb * nb);
+                    const int oz = z0 / GB + wz, oy = y0 / GB + wy, ox = x0 / GB + wx;
+                    if (oz >= Ho || oy >= Wo || ox >= Do) continue;
+                    float q[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[j] = mp_window_mean<T, GB>(E, 4 * cq + j, wz, wy, wx);
+                    const size_t at = (size_t)cq * (V2 + 1) + ((size_t)oz * Wo + oy) * Do + ox;
+                    if (rec_half) {
+                        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                        const h16x4 o = {(_Float16)q[0], (_Float16)q[1], (_Float16)q[2], (_Float16)q[3]};
+                        static_cast<uint2*>(rec2)[at] = __builtin_bit_cast(uint2, o);
+                    } else static_cast<float4*>(rec2)[at] = make_float4(q[0], q[1], q[2], q[3]);
+                }
+            } else if (out2) {
+                for (int i = tid; i < 12 * nb * nb * nb; i += MR_NT) {
+                    const int wx = i % nb, wy = (i / nb) % nb, wz = (i / (nb * nb)) % nb, c = i / (nb * nb * nb);
+                    mp_window<T, GB>(E, c, wz, wy, wx, z0, y0, x0, H, W, D, out2);
+                }
+            }
+            if (tid == 0) atomicAdd(&st->n_repair, 1u);
+        }
+    }
+    // the zero record that closes every chunk of feature records (k_to_chunked layout)
+    if (rec2 && blockIdx.x == 0 && tid < 3) {
+        const size_t V2 = (size_t)(H / GB) * (W / GB) * (D / GB), at = (size_t)tid * (V2 + 1) + V2;
+        if (rec_half) static_cast<uint2*>(rec2)[at] = make_uint2(0u, 0u);
+        else static_cast<float4*>(rec2)[at] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 static size_t mind_lds_bytes(int R, int dil, int nbuf, int TX) {
     const int halo = R + dil;
     const int IZ = TZ + 2 * halo, IY = TY + 2 * halo, IX = TX + 2 * halo;
@@ -719,6 +828,12 @@ size_t mind_pooled_raw_floats(int H, int W, int D, int g1, int g2) {
     const size_t blocked = (size_t)cdiv(D, MP_TX) * cdiv(W, T) * cdiv(H, T) * 12 * T * T * MP_TX;
     return blocked > planar ? blocked : planar;
 }
+// the single-pass kernel applies: the marching stencil's geometry, a window pair it is instantiated for, the library's own exp and the exactly
+// rounded mean (reference-bits mode walks the planar variance volume and corrects exp through a table)
+static bool mind_single_pass(const float* img, int H, int W, int D, int radius, int dilation, int ga, int gb) {
+    return options().mind_single != 0 && options().mind_tiled == 0 && options().mind_mean_threads <= 0 && mind_exp_table().tbl == nullptr &&
+           mind_single_supported(ga, gb) && mind_march_supported(img, img, H, W, D, radius, dilation);
+}
 // records (with out2): out2 receives the g2-pooled descriptor as feature records instead of planar channels (needs g2 <= g1); see
 // mind_pooled_records_supported
 bool mind_pooled_records_supported(int H, int W, int D, int g1, int g2) { return g2 > 0 && g2 <= g1 && mind_pool_tile(H, W, D, g1, g2) != 0; }
@@ -729,10 +844,6 @@ int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int di
     const int T = mind_pool_tile(H, W, D, g1, g2 > 0 ? g2 : g1);
     if (T == 0 || !out1) return fail(CVX_ERR_UNSUPPORTED, "mind_pooled: window sizes %d, %d do not tile", g1, g2);
     MindStats* st = nullptr;
-    const dim3 grid(cdiv(D, MP_TX), cdiv(W, T), cdiv(H, T));
-    const MindRawLayout lay = mind_pooled_blocked(img, raw, H, W, D, radius, dilation, g1, g2)
-                                  ? MindRawLayout{T, (int)grid.x, (int)grid.y, (size_t)12 * T * T * MP_TX, (size_t)T * T * MP_TX} : MindRawLayout{0, 0, 0, 0, 0};
-    if ((rc = mind_stencil(img, H, W, D, radius, dilation, raw, workspace, workspace_bytes, &st, s, lay))) return rc;
     // (ga, gb) = (larger, smaller) window; the larger one goes to the matching output
     const bool swap = g2 > g1;
     const int ga = swap ? g2 : g1, gb = g2 > 0 ? (swap ? g1 : g2) : g1;
@@ -741,6 +852,35 @@ int launch_mind_pooled(const float* img, int H, int W, int D, int radius, int di
     if (records && (swap || !out2)) return fail(CVX_ERR_UNSUPPORTED, "mind_pooled: feature records need 0 < g2 <= g1");
     void* rec = records ? out2 : nullptr;             // records: 1 = float32, 2 = half precision
     if (records) ob = nullptr;
+    if (mind_single_pass(img, H, W, D, radius, dilation, ga, gb)) {
+        // ONE pass over the image (mindmarch.hip::k_mind_march_pool) + the repair of the blocks where the variance clamp binds; `raw` is not touched
+        Carver cv(workspace, workspace_bytes);
+        float* part = cv.take<float>(2 * 1024);
+        st = cv.take<MindStats>(1);
+        const size_t nblk = (size_t)cdiv(H, ga) * cdiv(W, ga) * cdiv(D, ga);
+        unsigned* blk = cv.take<unsigned>(3 * nblk);
+        if (!cv.ok()) return fail(CVX_ERR_WORKSPACE, "mind_pooled: workspace too small");
+        const size_t V = (size_t)H * W * D;
+        const int nb = (int)(V / 4096 + 1 < 1024 ? V / 4096 + 1 : 1024);
+        hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(256), 0, s, img, V, part);
+        hipLaunchKernelGGL(k_mind_stats_init, dim3(1), dim3(256), 0, s, part, nb, (double)V, st);
+        launch_mind_march_pool(img, H, W, D, ga, oa, gb, records ? rec : static_cast<void*>(ob), records, st, blk, s);
+        const unsigned rgrid = (unsigned)(nblk / 64 + 1 < 1024 ? nblk / 64 + 1 : 1024);
+        const int force = options().mind_single == 2 ? 1 : 0;           // 2: every block through the repair kernel (test of the exact recomputation)
+#define CVX_MR(GA, GB) hipLaunchKernelGGL((k_mind_repair<GA, GB>), dim3(rgrid), dim3(MR_NT), 0, s, img, H, W, D, st, blk, oa, ob, rec, records == 2 ? 1 : 0, mind_exp_table(), force)
+        if (ga == 6 && gb == 2) CVX_MR(6, 2);
+        else if (ga == 6 && gb == 3) CVX_MR(6, 3);
+        else if (ga == 6 && gb == 6) CVX_MR(6, 6);
+        else if (ga == 4 && gb == 2) CVX_MR(4, 2);
+        else if (ga == 4 && gb == 4) CVX_MR(4, 4);
+        else CVX_MR(2, 2);
+#undef CVX_MR
+        return check_last("mind_march_pool");
+    }
+    const dim3 grid(cdiv(D, MP_TX), cdiv(W, T), cdiv(H, T));
+    const MindRawLayout lay = mind_pooled_blocked(img, raw, H, W, D, radius, dilation, g1, g2)
+                                  ? MindRawLayout{T, (int)grid.x, (int)grid.y, (size_t)12 * T * T * MP_TX, (size_t)T * T * MP_TX} : MindRawLayout{0, 0, 0, 0, 0};
+    if ((rc = mind_stencil(img, H, W, D, radius, dilation, raw, workspace, workspace_bytes, &st, s, lay))) return rc;
 #define CVX_MP(GA, GB) hipLaunchKernelGGL((k_mind_finish_pool<GA, GB>), grid, dim3(MP_NT), 0, s, raw, H, W, D, st, oa, ob, rec, records == 2 ? 1 : 0, mind_exp_table(), lay)
     if (ga == 6 && gb == 2) CVX_MP(6, 2);
     else if (ga == 6 && gb == 3) CVX_MP(6, 3);
@@ -759,9 +899,50 @@ using namespace cvx;
 extern "C" size_t cvx_mindssc_workspace_bytes(int H, int W, int D, int radius, int dilation) {
     (void)radius; (void)dilation;
     size_t n = 256 + 2 * 1024 * sizeof(float) + 256 + sizeof(MindStats) + 256;
+    n += 256 + 3 * sizeof(unsigned) * (size_t)cdiv(H, 2) * cdiv(W, 2) * cdiv(D, 2);             // block statistics of the single-pass pooled path (smallest window: 2)
     if (options().mind_mean_threads > 0)                                       // var, thread slots, three cascade levels (< V / 14 floats)
         n += 256 + (size_t)H * W * D * sizeof(float) + 256 + 1024 * sizeof(float) + (size_t)H * W * D / 14 * sizeof(float) + 3 * (256 + 1024 * 64 * sizeof(float));
     return n;
+}
+
+extern "C" size_t cvx_mindssc_pooled_scratch_bytes(int H, int W, int D, int radius, int dilation, int g1, int g2) {
+    if (H <= 0 || W <= 0 || D <= 0) return 0;
+    const bool swap = g2 > g1;
+    const int ga = swap ? g2 : g1, gb = g2 > 0 ? (swap ? g1 : g2) : g1;
+    // (alignment is the caller's hipMalloc: the predicate is asked with an aligned pointer)
+    if (mind_single_pass(reinterpret_cast<const float*>(uintptr_t(256)), H, W, D, radius, dilation, ga, gb)) return 0;
+    return mind_pooled_raw_floats(H, W, D, g1, g2) * sizeof(float);
+}
+
+extern "C" int cvx_mindssc_pooled_f32(const float* img, int H, int W, int D, int radius, int dilation, int g1, float* out1, int g2, float* out2,
+                                      void* scratch, size_t scratch_bytes, void* workspace, size_t workspace_bytes, int* repaired_host, void* stream) {
+    CVX_REQUIRE(img && out1 && workspace, "cvx_mindssc_pooled_f32: null pointer");
+    CVX_REQUIRE(H > 0 && W > 0 && D > 0, "cvx_mindssc_pooled_f32: bad extent %dx%dx%d", H, W, D);
+    CVX_REQUIRE(g1 >= 1 && g2 >= 0, "cvx_mindssc_pooled_f32: bad windows %d, %d", g1, g2);
+    CVX_REQUIRE(g2 == 0 || out2, "cvx_mindssc_pooled_f32: second output missing");
+    if (!mind_pooled_supported(H, W, D, g1, g2)) return fail(CVX_ERR_UNSUPPORTED, "cvx_mindssc_pooled_f32: windows %d, %d do not tile", g1, g2);
+    const size_t need = cvx_mindssc_pooled_scratch_bytes(H, W, D, radius, dilation, g1, g2);
+    const bool single = need == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0;
+    if (!single) {
+        const size_t two = mind_pooled_raw_floats(H, W, D, g1, g2) * sizeof(float);
+        if (!scratch || scratch_bytes < two) return fail(CVX_ERR_WORKSPACE, "cvx_mindssc_pooled_f32: scratch %zu < %zu bytes", scratch_bytes, two);
+    }
+    hipStream_t s = as_stream(stream);
+    // (launch_mind_pooled validates through `raw`: the image itself stands in when the single pass needs no scratch)
+    int rc = launch_mind_pooled(img, H, W, D, radius, dilation, g1, out1, g2, g2 > 0 ? out2 : nullptr, single ? const_cast<float*>(img) : static_cast<float*>(scratch),
+                                workspace, workspace_bytes, s, 0);
+    if (rc || !repaired_host) return rc;
+    *repaired_host = 0;
+    if (single) {
+        Carver cv(workspace, workspace_bytes);
+        (void)cv.take<float>(2 * 1024);
+        const MindStats* st = cv.take<MindStats>(1);
+        unsigned n = 0;
+        if (hipMemcpyAsync(&n, &st->n_repair, sizeof(n), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+            return check_last("cvx_mindssc_pooled_f32: repair count");
+        *repaired_host = (int)n;
+    }
+    return CVX_OK;
 }
 
 extern "C" int cvx_mindssc_f32(const float* img, int H, int W, int D, int radius, int dilation, float* out,

@@ -21,6 +21,7 @@ struct MindStats {
     float imin, imax;
     float mean_override;   // reference-bits mode (option mind_mean_threads): torch's own mean, see k_torch_sum_* in mind.hip
     int use_override;
+    unsigned n_repair;     // single-pass pooled path: blocks whose pooled cells k_mind_repair recomputed
 };
 
 // z-marching stencil (mindmarch.hip): radius 1, dilation 2, rows of a multiple of 4 voxels, 16-byte aligned pointers
@@ -34,5 +35,8 @@ struct MindRawLayout {
     size_t tile_floats, chan_floats; // 12 T T 24 and T T 24 (planar: unused / H W D)
 };
 void launch_mind_march(const float* img, int H, int W, int D, MindStats* st, float* out, hipStream_t s, MindRawLayout lay = MindRawLayout{0, 0, 0, 0, 0});
+// single-pass pooled descriptor (mindmarch.hip): stencil + unclamped normalisation + both poolings, block statistics for k_mind_repair (mind.hip)
+bool mind_single_supported(int ga, int gb);
+void launch_mind_march_pool(const float* img, int H, int W, int D, int ga, float* out1, int gb, void* out2, int records, MindStats* st, unsigned* blk, hipStream_t s);
 
 }  // namespace cvx

@@ -123,6 +123,20 @@ size_t cvx_mindssc_workspace_bytes(int H, int W, int D, int radius, int dilation
 int cvx_mindssc_f32(const float* img, int H, int W, int D, int radius, int dilation, float* out,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* MIND-SSC as the registration consumes it -- only through its stride poolings ------------------------
+ * replaces F.avg_pool3d(MINDSSC(img, radius, dilation), g, stride=g) for the two window sizes of a pair
+ *                                                            convex_adam_utils.py:24-68 + convex_adam_MIND.py:118-119,149-150
+ *   img [H][W][D] -> out1 [12][H/g1][W/g1][D/g1]; g2 > 0: out2 [12][H/g2][W/g2][D/g2] as well (out2 NULL / g2 == 0: one pooling).
+ *   Same bits as cvx_mindssc_f32 followed by cvx_avgpool_f32; the full-resolution descriptor is never written.  Radius 1, dilation 2, rows of a
+ *   multiple of 4 voxels and the window pairs (6; 2|3|6), (4; 2|4), (2; 2) run in ONE pass over the image (the normalisation with the
+ *   unclamped variance inside the stencil kernel, the pooled cells of the few blocks where the variance clamp of :60-62 binds recomputed once
+ *   the global mean is known); other settings take two passes through `scratch` (cvx_mindssc_pooled_scratch_bytes, may be 0 bytes / NULL
+ *   ONLY when that function returns 0).  CVX_ERR_UNSUPPORTED when the windows do not tile (use the two separate operators).
+ *   workspace: cvx_mindssc_workspace_bytes.  repaired_host (nullable): receives the number of recomputed blocks (synchronises the stream). */
+size_t cvx_mindssc_pooled_scratch_bytes(int H, int W, int D, int radius, int dilation, int g1, int g2);
+int cvx_mindssc_pooled_f32(const float* img, int H, int W, int D, int radius, int dilation, int g1, float* out1, int g2, float* out2,
+                           void* scratch, size_t scratch_bytes, void* workspace, size_t workspace_bytes, int* repaired_host, void* stream);
+
 /* F.avg_pool3d(x, g, stride=g)                              convex_adam_MIND.py:118-119,149-150
  *   in [C][H][W][D] -> out [C][H/g][W/g][D/g] (floor) */
 int cvx_avgpool_f32(const float* in, int C, int H, int W, int D, int g, float* out, void* stream);

@@ -53,6 +53,7 @@ def _draw_options(rng):
     L.cvx_set_option(b"prune_refine", int(rng.integers(0, 4) > 0))
     L.cvx_set_option(b"mind_records", int(rng.integers(0, 4) > 0))
     L.cvx_set_option(b"mind_blocked", int(rng.integers(0, 4) > 0))
+    L.cvx_set_option(b"mind_single", int(rng.choice([0, 0, 1, 1, 2])))          # two passes / single pass + repair / every block through the repair kernel
     L.cvx_set_option(b"resize_up2", int(rng.integers(0, 4) > 0))
     # round 6: the certified-fast correlation path (1 = role kernel in fast arithmetic, 2 = staged kernel) or the exact volumes (0)
     L.cvx_set_option(b"corr_cert", int(rng.choice([1, 1, 2, 2, 0])))
