@@ -339,6 +339,16 @@ def test_full_size_masked_config3_and_label_features_in_fast_adam_mode(M, U, orc
     e_exact = epe(np.moveaxis(exact[:, ::s, ::s, ::s], 0, -1), np.moveaxis(g["c3_adam_20_sub"], 0, -1))
     print("configs[2] full size, 20 Adam iterations: adam_mode=fast vs reference mean EPE %.3e (exact mode %.3e)" % (e, e_exact))
     assert e < 2e-3 and e_exact < 1e-3
+    # WHERE the distance sits (tools/experiments/config3_epe_map.py): 98 % of it outside both masks -- the replicate-filled,
+    # flat part of the features, 81 % of the volume, where the data term is at rounding level and Adam's normalisation turns it into steps;
+    # the worst 1 % of the voxels carry 63 % (median 1e-6).  Inside both masks -- the voxels a masked registration is asked about -- the 1e-3
+    # bar holds with a wide margin in both modes: measured 6.9e-5 (fast) and 1.5e-5 (exact).
+    both = (mf.numpy()[::s, ::s, ::s] > 0) & (mm.numpy()[::s, ::s, ::s] > 0)
+    d_fast = np.sqrt(((np.moveaxis(out[:, ::s, ::s, ::s], 0, -1).astype(np.float64) - np.moveaxis(g["c3_adam_20_sub"], 0, -1)) ** 2).sum(-1))
+    d_exact = np.sqrt(((np.moveaxis(exact[:, ::s, ::s, ::s], 0, -1).astype(np.float64) - np.moveaxis(g["c3_adam_20_sub"], 0, -1)) ** 2).sum(-1))
+    print("   inside both masks: fast %.3e  exact %.3e;  outside both: fast %.3e  exact %.3e" % (d_fast[both].mean(), d_exact[both].mean(), d_fast[~both].mean(), d_exact[~both].mean()))
+    assert d_fast[both].mean() < 2e-4 and d_exact[both].mean() < 1e-4
+    assert np.median(d_fast) < 1e-5 and np.median(d_exact) < 1e-5
     ref = orc.convex_adam_pipeline(None, None, features=(host(ff)[0], host(fm)[0]), adam_mode="fast", **kw)
     assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), ref)
     # label features (C = 18 -> five chunks, the last one half empty), smaller grid
