@@ -698,17 +698,22 @@ extern "C" int cvx_surface_distance_hist_i64(const float* seg_b, const uint64_t*
 }
 
 // capacity of one of the SURF_NL sub-lists: at most 2^14 entries (4 M surface words / far voxels in all), and no more than a small volume
-// can fill -- every word of the maps, spread over the sub-lists with a factor 4 for their imbalance (the workspace is
-// grow-only per thread, device and stream; tiny label maps no longer pin 224 MB)
+// can fill.  The sub-list of an entry follows from the block and wavefront that found it, so a volume of a few blocks fills only a few
+// sub-lists: the bound for ONE sub-list is every word of the maps (the workspace is grow-only per thread, device and stream;
+// tiny label maps no longer pin 224 MB.  Round 6: the first version divided by the number of sub-lists and overflowed on 12 x 10 x 64 maps)
 static size_t surf_list_cap(int H, int W, int D, int num_labels) {
-    const size_t words = (size_t)num_labels * H * W * ((D + 63) / 64);
-    const size_t per = (4 * words + SURF_NL - 1) / SURF_NL + 64;
-    return per < ((size_t)1 << 14) ? per : ((size_t)1 << 14);
+    const size_t words = (size_t)num_labels * H * W * ((D + 63) / 64) + 64;
+    return words < ((size_t)1 << 14) ? words : ((size_t)1 << 14);
+}
+// the voxel lists (near / far surface voxels) hold VOXELS: a voxel carries one label, so H W D bounds all of them together
+static size_t surf_vox_cap(int H, int W, int D) {
+    const size_t vox = (size_t)H * W * D + 64;
+    return vox < ((size_t)1 << 14) ? vox : ((size_t)1 << 14);
 }
 // bits_b / bits_a = cvx_label_bits_u64 of the two maps; otherwise as cvx_surface_distance_hist_i64 (same counts, same flags)
 extern "C" size_t cvx_surface_distance_hist_bits_workspace_bytes(int H, int W, int D, int num_labels) {
     if (H <= 0 || W <= 0 || D <= 0 || num_labels <= 0) return 0;
-    const size_t cap_words = surf_list_cap(H, W, D, num_labels), cap_far = cap_words;       // per sub-list; beyond that the call reports flag 2
+    const size_t cap_words = surf_list_cap(H, W, D, num_labels), cap_far = surf_vox_cap(H, W, D);       // per sub-list; beyond that the call reports flag 2
     return 256 + sizeof(unsigned) * 5 * SURF_NL + 2 * (256 + sizeof(SurfWord) * cap_words * SURF_NL) + 3 * (256 + sizeof(unsigned long long) * cap_far * SURF_NL) + 256;
 }
 
@@ -731,7 +736,7 @@ extern "C" int cvx_surface_distance_hist_bits_i64(const uint64_t* bits_b, const 
     unsigned* counters = cv.take<unsigned>(5 * SURF_NL);
     SurfLists L;
     L.cap_words = (unsigned)surf_list_cap(H, W, D, num_labels);
-    L.cap_far = L.cap_words;
+    L.cap_far = (unsigned)surf_vox_cap(H, W, D);
     L.cap_vox = L.cap_far;
     for (int i = 0; i < 2; ++i) { L.words[i] = cv.take<SurfWord>((size_t)L.cap_words * SURF_NL); L.n_words[i] = counters + i * SURF_NL; }
     for (int i = 0; i < 2; ++i) { L.vox[i] = cv.take<unsigned long long>((size_t)L.cap_vox * SURF_NL); L.n_vox[i] = counters + (2 + i) * SURF_NL; }
