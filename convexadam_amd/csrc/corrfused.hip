@@ -46,6 +46,7 @@ struct CFGeom {
     int PF;                 // floats per LDS plane: 4 + (w + 2) * RS + 4
     int64_t tail_from;      // first flat index (h, n^2, w, d order) of ATen's interleaved-order tail; ntail = ncols - tail_from
     int ntail;
+    int colocate;           // option cf_map = 1 (see k_corr_fused)
     int prio;               // issue priorities (option cf_prio): base-4 digits first-round raw / box, second-round raw / box
     unsigned long long* dbg;   // optional residency census (CVX_CF_CENSUS): per workgroup {start, end, HW_ID, XCC_ID}
 };
@@ -420,7 +421,15 @@ __global__ __launch_bounds__(1024, (CASC ? 4 : 8)) void k_corr_fused(const float
     int pair;
     const int bi = TILED ? bx / g.nyt : bx;
     it.y0 = TILED ? (bx - bi * g.nyt) * g.T : 0;
-    if (bi < nn) { it.grp = g.ng - 1; pair = bi; }
+    if (g.colocate) {
+        // co-location experiment (option cf_map = 1; one round of <= 512 workgroups, three groups): workgroups b and b + 256 share a CU (census), so
+        // slot s < nn holds (pair s, last group) then (pair s, the group next to it) -- the same moving rows, 16 bytes apart, through one L1 --
+        // and the first groups of all pairs fill the remaining slots two by two
+        const int rnd = bx >> 8, sl = bx & 255;
+        if (sl < nn) { pair = sl; it.grp = rnd == 0 ? g.ng - 1 : g.ng - 2; }
+        else { pair = (sl - nn) + rnd * (256 - nn); it.grp = 0; }
+        if (pair >= nn) return;
+    } else if (bi < nn) { it.grp = g.ng - 1; pair = bi; }
     else { const int b = bi - nn; it.grp = b / nn; pair = b - it.grp * nn; }
     it.iH = pair % n; it.iW = pair / n;
     const int G = cf_group_size(n, g.ng, it.grp);
@@ -508,7 +517,7 @@ size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw) {
     used = carve_size(used, sizeof(float) * (size_t)C * h * w * g.RS);            // Fp
     used = carve_size(used, sizeof(float) * ((size_t)C * g.hq * g.wq * g.dq + 8));  // Mp
     used = carve_size(used, sizeof(float) * 32 * g.n);                             // tail values
-    used = carve_size(used, 32 * (size_t)g.n * g.n * g.ng * (g.nyt > 0 ? g.nyt : 1));  // residency census (CVX_CF_CENSUS)
+    used = carve_size(used, 32 * ((size_t)g.n * g.n * g.ng * (g.nyt > 0 ? g.nyt : 1) + 8));  // residency census (CVX_CF_CENSUS; + 8: the 512 slots of option cf_map)
     return used + 256;
 }
 
@@ -526,7 +535,7 @@ static void cf_launch_c(const CFGeom& gl, const float* Fp, const float* Mp, cons
     const int items = gl.n * gl.n * gl.ng * gl.nyt;
     CFSecond two = {nullptr, nullptr, nullptr, nullptr, 0};
     if (second) { two = *second; two.items1 = items; }
-    hipLaunchKernelGGL((k_corr_fused<CF_GMAX, MODE, CASC, TILED>), dim3(second ? 2 * items : items), dim3((ONEBOX ? 2 : 3) * 64 * gl.wpr), lds, s, Fp, Mp, tail, gl, ssd, two);
+    hipLaunchKernelGGL((k_corr_fused<CF_GMAX, MODE, CASC, TILED>), dim3(second ? 2 * items : (gl.colocate ? 512 : items)), dim3((ONEBOX ? 2 : 3) * 64 * gl.wpr), lds, s, Fp, Mp, tail, gl, ssd, two);
 }
 template <int MODE>
 static void cf_launch(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, void* ssd, hipStream_t s, const CFSecond* second = nullptr) {
@@ -559,7 +568,7 @@ int launch_corr_fused_dual(const float* fix, const float* mov, int C, int h, int
     float* Fp = cv.take<float>((size_t)C * h * w * g.RS);
     float* Mp = cv.take<float>((size_t)C * g.hq * g.wq * g.dq + 8);
     float* tail = cv.take<float>((size_t)32 * g.n);
-    unsigned long long* census_buf = cv.take<unsigned long long>((size_t)4 * g.n * g.n * g.ng * g.nyt);
+    unsigned long long* census_buf = cv.take<unsigned long long>((size_t)4 * (g.n * g.n * g.ng * g.nyt + 8));
     launch_corr_prep_generic(fix, mov, C, h, w, d, hw, g.RS, hw, g.dq, Fp, Mp, s);
     if (g.ntail > 0 && !fast) launch_corr_tail_compact(fix, mov, C, h, w, d, hw, cost, tail, s);
     CFSecond two = {nullptr, nullptr, nullptr, nullptr, 0};
@@ -576,6 +585,8 @@ int launch_corr_fused_dual(const float* fix, const float* mov, int C, int h, int
     const CFSecond* sec = ssd_rev ? &two : nullptr;
     CFGeom gl = g;
     gl.prio = (int)options().cf_prio;
+    // (pairs of a slot: 2 x (256 - nn) >= nn first groups)
+    gl.colocate = (options().cf_map == 1 && !ssd_rev && !g.tiled && g.ng == 3 && g.n * g.n <= 256 && 2 * (256 - g.n * g.n) >= g.n * g.n) ? 1 : 0;
     gl.dbg = (options().cf_census && !ssd_rev) ? census_buf : nullptr;      // debugging aid: per-workgroup start / end / placement in the workspace
     if (fast == 2) cf_launch<1 + 32>(gl, Fp, Mp, tail, ssd, s, sec);
     else if (fast && f16 == 2) cf_launch<1 + 8 + 16>(gl, Fp, Mp, tail, ssd, s, sec);

@@ -119,6 +119,9 @@ struct Options {
                                    //    the algorithmic bytes; bit-identical).  MEASURED SLOWER (0.546 vs 0.499 ms for both images: both forms are bound by instruction
                                    //    issue, not by memory); 2 = every block through the repair kernel (test); 0 (default) = two passes
     long long ms_zlen;             // planes per z chunk of the single-pass kernel (0 = automatic)
+    long long cf_map;              // fused correlation kernel, item -> workgroup order: 1 (default) = the two adjacent D-shift groups of a (dH, dW) pair in the two workgroup
+                                   //    slots of ONE CU (blocks b and b + 256 share a CU: 251 of 251 in the census), so that their moving rows meet in that CU's L1
+                                   //    (154 -> 152 us, three alternating rounds; bit-identical); 0 = large groups first
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };

@@ -57,6 +57,7 @@ def _draw_options(rng):
     L.cvx_set_option(b"resize_up2", int(rng.integers(0, 4) > 0))
     # round 6: the certified-fast correlation path (1 = role kernel in fast arithmetic, 2 = staged kernel) or the exact volumes (0)
     L.cvx_set_option(b"corr_cert", int(rng.choice([1, 1, 2, 2, 0])))
+    L.cvx_set_option(b"cf_map", int(rng.integers(0, 2)))
 
 
 def trial_pipeline(rng, t):
