@@ -691,6 +691,51 @@ def main():
                                 convex_stage_voxels_changed=float((conv16 != conv32).any(0).float().mean()),
                                 convex_stage_epe=float((conv16 - conv32).square().sum(0).sqrt().mean()))
 
+    # the descriptor stage in ONE stencil pass (option mind_single, off by default because it is slower): both forms timed on the same images through
+    # the pooled-descriptor operator (cvx_mindssc_pooled_f32), the repair-list length on the phantom and on the zero-background pair
+    mind_single = None
+    if rank == 0 and not a.no_batched:
+        from convexadam_amd import _lib
+        from convexadam_amd.convex_adam_utils import mind_pooled
+        from convexadam_amd.phantom import ellipsoid_mask
+        L = _lib.lib()
+        old_single = L.cvx_get_option(b"mind_single")
+        mind_single = {}
+        try:
+            mz_ = ellipsoid_mask(SHAPE, 0.3).to(dev)
+            imgs = {"phantom": (fix, mov), "zero_background": ((fix * mz_).contiguous(), (mov * mz_).contiguous())}
+            for tag, pair in imgs.items():
+                row = {}
+                for name, val in (("two_pass", 0), ("single_pass", 1)):
+                    L.cvx_set_option(b"mind_single", val)
+                    outs, reps = [], 0
+                    for im in pair:
+                        r_ = mind_pooled(im[None, None], CFG["mind_r"], CFG["mind_d"], CFG["grid_sp"], CFG["grid_sp_adam"], device=dev, return_repairs=True)
+                        outs.append(r_[:2]); reps += r_[2]
+                    torch.cuda.synchronize(dev)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        for im in pair:
+                            mind_pooled(im[None, None], CFG["mind_r"], CFG["mind_d"], CFG["grid_sp"], CFG["grid_sp_adam"], device=dev)
+                    e1.record(); torch.cuda.synchronize(dev)
+                    row[name] = {"ms_both_images": e0.elapsed_time(e1) / 5, "blocks_repaired": reps}
+                    row["_" + name] = outs
+                row["bit_identical"] = all(bool(torch.equal(x_, y_)) for p_, q_ in zip(row.pop("_two_pass"), row.pop("_single_pass")) for x_, y_ in zip(p_, q_))
+                mind_single[tag] = row
+        finally:
+            L.cvx_set_option(b"mind_single", old_single)
+        nblk = -(-SHAPE[0] // CFG["grid_sp"]) * -(-SHAPE[1] // CFG["grid_sp"]) * -(-SHAPE[2] // CFG["grid_sp"])
+        mind_single["blocks_per_image"] = nblk
+        for key in ("mind_two_pass_bytes_per_image", "mind_single_pass_bytes_per_image"):
+            if pmc_extra(key) is not None:
+                mind_single[key] = pmc_extra(key)
+        mind_single["note"] = ("avg_pool3d(MINDSSC(img), 6 | 2) of both images through cvx_mindssc_pooled_f32 (hipEvents, kernels + the 2 tiny statistics launches): two_pass = "
+                               "k_mind_march + k_mind_finish_pool through 330 MB of raw patch distances per image (the pipeline's default); single_pass = k_mind_march_pool "
+                               "(normalisation with the unclamped variance and both poolings inside the stencil kernel) + k_mind_repair (pooled cells of the blocks where the "
+                               "variance clamp binds, recomputed with the global mean); same bits; the single pass moves a fifth of the bytes and is SLOWER: both forms are "
+                               "bound by instruction issue (27 additions per patch distance, 12 IEEE divisions + 12 exp per voxel), DESIGN.md 12.11")
+
     if rank == 0:
         n = world
         h, w, d = (s // CFG["grid_sp"] for s in SHAPE)
@@ -748,7 +793,12 @@ def main():
         by_stage["pair"] = {"algorithmic_bytes": pair_bytes, "ms": res["ms_per_step"], "achieved_GBps": pair_bytes / (res["ms_per_step"] * 1e-3) / 1e9,
                             "frac": pair_bytes / (res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "note": "coupled convex counted at 6 full reads of the cost volume per direction (SURVEY 8(d)); the branch-and-bound passes read less"}
+        mind_meas = pmc_extra("mind_two_pass_bytes_per_image")
+        if mind_meas is not None and "mind" in by_stage:
+            by_stage["mind"]["traffic"] = 2 * mind_meas                                 # both images: HBM bytes from the PMC passes (profiles/pmc_hbm_traffic.json)
         res["roofline_by_stage"] = by_stage
+        if mind_single is not None:
+            res["mind_single_pass"] = mind_single
         # the pair with the coupled-convex stage at its MEASURED bytes (PMC passes of tools/profile_round.sh; the branch-and-bound passes touch ~1 % of
         # the 6 x 270 MB the reference's formulation streams): the figure to quote for "fraction of the HBM roofline of the whole pair"
         cc_meas = pmc_extra("coupled_convex_bytes_per_pair")

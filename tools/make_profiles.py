@@ -119,7 +119,42 @@ def main(src, tag):
     cc = [r for r in rows if any(k in r[0] for k in ("k_argmin_voxel", "k_argmin_wave", "k_gather_box3", "k_keys_to_idx_min", "k_cert_voxel", "k_cert_wave", "k_cert_gather",
                                                        "k_cert_arm", "k_cert_plain_finalize", "k_cert_plain_resolve"))]
     cc_pair = sum(r[4] * r[1] for r in cc) * 1e6              # the PMC passes register ONE pair: calls x bytes per call
-    json.dump({"correlate_stage_bytes_per_launch": total, "coupled_convex_bytes_per_pair": cc_pair,
+    # the descriptor stage, bytes per image: two passes (this run) and the single-pass kernels (the passes made with CVX_MIND_SINGLE=1)
+    def mind_bytes(rs, names):
+        return sum(r[4] for r in rs if any(nm in r[0] for nm in names)) * 1e6
+    two_pass_names = ("k_minmax_partial", "k_mind_stats_init", "k_mind_march<", "k_mind_finish_pool")
+    single_names = ("k_minmax_partial", "k_mind_stats_init", "k_mind_march_pool", "k_mind_repair")
+    mind_two = mind_bytes(rows, two_pass_names)
+    sfa, sfc = pmc(src + "/single_fetch")
+    swa, swc = pmc(src + "/single_write")
+    srows = []
+    for k in sorted(set(sfa) | set(swa)):
+        n = max(sfc[k].get("FETCH_SIZE", 0), swc[k].get("WRITE_SIZE", 0))
+        fe = sfa[k].get("FETCH_SIZE", 0.0) / max(sfc[k].get("FETCH_SIZE", 1), 1)
+        wr = swa[k].get("WRITE_SIZE", 0.0) / max(swc[k].get("WRITE_SIZE", 1), 1)
+        srows.append((k, n, fe, wr, (fetch_factor(k) * fe + wr) * 1024 / 1e6))
+    mind_one = mind_bytes(srows, single_names) if srows else None
+    if srows:
+        ssa, ssc = pmc(src + "/single_sq")
+        sqa, sqc = pmc(src + "/sq")
+        sb = io.StringIO()
+        sb.write("# MIND-SSC descriptor stage of the benchmark pair, per image: two passes (default) against the single-pass kernels (CVX_MIND_SINGLE=1)\n"
+                 "# traffic = (factor*FETCH_SIZE + WRITE_SIZE)*1024 per launch (factor 2.00 = upper bound for 16-byte streamed reads), algorithmic bytes 97.8 MB per image\n")
+        sb.write("%-40s %8s %12s %12s %12s %14s %14s %14s\n" % ("kernel", "calls", "FETCH_KiB", "WRITE_KiB", "MB/call", "insts_valu", "insts_lds", "lds_conflict"))
+        for title, rs, names, qa, qc in (("two passes", rows, two_pass_names, sqa, sqc), ("single pass", srows, single_names, ssa, ssc)):
+            sb.write("# %s\n" % title)
+            for r in rs:
+                if any(nm in r[0] for nm in names):
+                    q = lambda nm: qa[r[0]].get(nm, 0) / max(qc[r[0]].get(nm, 1), 1)
+                    sb.write("%-40s %8d %12.1f %12.1f %12.1f %14.0f %14.0f %14.0f\n" % (r[0][-40:], r[1], r[2], r[3], r[4], q("SQ_INSTS_VALU"), q("SQ_INSTS_LDS"), q("SQ_LDS_BANK_CONFLICT")))
+        sb.write("# per image: two passes %.1f MB, single pass %.1f MB (algorithmic 97.8 MB)\n" % (mind_two / 1e6, mind_one / 1e6))
+        db = glob.glob(src + "/single_stats/**/*_results.db", recursive=True)
+        if db:
+            out = subprocess.run([sys.executable, os.path.join(HERE, "rocpd_stats.py"), db[0]], stdout=subprocess.PIPE, text=True).stdout
+            sb.write("# kernel durations with CVX_MIND_SINGLE=1 (rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1): MIND kernels only\n")
+            sb.write("".join(l + "\n" for l in out.splitlines() if "k_mind" in l or "k_minmax" in l or l.startswith("kernel")))
+        open(os.path.join(prof, tag + "_mind_single_pass.txt"), "w").write(sb.getvalue())
+    json.dump({"correlate_stage_bytes_per_launch": total, "coupled_convex_bytes_per_pair": cc_pair, "mind_two_pass_bytes_per_image": mind_two, "mind_single_pass_bytes_per_image": mind_one,
                "plain_argmin_bytes_per_direction": sum(r[4] * r[1] for r in rows if "k_cert_plain_stream" in r[0] or "k_argmin4" in r[0]) * 1e6 / 2,
                "coupled_convex_kernels": {r[0]: {"calls": r[1], "bytes_per_call": r[4] * 1e6} for r in cc}, "source": "profiles/%s_pmc_hbm_traffic.txt" % tag,
                "kernels": {r[0]: r[4] * 1e6 for r in stage},

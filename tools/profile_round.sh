@@ -11,5 +11,10 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats_fast -o r -- python $R/
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched > /dev/null 2> $O/fetch.log
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched > /dev/null 2> $O/write.log
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/sq -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched > /dev/null 2> $O/sq.log
+# the single-pass descriptor (option mind_single = 1): kernel durations and the three counter passes of its kernels
+CVX_MIND_SINGLE=1 timeout 600 rocprofv3 --kernel-trace --stats -d $O/single_stats -o r -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batched > /dev/null 2> $O/single_stats.log
+CVX_MIND_SINGLE=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/single_fetch -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched > /dev/null 2> $O/single_fetch.log
+CVX_MIND_SINGLE=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/single_write -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched > /dev/null 2> $O/single_write.log
+CVX_MIND_SINGLE=1 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/single_sq -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched > /dev/null 2> $O/single_sq.log
 cd $R && python bench.py --steps 10 --warmup 2 > $O/bench_line.json 2> $O/bench.log
 ls $O
