@@ -48,7 +48,8 @@ struct CertProb {
     unsigned long long* key; unsigned* sec;       // plain pass: (min, index) and the runner-up value
     int* idx0; int* idxA; int* idxB;              // winners: plain pass, coupled passes (ping-pong)
     float* smin;                                  // min_k ssdu[k,x] (NaN: the column holds a NaN)
-    unsigned* list; int* counts;                  // flagged voxels of the plain pass; one counter per pass: [0] plain, [1..6] coupled
+    unsigned* list; int* counts;                  // flagged voxels of the plain pass; one counter per pass: [0] plain, [1..6] coupled, [7] statistics, [8] work items
+    unsigned long long* work; unsigned work_cap;  // plain pass: (voxel << 32 | displacement) entries that need the exact evaluator
     struct CertRec* rec;                          // work records of the coupled passes (the voxel kernel hands its box to the wavefront kernel)
     float* u;                                     // [3][v] running smoothed field = the result
     int64_t* argmin_out;                          // optional int64 copy of the plain winners
@@ -214,8 +215,14 @@ __global__ __launch_bounds__(256) void k_cert_plain_finalize(CertArgs A) {
     if (!certain) P.list[atomicAdd(&P.counts[0], 1)] = (unsigned)x;
 }
 
-// flagged voxels of the plain pass: one wavefront per voxel; the smallest upper bound is the one of the minimum (the key), the column is
-// scanned 1 024 entries at a time with 16 loads per lane in flight, the candidates are evaluated exactly
+// flagged voxels of the plain pass.  The smallest upper bound is the one of the minimum (the key); every entry whose lower bound does not exceed it
+// must be evaluated exactly, and the first minimum of the exact values wins.  Three launches:
+//   k_cert_plain_resolve  one wavefront per flagged voxel scans the column (1 024 entries at a time, 16 loads per lane in flight) and APPENDS its
+//                         candidates to a work list; exact zeros need no evaluation (the first of them is a candidate at cost 0)
+//   k_cert_plain_eval     one wavefront per work item: the exact entry, a 64-bit atomicMin on (value, index) of its voxel
+//   k_cert_plain_commit   winners of the flagged voxels
+// (round 6, first version: the scanning wavefront evaluated its candidates itself, one after the other -- a boundary voxel of a masked image whose
+// column holds 720 IDENTICAL tiny non-zero sums (every displacement into the flat background of the other image) took 1.8 ms, the stage 4.3 ms.)
 __global__ __launch_bounds__(64) void k_cert_plain_resolve(CertArgs A) {
     __shared__ float sm[160];
     const CertProb& P = A.p[blockIdx.y];
@@ -239,22 +246,52 @@ __global__ __launch_bounds__(64) void k_cert_plain_resolve(CertArgs A) {
                     const unsigned long long key = pack_min_key(0.0f, (unsigned)(kb + 64 * i + __ffsll((long long)mz) - 1));
                     bestkey = key < bestkey ? key : bestkey;
                 }
-                unsigned long long m = __ballot(s[i] != 0.0f && cert_lower(s[i]) <= U);
-                while (m) {
-                    const int l = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int kk = kb + 64 * i + l;
-                    const float ex = cert_exact_entry(A.g, P, kk, (int)x, sm, lane);
-                    const unsigned long long key = pack_min_key(ex, (unsigned)kk);
-                    bestkey = key < bestkey ? key : bestkey;
+                const bool mine = s[i] != 0.0f && cert_lower(s[i]) <= U;
+                const unsigned long long m = __ballot(mine);
+                if (m) {
+                    const int nm = __popcll(m);
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&P.counts[8], nm);
+                    base = __shfl(base, 0);
+                    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (mine && (unsigned)slot < P.work_cap) P.work[slot] = ((unsigned long long)x << 32) | (unsigned)(kb + 64 * i + lane);
+                    // a full list (cannot happen with the capacity of the carve unless thousands of voxels tie): the rest is evaluated here
+                    unsigned long long rest = __ballot(mine && (unsigned)slot >= P.work_cap);
+                    while (rest) {
+                        const int l = __ffsll((long long)rest) - 1;
+                        rest &= rest - 1;
+                        const int kk = kb + 64 * i + l;
+                        const float ex = cert_exact_entry(A.g, P, kk, (int)x, sm, lane);
+                        const unsigned long long key = pack_min_key(ex, (unsigned)kk);
+                        bestkey = key < bestkey ? key : bestkey;
+                    }
                 }
             }
         }
-        if (lane == 0) {
-            const int kw = (int)(unsigned)(bestkey & 0xffffffffull);
-            P.idx0[x] = kw;
-            if (P.argmin_out) P.argmin_out[x] = kw;
-        }
+        if (lane == 0) P.key[x] = bestkey;             // (the plain pass's key is spent: its value and index live in smin / idx0)
+    }
+}
+__global__ __launch_bounds__(256) void k_cert_plain_eval(CertArgs A) {
+    __shared__ float smem[4][160];
+    const CertProb& P = A.p[blockIdx.y];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = min(P.counts[8], (int)P.work_cap);
+    for (int e = blockIdx.x * 4 + wv; e < n; e += gridDim.x * 4) {
+        const unsigned long long it = P.work[e];
+        const unsigned x = (unsigned)(it >> 32);
+        const int kk = (int)(unsigned)(it & 0xffffffffull);
+        const float ex = cert_exact_entry_wave(A.g, P, kk, (int)x, smem[wv], lane);
+        if (lane == 0) atomicMin(&P.key[x], pack_min_key(ex, (unsigned)kk));
+    }
+}
+__global__ __launch_bounds__(256) void k_cert_plain_commit(CertArgs A) {
+    const CertProb& P = A.p[blockIdx.y];
+    const int cnt = P.counts[0];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += gridDim.x * blockDim.x) {
+        const unsigned x = P.list[e];
+        const int kw = (int)(unsigned)(P.key[x] & 0xffffffffull);
+        P.idx0[x] = kw;
+        if (P.argmin_out) P.argmin_out[x] = kw;
     }
 }
 
@@ -522,7 +559,7 @@ __global__ __launch_bounds__(256) void k_cert_arm(CertArgs A, int nprob) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int q = 0; q < nprob; ++q) {
         if (i < v) { A.p[q].key[i] = ~0ull; A.p[q].sec[i] = 0xffffffffu; }
-        if (i < 8) A.p[q].counts[i] = 0;
+        if (i < 16) A.p[q].counts[i] = 0;
     }
 }
 
@@ -531,6 +568,8 @@ void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, 
 
 // plain = the plain argmin only (cvx_correlate_ex_f32 with fast = 2): keys, runner-up, winners, minimum, list -- 24 bytes per voxel;
 // the coupled passes add the two ping-pong winner arrays and the work records
+// capacity of the plain pass's work list: four candidates per voxel on average, at least 64 K (a column holds n^3 entries)
+static size_t cert_work_cap(size_t v) { return 4 * v + 65536; }
 size_t corr_certify_workspace_bytes(int C, int h, int w, int d, int hw, bool plain) {
     (void)C;
     const size_t v = (size_t)h * w * d;
@@ -541,7 +580,8 @@ size_t corr_certify_workspace_bytes(int C, int h, int w, int d, int hw, bool pla
     used = carve_size(used, sizeof(int) * v);                     // idx0
     used = carve_size(used, sizeof(float) * v);                   // smin
     used = carve_size(used, sizeof(unsigned) * v);                // list
-    used = carve_size(used, sizeof(int) * 8);                     // counts
+    used = carve_size(used, sizeof(int) * 16);                    // counts
+    used = carve_size(used, sizeof(unsigned long long) * cert_work_cap(v));   // work list of the plain pass
     used = carve_size(used, sizeof(float) * 32 * n);              // tail
     if (!plain) {
         for (int i = 0; i < 2; ++i) used = carve_size(used, sizeof(int) * v);   // idxA, idxB
@@ -550,7 +590,7 @@ size_t corr_certify_workspace_bytes(int C, int h, int w, int d, int hw, bool pla
     return used + 256;
 }
 
-struct CertCarve { unsigned long long* key; unsigned* sec; int* idx0; int* idxA; int* idxB; float* smin; unsigned* list; CertRec* rec; int* counts; float* tail; };
+struct CertCarve { unsigned long long* key; unsigned* sec; int* idx0; int* idxA; int* idxB; float* smin; unsigned* list; CertRec* rec; int* counts; float* tail; unsigned long long* work; unsigned work_cap; };
 static CertCarve cert_carve(void* workspace, size_t workspace_bytes, int h, int w, int d, int hw, bool plain = false) {
     const size_t v = (size_t)h * w * d;
     const int n = 2 * hw + 1;
@@ -561,7 +601,9 @@ static CertCarve cert_carve(void* workspace, size_t workspace_bytes, int h, int 
     c.idx0 = cv.take<int>(v);
     c.smin = cv.take<float>(v);
     c.list = cv.take<unsigned>(v);
-    c.counts = cv.take<int>(8);
+    c.counts = cv.take<int>(16);
+    c.work_cap = (unsigned)cert_work_cap(v);
+    c.work = cv.take<unsigned long long>(c.work_cap);
     c.tail = cv.take<float>((size_t)32 * n);
     if (!plain) {
         c.idxA = cv.take<int>(v); c.idxB = cv.take<int>(v);
@@ -578,7 +620,7 @@ static CertGeo cert_geo(int C, int h, int w, int d, int hw) {
     return g;
 }
 static CertProb cert_prob(const float* ssdu, const float* fix, const float* mov, const CertCarve& c, float* u, int64_t* argmin_out) {
-    return CertProb{ssdu, fix, mov, c.tail, c.key, c.sec, c.idx0, c.idxA, c.idxB, c.smin, c.list, c.counts, c.rec, u, argmin_out};
+    return CertProb{ssdu, fix, mov, c.tail, c.key, c.sec, c.idx0, c.idxA, c.idxB, c.smin, c.list, c.counts, c.work, c.work_cap, c.rec, u, argmin_out};
 }
 
 // the plain argmin in three parts so that a caller can stream each volume while it is still in the Infinity Cache (right behind its
@@ -586,7 +628,7 @@ static CertProb cert_prob(const float* ssdu, const float* fix, const float* mov,
 static void cert_arm(CertArgs& A, int nprob, hipStream_t s) {
     const CertGeo& g = A.g;
     const size_t v = (size_t)g.h * g.w * g.d;
-    hipLaunchKernelGGL(k_cert_arm, dim3((unsigned)cdiv64((int64_t)(v > 8 ? v : 8), 256)), dim3(256), 0, s, A, nprob);
+    hipLaunchKernelGGL(k_cert_arm, dim3((unsigned)cdiv64((int64_t)(v > 16 ? v : 16), 256)), dim3(256), 0, s, A, nprob);
     for (int q = 0; q < nprob; ++q)
         if (g.ntail > 0) launch_corr_tail_compact(A.p[q].fix, A.p[q].mov, g.C, g.h, g.w, g.d, g.hw, 0, const_cast<float*>(A.p[q].tail), s);
 }
@@ -610,6 +652,8 @@ static int cert_finish(CertArgs& A, int nprob, hipStream_t s) {
     const size_t v = (size_t)A.g.h * A.g.w * A.g.d;
     hipLaunchKernelGGL(k_cert_plain_finalize, dim3((unsigned)cdiv64((int64_t)v, 256), nprob), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_cert_plain_resolve, dim3(256, nprob), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(k_cert_plain_eval, dim3(256, nprob), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_cert_plain_commit, dim3(8, nprob), dim3(256), 0, s, A);
     return check_last("certified argmin");
 }
 static int cert_plain(CertArgs& A, int nprob, bool arm, hipStream_t s) {
