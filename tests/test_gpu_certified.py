@@ -99,7 +99,7 @@ def test_certified_kernels_cover_the_benchmark_geometries(U, L, orc):
         assert check(U, L, orc, f, m, hw, must_run=True) == 2
 
 
-@pytest.mark.parametrize("kind", ["periodic", "shifted_copy", "constant", "blocks", "zero_background", "zero_everything", "tiny_values"])
+@pytest.mark.parametrize("kind", ["periodic", "shifted_copy", "constant", "blocks", "zero_background", "zero_everything", "tiny_values", "plateau"])
 @pytest.mark.parametrize("C,shape,hw", [(12, (9, 12, 14), 3), (4, (6, 8, 37), 2), (12, (7, 32, 13), 4)])
 def test_certified_argmin_on_near_ties(U, L, orc, kind, C, shape, hw):
     """Volumes whose cost columns hold exact ties, near ties at rounding level and exact zeros: the certified argmin is the first minimum of
@@ -126,6 +126,11 @@ def test_certified_argmin_on_near_ties(U, L, orc, kind, C, shape, hw):
     elif kind == "zero_everything":
         f[:] = 0
         m = f.copy()
+    elif kind == "plateau":          # a flat moving image (the descriptor of an exact-zero background is 1 everywhere) and a fixed image one ulp away
+        m = np.ones((C,) + shape, np.float32)           # from it in places: hundreds of IDENTICAL tiny non-zero sums per column (the masked benchmark pair's
+        f = np.ones((C,) + shape, np.float32)           # boundary voxels) -- every one of them goes through the exact evaluator, the first one wins
+        f[:, 2:5, 3:7, 2:9] = np.nextafter(np.float32(1), np.float32(0))
+        f[0, 4, 5, 6] = np.float32(0.999)
     else:                            # differences whose squares fall into the denormal range: ATen's divisions round some entries to zero
         f = (rng.random((C,) + shape, dtype=np.float32) * np.float32(1e-21)).astype(np.float32)
         m = (rng.random((C,) + shape, dtype=np.float32) * np.float32(1e-21)).astype(np.float32)
