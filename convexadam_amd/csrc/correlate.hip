@@ -239,12 +239,12 @@ static void corr_raw_dispatch(const float* Fp, const float* Mp, const CorrGeom& 
 // ---- the certified-fast volume: which kernel produces it (option corr_cert: 1 = the role kernel of corrfused.hip in its fast arithmetic
 // without the final scaling -- the faster one as measured --, 2 = the staged kernel of corrcert.hip; 0 in the pipeline = exact volumes) -------
 static bool certfast_use_staged(int C, int h, int w, int d, int hw) {
-    const bool staged_ok = corr_cert_supported(C, h, w, d, hw), fused_ok = corr_fused_supported(C, h, w, d, hw) && C < 16;
+    const bool staged_ok = corr_cert_supported(C, h, w, d, hw), fused_ok = corr_fused_supported(C, h, w, d, hw) && C <= 128;
     if (options().corr_cert == 2) return staged_ok;
     return staged_ok && !fused_ok;
 }
 bool corr_certfast_supported(int C, int h, int w, int d, int hw) {
-    return corr_cert_supported(C, h, w, d, hw) || (corr_fused_supported(C, h, w, d, hw) && C < 16);
+    return corr_cert_supported(C, h, w, d, hw) || (corr_fused_supported(C, h, w, d, hw) && C <= 128);
 }
 size_t corr_certfast_workspace_bytes(int C, int h, int w, int d, int hw) {
     const size_t a = corr_cert_supported(C, h, w, d, hw) ? corr_cert_workspace_bytes(C, h, w, d, hw) : 0;

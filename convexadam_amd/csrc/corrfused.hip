@@ -39,7 +39,7 @@ struct CFGeom {
     int C, h, w, d, hw, n;
     int lpr, RS;            // quads per row; row pitch of LDS planes and of Fp (floats) = 4 * lpr
     int dq, hq, wq;         // Mp row pitch, plane extents (h + 2hw, w + 2hw); element x at index x + 1 + hw
-    int ng;                 // D-shift groups per (dH, dW)
+    int ng, gs;             // D-shift groups per (dH, dW); shifts per group (the last group takes the rest, <= 5)
     int tiled, T, nyt;      // planes taller than one role can hold (5 wavefronts x 64 quads) are cut into y tiles of T output rows; the
                             // raw stage then evaluates rows y0-2 .. y0+T+1 and the first box y0-1 .. y0+T (halo rows are recomputed)
     int wpr;                // wavefronts per role
@@ -53,7 +53,7 @@ struct CFGeom {
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte global access at 4-byte alignment
 
-__device__ __forceinline__ int cf_group_size(int n, int ng, int grp) { return grp < ng - 1 ? 4 : n - 4 * (ng - 1); }
+__device__ __forceinline__ int cf_group_size(int n, int ng, int grp, int gs) { return grp < ng - 1 ? gs : n - gs * (ng - 1); }
 
 // box stage of one displacement: `src` = window origin of the thread in the newest input plane, `rs` = its row pitch (a zero
 // block with pitch 0 stands in for an all-zero plane); mid / pre = the two running sums per column.  Returns the four finished sums
@@ -142,7 +142,7 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
     const int yc = !TILED ? y : (y < 0 ? 0 : (y >= g.w ? g.w - 1 : y));
     // per-thread byte offsets; everything else of an address is wave-uniform and travels in the scalar offset
     const unsigned foff = 4u * (unsigned)(yc * RS + 4 * q);
-    const unsigned moff = 4u * (unsigned)((yc + it.iW) * g.dq + 4 * q + 4 * it.grp);
+    const unsigned moff = 4u * (unsigned)((yc + it.iW) * g.dq + 4 * q + g.gs * it.grp);
     const unsigned doff = (unsigned)((TILED ? it.y : it.y + 1) * RS + 4 * q);
     const unsigned fstride = 4u * (unsigned)(g.h * g.w * RS), mstride = 4u * (unsigned)(g.hq * g.wq * g.dq);     // bytes per channel
     const unsigned fplane = 4u * (unsigned)(g.w * RS), mplane = 4u * (unsigned)(g.wq * g.dq);                    // bytes per plane
@@ -150,7 +150,7 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
     const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Mp), 0, (int)(mstride * (unsigned)g.C + 32u), 0x00020000);
     // does this item hold elements of ATen's interleaved-order tail (the last < 32 elements of the (h, n^2, w, d) tensor)?
     const int ylast = TILED ? min(g.w - 1, it.y0 + g.T + 1) : g.w - 1;              // last row this workgroup evaluates
-    const int64_t item_last = (((int64_t)(g.h - 1) * nn + it.iW * n + 4 * it.grp + G - 1) * g.w + ylast) * g.d + g.d - 1;
+    const int64_t item_last = (((int64_t)(g.h - 1) * nn + it.iW * n + g.gs * it.grp + G - 1) * g.w + ylast) * g.d + g.d - 1;
     const bool tail_item = !FAST && g.ntail > 0 && item_last >= g.tail_from;
     int base = 0;                                          // (s * G) mod R
     for (int s = 0; s < nsteps; ++s) {
@@ -241,7 +241,7 @@ __device__ __forceinline__ void cf_raw(const float* __restrict__ Fp, const float
 #pragma unroll 1
                     for (int j = 0; j < 4; ++j) {
                         const int x = 4 * q + j - 1;
-                        const int64_t flat = (((int64_t)s * nn + it.iW * n + 4 * it.grp + k) * g.w + y) * g.d + x;
+                        const int64_t flat = (((int64_t)s * nn + it.iW * n + g.gs * it.grp + k) * g.w + y) * g.d + x;
                         if (x >= 0 && x < g.d && flat >= g.tail_from) {
                             const float t = tail[it.iH * 32 + (int)(flat - g.tail_from)];
 #pragma unroll
@@ -297,7 +297,7 @@ __device__ __forceinline__ void cf_box(const CFGeom& g, const CFItem& it, const 
     const int c0 = FIRST ? 4 * q : 4 * q - 3;                                          // first column of the four outputs
     const unsigned vol = (unsigned)(g.h * g.w * g.d), plane = (unsigned)(g.w * g.d);
     const unsigned ooff = (unsigned)sizeof(OT) * (unsigned)(y * g.d + 4 * q);          // bytes, relative to (plane base + c0 - 4q)
-    OT* ssd_item = ssd + ((size_t)((4 * it.grp) * n + it.iW) * n + it.iH) * vol - (FIRST ? 0 : 3);   // uniform
+    OT* ssd_item = ssd + ((size_t)((g.gs * it.grp) * n + it.iW) * n + it.iH) * vol - (FIRST ? 0 : 3);   // uniform
     const size_t kstride = (size_t)nn * vol;                                           // next D-shift
     const bool full = c0 >= 0 && c0 + 3 < g.d;
     const int jlo = c0 < 0 ? -c0 : 0, jhi = min(4, g.d - c0);                          // valid columns of a partial quad
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(1024, (CASC ? 4 : 8)) void k_corr_fused(const float
     } else if (bi < nn) { it.grp = g.ng - 1; pair = bi; }
     else { const int b = bi - nn; it.grp = b / nn; pair = b - it.grp * nn; }
     it.iH = pair % n; it.iW = pair / n;
-    const int G = cf_group_size(n, g.ng, it.grp);
+    const int G = cf_group_size(n, g.ng, it.grp, g.gs);
     if (g.dbg && tid == 0) {
         g.dbg[4 * blockIdx.x] = __builtin_amdgcn_s_memtime();
         g.dbg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
@@ -480,6 +480,7 @@ static CFGeom cf_geom(int C, int h, int w, int d, int hw) {
     g.lpr = (d + 3 + 3) / 4;
     g.RS = 4 * g.lpr;
     const int n = g.n;
+    g.gs = 4;
     g.ng = (n >= 4 && n % 4 <= 1) ? n / 4 : (n + 3) / 4;
     g.dq = g.RS + 4 * g.ng + 4;
     g.hq = h + 2 * hw; g.wq = w + 2 * hw;
@@ -509,6 +510,13 @@ bool corr_fused_supported(int C, int h, int w, int d, int hw) {
     if (g.T < 1 || g.wpr < 1 || 3 * g.wpr > 16 || cf_lds_bytes(g) > 160 * 1024) return false;
     // 32-bit byte offsets inside a feature copy and inside one displacement plane of the cost volume
     return (size_t)C * g.hq * g.wq * g.dq * 4 + 64 < ((size_t)1 << 31) && (size_t)h * w * d * 4 < ((size_t)1 << 31);
+}
+
+// work items of one launch (0: geometry not supported) -- the callers' measure of whether the kernel fills the 2 x 256 workgroup slots
+int corr_fused_items(int C, int h, int w, int d, int hw) {
+    if (!corr_fused_supported(C, h, w, d, hw)) return 0;
+    const CFGeom g = cf_geom(C, h, w, d, hw);
+    return g.n * g.n * g.ng * (g.nyt > 0 ? g.nyt : 1);
 }
 
 size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw) {
@@ -541,7 +549,9 @@ template <int MODE>
 static void cf_launch(const CFGeom& gl, const float* Fp, const float* Mp, const float* tail, void* ssd, hipStream_t s, const CFSecond* second = nullptr) {
     // C >= 16: ATen's cascade channel sum; tiled: planes taller than one role holds (both are separate instantiations so that the
     // packaged configuration keeps its 64-register budget)
-    if (gl.C >= 16) { if (gl.tiled) cf_launch_c<MODE, true, true>(gl, Fp, Mp, tail, ssd, second, s); else cf_launch_c<MODE, true, false>(gl, Fp, Mp, tail, ssd, second, s); }
+    // (the fast arithmetics sum the channels as ONE FMA chain -- no cascade, the 64-register instantiation and two workgroups per CU also for C >= 16:
+    //  the certification bound of certify.hip counts C + 18 roundings for it, C <= 128)
+    if (gl.C >= 16 && !(MODE & 1)) { if (gl.tiled) cf_launch_c<MODE, true, true>(gl, Fp, Mp, tail, ssd, second, s); else cf_launch_c<MODE, true, false>(gl, Fp, Mp, tail, ssd, second, s); }
     else if (gl.tiled) cf_launch_c<MODE, false, true>(gl, Fp, Mp, tail, ssd, second, s);
     else cf_launch_c<MODE, false, false>(gl, Fp, Mp, tail, ssd, second, s);
 }
@@ -586,7 +596,7 @@ int launch_corr_fused_dual(const float* fix, const float* mov, int C, int h, int
     CFGeom gl = g;
     gl.prio = (int)options().cf_prio;
     // (pairs of a slot: 2 x (256 - nn) >= nn first groups)
-    gl.colocate = (options().cf_map == 1 && !ssd_rev && !g.tiled && g.ng == 3 && g.n * g.n <= 256 && 2 * (256 - g.n * g.n) >= g.n * g.n) ? 1 : 0;
+    gl.colocate = (options().cf_map == 1 && !ssd_rev && !g.tiled && g.ng == 3 && g.gs == 4 && g.n * g.n <= 256 && 2 * (256 - g.n * g.n) >= g.n * g.n) ? 1 : 0;
     gl.dbg = (options().cf_census && !ssd_rev) ? census_buf : nullptr;      // debugging aid: per-workgroup start / end / placement in the workspace
     if (fast == 2) cf_launch<1 + 32>(gl, Fp, Mp, tail, ssd, s, sec);
     else if (fast && f16 == 2) cf_launch<1 + 8 + 16>(gl, Fp, Mp, tail, ssd, s, sec);

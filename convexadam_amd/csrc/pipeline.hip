@@ -420,11 +420,12 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     // Certified-fast path (option corr_cert, default): the cost volumes in the fast arithmetic (unscaled, 2^-16 relative to ATen's), every
     // argmin decision certified against the exact arithmetic or evaluated exactly (certify.hip) -- the SAME winners, hence the same field bits,
     // as the exact kernels below; packaged operator only (SSD, two boxes, float32, pruned passes).
-    // (below 16 channels by default: from 16 on the fast kernels carry the channel sums in a third of their wavefronts / through the staging and are no
-    // faster than the exact path -- C = 32 at 26x32x37 hw 6: 0.50 vs 0.47 ms, C = 64 hw 4: 0.55 vs 0.22 ms, tools/experiments/corr_time_c.py --;
+    // (C >= 16: the role kernel carries the channel sums in a third of its wavefronts.  In the fast arithmetic it needs no cascade -- 64 registers, two
+    // workgroups per CU -- and beats the exact kernels up to 32 channels where its items fill the chip: C = 32 at 26x32x37 hw 6 0.36 vs 0.45 ms,
+    // C = 16 0.21 vs 0.33; with 162 items (hw 4) or 64 channels it loses -- C = 64 hw 4: 0.56 vs 0.23 ms --, tools/experiments/corr_time_c.py;
     // corr_cert = 2 keeps the staged kernel selectable for every supported C)
     const bool cert = options().corr_cert != 0 && !variant && !no_prune && corr_certfast_supported(L.C, L.h, L.w, L.d, p->disp_hw) &&
-                      (L.C < 16 || options().corr_cert == 2);
+                      (L.C < 16 || options().corr_cert == 2 || (L.C <= 32 && corr_fused_items(L.C, L.h, L.w, L.d, p->disp_hw) >= 384));
     int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
     if (cert) {
         const size_t fws = corr_certfast_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw), qws = corr_certify_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);
