@@ -57,39 +57,6 @@ __global__ __launch_bounds__(256) void k_corr_prep(const float* __restrict__ fix
     }
 }
 
-// the same copies, one 16-byte store per thread and no 64-bit index arithmetic: grid (quads of a padded moving plane, hq planes, C channels); the
-// thread of Mp quad (zq, yq, xq4) also writes the Fp quad of the same indices where the fixed copy has one (h <= hq, w <= wq, px <= dq).
-// Row pitches px and dq are multiples of 4 at every call site (checked by the launcher); 7.4 -> 4.5 us on the benchmark geometry.
-__global__ __launch_bounds__(256) void k_corr_prep4(const float* __restrict__ fix, const float* __restrict__ mov, CorrGeom g,
-                                                    float* __restrict__ Fp, float* __restrict__ Mp) {
-    const int dq4 = g.dq >> 2, px4 = g.px >> 2;
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t >= g.wq * dq4) return;
-    const int yq = t / dq4, xq4 = t - yq * dq4, zq = (int)blockIdx.y, c = (int)blockIdx.z;
-    {
-        const int y = yq - g.hw, z = zq - g.hw, x0 = 4 * xq4 - g.PL - 1;
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < g.w && z >= 0 && z < g.h && x0 + 3 >= 0 && x0 < g.d) {
-            const float* row = mov + (((size_t)c * g.h + z) * g.w + y) * g.d;
-            o.x = (x0 >= 0 && x0 < g.d) ? row[x0] : 0.0f;
-            o.y = (x0 + 1 >= 0 && x0 + 1 < g.d) ? row[x0 + 1] : 0.0f;
-            o.z = (x0 + 2 >= 0 && x0 + 2 < g.d) ? row[x0 + 2] : 0.0f;
-            o.w = (x0 + 3 >= 0 && x0 + 3 < g.d) ? row[x0 + 3] : 0.0f;
-        }
-        *reinterpret_cast<float4*>(Mp + ((((size_t)c * g.hq + zq) * g.wq + yq) * g.dq + 4 * xq4)) = o;
-    }
-    if (zq < g.h && yq < g.w && xq4 < px4) {
-        const int x0 = 4 * xq4 - 1;
-        const float* row = fix + (((size_t)c * g.h + zq) * g.w + yq) * g.d;
-        float4 o;
-        o.x = (x0 >= 0 && x0 < g.d) ? row[x0] : 0.0f;
-        o.y = (x0 + 1 < g.d) ? row[x0 + 1] : 0.0f;
-        o.z = (x0 + 2 < g.d) ? row[x0 + 2] : 0.0f;
-        o.w = (x0 + 3 < g.d) ? row[x0 + 3] : 0.0f;
-        *reinterpret_cast<float4*>(Fp + ((((size_t)c * g.h + zq) * g.w + yq) * g.px + 4 * xq4)) = o;
-    }
-}
-
 // ---- raw SSD: register tile of 4 row indices x n D-shifts ---------------------------------------------
 template <int HW, bool CASCADE>
 __global__ __launch_bounds__(256) void k_corr_raw(const float* __restrict__ Fp, const float* __restrict__ Mp, CorrGeom g,
@@ -250,11 +217,6 @@ void launch_corr_prep_generic(const float* fix, const float* mov, int C, int h, 
                               float* Mp, hipStream_t s) {
     CorrGeom g = corr_geom(C, h, w, d, hw);
     g.px = px; g.PL = PL; g.dq = dq;
-    const bool al = (reinterpret_cast<uintptr_t>(Fp) & 15) == 0 && (reinterpret_cast<uintptr_t>(Mp) & 15) == 0;
-    if ((g.px & 3) == 0 && (g.dq & 3) == 0 && g.px <= g.dq && al && g.hq <= 65535 && C <= 65535) {
-        hipLaunchKernelGGL(k_corr_prep4, dim3((unsigned)cdiv(g.wq * (g.dq >> 2), 256), (unsigned)g.hq, (unsigned)C), dim3(256), 0, s, fix, mov, g, Fp, Mp);
-        return;
-    }
     const size_t nprep = std::max((size_t)C * g.hq * g.wq * g.dq, (size_t)C * h * w * g.px);
     hipLaunchKernelGGL(k_corr_prep, dim3((unsigned)cdiv64((int64_t)nprep, 256)), dim3(256), 0, s, fix, mov, g, Fp, Mp);
 }
