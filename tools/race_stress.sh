@@ -11,6 +11,7 @@ echo "library: $CONVEXADAM_HIP_LIB (CVX_RACE_JITTER build); 3 repetitions of the
 for rep in 1 2 3; do
   timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fast_modes.py tests/test_gpu_surfdist.py -q -x -p no:cacheprovider \
     -k "vs_oracle or bit_exact or bit_identical or variants or marching or worst_case or snapshots or kernel_variants or x_tiles or torch_mean or reference or fp16 or workgroups_per_cu or search_widths or nnunet or threads or fast or hd95 or edt or drop_in or surface or label_bits" 2>&1 | tail -3 >> $O
+  timeout 900 python -m pytest tests/test_gpu_mind_single.py tests/test_gpu_certified.py tests/test_gpu_ic_fused.py -q -x -p no:cacheprovider 2>&1 | tail -2 >> $O
 done
 python - >> $O <<'PY'
 import ctypes, os
