@@ -563,6 +563,11 @@ int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, i
     return launch_corr_fused_dual(fix, mov, C, h, w, d, hw, cost, n_box, fast, f16, ssd, nullptr, workspace, workspace_bytes, nullptr, s);
 }
 
+// profiling aid of the whole-pair pipeline: called on the stream between the feature copies (k_corr_prep, tail values) and the kernel, so that a
+// stage interval can be the KERNEL's own duration (bench.py's `roofline`); nullptr (default) = nothing.  Per calling thread.
+static thread_local void (*t_after_prep)(hipStream_t) = nullptr;
+void corr_fused_set_prep_hook(void (*hook)(hipStream_t)) { t_after_prep = hook; }
+
 // ssd_rev != nullptr: BOTH directions of a pair in one launch -- ssd = correlate(fix, mov), ssd_rev = correlate(mov, fix); workspace_rev
 // = a second workspace of corr_fused_workspace_bytes (the reverse direction's padded feature copies)
 int launch_corr_fused_dual(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
@@ -593,6 +598,7 @@ int launch_corr_fused_dual(const float* fix, const float* mov, int C, int h, int
         two.Fp = Fp2; two.Mp = Mp2; two.tail = tail2; two.ssd = ssd_rev;
     }
     const CFSecond* sec = ssd_rev ? &two : nullptr;
+    if (t_after_prep) t_after_prep(s);
     CFGeom gl = g;
     gl.prio = (int)options().cf_prio;
     // (pairs of a slot: 2 x (256 - nn) >= nn first groups)

@@ -412,6 +412,7 @@ bool corr_box2_supported(int h, int w, int d, int px);
 int launch_corr_box2(const float* raw, int K, int h, int w, int d, int px, float* ssd, hipStream_t s);
 // corrfused.hip: raw SSD + both boxes in one kernel (C < 16, planes of at most 320 quads); else the unfused path above
 bool corr_fused_supported(int C, int h, int w, int d, int hw);
+void corr_fused_set_prep_hook(void (*hook)(hipStream_t));         // profiling: called between the feature copies and the fused kernel (per thread; nullptr = off)
 int corr_fused_items(int C, int h, int w, int d, int hw);            // work items of one launch of the fused kernel (0: unsupported geometry)
 size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw);
 int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,

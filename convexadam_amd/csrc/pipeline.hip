@@ -346,6 +346,10 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     if (g_profiling < 2) { g_marks.clear(); g_pool_used = 0; }
     mark("start", s);
+    // stage intervals "correlate" / "correlate_rev" = the fused kernel alone; the padded feature copies (and the certification set-up before them) are
+    // "correlate_prep" (only while profiling: the hook records an event)
+    corr_fused_set_prep_hook(g_profiling ? +[](hipStream_t st) { mark("correlate_prep", st); } : nullptr);
+    struct HookReset { ~HookReset() { corr_fused_set_prep_hook(nullptr); } } hook_reset;
 
     // 1. features                                                              (:106-116)
     const float *featF = feat_fixed, *featM = feat_moving;
