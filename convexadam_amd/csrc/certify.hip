@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_cert_plain_stream(CertArgs A, int kslic
         for (int j = 0; j < 4; ++j) { best[j] = c4[j]; bi[j] = k0; second[j] = INF; tiny[j] = (c4[j] > 0.0f) & (c4[j] < 1.0e-36f); }
         p += v;
     }
-#pragma unroll 4
+#pragma unroll 8
     for (int k = k0 + 1; k < k1; ++k, p += v) {
         float c4[4];
         load4(p, c4);

@@ -96,6 +96,14 @@ def test_argument_validation_without_gpu(L):
     assert L.cvx_box_grow_f32(dummy, 3, 4, 4, 4, 3, C.c_void_p(512), None) == -1 and b"even" in L.cvx_last_error()   # odd kernel: the other entry
     assert L.cvx_box_grow_f32(dummy, 3, 4, 4, 4, 2, dummy, None) == -1                                               # in place
     assert L.cvx_box_grow_f32(dummy, 3, 4, 4, 1, 4, C.c_void_p(512), None) == -1 and b"padding" in L.cvx_last_error()
+    # pooled descriptor (round 6): null pointers, bad windows, windows that do not tile, missing scratch for the two-pass settings
+    assert L.cvx_mindssc_pooled_f32(None, 8, 8, 8, 1, 2, 2, None, 0, None, None, 0, None, 0, None, None) == -1 and b"null" in L.cvx_last_error()
+    assert L.cvx_mindssc_pooled_f32(dummy, 8, 8, 8, 1, 2, 0, dummy, 0, None, None, 0, dummy, 1 << 30, None, None) == -1 and b"windows" in L.cvx_last_error()
+    assert L.cvx_mindssc_pooled_f32(dummy, 8, 8, 8, 1, 2, 2, dummy, 2, None, None, 0, dummy, 1 << 30, None, None) == -1 and b"second output" in L.cvx_last_error()
+    assert L.cvx_mindssc_pooled_f32(dummy, 20, 20, 20, 1, 2, 5, dummy, 0, None, None, 0, dummy, 1 << 30, None, None) == -4        # 5^3 windows: use the two operators
+    assert L.cvx_mindssc_pooled_scratch_bytes(24, 24, 24, 2, 2, 6, 2) == 12 * 24 * 24 * 24 * 4       # radius 2: two passes through the raw distances
+    assert L.cvx_mindssc_pooled_f32(dummy, 24, 24, 24, 2, 2, 6, dummy, 2, dummy, None, 0, dummy, 1 << 30, None, None) == -2 and b"scratch" in L.cvx_last_error()
+    assert L.cvx_mindssc_pooled_scratch_bytes(24, 24, 24, 1, 2, 6, 2) in (0, 12 * 24 * 24 * 24 * 4)   # (0 with option mind_single, the single pass)
     # evaluation operators: null pointers and degenerate extents
     assert L.cvx_jacobian_det_f32(None, 8, 8, 8, 0, None, None) == -1
     assert L.cvx_jacobian_det_f32(dummy, 4, 8, 8, 0, dummy, None) == -1 and b"crop" in L.cvx_last_error()
