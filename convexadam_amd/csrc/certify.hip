@@ -296,8 +296,29 @@ __global__ __launch_bounds__(256) void k_cert_plain_commit(CertArgs A) {
 }
 
 // ---- coupled passes --------------------------------------------------------------------------------------------------------------
+// The pipeline's search mesh is a product grid (cvx_disp_mesh_f32: component a of displacement k depends on the a-th digit of
+// k = (ia * n + ib) * n + ic only), so the kernels of the coupled passes keep its 3 x n axis values in LDS and never wait for a mesh load: one
+// dependent memory round trip less in every stage of these latency-bound kernels.  Same values, same operations -- same bits.
+struct CertMesh {
+    const float* ax;        // LDS [3][32]: ax[a * 32 + i] = mesh[a][i * n^a]
+    int n; float rn;
+    __device__ __forceinline__ void split(int k, int& ic, int& ib, int& ia) const {
+        // k < 2^15, n < 2^10: (k + 0.5) / n stays 0.5 / n away from every integer -- far more than the rounding of the float product
+        const int q = (int)(((float)k + 0.5f) * rn);
+        ic = k - q * n;
+        ia = (int)(((float)q + 0.5f) * rn);
+        ib = q - ia * n;
+    }
+};
+__device__ __forceinline__ CertMesh cert_mesh_load(float* lds96, const float* __restrict__ mesh, int K, int n) {
+    const int t = threadIdx.x;
+    if (t < n) { lds96[t] = mesh[t]; lds96[32 + t] = mesh[K + t * n]; lds96[64 + t] = mesh[2 * K + t * n * n]; }
+    __syncthreads();
+    return CertMesh{lds96, n, 1.0f / (float)n};
+}
+
 // u_a(x) = avg_pool3d(mesh[a, idx], 3, padding=1)(x): raster-order sum of the in-range taps, / 27  (convex_adam_utils.py:96,107)
-__device__ __forceinline__ void cert_smooth_winner(const int* __restrict__ idx, const float* __restrict__ mesh, int K, int h, int w, int d, size_t i,
+__device__ __forceinline__ void cert_smooth_winner(const int* __restrict__ idx, const CertMesh& M, int h, int w, int d, size_t i,
                                                    float& o0, float& o1, float& o2) {
     const int x = (int)(i % d), y = (int)((i / d) % w), z = (int)(i / ((size_t)d * w));
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -320,7 +341,11 @@ __device__ __forceinline__ void cert_smooth_winner(const int* __restrict__ idx, 
             }
         float m0[9], m1[9], m2[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) { m0[t] = mesh[kk[t]]; m1[t] = mesh[K + kk[t]]; m2[t] = mesh[2 * K + kk[t]]; }
+        for (int t = 0; t < 9; ++t) {
+            int ic, ib, ia;
+            M.split(kk[t], ic, ib, ia);
+            m0[t] = M.ax[ic]; m1[t] = M.ax[32 + ib]; m2[t] = M.ax[64 + ia];
+        }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             s0 += ok[t] ? m0[t] : 0.0f;
@@ -333,8 +358,10 @@ __device__ __forceinline__ void cert_smooth_winner(const int* __restrict__ idx, 
     o2 = fdiv(s2, 27.0f);
 }
 
-__device__ __forceinline__ float cert_pen(const float* __restrict__ mesh, int K, int k, float uc, float ub, float ua, float coef) {
-    const float e0 = mesh[k] - uc, e1 = mesh[K + k] - ub, e2 = mesh[2 * K + k] - ua;
+__device__ __forceinline__ float cert_pen(const CertMesh& M, int k, float uc, float ub, float ua, float coef) {
+    int ic, ib, ia;
+    M.split(k, ic, ib, ia);
+    const float e0 = M.ax[ic] - uc, e1 = M.ax[32 + ib] - ub, e2 = M.ax[64 + ia] - ua;
     float q = e0 * e0;          // (..).pow(2).sum(0): sequential over the 3 components
     q += e1 * e1;
     q += e2 * e2;
@@ -348,12 +375,12 @@ struct CertBox {
     bool degenerate;
 };
 // the admissible box: every displacement whose lower cost bound fl(slo + pen) does not exceed `bound` (an upper bound of the minimum)
-__device__ __forceinline__ CertBox cert_box(const float* __restrict__ mesh, float uc, float ub, float ua, float coef, int K, int n, int kp,
+__device__ __forceinline__ CertBox cert_box(const CertMesh& M, float uc, float ub, float ua, float coef, int K, int n, int kp,
                                             float ssdu_kp, float smin_u, const float* __restrict__ col, size_t v, int refine_above) {
     CertBox c;
     c.uc = uc; c.ub = ub; c.ua = ua;
     c.slo = cert_lower(smin_u);
-    c.bound = cert_upper(ssdu_kp) + cert_pen(mesh, K, kp, uc, ub, ua, coef);
+    c.bound = cert_upper(ssdu_kp) + cert_pen(M, kp, uc, ub, ua, coef);
     const float hwf = (float)((n - 1) / 2);
     auto close_box = [&]() {
         const float qmax = fdiv((c.bound - c.slo) + fabsf(c.bound) * 2.384185791015625e-07f, coef) * 1.00001f;
@@ -368,7 +395,7 @@ __device__ __forceinline__ CertBox cert_box(const float* __restrict__ mesh, floa
     if (!c.degenerate && c.vol > refine_above && uc == uc && ub == ub && ua == ua) {
         const int kn = (min(max((int)rintf(ua + hwf), 0), n - 1) * n + min(max((int)rintf(ub + hwf), 0), n - 1)) * n + min(max((int)rintf(uc + hwf), 0), n - 1);
         if (kn != kp) {
-            const float near_hi = cert_upper(col[(size_t)kn * v]) + cert_pen(mesh, K, kn, uc, ub, ua, coef);
+            const float near_hi = cert_upper(col[(size_t)kn * v]) + cert_pen(M, kn, uc, ub, ua, coef);
             if (near_hi < c.bound) { c.bound = near_hi; close_box(); }
         }
     }
@@ -382,6 +409,8 @@ __global__ __launch_bounds__(64) void k_cert_voxel(CertArgs A, int refine) {
     const int h = A.g.h, w = A.g.w, d = A.g.d, K = A.g.K, n = A.g.n;
     const size_t v = (size_t)h * w * d;
     const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float axes[96];
+    const CertMesh M = cert_mesh_load(axes, A.mesh, K, n);
     if (x >= v) return;
     const int* prev = A.pass == 1 ? P.idx0 : ((A.pass & 1) ? P.idxB : P.idxA);
     int* next = (A.pass & 1) ? P.idxA : P.idxB;
@@ -389,11 +418,11 @@ __global__ __launch_bounds__(64) void k_cert_voxel(CertArgs A, int refine) {
     const float s_kp = P.ssdu[(size_t)kp * v + x];
     const float sm_x = P.smin[x];
     float uc, ub, ua;
-    cert_smooth_winner(prev, A.mesh, K, h, w, d, x, uc, ub, ua);
+    cert_smooth_winner(prev, M, h, w, d, x, uc, ub, ua);
     P.u[x] = uc; P.u[v + x] = ub; P.u[2 * v + x] = ua;
     // a column with a NaN: torch.argmin returns the first NaN in every pass (the penalty is finite) = the plain pass's winner
     if (sm_x != sm_x) { next[x] = P.idx0[x]; return; }
-    const CertBox c = cert_box(A.mesh, uc, ub, ua, A.coef, K, n, kp, s_kp, sm_x, P.ssdu + x, v, refine);
+    const CertBox c = cert_box(M, uc, ub, ua, A.coef, K, n, kp, s_kp, sm_x, P.ssdu + x, v, refine);
     constexpr int NB = 8;
     const unsigned boxpack = (unsigned)c.c_lo | ((unsigned)c.c_hi << 5) | ((unsigned)c.b_lo << 10) | ((unsigned)c.b_hi << 15) | ((unsigned)c.a_lo << 20) | ((unsigned)c.a_hi << 25) | (c.degenerate ? 1u << 30 : 0u);
     const CertRec rec = {(unsigned)x, boxpack, kp, c.bound, c.slo, c.uc, c.ub, c.ua};
@@ -407,7 +436,7 @@ __global__ __launch_bounds__(64) void k_cert_voxel(CertArgs A, int refine) {
         for (int j = 0; j < NB; ++j) {
             const bool in = j < (int)c.vol;
             kk[j] = (ia * n + ib) * n + ic;
-            pen[j] = cert_pen(A.mesh, K, kk[j], c.uc, c.ub, c.ua, A.coef);
+            pen[j] = cert_pen(M, kk[j], c.uc, c.ub, c.ua, A.coef);
             need[j] = in && !(c.slo + pen[j] > c.bound);
             if (j + 1 < (int)c.vol) {
                 if (++ic > c.c_hi) { ic = c.c_lo; if (++ib > c.b_hi) { ib = c.b_lo; ++ia; } }
@@ -437,11 +466,13 @@ __global__ __launch_bounds__(64) void k_cert_voxel(CertArgs A, int refine) {
 // evaluation of what the intervals leave open
 __global__ __launch_bounds__(256) void k_cert_wave(CertArgs A) {
     __shared__ float smem[4][160];
+    __shared__ float axes[96];
     const CertProb& P = A.p[blockIdx.y];
     const int h = A.g.h, w = A.g.w, d = A.g.d, K = A.g.K, n = A.g.n;
     const size_t v = (size_t)h * w * d;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* sm = smem[wv];
+    const CertMesh M = cert_mesh_load(axes, A.mesh, K, n);
     int* next = (A.pass & 1) ? P.idxA : P.idxB;
     const int cnt = P.counts[A.pass];
     const float INF = __uint_as_float(0x7f800000u);
@@ -479,7 +510,7 @@ __global__ __launch_bounds__(256) void k_cert_wave(CertArgs A) {
                     const int qb = (int)(((float)ra + 0.5f) * rc);
                     const int ic = c.c_lo + ra - qb * nc, ib = c.b_lo + qb, ia = c.a_lo + qa;
                     kk[j] = (ia * n + ib) * n + ic;
-                    pen[j] = cert_pen(A.mesh, K, kk[j], c.uc, c.ub, c.ua, A.coef);
+                    pen[j] = cert_pen(M, kk[j], c.uc, c.ub, c.ua, A.coef);
                     need[j] = need[j] && (c.degenerate || !(c.slo + pen[j] > c.bound));
                 }
             }
@@ -518,7 +549,7 @@ __global__ __launch_bounds__(256) void k_cert_wave(CertArgs A) {
                     const int qa = (int)(((float)ii + 0.5f) * rab), ra = ii - qa * ncb;
                     const int qb = (int)(((float)ra + 0.5f) * rc);
                     kk[j] = ((c.a_lo + qa) * n + c.b_lo + qb) * n + c.c_lo + ra - qb * nc;
-                    pen[j] = cert_pen(A.mesh, K, kk[j], c.uc, c.ub, c.ua, A.coef);
+                    pen[j] = cert_pen(M, kk[j], c.uc, c.ub, c.ua, A.coef);
                     need[j] = need[j] && (c.degenerate || !(c.slo + pen[j] > c.bound));
                 }
             }
@@ -547,10 +578,12 @@ __global__ __launch_bounds__(256) void k_cert_gather(CertArgs A) {
     const CertProb& P = A.p[blockIdx.y];
     const size_t v = (size_t)A.g.h * A.g.w * A.g.d;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float axes[96];
+    const CertMesh M = cert_mesh_load(axes, A.mesh, A.g.K, A.g.n);
     if (i >= v) return;
     const int* prev = A.pass == 1 ? P.idx0 : ((A.pass & 1) ? P.idxB : P.idxA);
     float o0, o1, o2;
-    cert_smooth_winner(prev, A.mesh, A.g.K, A.g.h, A.g.w, A.g.d, i, o0, o1, o2);
+    cert_smooth_winner(prev, M, A.g.h, A.g.w, A.g.d, i, o0, o1, o2);
     P.u[i] = o0; P.u[v + i] = o1; P.u[2 * v + i] = o2;
 }
 
