@@ -55,7 +55,7 @@ static Options env_options() {
             env_ll("CVX_NO_PRUNE", 0),     env_ll("CVX_CORR_UNFUSED", 0), env_ll("CVX_CORR_FUSED_ALL", 0), env_ll("CVX_PRUNE_STREAM_ABOVE", -1), env_ll("CVX_CF_CENSUS", 0), env_ll("CVX_CF_PRIO", 136),
             env_ll("CVX_WARP_FLAT", 0),    env_ll("CVX_BOX_YT", 8),       env_ll("CVX_BOX_WG_TARGET", 0),
             env_ll("CVX_BOX_XSPLIT", -1),  env_ll("CVX_BOX_CPT", 4),      env_ll("CVX_BOX_UNEVEN", 200), env_ll("CVX_BOX_ADAM_ROLE", 0), env_ll("CVX_BOX_DPP", 0),      env_ll("CVX_BOX_PK", 0),       env_ll("CVX_BOX_PRIO", 0),     env_ll("CVX_LABEL_POW_BLOCK", 32), 0,                             env_ll("CVX_MIND_MEAN_THREADS", 0),
-            env_ll("CVX_EDT_SEQUENTIAL", 0), env_ll("CVX_WARP_OCTANT", 4), env_ll("CVX_BOX_FWD_TILE", -1), env_ll("CVX_BOX_BWD_TILE", -1), env_ll("CVX_BOX_WALK", 1), env_ll("CVX_CORR_DUAL", 0), env_ll("CVX_PRUNE_REFINE", 1), env_ll("CVX_MIND_RECORDS", 1), env_ll("CVX_RESIZE_UP2", 1), env_ll("CVX_MIND_BLOCKED", 1), env_ll("CVX_CORR_CERT", 1), env_ll("CVX_CC_DEBUG", 0), env_ll("CVX_IC_FUSED", 0), env_ll("CVX_MIND_SINGLE", 0), env_ll("CVX_MS_ZLEN", 0), env_ll("CVX_CF_MAP", 1), env_ll("CVX_FBOX_TILE", 0)};
+            env_ll("CVX_EDT_SEQUENTIAL", 0), env_ll("CVX_WARP_OCTANT", 4), env_ll("CVX_BOX_FWD_TILE", -1), env_ll("CVX_BOX_BWD_TILE", -1), env_ll("CVX_BOX_WALK", 1), env_ll("CVX_CORR_DUAL", 0), env_ll("CVX_PRUNE_REFINE", 1), env_ll("CVX_MIND_RECORDS", 1), env_ll("CVX_RESIZE_UP2", 1), env_ll("CVX_MIND_BLOCKED", 1), env_ll("CVX_CORR_CERT", 1), env_ll("CVX_CC_DEBUG", 0), env_ll("CVX_IC_FUSED", 0), env_ll("CVX_MIND_SINGLE", 0), env_ll("CVX_MS_ZLEN", 0), env_ll("CVX_CF_MAP", 1), env_ll("CVX_CERT_UNFUSED", 0), env_ll("CVX_FBOX_TILE", 0)};
 }
 static cvx_context& default_context() {
     static cvx_context c = [] { cvx_context d; d.opt = env_options(); return d; }();
@@ -119,7 +119,7 @@ static const OptName kOptNames[] = {{"mind_tiled", &Options::mind_tiled},     {"
                                     {"prune_stream_above", &Options::prune_stream_above}, {"cf_census", &Options::cf_census}, {"cf_prio", &Options::cf_prio},
                                     {"warp_flat", &Options::warp_flat},       {"box_yt", &Options::box_yt},             {"box_wg_target", &Options::box_wg_target},
                                     {"box_xsplit", &Options::box_xsplit},     {"box_cpt", &Options::box_cpt},           {"box_uneven", &Options::box_uneven},     {"box_adam_role", &Options::box_adam_role}, {"box_dpp", &Options::box_dpp},           {"box_pk", &Options::box_pk},             {"box_prio", &Options::box_prio},         {"label_pow_block", &Options::label_pow_block}, {"census_ptr", &Options::census_ptr},     {"mind_mean_threads", &Options::mind_mean_threads},
-                                    {"edt_sequential", &Options::edt_sequential}, {"warp_octant", &Options::warp_octant}, {"box_fwd_tile", &Options::box_fwd_tile}, {"box_bwd_tile", &Options::box_bwd_tile}, {"box_walk", &Options::box_walk}, {"corr_dual", &Options::corr_dual}, {"prune_refine", &Options::prune_refine}, {"mind_records", &Options::mind_records}, {"resize_up2", &Options::resize_up2}, {"mind_blocked", &Options::mind_blocked}, {"corr_cert", &Options::corr_cert}, {"cc_debug", &Options::cc_debug}, {"ic_fused", &Options::ic_fused}, {"mind_single", &Options::mind_single}, {"ms_zlen", &Options::ms_zlen}, {"cf_map", &Options::cf_map}, {"fbox_tile", &Options::fbox_tile}};
+                                    {"edt_sequential", &Options::edt_sequential}, {"warp_octant", &Options::warp_octant}, {"box_fwd_tile", &Options::box_fwd_tile}, {"box_bwd_tile", &Options::box_bwd_tile}, {"box_walk", &Options::box_walk}, {"corr_dual", &Options::corr_dual}, {"prune_refine", &Options::prune_refine}, {"mind_records", &Options::mind_records}, {"resize_up2", &Options::resize_up2}, {"mind_blocked", &Options::mind_blocked}, {"corr_cert", &Options::corr_cert}, {"cc_debug", &Options::cc_debug}, {"ic_fused", &Options::ic_fused}, {"mind_single", &Options::mind_single}, {"ms_zlen", &Options::ms_zlen}, {"cf_map", &Options::cf_map}, {"cert_unfused", &Options::cert_unfused}, {"fbox_tile", &Options::fbox_tile}};
 
 }  // namespace cvx
 

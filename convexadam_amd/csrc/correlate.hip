@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256) void k_corr_prep(const float* __restrict__ fix
 }
 
 // ---- raw SSD: register tile of 4 row indices x n D-shifts ---------------------------------------------
-template <int HW, bool CASCADE>
+// FAST (certified-fast arithmetic, certify.hip): one FMA per channel and output in plain channel order -- a chain of C roundings, no cascade
+template <int HW, bool CASCADE, bool FAST = false>
 __global__ __launch_bounds__(256) void k_corr_raw(const float* __restrict__ Fp, const float* __restrict__ Mp, CorrGeom g,
                                                   float* __restrict__ raw) {
+    static_assert(!(CASCADE && FAST), "the fast arithmetic has no cascade");
     constexpr int N = 2 * HW + 1;
     constexpr int PL = (HW + 3) / 4 * 4;
     constexpr int NCH = (2 * PL + 4) / 4;          // float4 chunks of the M row segment
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256) void k_corr_raw(const float* __restrict__ Fp, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float df = f[j] - m[PL + j + k - HW];
-                acc[k][j] += df * df;
+                if (FAST) acc[k][j] = __builtin_fmaf(df, df, acc[k][j]);
+                else acc[k][j] += df * df;
             }
         if (CASCADE && ((c & 15) == 15)) {           // ATen multi_row_sum: fold every 16 rows
 #pragma unroll
@@ -229,30 +232,91 @@ void launch_corr_tail_compact(const float* fix, const float* mov, int C, int h, 
 }
 
 template <int HW>
-static void corr_raw_dispatch(const float* Fp, const float* Mp, const CorrGeom& g, float* raw, hipStream_t s) {
+static void corr_raw_dispatch(const float* Fp, const float* Mp, const CorrGeom& g, float* raw, hipStream_t s, bool fast = false) {
     const int nruns = g.h * g.w * (g.px / 4);
     const dim3 grid(cdiv(nruns, 256), g.n * g.n);
-    if (g.C >= 16) hipLaunchKernelGGL((k_corr_raw<HW, true>), grid, dim3(256), 0, s, Fp, Mp, g, raw);
+    if (fast) hipLaunchKernelGGL((k_corr_raw<HW, false, true>), grid, dim3(256), 0, s, Fp, Mp, g, raw);
+    else if (g.C >= 16) hipLaunchKernelGGL((k_corr_raw<HW, true>), grid, dim3(256), 0, s, Fp, Mp, g, raw);
     else hipLaunchKernelGGL((k_corr_raw<HW, false>), grid, dim3(256), 0, s, Fp, Mp, g, raw);
 }
 
 // ---- the certified-fast volume: which kernel produces it (option corr_cert: 1 = the role kernel of corrfused.hip in its fast arithmetic
 // without the final scaling -- the faster one as measured --, 2 = the staged kernel of corrcert.hip; 0 in the pipeline = exact volumes) -------
+// ---- C >= 16 with few work items or many channels: the ROUND-1 PAIR OF KERNELS in the certified-fast arithmetic -- k_corr_raw with one FMA per
+// channel (every wavefront on the channel sums, where the role kernel has a third of them) through the raw intermediate, then the two boxes as
+// separable running sums without divisions (corrbox.hip, FAST).  Same class of arithmetic as the role kernel's (C + 13 roundings, non-negative
+// terms only): the certification constants cover it.  Taken when the work is large enough to pay for the certified passes (K v C >= 1e9:
+// BASELINE configs[3], 32 label channels on 40 x 48 x 40 with 729 displacements).
+static bool certfast_unfused_ok(int C, int h, int w, int d, int hw) {
+    if (C < 16 || C > 128 || hw > 8 || options().corr_cert == 2 || options().cert_unfused == 0) return false;
+    const CorrGeom g = corr_geom(C, h, w, d, hw);
+    const size_t K = (size_t)g.n * g.n * g.n;
+    return corr_box2_supported(h, w, d, g.px) && K * h * w * g.px * sizeof(float) <= ((size_t)2 << 30) && ((double)K * h * w * d * C >= 1e9 || options().cert_unfused == 2);
+}
+static bool certfast_use_unfused(int C, int h, int w, int d, int hw) {
+    if (!certfast_unfused_ok(C, h, w, d, hw)) return false;
+    const bool role_good = corr_fused_supported(C, h, w, d, hw) && C <= 32 && corr_fused_items(C, h, w, d, hw) >= 384 && !corr_fused_tiled(C, h, w, d, hw);
+    return !role_good;
+}
+static size_t certfast_unfused_workspace(int C, int h, int w, int d, int hw) {
+    const CorrGeom g = corr_geom(C, h, w, d, hw);
+    const size_t K = (size_t)g.n * g.n * g.n;
+    size_t used = 0;
+    used = carve_size(used, sizeof(float) * (size_t)C * h * w * g.px);
+    used = carve_size(used, sizeof(float) * (size_t)C * g.hq * g.wq * g.dq);
+    used = carve_size(used, sizeof(float) * K * h * w * g.px);
+    return used + 256;
+}
+static int launch_corr_certfast_unfused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* ssdu, void* workspace, size_t workspace_bytes,
+                                        hipStream_t s) {
+    if (workspace_bytes < certfast_unfused_workspace(C, h, w, d, hw)) return fail(CVX_ERR_WORKSPACE, "correlate (certified-fast, two kernels): workspace too small");
+    const CorrGeom g = corr_geom(C, h, w, d, hw);
+    const size_t K = (size_t)g.n * g.n * g.n;
+    Carver cv(workspace, workspace_bytes);
+    float* Fp = cv.take<float>((size_t)C * h * w * g.px);
+    float* Mp = cv.take<float>((size_t)C * g.hq * g.wq * g.dq);
+    float* raw = cv.take<float>(K * h * w * g.px);
+    const size_t nprep = (size_t)C * g.hq * g.wq * g.dq;
+    hipLaunchKernelGGL(k_corr_prep, dim3((unsigned)cdiv64((int64_t)nprep, 256)), dim3(256), 0, s, fix, mov, g, Fp, Mp);
+    corr_call_prep_hook(s);
+    switch (hw) {
+        case 0: corr_raw_dispatch<0>(Fp, Mp, g, raw, s, true); break;
+        case 1: corr_raw_dispatch<1>(Fp, Mp, g, raw, s, true); break;
+        case 2: corr_raw_dispatch<2>(Fp, Mp, g, raw, s, true); break;
+        case 3: corr_raw_dispatch<3>(Fp, Mp, g, raw, s, true); break;
+        case 4: corr_raw_dispatch<4>(Fp, Mp, g, raw, s, true); break;
+        case 5: corr_raw_dispatch<5>(Fp, Mp, g, raw, s, true); break;
+        case 6: corr_raw_dispatch<6>(Fp, Mp, g, raw, s, true); break;
+        case 7: corr_raw_dispatch<7>(Fp, Mp, g, raw, s, true); break;
+        default: corr_raw_dispatch<8>(Fp, Mp, g, raw, s, true); break;
+    }
+    return launch_corr_box2(raw, (int)K, h, w, d, g.px, ssdu, s, true);
+}
+
 static bool certfast_use_staged(int C, int h, int w, int d, int hw) {
     const bool staged_ok = corr_cert_supported(C, h, w, d, hw), fused_ok = corr_fused_supported(C, h, w, d, hw) && C <= 128;
     if (options().corr_cert == 2) return staged_ok;
     return staged_ok && !fused_ok;
 }
 bool corr_certfast_supported(int C, int h, int w, int d, int hw) {
-    return corr_cert_supported(C, h, w, d, hw) || (corr_fused_supported(C, h, w, d, hw) && C <= 128);
+    return corr_cert_supported(C, h, w, d, hw) || (corr_fused_supported(C, h, w, d, hw) && C <= 128) || certfast_unfused_ok(C, h, w, d, hw);
+}
+// does the certified path pay for this geometry in the whole-pair pipeline?  (below 16 channels always; from 16 on where a fast kernel beats the exact pair)
+bool corr_certfast_pays(int C, int h, int w, int d, int hw) {
+    if (C < 16) return true;
+    if (certfast_use_unfused(C, h, w, d, hw)) return true;
+    return C <= 32 && corr_fused_supported(C, h, w, d, hw) && corr_fused_items(C, h, w, d, hw) >= 384 && !corr_fused_tiled(C, h, w, d, hw);
 }
 size_t corr_certfast_workspace_bytes(int C, int h, int w, int d, int hw) {
     const size_t a = corr_cert_supported(C, h, w, d, hw) ? corr_cert_workspace_bytes(C, h, w, d, hw) : 0;
     const size_t b = corr_fused_supported(C, h, w, d, hw) ? corr_fused_workspace_bytes(C, h, w, d, hw) : 0;
-    return align_up(a > b ? a : b, 256);
+    const size_t c = certfast_unfused_ok(C, h, w, d, hw) ? certfast_unfused_workspace(C, h, w, d, hw) : 0;
+    const size_t m = a > b ? a : b;
+    return align_up(m > c ? m : c, 256);
 }
 int launch_corr_certfast(const float* fix, const float* mov, int C, int h, int w, int d, int hw, float* ssdu, void* workspace, size_t workspace_bytes,
                          hipStream_t s) {
+    if (certfast_use_unfused(C, h, w, d, hw)) return launch_corr_certfast_unfused(fix, mov, C, h, w, d, hw, ssdu, workspace, workspace_bytes, s);
     if (certfast_use_staged(C, h, w, d, hw)) return launch_corr_cert(fix, mov, C, h, w, d, hw, ssdu, workspace, workspace_bytes, s);
     return launch_corr_fused(fix, mov, C, h, w, d, hw, 0, 2, /*fast=*/2, 0, ssdu, workspace, workspace_bytes, s);
 }

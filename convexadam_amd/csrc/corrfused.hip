@@ -519,6 +519,8 @@ int corr_fused_items(int C, int h, int w, int d, int hw) {
     return g.n * g.n * g.ng * (g.nyt > 0 ? g.nyt : 1);
 }
 
+bool corr_fused_tiled(int C, int h, int w, int d, int hw) { return cf_geom(C, h, w, d, hw).tiled != 0; }
+
 size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw) {
     const CFGeom g = cf_geom(C, h, w, d, hw);
     size_t used = 0;
@@ -567,6 +569,7 @@ int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, i
 // stage interval can be the KERNEL's own duration (bench.py's `roofline`); nullptr (default) = nothing.  Per calling thread.
 static thread_local void (*t_after_prep)(hipStream_t) = nullptr;
 void corr_fused_set_prep_hook(void (*hook)(hipStream_t)) { t_after_prep = hook; }
+void corr_call_prep_hook(hipStream_t s) { if (t_after_prep) t_after_prep(s); }
 
 // ssd_rev != nullptr: BOTH directions of a pair in one launch -- ssd = correlate(fix, mov), ssd_rev = correlate(mov, fix); workspace_rev
 // = a second workspace of corr_fused_workspace_bytes (the reverse direction's padded feature copies)

@@ -122,6 +122,10 @@ struct Options {
     long long cf_map;              // fused correlation kernel, item -> workgroup order: 1 (default) = the two adjacent D-shift groups of a (dH, dW) pair in the two workgroup
                                    //    slots of ONE CU (blocks b and b + 256 share a CU: 251 of 251 in the census), so that their moving rows meet in that CU's L1
                                    //    (154 -> 152 us, three alternating rounds; bit-identical); 0 = large groups first
+    long long cert_unfused;        // C >= 16: the round-1 pair of kernels in the certified-fast arithmetic (correlate.hip: FMA channel chain, separable boxes without divisions)
+                                   //    1 = from K v C >= 1e9 on, 2 = whenever the geometry allows (tests), 0 (default) = never.  MEASURED: configs[3] 462 vs 503 us per
+                                   //    direction -- the raw kernel is bound by L1 bandwidth (290 us either way), only the boxes gain (191 -> 145 us) -- which the certified
+                                   //    passes' 0.08 ms per pair takes back
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
 };
@@ -409,11 +413,14 @@ bool mind_pooled_records_supported(int H, int W, int D, int g1, int g2);
 size_t mind_pooled_raw_floats(int H, int W, int D, int g1, int g2);      // floats of launch_mind_pooled's `raw` scratch (>= 12 H W D: blocked tiles overhang)
 // corrbox.hip: the two box filters of the SSD volume (z-marching pipeline); raw [K][h][w][px] -> ssd [K][h][w][d]
 bool corr_box2_supported(int h, int w, int d, int px);
-int launch_corr_box2(const float* raw, int K, int h, int w, int d, int px, float* ssd, hipStream_t s);
+int launch_corr_box2(const float* raw, int K, int h, int w, int d, int px, float* ssd, hipStream_t s, bool fast = false);   // fast: separable running sums, no divisions (certified-fast arithmetic)
 // corrfused.hip: raw SSD + both boxes in one kernel (C < 16, planes of at most 320 quads); else the unfused path above
 bool corr_fused_supported(int C, int h, int w, int d, int hw);
 void corr_fused_set_prep_hook(void (*hook)(hipStream_t));         // profiling: called between the feature copies and the fused kernel (per thread; nullptr = off)
-int corr_fused_items(int C, int h, int w, int d, int hw);            // work items of one launch of the fused kernel (0: unsupported geometry)
+int corr_fused_items(int C, int h, int w, int d, int hw);
+bool corr_fused_tiled(int C, int h, int w, int d, int hw);          // planes cut into y tiles (halo rows recomputed)
+void corr_call_prep_hook(hipStream_t s);                            // the hook of corr_fused_set_prep_hook, for the other correlation paths
+bool corr_certfast_pays(int C, int h, int w, int d, int hw);        // (correlate.hip) the whole-pair pipeline's rule for taking the certified path            // work items of one launch of the fused kernel (0: unsupported geometry)
 size_t corr_fused_workspace_bytes(int C, int h, int w, int d, int hw);
 int launch_corr_fused(const float* fix, const float* mov, int C, int h, int w, int d, int hw, int cost, int n_box, int fast, int f16,
                       void* ssd, void* workspace, size_t workspace_bytes, hipStream_t s);

@@ -429,7 +429,7 @@ static int cvx::register_pair_core(const float* img_fixed, const float* img_movi
     // C = 16 0.21 vs 0.33; with 162 items (hw 4) or 64 channels it loses -- C = 64 hw 4: 0.56 vs 0.23 ms --, tools/experiments/corr_time_c.py;
     // corr_cert = 2 keeps the staged kernel selectable for every supported C)
     const bool cert = options().corr_cert != 0 && !variant && !no_prune && corr_certfast_supported(L.C, L.h, L.w, L.d, p->disp_hw) &&
-                      (L.C < 16 || options().corr_cert == 2 || (L.C <= 32 && corr_fused_items(L.C, L.h, L.w, L.d, p->disp_hw) >= 384));
+                      (options().corr_cert == 2 || corr_certfast_pays(L.C, L.h, L.w, L.d, p->disp_hw));
     int64_t* am2 = p->ic ? reinterpret_cast<int64_t*>(ws + L.argmin2) : nullptr;
     if (cert) {
         const size_t fws = corr_certfast_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw), qws = corr_certify_workspace_bytes(L.C, L.h, L.w, L.d, p->disp_hw);

@@ -58,6 +58,7 @@ def _draw_options(rng):
     # round 6: the certified-fast correlation path (1 = role kernel in fast arithmetic, 2 = staged kernel) or the exact volumes (0)
     L.cvx_set_option(b"corr_cert", int(rng.choice([1, 1, 2, 2, 0])))
     L.cvx_set_option(b"cf_map", int(rng.integers(0, 2)))
+    L.cvx_set_option(b"cert_unfused", int(rng.choice([1, 2, 2, 0])))          # C >= 16: two-kernel certified-fast path by its default rule / always / never
 
 
 def trial_pipeline(rng, t):

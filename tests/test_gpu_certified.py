@@ -89,6 +89,59 @@ def test_certified_argmin_vs_oracle(U, L, orc, C, shape, hw):
     check(U, L, orc, f, m, hw)
 
 
+@pytest.mark.parametrize("C,shape,hw", [(16, (7, 9, 11), 3), (20, (7, 5, 9), 1), (32, (13, 16, 20), 5), (33, (6, 5, 8), 2), (64, (4, 9, 10), 2), (67, (3, 5, 6), 1),
+                                        (18, (6, 40, 37), 3), (32, (5, 48, 56), 2), (128, (3, 4, 5), 2), (32, (9, 8, 37), 8)])
+@pytest.mark.parametrize("kind", ["random", "zero_background", "plateau"])
+def test_certified_two_kernel_path_for_many_channels(U, L, orc, C, shape, hw, kind):
+    """C >= 16 through the round-1 pair of kernels in the certified-fast arithmetic (option cert_unfused = 2: whenever the geometry allows; the
+    default takes it from K v C >= 1e9 on): distance bound, zero pattern and argmin indices against the oracle."""
+    rng = np.random.default_rng(C + hw)
+    f = rng.random((C,) + shape, dtype=np.float32)
+    m = rng.random((C,) + shape, dtype=np.float32)
+    if kind == "zero_background":
+        m = np.roll(f, (0, 1, 1), (1, 2, 3)).copy()
+        f[:, :, : shape[1] // 2] = 0
+        m[:, :, : shape[1] // 2 + 1] = 0
+    elif kind == "plateau":
+        m = np.ones((C,) + shape, np.float32)
+        f = np.ones((C,) + shape, np.float32)
+        f[:, 1:3, 2:5, 1:4] = np.nextafter(np.float32(1), np.float32(0))
+    old = L.cvx_get_option(b"cert_unfused")
+    L.cvx_set_option(b"cert_unfused", 2)
+    try:
+        rs, ra = orc.correlate(f, m, hw)
+        got = certified(U, L, f, m, hw, 1)
+        assert got is not None
+        ssdu, am = host(got[0]).astype(np.float64) / 729.0, host(got[1])
+        assert np.array_equal(am, ra), "%d of %d argmins differ from the oracle's" % (int((am != ra).sum()), ra.size)
+        ref = rs.astype(np.float64)
+        assert np.array_equal(ssdu == 0, ref == 0)
+        assert bool((np.abs(ssdu - ref) <= E_REL * ref + 1e-38).all()), float((np.abs(ssdu - ref) / np.maximum(ref, 1e-30)).max())
+    finally:
+        L.cvx_set_option(b"cert_unfused", old)
+
+
+@pytest.mark.parametrize("C,sh,hw,gs", [(18, (48, 40, 56), 3, 4), (32, (36, 40, 44), 4, 4), (20, (40, 36, 44), 2, 4)])
+def test_pipeline_with_label_features_through_the_two_kernel_certified_path(L, orc, C, sh, hw, gs):
+    """The whole-pair pipeline on one-hot label features (convex_adam_nnUNet.py:96-100) with the certified passes on the two-kernel fast volume:
+    the field equals the oracle's bit for bit, and the exact path's."""
+    from convexadam_amd import convex_adam_MIND as M
+    rng = np.random.default_rng(C)
+    lab_f = rng.integers(0, C, sh).astype(np.float32)
+    lab_m = np.roll(lab_f, (1, -2, 1), (0, 1, 2))
+    f, m, _ = orc.label_features(lab_f, lab_m)
+    kw = dict(lambda_weight=1.25, grid_sp=gs, disp_hw=hw, selected_niter=4, grid_sp_adam=2, ic=True)
+    ref = orc.convex_adam_pipeline(None, None, features=(f, m), **kw)
+    old = L.cvx_get_option(b"cert_unfused"), L.cvx_get_option(b"corr_cert")
+    try:
+        for unf, cert in ((2, 1), (0, 1), (0, 0)):
+            L.cvx_set_option(b"cert_unfused", unf); L.cvx_set_option(b"corr_cert", cert)
+            out = host(M.register_pair_device(feat_fixed=dev(f), feat_moving=dev(m), **kw))
+            assert np.array_equal(np.moveaxis(out, 0, -1).astype(np.float64), ref), (unf, cert)
+    finally:
+        L.cvx_set_option(b"cert_unfused", old[0]); L.cvx_set_option(b"corr_cert", old[1])
+
+
 def test_certified_kernels_cover_the_benchmark_geometries(U, L, orc):
     """BASELINE configs 1-3 (coarse grids 16^3 hw 4, 26x32x37 hw 6, 37x32x37 hw 8) must take the certified path with both kernels"""
     from convexadam_amd import _lib
