@@ -76,6 +76,22 @@ def test_single_pass_vs_oracle(U, orc, single, shape, g1, g2):
     assert nrep == 0                          # white noise: the clamp never binds
 
 
+@pytest.mark.parametrize("r,d", [(2, 2), (1, 1), (3, 1), (1, 3)])
+@pytest.mark.parametrize("g1,g2", [(6, 2), (4, 2), (2, 0)])
+def test_other_radii_take_two_passes_through_the_scratch(U, orc, single, r, d, g1, g2):
+    """cvx_mindssc_pooled_f32 outside the marching stencil's setting (radius 1, dilation 2): the tiled stencil + the fused normalise / pool pass through
+    the caller's scratch (cvx_mindssc_pooled_scratch_bytes > 0) -- same operator, same bits as MINDSSC + avg_pool3d."""
+    from convexadam_amd._lib import lib
+    img = textured((18, 20, 28), 3 * r + d)
+    single(1)
+    assert lib().cvx_mindssc_pooled_scratch_bytes(18, 20, 28, r, d, g1, g2) >= 12 * 18 * 20 * 28 * 4
+    out = U.mind_pooled(dev(img)[None, None], r, d, g1, g2, device=DEV, return_repairs=True)
+    m = orc.mindssc(img, r, d)
+    assert same(host(out[0])[0], orc.avgpool_stride(m, g1)) and out[-1] == 0
+    if g2:
+        assert same(host(out[1])[0], orc.avgpool_stride(m, g2))
+
+
 @pytest.mark.parametrize("zlen", [6, 12, 18, 36])
 def test_z_chunk_lengths(U, orc, single, zlen):
     img = textured((47, 20, 100), 5)
