@@ -124,7 +124,7 @@ struct Options {
                                    //    (154 -> 152 us, three alternating rounds; bit-identical); 0 = large groups first
     long long cert_unfused;        // C >= 16: the round-1 pair of kernels in the certified-fast arithmetic (correlate.hip: FMA channel chain, separable boxes without divisions)
                                    //    1 = from K v C >= 1e9 on, 2 = whenever the geometry allows (tests), 0 (default) = never.  MEASURED: configs[3] 462 vs 503 us per
-                                   //    direction -- the raw kernel is bound by L1 bandwidth (290 us either way), only the boxes gain (191 -> 145 us) -- which the certified
+                                   //    direction -- the raw kernel takes 290 us with either arithmetic (not issue-bound), only the boxes gain (191 -> 145 us) -- which the certified
                                    //    passes' 0.08 ms per pair takes back
     long long fbox_tile;           // adam_mode "fast": tile shape of the separable adjoint-box + Adam kernel (adamfast.hip): 0 = automatic, 1 = 8x10x24,
                                    //    2 = 8x10x56, 3 = 16x10x24, 4 = 16x10x56, 5 = 8x8x32, 6 = 4x10x24 (bit-identical)
