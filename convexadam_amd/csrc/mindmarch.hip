@@ -320,8 +320,10 @@ template <int GW, typename G> struct MSPlan {
 };
 constexpr int ms_cdiv(int a, int b) { return (a + b - 1) / b; }
 
-template <typename G, int SET, int GA, int GB, bool REC>
-__device__ __forceinline__ void ms_run(const MSArgs& a, float* ring, float* X, float* E, unsigned* cst, double (*red)[MM_NT / 64], int z0, int z1, int y0, int x0, MMLoader& L) {
+// (one instance for the four wave groups: only the stencil step depends on the group's channel set -- a wave-uniform switch around mm_box_step --, the
+// normalisation and the pooling are shared code: 66 KB of instructions per kernel became 35 KB, inside the 64 KB instruction cache of a CU pair)
+template <typename G, int GA, int GB, bool REC>
+__device__ __forceinline__ void ms_run(const MSArgs& a, float* ring, float* X, float* E, unsigned* cst, double (*red)[MM_NT / 64], int z0, int z1, int y0, int x0, MMLoader& L, int grp) {
     const int H = a.H, W = a.W, D = a.D;
     const int tid = threadIdx.x, t128 = tid & 127;
     int row, q; bool qon;
@@ -482,8 +484,17 @@ __device__ __forceinline__ void ms_run(const MSArgs& a, float* ring, float* X, f
         mm_fetch(a.img, H, W, D, L, zc + 3, L.pre);
         const int gz = z0 + s - 2;
         if (s >= 3) pool(gz - 1);
-        if (s >= 2) mm_box_step<G, SET, true>(ring, X, nullptr, 0, 0, false, zc, rowoff, colbase, left, right, row, q, A, P, qon);
-        else mm_box_step<G, SET, false>(ring, X, nullptr, 0, 0, false, zc, rowoff, colbase, left, right, row, q, A, P, qon);
+        if (s >= 2) {
+            if (grp == 0) mm_box_step<G, 0, true>(ring, X, nullptr, 0, 0, false, zc, rowoff, colbase, left, right, row, q, A, P, qon);
+            else if (grp == 1) mm_box_step<G, 1, true>(ring, X, nullptr, 0, 0, false, zc, rowoff, colbase, left, right, row, q, A, P, qon);
+            else if (grp == 2) mm_box_step<G, 2, true>(ring, X, nullptr, 0, 0, false, zc, rowoff, colbase, left, right, row, q, A, P, qon);
+            else mm_box_step<G, 3, true>(ring, X, nullptr, 0, 0, false, zc, rowoff, colbase, left, right, row, q, A, P, qon);
+        } else {
+            if (grp == 0) mm_box_step<G, 0, false>(ring, X, nullptr, 0, 0, false, zc, rowoff, colbase, left, right, row, q, A, P, qon);
+            else if (grp == 1) mm_box_step<G, 1, false>(ring, X, nullptr, 0, 0, false, zc, rowoff, colbase, left, right, row, q, A, P, qon);
+            else if (grp == 2) mm_box_step<G, 2, false>(ring, X, nullptr, 0, 0, false, zc, rowoff, colbase, left, right, row, q, A, P, qon);
+            else mm_box_step<G, 3, false>(ring, X, nullptr, 0, 0, false, zc, rowoff, colbase, left, right, row, q, A, P, qon);
+        }
         ms_barrier();                                                  // B
         if (s >= 2) norm(gz);
     }
@@ -535,10 +546,7 @@ __global__ __launch_bounds__(MM_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         for (int o = 0; o < 5; ++o) mm_publish<G::PLANE>(L, ring, zc0 - 2 + o, v[o]);
     }
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 7);
-    if (grp == 0) ms_run<G, 0, GA, GB, REC>(a, ring, X, E, cst, red, z0, z1, y0, x0, L);
-    else if (grp == 1) ms_run<G, 1, GA, GB, REC>(a, ring, X, E, cst, red, z0, z1, y0, x0, L);
-    else if (grp == 2) ms_run<G, 2, GA, GB, REC>(a, ring, X, E, cst, red, z0, z1, y0, x0, L);
-    else ms_run<G, 3, GA, GB, REC>(a, ring, X, E, cst, red, z0, z1, y0, x0, L);
+    ms_run<G, GA, GB, REC>(a, ring, X, E, cst, red, z0, z1, y0, x0, L, grp);
 }
 
 template <int GA, int GB, bool REC>
